@@ -1,0 +1,303 @@
+"""
+Golden-vector generator: runs the UNMODIFIED reference (imported from /root/reference with the
+import shims of SURVEY.md section 8c) on seeded inputs and writes tests/golden/*.npz.
+
+Runs only in the build container (the reference tree does not travel to the GPU box).  The
+committed fixtures pin oracle/coot_oracle.py (tests/test_oracle_golden.py); the HIP path is then
+checked against the oracle and, for the end-to-end cases, directly against these fixtures.
+
+    python oracle/gen_golden.py            # regenerate everything
+"""
+import collections
+import collections.abc
+import copy
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("COOT_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# ---- import shims (no reference edits) -------------------------------------------------------
+for _n in ("Iterable", "Mapping", "Sequence", "MutableMapping"):
+    setattr(collections, _n, getattr(collections.abc, _n))
+for _name in ("GPUtil", "h5py"):
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+_tb = types.ModuleType("torch.utils.tensorboard")  # nntrainer/metric.py:17 (tensorboard absent here)
+_tb.SummaryWriter = type("SummaryWriter", (), {"add_scalar": lambda *a, **k: None, "close": lambda *a, **k: None})
+sys.modules.setdefault("torch.utils.tensorboard", _tb)
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+import torch as th  # noqa: E402
+from torch.nn import functional as F  # noqa: E402
+
+from coot import model_retrieval  # noqa: E402
+from coot.configs_retrieval import RetrievalConfig  # noqa: E402
+from coot.dataset_retrieval import RetrievalDataBatchTuple  # noqa: E402
+from coot.loss_fn import ContrastiveLoss, CycleConsistencyLoss  # noqa: E402
+from coot.trainer_retrieval import RetrievalTrainer  # noqa: E402
+from nntrainer import models, retrieval, utils_yaml  # noqa: E402
+
+from oracle import coot_oracle as O  # noqa: E402
+
+th.set_num_threads(4)
+
+
+def ref_config(dv, dt, hidden, heads, ff, pool_hidden, layers=1):
+    d = utils_yaml.load_yaml_config_file(os.path.join(REF, "config/retrieval/paper2020/anet_coot.yaml"))
+    d["use_cuda"] = False
+    d["fp16_train"] = False
+    d["fp16_val"] = False
+    d["dataset_train"]["vid_feat_dim"] = dv
+    d["dataset_train"]["text_feat_dim"] = dt
+    loc = d["net_video_local"]
+    loc["output_dim"] = hidden
+    loc["input_fc_config"]["output_dim"] = hidden
+    loc["selfatn_config"].update(hidden_dim=hidden, num_heads=heads, pointwise_ff_dim=ff, num_layers=layers)
+    loc["pooler_config"]["hidden_dim"] = pool_hidden
+    glob = d["net_video_global"]
+    glob["output_dim"] = 2 * hidden
+    glob["crossatn_config"].update(hidden_dim=hidden, num_heads=heads, pointwise_ff_dim=ff)
+    return RetrievalConfig(d)
+
+
+def oracle_cfgs(dv, dt, hidden, heads, ff, pool_hidden, layers=1):
+    kw = dict(hidden_dim=hidden, num_heads=heads, ff_dim=ff, num_layers=layers, pool_hidden=pool_hidden)
+    loc_v = O.NetConfig(input_dim=dv, **kw)
+    loc_t = O.NetConfig(input_dim=dt, **kw)
+    glob = O.NetConfig(input_dim=hidden, use_input_fc=False, use_context=True, pooler="avg_special", **kw)
+    return loc_v, glob, loc_t, copy.deepcopy(glob)
+
+
+NET_KEYS = ["net_video_local", "net_video_global", "net_text_local", "net_text_global"]
+
+
+def load_params(module, P):
+    sd = module.state_dict()
+    for k in sd:
+        if k in P:
+            sd[k] = th.from_numpy(np.asarray(P[k], dtype=np.float32))
+    module.load_state_dict(sd)
+
+
+def to_batch(b):
+    t = {k: th.from_numpy(np.asarray(v)) for k, v in b.items()}
+    B = len(b["clip_num"])
+    f = lambda k: t[k].float()
+    return RetrievalDataBatchTuple(
+        key=[str(i) for i in range(B)], data_key=[str(i) for i in range(B)], sentences=[[""]] * B,
+        vid_feat=f("vid_feat"), vid_feat_mask=t["vid_feat_mask"], vid_feat_len=t["vid_feat_len"],
+        par_feat=f("par_feat"), par_feat_mask=t["par_feat_mask"], par_feat_len=t["par_feat_len"],
+        clip_num=t["clip_num"], clip_feat=f("clip_feat"), clip_feat_mask=t["clip_feat_mask"],
+        clip_feat_len=t["clip_feat_len"], sent_num=t["sent_num"], sent_feat=f("sent_feat"),
+        sent_feat_mask=t["sent_feat_mask"], sent_feat_len=t["sent_feat_len"])
+
+
+class _FakeTrainer:
+    """Just enough of RetrievalTrainer to call its loss hooks unbound (no dirs/loggers)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.loss_contr = ContrastiveLoss(cfg.train.contrastive_loss_config.margin, use_cuda=False)
+        self.loss_cycle_cons = CycleConsistencyLoss(num_samples=1, use_cuda=False)
+
+    compute_align_loss = RetrievalTrainer.compute_align_loss
+    compute_cluster_loss = RetrievalTrainer.compute_cluster_loss
+    compute_total_constrastive_loss = RetrievalTrainer.compute_total_constrastive_loss
+    compute_cyclecons_loss = RetrievalTrainer.compute_cyclecons_loss
+
+
+def draw_cc_indices(seed, clip_mask, sent_mask):
+    """Replays the RNG consumption order of CycleConsistencyLoss.get_total_loss
+    (coot/loss_fn.py:306-314): B draws for the clip cycle, then B for the sentence cycle."""
+    th.manual_seed(seed)
+    ic = [int(th.multinomial((~m).float(), 1)) for m in clip_mask]
+    is_ = [int(th.multinomial((~m).float(), 1)) for m in sent_mask]
+    return np.array(ic), np.array(is_)
+
+
+def subsample(a, step=97):
+    return np.asarray(a, dtype=np.float32).reshape(-1)[::step].copy()
+
+
+def gen_single_net(name, cfg_o: O.NetConfig, N, L, seed, with_ctx):
+    """One TransformerLegacy: forward (pooled, per-token) + grads of sum(pooled * R)."""
+    tc = dict(name="transformer", output_dim=cfg_o.hidden_dim * (2 if with_ctx else 1), dropout_input=0,
+              norm_input="layernorm_coot", positional_encoding="sincos", add_local_cls_token=False,
+              use_input_fc=cfg_o.use_input_fc,
+              selfatn_config=dict(hidden_dim=cfg_o.hidden_dim, num_layers=cfg_o.num_layers, dropout=0.025,
+                                  num_heads=cfg_o.num_heads, pointwise_ff_dim=cfg_o.ff_dim, activation="gelu",
+                                  norm="layernorm_coot"),
+              use_output_fc=False, use_context=with_ctx,
+              pooler_config=(dict(name="atn", hidden_dim=cfg_o.pool_hidden, num_heads=cfg_o.pool_heads,
+                                  num_layers=1, dropout=0.025, activation="gelu") if cfg_o.pooler == "atn"
+                             else dict(name="avg_special")),
+              weight_init_type="truncnorm", weight_init_std=0.01)
+    if cfg_o.use_input_fc:
+        tc["input_fc_config"] = dict(output_dim=cfg_o.hidden_dim, num_layers=1, hidden_dim=0,
+                                     activation_middle="none", activation_output="gelu", dropout_middle=0,
+                                     dropout_output=0, norm_middle="none", norm_output="none", residual="none")
+    if with_ctx:
+        tc["crossatn_config"] = dict(hidden_dim=cfg_o.hidden_dim, num_layers=cfg_o.ctx_num_layers, dropout=0.025,
+                                     num_heads=cfg_o.num_heads, pointwise_ff_dim=cfg_o.ff_dim,
+                                     activation="gelu", norm="layernorm_coot")
+    net = models.TransformerLegacy(models.TransformerConfig(tc), cfg_o.input_dim)
+    P = O.make_params(cfg_o, seed)
+    load_params(net, P)
+    net.eval()
+    rs = np.random.RandomState(seed + 1)
+    lens = rs.randint(1, L + 1, size=N)
+    lens[0] = L
+    x = rs.randn(N, L, cfg_o.input_dim)
+    x[np.arange(L)[None, :] >= lens[:, None]] = 0
+    hid = rs.randn(N, cfg_o.hidden_dim) if with_ctx else None
+    R = rs.randn(N, cfg_o.hidden_dim * (2 if with_ctx else 1))
+    xt = th.from_numpy(x).float().requires_grad_(True)
+    ht = th.from_numpy(hid).float().requires_grad_(True) if with_ctx else None
+    mask = th.from_numpy(np.arange(L)[None, :] >= lens[:, None])
+    pooled, per_tok = net(xt, mask, th.from_numpy(lens), ht)
+    (pooled * th.from_numpy(R).float()).sum().backward()
+    out = dict(x=x.astype(np.float32), lens=lens, R=R.astype(np.float32), pooled=pooled.detach().numpy(),
+               per_token=per_tok.detach().numpy(), dx=xt.grad.numpy())
+    if with_ctx:
+        out["hidden"] = hid.astype(np.float32)
+        out["dhidden"] = ht.grad.numpy()
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            out["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items() if not k.startswith("grad:")})
+
+
+def gen_full(name, dims, B, counts, Ls, seed, full_grads):
+    """encode_visual + encode_text + total contrastive + cycle-consistency, fwd and bwd."""
+    dv, dt, hidden, heads, ff, pool_hidden = dims
+    Lv, Lc, Lp, Lsent = Ls
+    cfg = ref_config(*dims)
+    ocfgs = oracle_cfgs(*dims)
+    th.manual_seed(0)
+    mgr = model_retrieval.RetrievalModelManager(cfg)
+    for i, k in enumerate(NET_KEYS):
+        load_params(mgr.model_dict[k], O.make_params(ocfgs[i], seed + 10 * i))
+    mgr.set_all_models_eval()
+    b = O.make_batch(seed + 100, B, counts, Lv, Lc, Lp, Lsent, dv, dt, ragged=True, corr=0.5)
+    batch = to_batch(b)
+    vis = mgr.encode_visual(batch)
+    txt = mgr.encode_text(batch)
+    tr = _FakeTrainer(cfg)
+    contr = tr.compute_total_constrastive_loss(vis, txt)
+    ic, isent = draw_cc_indices(seed + 7, vis.clip_emb_mask, txt.sent_emb_mask)
+    th.manual_seed(seed + 7)
+    cc = tr.compute_cyclecons_loss(vis, txt)
+    loss = contr + cc
+    loss.backward()
+    # full per-position cycle losses (deterministic comparison target)
+    with th.no_grad():
+        ccl = tr.loss_cycle_cons
+        cm, sm = ~vis.clip_emb_mask, ~txt.sent_emb_mask
+        nn1, _, _ = ccl.get_soft_nn(vis.clip_emb_reshape, cm, txt.sent_emb_reshape, sm)
+        _, beta, _ = ccl.get_soft_nn(nn1, cm, vis.clip_emb_reshape, cm)
+        lrow_c, _, _ = ccl.compute_loss_index_gauss(cm, None, cm.shape[1], beta)
+        nn2, _, _ = ccl.get_soft_nn(txt.sent_emb_reshape, sm, vis.clip_emb_reshape, cm)
+        _, beta2, _ = ccl.get_soft_nn(nn2, sm, txt.sent_emb_reshape, sm)
+        lrow_s, _, _ = ccl.compute_loss_index_gauss(sm, None, sm.shape[1], beta2)
+    out = dict(vid_emb=vis.vid_emb, clip_emb=vis.clip_emb, vid_context=vis.vid_context,
+               clip_emb_reshape=vis.clip_emb_reshape, clip_emb_mask=vis.clip_emb_mask,
+               clip_emb_lens=vis.clip_emb_lens, par_emb=txt.par_emb, sent_emb=txt.sent_emb,
+               par_context=txt.par_context, sent_emb_reshape=txt.sent_emb_reshape,
+               sent_emb_mask=txt.sent_emb_mask, sent_emb_lens=txt.sent_emb_lens,
+               contr_loss=contr, cc_loss=cc, cc_rows_clip=lrow_c, cc_rows_sent=lrow_s)
+    out = {k: v.detach().numpy() for k, v in out.items()}
+    out["cc_idx_clip"], out["cc_idx_sent"] = ic, isent
+    out["meta"] = np.array([seed, B, Lv, Lc, Lp, Lsent, dv, dt, hidden, heads, ff, pool_hidden])
+    out["counts"] = np.asarray(counts)
+    for k in NET_KEYS:
+        for n, p in mgr.model_dict[k].named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.numpy()
+            if full_grads:
+                out[f"grad:{k}:{n}"] = g
+            else:
+                out[f"gnorm:{k}:{n}"] = np.array(np.linalg.norm(g.astype(np.float64)))
+                out[f"gsub:{k}:{n}"] = subsample(g)
+    # retrieval metrics on these embeddings (nntrainer/retrieval.py)
+    for (a, c, tag) in (("vid_emb", "par_emb", "vp"), ("clip_emb", "sent_emb", "cs")):
+        e1 = out[a] / np.sqrt((out[a] ** 2).sum(-1, keepdims=True))
+        e2 = out[c] / np.sqrt((out[c] ** 2).sum(-1, keepdims=True))
+        r1, r2, s1, _ = retrieval.compute_retrieval({"a": e1, "b": e2}, "a", "b", print_fn=lambda *_: None)
+        out[f"ret_{tag}"] = np.array([r1[k] for k in ("r1", "r5", "r10", "r50", "medr", "meanr")] +
+                                     [r2[k] for k in ("r1", "r5", "r10", "r50", "medr", "meanr")] + [s1])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "contr", float(contr), "cc", float(cc))
+
+
+def gen_retrieval_metrics():
+    rs = np.random.RandomState(5)
+    out = {}
+    for i, n in enumerate((7, 64, 301)):
+        d = rs.randn(n, n).astype(np.float32)
+        d[np.arange(n), np.arange(n)] += 1.5
+        if i == 1:  # force ties, incl. ties with the diagonal (argsort()[::-1] tie order matters)
+            d = np.round(d * 2) / 2
+        res, top1, ranks = retrieval.compute_retrieval_cosine(d)
+        out[f"d{i}"] = d
+        out[f"ranks{i}"] = ranks
+        out[f"res{i}"] = np.array([res[k] for k in ("r1", "r5", "r10", "r50", "medr", "meanr")])
+    np.savez_compressed(os.path.join(OUT, "retrieval_metrics.npz"), **out)
+    print("wrote retrieval_metrics")
+
+
+def gen_mask_semantics():
+    """Numeric version of tests_nntrainer/test_transformers.py:22-79: perturbing masked inputs
+    must not change un-masked outputs of the encoder; we store outputs before/after."""
+    cfg_o = O.NetConfig(input_dim=24, hidden_dim=32, num_heads=4, ff_dim=32, pool_hidden=64)
+    P = O.make_params(cfg_o, 3)
+    tc = dict(hidden_dim=32, num_layers=1, dropout=0.0, num_heads=4, pointwise_ff_dim=32, activation="gelu",
+              norm="layernorm_coot")
+    enc = models.transformer_legacy.TransformerEncoder(models.transformer_legacy.TransformerEncoderConfig(tc))
+    sd = enc.state_dict()
+    for k in sd:
+        sd[k] = th.from_numpy(P["tf." + k].astype(np.float32))
+    enc.load_state_dict(sd)
+    enc.eval()
+    rs = np.random.RandomState(9)
+    x = rs.randn(3, 6, 32).astype(np.float32)
+    lens = np.array([6, 4, 2])
+    mask = th.from_numpy(np.arange(6)[None, :] >= lens[:, None])
+    y0 = enc(th.from_numpy(x), mask).detach().numpy()
+    x2 = x.copy()
+    x2[np.arange(6)[None, :] >= lens[:, None]] += 3.0
+    y1 = enc(th.from_numpy(x2), mask).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "mask_semantics.npz"), x=x, x2=x2, lens=lens, y0=y0, y1=y1)
+    print("wrote mask_semantics")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    small = O.NetConfig(input_dim=40, hidden_dim=32, num_heads=4, ff_dim=32, pool_hidden=64)
+    gen_single_net("net_local_small", small, N=5, L=7, seed=11, with_ctx=False)
+    smallg = O.NetConfig(input_dim=32, hidden_dim=32, num_heads=4, ff_dim=32, pool_hidden=64,
+                         use_input_fc=False, use_context=True, pooler="avg_special")
+    gen_single_net("net_global_small", smallg, N=4, L=5, seed=13, with_ctx=True)
+    two = O.NetConfig(input_dim=40, hidden_dim=32, num_heads=4, ff_dim=48, pool_hidden=32, num_layers=2)
+    gen_single_net("net_local_2layer", two, N=3, L=6, seed=17, with_ctx=False)
+    # full path, small dims, full gradients
+    gen_full("full_small", (40, 24, 32, 4, 32, 64), B=4, counts=[2, 1, 3, 2], Ls=(9, 7, 8, 5), seed=21,
+             full_grads=True)
+    # full path, ActivityNet paper dims (d_model 384, 8 heads, Dv 2048, Dt 1536), sub-sampled grads
+    gen_full("full_anet", (2048, 1536, 384, 8, 384, 768), B=6, counts=[3, 1, 4, 2, 2, 5], Ls=(20, 16, 18, 9),
+             seed=31, full_grads=False)
+    gen_retrieval_metrics()
+    gen_mask_semantics()
+
+
+if __name__ == "__main__":
+    main()
