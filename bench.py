@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""
+bench.py — COOT retrieval TRAINING step throughput on MI355X (clip-pairs/sec, whole job).
+
+One step = encode_visual + encode_text + contrastive + cycle-consistency losses + backward (+ gradient
+all-reduce for N > 1) + Adam step on one synthetic ActivityNet-shaped batch per GPU (BASELINE.json configs[1]:
+B = 64 videos x 4 clips/GPU, Lc = Lv = 80 frames, Ls = 16 / Lp = 64 tokens, Dv = 2048, Dt = 1536, d_model 384;
+bf16 MFMA operands, fp32 accumulation/statistics/master weights; dropout ON as in training).  Inputs are
+resident in HBM before the timed region.  Weak scaling: per-GPU batch fixed, global batch = 64 N videos.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline": dominant kernel (bf16 MFMA GEMM gemm_nt_kernel) algorithmic FLOP/s from HIP events vs 2.5 PF dense,
+  "cpu_baseline": the numpy oracle ("port") timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="anet")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
+    return ap.parse_args()
+
+
+def algorithmic_flops_per_step(w, cfg):
+    """forward GEMM MACs x 2 of the four networks + losses; train = 3 x forward."""
+    D = 384
+
+    def f_loc(din, L):
+        return 2 * din * D + 18 * D * D + 4 * L * D
+
+    B, Cn = w["B"], w["C"]
+    Nc = B * Cn
+    fwd = (Nc * w["Lc"] * f_loc(w["Dv"], w["Lc"]) + B * w["Lv"] * f_loc(w["Dv"], w["Lv"]) +
+           Nc * w["Ls"] * f_loc(w["Dt"], w["Ls"]) + B * w["Lp"] * f_loc(w["Dt"], w["Lp"]))
+    glob = B * (Cn * (12 * D * D + 4 * Cn * D) + Cn * 4 * D * D + 8 * D * D + 4 * Cn * D)
+    fwd += 2 * glob
+    # 7 similarity GEMMs (3 align + 4 cluster), 2*N^2*d each (trainer_retrieval.py:168-182)
+    fwd += 2 * (3 * B * B * 768 + 3 * Nc * Nc * D + B * B * D)
+    return fwd, 3 * fwd
+
+
+def cpu_baseline(w, steps=2):
+    """The numpy oracle (fp32, BLAS threads = all host cores) on a bounded sample: B_s videos of the same
+    shape, forward + losses + backward (no optimizer), clip-pairs/s = clips / step time."""
+    from oracle import coot_oracle as O
+    from tests import helpers as H
+    Bs = 4
+    dims = (w["Dv"], w["Dt"], 384, 8, 384, 768)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 5 + 10 * i, dtype=np.float32) for i in range(4)]
+    b = O.make_batch(1, Bs, w["C"], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=False, dtype=np.float32)
+    idx = np.zeros(Bs, dtype=np.int64)
+    H.oracle_full(cfgs, Ps, b, idx, idx)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        H.oracle_full(cfgs, Ps, b, idx, idx)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": Bs * w["C"] / dt, "unit": "clip-pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"numpy oracle fp32, {Bs} videos x {w['C']} clips of the same shape, fwd+loss+bwd, {steps} steps, "
+                      f"{dt:.2f} s/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    import coot_videotext_amd as cva
+    from coot_videotext_amd import dist as cdist
+    lib = cva.lib.load()
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dp = cdist.DataParallelContext()
+    w = cva.synthetic.WORKLOADS[args.workload]
+    cfg = cva.load_named_config({"anet": "anet_coot", "yc2_100m": "yc2_100m_coot", "yc2_2d3d": "yc2_2d3d_coot"}[args.workload])
+    torch.manual_seed(0)  # identical initial weights on every rank
+    mgr = cva.RetrievalModelManager(cfg).cuda()
+    trainer = cva.RetrievalTrainer(cfg, mgr, is_test=args.eval)
+    if dp is not None:
+        trainer.dp = dp
+        trainer.comm_stream = torch.cuda.Stream()
+    batch = cva.synthetic.make_batch(1234 + rank, w["B"], w["C"], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=False)
+    vid_counts = [w["B"]] * world
+    clip_counts = [w["B"] * w["C"]] * world
+    clip_pairs = w["B"] * w["C"] * world
+
+    if args.eval:
+        mgr.set_all_models_eval()
+
+        def step():
+            with torch.no_grad():
+                v = mgr.encode_visual(batch)
+                t = mgr.encode_text(batch)
+            return v.vid_emb.sum() + t.par_emb.sum()
+    else:
+        mgr.set_all_models_train()
+
+        def step():
+            return trainer.train_step(batch, vid_counts, clip_counts)[0]
+
+    def barrier():
+        if dp is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dp is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(last)
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = clip_pairs * args.steps / elapsed
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # same steps again with HIP events around every gemm_nt launch (the dominant kernel: all Linear layers,
+        # forward and dX).  Kept out of the timed region so `value` carries no instrumentation overhead.
+        nst = max(2, min(5, args.steps))
+        lib.coot_timing_enable(1)
+        for _ in range(nst):
+            step()
+        torch.cuda.synchronize()
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+        cva.lib.check(lib.coot_timing_collect(0, C.byref(ms), C.byref(fl), C.byref(n)), "timing_collect")
+        ms2, fl2, n2 = C.c_double(), C.c_double(), C.c_int()
+        cva.lib.check(lib.coot_timing_collect(1, C.byref(ms2), C.byref(fl2), C.byref(n2)), "timing_collect")
+        lib.coot_timing_enable(0)
+        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        ach2 = fl2.value / (ms2.value * 1e-3) / 1e12 if ms2.value > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all Linear fwd + dX)",
+                    "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                    "traffic": None, "launches_per_step": n.value // nst,
+                    "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2),
+                    "gemm_ms_per_step": round(ms.value / nst, 3),
+                    "input_fc_instances": {"achieved": round(ach2, 2), "frac": round(ach2 / 2500.0, 4),
+                                           "launches_per_step": n2.value // nst,
+                                           "avg_launch_us": round(1e3 * ms2.value / max(n2.value, 1), 2)}}
+    if dp is not None:
+        torch.distributed.barrier()
+
+    if rank == 0:
+        fwd_flops, train_flops = algorithmic_flops_per_step(w, cfg)
+        out = {
+            "metric": "clip-pairs/sec (COOT retrieval " + ("eval forward" if args.eval else "train step") + ", whole job)",
+            "value": round(value, 1), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ActivityNet-shaped paper config (anet_coot): {w['B']} videos x {w['C']} clips per GPU, "
+                                   f"Lc=Lv={w['Lc']}, Ls={w['Ls']}, Lp={w['Lp']}, Dv={w['Dv']}, Dt={w['Dt']}, d_model=384",
+                       "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
+                       "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",
+                       "final_loss": round(loss_val, 5)},
+            "per_gpu": round(value / world, 1),
+            "algorithmic_tflops_per_s": round((fwd_flops if args.eval else train_flops) * world / (ms_per_step * 1e-3) / 1e12, 2),
+        }
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if dp is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

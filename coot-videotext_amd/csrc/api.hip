@@ -1,0 +1,637 @@
+// C-ABI of libcoot_hip.so and the native orchestration of the COOT retrieval hot path:
+// which kernel runs when, on which buffers.  See include/coot_hip.h for the contract.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/coot_hip.h"
+#include "attention.h"
+#include "common.h"
+#include "gemm.h"
+#include "loss.h"
+#include "pool.h"
+#include "rowops.h"
+
+namespace coot {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return -1;
+}
+
+// ---- bump allocator over caller-provided memory (or size planning when base == nullptr) -------
+struct Arena {
+  char* base; size_t cap; size_t off = 0; bool overflow = false;
+  Arena(void* b, size_t c) : base((char*)b), cap(c) {}
+  template <typename T> T* get(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    size_t bytes = n * sizeof(T);
+    char* p = base ? base + off : nullptr;
+    off += bytes;
+    if (base && off > cap) overflow = true;
+    return (T*)p;
+  }
+};
+
+// ---- parameter layout ---------------------------------------------------------------------------
+struct PEntry { std::string name; int64_t off; int64_t shape[4]; int ndim; };
+
+struct LayerP {  // offsets (floats) into the flat arena
+  int64_t wqkv, bq, bk, bv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+};
+struct NetLayout {
+  int64_t total = 0;
+  int64_t n_gain = -1, n_bias = -1, in_w = -1, in_b = -1;
+  std::vector<LayerP> layers, ctx;
+  int64_t pw1 = -1, pb1 = -1, pw2 = -1, pb2 = -1;
+  std::vector<PEntry> entries;
+};
+
+static int norm_cfg(const coot_net_config* c, coot_net_config* o) {
+  *o = *c;
+  if (o->ff_dim == 0) o->ff_dim = o->hidden_dim;
+  if (o->pool_hidden == 0) o->pool_hidden = o->hidden_dim;
+  if (o->ctx_num_layers <= 0) o->ctx_num_layers = 1;
+  COOT_REQUIRE(o->hidden_dim % o->num_heads == 0, "hidden_dim %d not divisible by %d heads", o->hidden_dim, o->num_heads);
+  const int dh = o->hidden_dim / o->num_heads;
+  COOT_REQUIRE(dh % 16 == 0 && dh <= 64, "d_head = %d unsupported (16, 32, 48 or 64)", dh);
+  COOT_REQUIRE(o->hidden_dim % 8 == 0 && o->ff_dim % 8 == 0 && o->input_dim % 8 == 0, "dims must be multiples of 8");
+  COOT_REQUIRE(o->use_input_fc || o->input_dim == o->hidden_dim, "without input_fc, input_dim must equal hidden_dim");
+  if (o->pooler == 0) {
+    COOT_REQUIRE(o->pool_heads > 0 && o->pool_hidden % o->pool_heads == 0 && o->hidden_dim % o->pool_heads == 0, "bad pooler heads");
+    COOT_REQUIRE((o->pool_hidden / o->pool_heads) % 8 == 0 && (o->hidden_dim / o->pool_heads) % 8 == 0, "pooler head dims must be multiples of 8");
+  }
+  COOT_REQUIRE(o->num_layers >= 1, "num_layers must be >= 1");
+  return 0;
+}
+
+static void build_layout(const coot_net_config& c, NetLayout& L) {
+  int64_t off = 0;
+  auto add = [&](const std::string& name, std::initializer_list<int64_t> shp) {
+    PEntry e; e.name = name; e.off = off; e.ndim = (int)shp.size();
+    int64_t n = 1; int i = 0;
+    for (auto s : shp) { e.shape[i++] = s; n *= s; }
+    for (; i < 4; ++i) e.shape[i] = 1;
+    L.entries.push_back(e);
+    int64_t o = off; off += n; return o;
+  };
+  const int64_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
+  L.n_gain = add("norm_input.gain", {Din});
+  L.n_bias = add("norm_input.bias", {Din});
+  if (c.use_input_fc) {
+    L.in_w = add("input_fc.mlp.0.weight", {D, Din});
+    L.in_b = add("input_fc.mlp.0.bias", {D});
+  }
+  auto layer = [&](const std::string& pre) {
+    LayerP p;
+    const std::string a = pre + "self_attention_layer.", f = pre + "pointwise_feedforward_layer.";
+    // q,k,v weights are contiguous ([3D, D]) and so are their biases ([3D]) for the fused QKV GEMM
+    p.wqkv = add(a + "sublayer.query_projection.weight", {D, D});
+    add(a + "sublayer.key_projection.weight", {D, D});
+    add(a + "sublayer.value_projection.weight", {D, D});
+    p.bq = add(a + "sublayer.query_projection.bias", {D});
+    p.bk = add(a + "sublayer.key_projection.bias", {D});
+    p.bv = add(a + "sublayer.value_projection.bias", {D});
+    p.wo = add(a + "sublayer.final_projection.weight", {D, D});
+    p.bo = add(a + "sublayer.final_projection.bias", {D});
+    p.ln1g = add(a + "layer_normalization.gain", {D});
+    p.ln1b = add(a + "layer_normalization.bias", {D});
+    p.w1 = add(f + "sublayer.feed_forward.0.weight", {F, D});
+    p.b1 = add(f + "sublayer.feed_forward.0.bias", {F});
+    p.w2 = add(f + "sublayer.feed_forward.3.weight", {D, F});
+    p.b2 = add(f + "sublayer.feed_forward.3.bias", {D});
+    p.ln2g = add(f + "layer_normalization.gain", {D});
+    p.ln2b = add(f + "layer_normalization.bias", {D});
+    return p;
+  };
+  for (int i = 0; i < c.num_layers; ++i) L.layers.push_back(layer("tf.encoder_layers." + std::to_string(i) + "."));
+  if (c.use_context)
+    for (int i = 0; i < c.ctx_num_layers; ++i) L.ctx.push_back(layer("tf_context.encoder_layers." + std::to_string(i) + "."));
+  if (c.pooler == 0) {
+    const int64_t H = c.pool_heads, dhp = c.pool_hidden / H, dop = D / H;
+    L.pw1 = add("pooler.pools.0.genpool_w1_head", {H, D, dhp});
+    L.pb1 = add("pooler.pools.0.genpool_b1_head", {H, dhp});
+    L.pw2 = add("pooler.pools.0.genpool_w2_head", {H, dhp, dop});
+    L.pb2 = add("pooler.pools.0.genpool_b2_head", {H, dop});
+  }
+  L.total = off;
+}
+
+// ---- bf16 weight pack layout ----------------------------------------------------------------------
+struct LayerW { bf16_t *wqkv_nk, *wqkv_kn, *wo_nk, *wo_kn, *w1_nk, *w1_kn, *w2_nk, *w2_kn; };
+struct WPack {
+  bf16_t* in_w = nullptr;     // [D, Din]  = W * gain (LN affine folded)
+  float* in_bias = nullptr;   // [D]       = b + W . norm_bias
+  std::vector<LayerW> layers, ctx;
+  bf16_t *pw1_nk = nullptr, *pw1_kn = nullptr, *pw2_nk = nullptr, *pw2_kn = nullptr;
+};
+static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
+  const size_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
+  if (c.use_input_fc) { W.in_w = A.get<bf16_t>(D * Din); W.in_bias = A.get<float>(D); }
+  auto lay = [&]() {
+    LayerW w;
+    w.wqkv_nk = A.get<bf16_t>(3 * D * D); w.wqkv_kn = A.get<bf16_t>(3 * D * D);
+    w.wo_nk = A.get<bf16_t>(D * D); w.wo_kn = A.get<bf16_t>(D * D);
+    w.w1_nk = A.get<bf16_t>(F * D); w.w1_kn = A.get<bf16_t>(F * D);
+    w.w2_nk = A.get<bf16_t>(F * D); w.w2_kn = A.get<bf16_t>(F * D);
+    return w;
+  };
+  for (int i = 0; i < c.num_layers; ++i) W.layers.push_back(lay());
+  if (c.use_context) for (int i = 0; i < c.ctx_num_layers; ++i) W.ctx.push_back(lay());
+  if (c.pooler == 0) {
+    const size_t PH = c.pool_hidden;
+    W.pw1_nk = A.get<bf16_t>(PH * D); W.pw1_kn = A.get<bf16_t>(PH * D);
+    W.pw2_nk = A.get<bf16_t>(PH * (D / c.pool_heads)); W.pw2_kn = A.get<bf16_t>(PH * (D / c.pool_heads));
+  }
+}
+
+// ---- saved-for-backward + scratch layouts ----------------------------------------------------------
+struct LayerS {
+  bf16_t *qkv, *ctx, *r1, *z1, *h1, *a1, *r2, *z2; float* lse;
+};
+struct CtxS {
+  bf16_t *q, *kv, *cctx, *r1, *z1, *h1, *a1, *r2, *z2; float* lse;
+};
+struct Saved {
+  bf16_t *xhat = nullptr, *h0 = nullptr, *z0 = nullptr;
+  std::vector<LayerS> layers; std::vector<CtxS> ctx;
+  bf16_t* cq_in = nullptr;
+  bf16_t *hp = nullptr, *ap = nullptr, *s = nullptr; float *smax = nullptr, *ssum = nullptr, *pooled = nullptr;
+};
+static void layout_saved(const coot_net_config& c, int N, int Lseq, Arena& A, Saved& S) {
+  const size_t T = (size_t)N * Lseq, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
+  if (c.use_input_fc) { S.xhat = A.get<bf16_t>(T * c.input_dim); S.h0 = A.get<bf16_t>(T * D); }
+  S.z0 = A.get<bf16_t>(T * D);
+  for (int i = 0; i < c.num_layers; ++i) {
+    LayerS l;
+    l.qkv = A.get<bf16_t>(T * 3 * D); l.lse = A.get<float>(T * H); l.ctx = A.get<bf16_t>(T * D);
+    l.r1 = A.get<bf16_t>(T * D); l.z1 = A.get<bf16_t>(T * D); l.h1 = A.get<bf16_t>(T * F); l.a1 = A.get<bf16_t>(T * F);
+    l.r2 = A.get<bf16_t>(T * D); l.z2 = A.get<bf16_t>(T * D);
+    S.layers.push_back(l);
+  }
+  if (c.use_context) {
+    S.cq_in = A.get<bf16_t>((size_t)N * D);
+    for (int i = 0; i < c.ctx_num_layers; ++i) {
+      CtxS l;
+      l.q = A.get<bf16_t>((size_t)N * D); l.kv = A.get<bf16_t>(T * 2 * D); l.lse = A.get<float>((size_t)N * H);
+      l.cctx = A.get<bf16_t>((size_t)N * D); l.r1 = A.get<bf16_t>((size_t)N * D); l.z1 = A.get<bf16_t>((size_t)N * D);
+      l.h1 = A.get<bf16_t>((size_t)N * F); l.a1 = A.get<bf16_t>((size_t)N * F); l.r2 = A.get<bf16_t>((size_t)N * D);
+      l.z2 = A.get<bf16_t>((size_t)N * D);
+      S.ctx.push_back(l);
+    }
+  }
+  if (c.pooler == 0) {
+    const size_t PH = c.pool_hidden;
+    S.hp = A.get<bf16_t>(T * PH); S.ap = A.get<bf16_t>(T * PH); S.s = A.get<bf16_t>(T * D);
+    S.smax = A.get<float>((size_t)N * D); S.ssum = A.get<float>((size_t)N * D); S.pooled = A.get<float>((size_t)N * D);
+  }
+}
+
+struct Scratch {  // backward temporaries
+  bf16_t *dzA, *dzB, *dr2, *dr2m, *dh1, *dz1, *dr1, *dctx, *dqkv, *ds, *dhp, *dzp;
+  float *delta, *Mbuf, *cvec;
+  bf16_t *c_dq, *c_dkv, *c_d1, *c_d2, *c_dh1, *c_dz1, *c_dr1, *c_dctx, *c_dqin; float* c_delta;
+};
+static void layout_scratch(const coot_net_config& c, int N, int Lseq, Arena& A, Scratch& S) {
+  const size_t T = (size_t)N * Lseq, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
+  S.dzA = A.get<bf16_t>(T * D); S.dzB = A.get<bf16_t>(T * D); S.dr2 = A.get<bf16_t>(T * D); S.dr2m = A.get<bf16_t>(T * D);
+  S.dh1 = A.get<bf16_t>(T * F); S.dz1 = A.get<bf16_t>(T * D); S.dr1 = A.get<bf16_t>(T * D); S.dctx = A.get<bf16_t>(T * D);
+  S.dqkv = A.get<bf16_t>(T * 3 * D); S.delta = A.get<float>(T * H);
+  S.ds = nullptr; S.dhp = nullptr; S.dzp = nullptr; S.Mbuf = nullptr; S.cvec = nullptr;
+  if (c.pooler == 0) { S.ds = A.get<bf16_t>(T * D); S.dhp = A.get<bf16_t>(T * c.pool_hidden); S.dzp = A.get<bf16_t>(T * D); }
+  if (c.use_input_fc) { S.Mbuf = A.get<float>(D * c.input_dim); S.cvec = A.get<float>(D); }
+  if (c.use_context) {
+    const size_t n = N;
+    S.c_dq = A.get<bf16_t>(n * D); S.c_dkv = A.get<bf16_t>(T * 2 * D); S.c_d1 = A.get<bf16_t>(n * D); S.c_d2 = A.get<bf16_t>(n * D);
+    S.c_dh1 = A.get<bf16_t>(n * F); S.c_dz1 = A.get<bf16_t>(n * D); S.c_dr1 = A.get<bf16_t>(n * D); S.c_dctx = A.get<bf16_t>(n * D);
+    S.c_dqin = A.get<bf16_t>(n * D); S.c_delta = A.get<float>(n * H);
+  }
+}
+
+static DropCfg mkdrop(int train, float p, uint64_t seed, unsigned site) {
+  DropCfg d;
+  if (train && p > 0.f) {
+    double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (d.thr == 0) d.thr = 1;
+    d.inv_keep = 1.0f / (1.0f - p);
+    d.seed = seed; d.site = site;
+  }
+  return d;
+}
+static void epi_drop(GemmEpi& e, const DropCfg& d, long ld) {
+  e.drop_thr = d.thr; e.drop_inv_keep = d.inv_keep; e.drop_seed = d.seed; e.drop_site = d.site; e.drop_ld = ld;
+}
+enum { SITE_ATTN = 1, SITE_POSTLN = 2, SITE_FF1 = 3, SITE_FF2 = 4, SITE_POOL1 = 5, SITE_POOL2 = 6, SITE_POOL3 = 7 };
+
+#define RUN(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+// One TransformerEncoderLayer forward on `rows` query rows (nntrainer/models/transformer_legacy.py:420-438).
+// Self-attention: xkv == xq, Lq == Lk.  Cross-attention (context block): xq = [N, D] (Lq = 1), xkv = tokens.
+struct LayerBufs {
+  bf16_t *q; long ldq; bf16_t *k; long ldk; bf16_t* v; long ldv;   // projected q/k/v (views of qkv or q + kv)
+  bf16_t *ctx, *r1, *z1, *h1, *a1, *r2, *z2; float* lse;
+};
+
+static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp, const LayerW& lw, const bf16_t* xq, int rows_q,
+                     int Lq, const bf16_t* xkv, int rows_kv, int Lk, int Nseq, const long long* lens, const LayerBufs& b,
+                     float* z2_f32, long ldz2_f32, float pdrop, int train, uint64_t seed, unsigned site_base, hipStream_t st) {
+  const int D = c.hidden_dim, F = c.ff_dim, H = c.num_heads, dh = D / H;
+  const bool self = (xq == xkv);
+  if (self) {
+    GemmNT g; g.X = xq; g.ldx = D; g.W = lw.wqkv_nk; g.ldw = D; g.M = rows_q; g.N = 3 * D; g.K = D;
+    g.epi.bias = P + lp.bq; g.epi.out = b.q; g.epi.ldc = 3 * D;
+    RUN(launch_gemm_nt(g, st));
+  } else {
+    GemmNT g; g.X = xq; g.ldx = D; g.W = lw.wqkv_nk; g.ldw = D; g.M = rows_q; g.N = D; g.K = D;
+    g.epi.bias = P + lp.bq; g.epi.out = b.q; g.epi.ldc = b.ldq;
+    RUN(launch_gemm_nt(g, st));
+    GemmNT g2; g2.X = xkv; g2.ldx = D; g2.W = lw.wqkv_nk + (size_t)D * D; g2.ldw = D; g2.M = rows_kv; g2.N = 2 * D; g2.K = D;
+    g2.epi.bias = P + lp.bk; g2.epi.out = b.k; g2.epi.ldc = b.ldk;
+    RUN(launch_gemm_nt(g2, st));
+  }
+  AttnArgs a; a.q = b.q; a.ldq = b.ldq; a.k = b.k; a.ldk = b.ldk; a.v = b.v; a.ldv = b.ldv; a.o = b.ctx; a.ldo = D; a.lse = b.lse;
+  a.lens = lens; a.Nseq = Nseq; a.Lq = Lq; a.Lk = Lk; a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+  a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
+  RUN(launch_attn_fwd(a, st));
+  {
+    GemmNT g; g.X = b.ctx; g.ldx = D; g.W = lw.wo_nk; g.ldw = D; g.M = rows_q; g.N = D; g.K = D;
+    g.epi.bias = P + lp.bo; g.epi.res = xq; g.epi.ldres = D; g.epi.out = b.r1; g.epi.ldc = D;
+    RUN(launch_gemm_nt(g, st));
+  }
+  {
+    LnFwd l; l.x = b.r1; l.x_f32 = 0; l.ldx = D; l.R = rows_q; l.D = D; l.gain = P + lp.ln1g; l.bias = P + lp.ln1b; l.y = b.z1; l.ldy = D;
+    l.drop = mkdrop(train, pdrop, seed, site_base + SITE_POSTLN);
+    RUN(launch_ln_fwd(l, st));
+  }
+  {
+    GemmNT g; g.X = b.z1; g.ldx = D; g.W = lw.w1_nk; g.ldw = D; g.M = rows_q; g.N = F; g.K = D;
+    g.epi.bias = P + lp.b1; g.epi.act = 1; g.epi.save_pre = b.h1; g.epi.ldpre = F; g.epi.out = b.a1; g.epi.ldc = F;
+    epi_drop(g.epi, mkdrop(train, pdrop, seed, site_base + SITE_FF1), F);
+    RUN(launch_gemm_nt(g, st));
+  }
+  {
+    GemmNT g; g.X = b.a1; g.ldx = F; g.W = lw.w2_nk; g.ldw = F; g.M = rows_q; g.N = D; g.K = F;
+    g.epi.bias = P + lp.b2; g.epi.res = b.z1; g.epi.ldres = D; g.epi.out = b.r2; g.epi.ldc = D;
+    epi_drop(g.epi, mkdrop(train, pdrop, seed, site_base + SITE_FF2), D);
+    RUN(launch_gemm_nt(g, st));
+  }
+  {
+    LnFwd l; l.x = b.r2; l.x_f32 = 0; l.ldx = D; l.R = rows_q; l.D = D; l.gain = P + lp.ln2g; l.bias = P + lp.ln2b; l.y = b.z2; l.ldy = D;
+    l.y32 = z2_f32; l.ldy32 = ldz2_f32;
+    RUN(launch_ln_fwd(l, st));
+  }
+  return 0;
+}
+
+// Backward of layer_fwd.  dz2: grad wrt the layer output (bf16 [rows_q, D]) or fp32 (dz2_f32).
+// Outputs: dxq (bf16 [rows_q, D], or fp32 dxq_f32), and for cross-attention dxkv_accum (bf16 [rows_kv, D], in-place +=).
+struct LayerBwdBufs { bf16_t *dr2, *dr2m, *dh1, *dz1, *dr1, *dctx, *dq; long lddq; bf16_t* dk; long lddk; bf16_t* dv; long lddv; float* delta; };
+
+static int layer_bwd(const coot_net_config& c, const float* P, float* G, const LayerP& lp, const LayerW& lw, const bf16_t* xq,
+                     int rows_q, int Lq, const bf16_t* xkv, int rows_kv, int Lk, int Nseq, const long long* lens,
+                     const LayerBufs& b, const LayerBwdBufs& w, const bf16_t* dz2, const float* dz2_f32, long lddz2_f32,
+                     bf16_t* dxq, float* dxq_f32, bf16_t* dxkv_accum, const bf16_t* gelu_aux, float* gelu_colsum, float pdrop,
+                     int train, uint64_t seed, unsigned site_base, hipStream_t st) {
+  const int D = c.hidden_dim, F = c.ff_dim, H = c.num_heads, dh = D / H;
+  const bool self = (xq == xkv);
+  const DropCfg d_ff2 = mkdrop(train, pdrop, seed, site_base + SITE_FF2);
+  {
+    LnBwd l; l.dy = dz2; l.lddy = D; l.dy32 = dz2_f32; l.lddy32 = lddz2_f32; l.x = b.r2; l.x_f32 = 0; l.ldx = D; l.gain = P + lp.ln2g;
+    l.R = rows_q; l.D = D; l.dx = w.dr2; l.lddx = D; l.dgain = G + lp.ln2g; l.dbias = G + lp.ln2b; l.dxcolsum = G + lp.b2;
+    if (d_ff2.thr) { l.dxm = w.dr2m; l.lddxm = D; l.dxm_drop = d_ff2; l.dxm_drop_ld = D; }
+    RUN(launch_ln_bwd(l, st));
+  }
+  const bf16_t* df2 = d_ff2.thr ? w.dr2m : w.dr2;
+  {  // dh1 = (df2 . W2) * gelu'(h1) * drop1 ; db1 = colsum(dh1)
+    GemmNT g; g.X = df2; g.ldx = D; g.W = lw.w2_kn; g.ldw = D; g.M = rows_q; g.N = F; g.K = D;
+    g.epi.act = 2; g.epi.aux = b.h1; g.epi.ldaux = F; g.epi.colsum = G + lp.b1; g.epi.out = w.dh1; g.epi.ldc = F;
+    epi_drop(g.epi, mkdrop(train, pdrop, seed, site_base + SITE_FF1), F);
+    RUN(launch_gemm_nt(g, st));
+  }
+  { GemmTN t; t.A = df2; t.lda = D; t.B = b.a1; t.ldb = F; t.T = rows_q; t.Mo = D; t.No = F; t.C = G + lp.w2; t.ldc = F; RUN(launch_gemm_tn(t, st)); }
+  {  // dz1 = dh1 . W1 + dr2
+    GemmNT g; g.X = w.dh1; g.ldx = F; g.W = lw.w1_kn; g.ldw = F; g.M = rows_q; g.N = D; g.K = F;
+    g.epi.res = w.dr2; g.epi.ldres = D; g.epi.out = w.dz1; g.epi.ldc = D;
+    RUN(launch_gemm_nt(g, st));
+  }
+  { GemmTN t; t.A = w.dh1; t.lda = F; t.B = b.z1; t.ldb = D; t.T = rows_q; t.Mo = F; t.No = D; t.C = G + lp.w1; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
+  {
+    LnBwd l; l.dy = w.dz1; l.lddy = D; l.x = b.r1; l.x_f32 = 0; l.ldx = D; l.gain = P + lp.ln1g; l.R = rows_q; l.D = D;
+    l.dx = w.dr1; l.lddx = D; l.dgain = G + lp.ln1g; l.dbias = G + lp.ln1b; l.dxcolsum = G + lp.bo;
+    l.drop = mkdrop(train, pdrop, seed, site_base + SITE_POSTLN);
+    RUN(launch_ln_bwd(l, st));
+  }
+  {
+    GemmNT g; g.X = w.dr1; g.ldx = D; g.W = lw.wo_kn; g.ldw = D; g.M = rows_q; g.N = D; g.K = D; g.epi.out = w.dctx; g.epi.ldc = D;
+    RUN(launch_gemm_nt(g, st));
+  }
+  { GemmTN t; t.A = w.dr1; t.lda = D; t.B = b.ctx; t.ldb = D; t.T = rows_q; t.Mo = D; t.No = D; t.C = G + lp.wo; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
+  AttnArgs a; a.q = b.q; a.ldq = b.ldq; a.k = b.k; a.ldk = b.ldk; a.v = b.v; a.ldv = b.ldv; a.o = b.ctx; a.ldo = D; a.lse = b.lse;
+  a.lens = lens; a.Nseq = Nseq; a.Lq = Lq; a.Lk = Lk; a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+  a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
+  a.dout = w.dctx; a.lddo = D; a.delta = w.delta; a.dq = w.dq; a.lddq = w.lddq; a.dk = w.dk; a.lddk = w.lddk; a.dv = w.dv; a.lddv = w.lddv;
+  RUN(launch_attn_bwd(a, st));
+  if (self) {
+    RUN(launch_colsum_bf16(w.dq, 3 * D, rows_q, 3 * D, G + lp.bq, st));
+    { GemmTN t; t.A = w.dq; t.lda = 3 * D; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = 3 * D; t.No = D; t.C = G + lp.wqkv; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
+    GemmNT g; g.X = w.dq; g.ldx = 3 * D; g.W = lw.wqkv_kn; g.ldw = 3 * D; g.M = rows_q; g.N = D; g.K = 3 * D;
+    g.epi.res = w.dr1; g.epi.ldres = D;
+    if (gelu_aux) { g.epi.act = 2; g.epi.aux = gelu_aux; g.epi.ldaux = D; g.epi.colsum = gelu_colsum; }
+    if (dxq_f32) { g.epi.out = dxq_f32; g.epi.out_f32 = 1; } else g.epi.out = dxq;
+    g.epi.ldc = D;
+    RUN(launch_gemm_nt(g, st));
+  } else {
+    RUN(launch_colsum_bf16(w.dq, w.lddq, rows_q, D, G + lp.bq, st));
+    RUN(launch_colsum_bf16(w.dk, w.lddk, rows_kv, 2 * D, G + lp.bk, st));
+    { GemmTN t; t.A = w.dq; t.lda = w.lddq; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = D; t.No = D; t.C = G + lp.wqkv; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
+    { GemmTN t; t.A = w.dk; t.lda = w.lddk; t.B = xkv; t.ldb = D; t.T = rows_kv; t.Mo = 2 * D; t.No = D; t.C = G + lp.wqkv + (size_t)D * D; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
+    {  // dxq = dq . Wq + dr1
+      GemmNT g; g.X = w.dq; g.ldx = w.lddq; g.W = lw.wqkv_kn; g.ldw = 3 * D; g.M = rows_q; g.N = D; g.K = D;
+      g.epi.res = w.dr1; g.epi.ldres = D;
+      if (dxq_f32) { g.epi.out = dxq_f32; g.epi.out_f32 = 1; } else g.epi.out = dxq;
+      g.epi.ldc = D;
+      RUN(launch_gemm_nt(g, st));
+    }
+    {  // dxkv += dkv . Wkv
+      GemmNT g; g.X = w.dk; g.ldx = w.lddk; g.W = lw.wqkv_kn + D; g.ldw = 3 * D; g.M = rows_kv; g.N = D; g.K = 2 * D;
+      g.epi.res = dxkv_accum; g.epi.ldres = D; g.epi.out = dxkv_accum; g.epi.ldc = D;
+      RUN(launch_gemm_nt(g, st));
+    }
+  }
+  return 0;
+}
+
+static LayerBufs self_bufs(const LayerS& s, int D) {
+  LayerBufs b; b.q = s.qkv; b.ldq = 3 * D; b.k = s.qkv + D; b.ldk = 3 * D; b.v = s.qkv + 2 * D; b.ldv = 3 * D;
+  b.ctx = s.ctx; b.r1 = s.r1; b.z1 = s.z1; b.h1 = s.h1; b.a1 = s.a1; b.r2 = s.r2; b.z2 = s.z2; b.lse = s.lse;
+  return b;
+}
+static LayerBufs ctx_bufs(const CtxS& s, int D) {
+  LayerBufs b; b.q = s.q; b.ldq = D; b.k = s.kv; b.ldk = 2 * D; b.v = s.kv + D; b.ldv = 2 * D;
+  b.ctx = s.cctx; b.r1 = s.r1; b.z1 = s.z1; b.h1 = s.h1; b.a1 = s.a1; b.r2 = s.r2; b.z2 = s.z2; b.lse = s.lse;
+  return b;
+}
+
+}  // namespace coot
+
+using namespace coot;
+
+extern "C" {
+
+const char* coot_last_error(void) { return coot::g_err; }
+int coot_version(void) { return 1; }
+int coot_set_option(const char* name, int value) {
+  if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
+  set_error("unknown option %s", name);
+  return -2;
+}
+
+int64_t coot_net_param_numel(const coot_net_config* cfg) {
+  coot_net_config c; if (norm_cfg(cfg, &c)) return -1;
+  NetLayout L; build_layout(c, L); return L.total;
+}
+int coot_net_param_count(const coot_net_config* cfg) {
+  coot_net_config c; if (norm_cfg(cfg, &c)) return -1;
+  NetLayout L; build_layout(c, L); return (int)L.entries.size();
+}
+int coot_net_param_info(const coot_net_config* cfg, int index, char* name, int name_len, int64_t* offset, int64_t shape[4], int* ndim) {
+  coot_net_config c; RUN(norm_cfg(cfg, &c));
+  NetLayout L; build_layout(c, L);
+  COOT_REQUIRE(index >= 0 && index < (int)L.entries.size(), "param index %d out of range", index);
+  const PEntry& e = L.entries[index];
+  snprintf(name, name_len, "%s", e.name.c_str());
+  *offset = e.off; *ndim = e.ndim;
+  for (int i = 0; i < 4; ++i) shape[i] = e.shape[i];
+  return 0;
+}
+int coot_net_out_dim(const coot_net_config* cfg) { return cfg->hidden_dim * (cfg->use_context ? 2 : 1); }
+
+size_t coot_net_wpack_bytes(const coot_net_config* cfg) {
+  coot_net_config c; if (norm_cfg(cfg, &c)) return 0;
+  Arena A(nullptr, 0); WPack W; layout_wpack(c, A, W); return A.off + 256;
+}
+
+int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpack, coot_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  coot_net_config c; RUN(norm_cfg(cfg, &c));
+  NetLayout L; build_layout(c, L);
+  Arena A(wpack, (size_t)-1); WPack W; layout_wpack(c, A, W);
+  const int D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
+  if (c.use_input_fc) {
+    RUN(launch_cast_weight(P + L.in_w, Din, D, Din, W.in_w, Din, 0, P + L.n_gain, st));
+    RUN(launch_matvec_bias(P + L.in_w, Din, D, Din, P + L.n_bias, P + L.in_b, W.in_bias, st));
+  }
+  auto pack_layer = [&](const LayerP& lp, const LayerW& lw) -> int {
+    RUN(launch_cast_weight(P + lp.wqkv, D, 3 * D, D, lw.wqkv_nk, D, 0, nullptr, st));
+    RUN(launch_cast_weight(P + lp.wqkv, D, 3 * D, D, lw.wqkv_kn, 3 * D, 1, nullptr, st));
+    RUN(launch_cast_weight(P + lp.wo, D, D, D, lw.wo_nk, D, 0, nullptr, st));
+    RUN(launch_cast_weight(P + lp.wo, D, D, D, lw.wo_kn, D, 1, nullptr, st));
+    RUN(launch_cast_weight(P + lp.w1, D, F, D, lw.w1_nk, D, 0, nullptr, st));
+    RUN(launch_cast_weight(P + lp.w1, D, F, D, lw.w1_kn, F, 1, nullptr, st));
+    RUN(launch_cast_weight(P + lp.w2, F, D, F, lw.w2_nk, F, 0, nullptr, st));
+    RUN(launch_cast_weight(P + lp.w2, F, D, F, lw.w2_kn, D, 1, nullptr, st));
+    return 0;
+  };
+  for (int i = 0; i < c.num_layers; ++i) RUN(pack_layer(L.layers[i], W.layers[i]));
+  for (size_t i = 0; i < L.ctx.size(); ++i) RUN(pack_layer(L.ctx[i], W.ctx[i]));
+  if (c.pooler == 0) {
+    const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
+    for (int h = 0; h < H; ++h) {
+      // W1[h]: [D, dhp].  nk: rows (h*dhp + e) = W1[h][:, e]  -> [PH, D].  kn: [D, PH] with row d = concat_h W1[h][d][:]
+      RUN(launch_cast_weight(P + L.pw1 + (size_t)h * D * dhp, dhp, D, dhp, W.pw1_nk + (size_t)h * dhp * D, D, 1, nullptr, st));
+      RUN(launch_cast_weight(P + L.pw1 + (size_t)h * D * dhp, dhp, D, dhp, W.pw1_kn + (size_t)h * dhp, PH, 0, nullptr, st));
+      // W2[h]: [dhp, dop].  nk (fwd): [dop, dhp] per head.  kn (dX): natural [dhp, dop] per head
+      RUN(launch_cast_weight(P + L.pw2 + (size_t)h * dhp * dop, dop, dhp, dop, W.pw2_nk + (size_t)h * dop * dhp, dhp, 1, nullptr, st));
+      RUN(launch_cast_weight(P + L.pw2 + (size_t)h * dhp * dop, dop, dhp, dop, W.pw2_kn + (size_t)h * dhp * dop, dop, 0, nullptr, st));
+    }
+  }
+  return 0;
+}
+
+size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int Lseq) {
+  coot_net_config c; if (norm_cfg(cfg, &c)) return 0;
+  Arena A(nullptr, 0); Saved S; layout_saved(c, N, Lseq, A, S); return A.off + 256;
+}
+size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int Lseq) {
+  coot_net_config c; if (norm_cfg(cfg, &c)) return 0;
+  Arena A(nullptr, 0); Scratch S; layout_scratch(c, N, Lseq, A, S); return A.off + 256;
+}
+
+int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, const float* pe, const float* feats,
+                 const int64_t* lengths, int N, int Lseq, const float* hidden, float* pooled, float* per_token, void* saved,
+                 size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed, coot_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  coot_net_config c; RUN(norm_cfg(cfg, &c));
+  COOT_REQUIRE(P && wpack && pe && feats && lengths && pooled && saved, "net_fwd: null pointer");
+  COOT_REQUIRE(!c.use_context || hidden, "net_fwd: context network needs hidden state (transformer_legacy.py:252)");
+  COOT_REQUIRE(Lseq <= 1000, "net_fwd: sequence length %d exceeds positional table (max_len 1000)", Lseq);
+  if (N <= 0) return 0;
+  NetLayout L; build_layout(c, L);
+  Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
+  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, N, Lseq, AS, S);
+  COOT_REQUIRE(!AS.overflow, "net_fwd: saved buffer too small (%zu < %zu)", saved_bytes, AS.off);
+  const int D = c.hidden_dim, T = N * Lseq, Din = c.input_dim;
+  const long long* lens = (const long long*)lengths;
+  const int out_dim = D * (c.use_context ? 2 : 1);
+
+  if (c.use_input_fc) {
+    LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T; l.D = Din; l.y = S.xhat; l.ldy = Din;
+    RUN(launch_ln_fwd(l, st));
+    GemmNT g; g.X = S.xhat; g.ldx = Din; g.W = W.in_w; g.ldw = Din; g.M = T; g.N = D; g.K = Din;
+    g.epi.bias = W.in_bias; g.epi.act = 1; g.epi.save_pre = S.h0; g.epi.ldpre = D; g.epi.pe = pe; g.epi.pe_L = Lseq;
+    g.epi.out = S.z0; g.epi.ldc = D;
+    RUN(launch_gemm_nt(g, st));
+  } else {
+    LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T; l.D = Din; l.gain = P + L.n_gain; l.bias = P + L.n_bias;
+    l.pe = pe; l.pe_L = Lseq; l.y = S.z0; l.ldy = D;
+    RUN(launch_ln_fwd(l, st));
+  }
+  const bf16_t* z = S.z0;
+  for (int i = 0; i < c.num_layers; ++i) {
+    LayerBufs b = self_bufs(S.layers[i], D);
+    const bool last = (i == c.num_layers - 1);
+    RUN(layer_fwd(c, P, L.layers[i], W.layers[i], z, T, Lseq, z, T, Lseq, N, lens, b, last ? per_token : nullptr, D, c.dropout,
+                  train, seed, 16u * i, st));
+    z = S.layers[i].z2;
+  }
+  if (c.use_context) {
+    RUN(launch_cast_f32_bf16(hidden, D, N, D, S.cq_in, D, st));
+    const bf16_t* cq = S.cq_in;
+    for (int i = 0; i < c.ctx_num_layers; ++i) {
+      LayerBufs b = ctx_bufs(S.ctx[i], D);
+      const bool last = (i == c.ctx_num_layers - 1);
+      RUN(layer_fwd(c, P, L.ctx[i], W.ctx[i], cq, N, 1, z, T, Lseq, N, lens, b, last ? pooled + D : nullptr, out_dim, c.ctx_dropout,
+                    train, seed, 16u * (8 + i), st));
+      cq = S.ctx[i].z2;
+    }
+  }
+  if (c.pooler == 0) {
+    const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
+    {
+      GemmNT g; g.X = z; g.ldx = D; g.W = W.pw1_nk; g.ldw = D; g.M = T; g.N = PH; g.K = D;
+      g.epi.bias = P + L.pb1; g.epi.act = 1; g.epi.save_pre = S.hp; g.epi.ldpre = PH; g.epi.out = S.ap; g.epi.ldc = PH;
+      epi_drop(g.epi, mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL1), PH);
+      RUN(launch_gemm_nt(g, st));
+    }
+    {
+      GemmNT g; g.X = S.ap; g.ldx = PH; g.W = W.pw2_nk; g.ldw = dhp; g.M = T; g.N = dop; g.K = dhp;
+      g.groups = H; g.zX = dhp; g.zW = (long)dop * dhp; g.zOut = dop;
+      g.epi.bias = P + L.pb2; g.epi.out = S.s; g.epi.ldc = D;
+      epi_drop(g.epi, mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2), D);
+      RUN(launch_gemm_nt(g, st));
+    }
+    PoolArgs p; p.s = S.s; p.lds = D; p.z = z; p.ldz = D; p.lens = lens; p.N = N; p.L = Lseq; p.D = D; p.pooled = pooled; p.ldp = out_dim;
+    p.pooled_copy = S.pooled; p.smax = S.smax; p.ssum = S.ssum; p.drop_w = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL3);
+    RUN(launch_pool_fwd(p, st));
+  } else {
+    RUN(launch_avgpool_fwd(z, D, lens, N, Lseq, D, pooled, out_dim, st));
+  }
+  (void)scratch; (void)scratch_bytes;
+  return 0;
+}
+
+int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, const float* pe, const float* feats,
+                 const int64_t* lengths, int N, int Lseq, const float* hidden, const float* dpooled, float* G, float* dhidden,
+                 float* dfeats, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed,
+                 coot_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  coot_net_config c; RUN(norm_cfg(cfg, &c));
+  COOT_REQUIRE(P && wpack && feats && lengths && dpooled && G && saved && scratch, "net_bwd: null pointer");
+  COOT_REQUIRE(!(dfeats && c.use_input_fc), "net_bwd: dfeats is only available for networks without input_fc");
+  if (N <= 0) return 0;
+  NetLayout L; build_layout(c, L);
+  Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
+  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, N, Lseq, AS, S);
+  COOT_REQUIRE(!AS.overflow, "net_bwd: saved buffer too small");
+  Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, N, Lseq, AX, X);
+  COOT_REQUIRE(!AX.overflow, "net_bwd: scratch buffer too small (%zu < %zu)", scratch_bytes, AX.off);
+  const int D = c.hidden_dim, T = N * Lseq, Din = c.input_dim;
+  const long long* lens = (const long long*)lengths;
+  const int out_dim = D * (c.use_context ? 2 : 1);
+  const bf16_t* zL = S.layers[c.num_layers - 1].z2;
+  bf16_t* dz = X.dzA;     // grad wrt the last layer's output tokens
+  bf16_t* dz_other = X.dzB;
+
+  if (c.pooler == 0) {
+    const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
+    PoolArgs p; p.s = S.s; p.lds = D; p.z = zL; p.ldz = D; p.lens = lens; p.N = N; p.L = Lseq; p.D = D;
+    p.pooled = S.pooled; p.ldp = D; p.smax = S.smax; p.ssum = S.ssum;
+    p.drop_w = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL3);
+    p.drop_s = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2); p.drop_s_ld = D;
+    p.dpooled = dpooled; p.lddp = out_dim; p.ds = X.ds; p.ldds = D; p.dz = X.dzp; p.lddz = D; p.ds_colsum = G + L.pb2;
+    RUN(launch_pool_bwd(p, st));
+    { GemmTN t; t.A = S.ap; t.lda = PH; t.B = X.ds; t.ldb = D; t.T = T; t.Mo = dhp; t.No = dop; t.C = G + L.pw2; t.ldc = dop;
+      t.groups = H; t.zA = dhp; t.zB = dop; t.zC = (long)dhp * dop; RUN(launch_gemm_tn(t, st)); }
+    {  // dhp = (ds_h . W2[h]^T) * gelu'(hp) * drop1 ; db1p = colsum
+      GemmNT g; g.X = X.ds; g.ldx = D; g.W = W.pw2_kn; g.ldw = dop; g.M = T; g.N = dhp; g.K = dop;
+      g.groups = H; g.zX = dop; g.zW = (long)dhp * dop; g.zOut = dhp;
+      g.epi.act = 2; g.epi.aux = S.hp; g.epi.ldaux = PH; g.epi.colsum = G + L.pb1; g.epi.out = X.dhp; g.epi.ldc = PH;
+      epi_drop(g.epi, mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL1), PH);
+      RUN(launch_gemm_nt(g, st));
+    }
+    { GemmTN t; t.A = zL; t.lda = D; t.B = X.dhp; t.ldb = PH; t.T = T; t.Mo = D; t.No = dhp; t.C = G + L.pw1; t.ldc = dhp;
+      t.groups = H; t.zA = 0; t.zB = dhp; t.zC = (long)D * dhp; RUN(launch_gemm_tn(t, st)); }
+    {  // dz = dhp . W1p + dz(pool direct)
+      GemmNT g; g.X = X.dhp; g.ldx = PH; g.W = W.pw1_kn; g.ldw = PH; g.M = T; g.N = D; g.K = PH;
+      g.epi.res = X.dzp; g.epi.ldres = D; g.epi.out = dz; g.epi.ldc = D;
+      RUN(launch_gemm_nt(g, st));
+    }
+  } else {
+    RUN(launch_avgpool_bwd(dpooled, out_dim, lens, N, Lseq, D, dz, D, st));
+  }
+
+  if (c.use_context) {
+    COOT_REQUIRE(dhidden, "net_bwd: dhidden required for context networks");
+    for (int i = c.ctx_num_layers - 1; i >= 0; --i) {
+      LayerBufs b = ctx_bufs(S.ctx[i], D);
+      LayerBwdBufs w; w.dr2 = X.c_d1; w.dr2m = X.c_d2; w.dh1 = X.c_dh1; w.dz1 = X.c_dz1; w.dr1 = X.c_dr1; w.dctx = X.c_dctx;
+      w.dq = X.c_dq; w.lddq = D; w.dk = X.c_dkv; w.lddk = 2 * D; w.dv = X.c_dkv + D; w.lddv = 2 * D; w.delta = X.c_delta;
+      const bf16_t* qin = i == 0 ? S.cq_in : S.ctx[i - 1].z2;
+      const bool last = (i == c.ctx_num_layers - 1);
+      const bool first = (i == 0);
+      RUN(layer_bwd(c, P, G, L.ctx[i], W.ctx[i], qin, N, 1, zL, T, Lseq, N, lens, b, w, last ? nullptr : X.c_dqin,
+                    last ? dpooled + D : nullptr, out_dim, first ? nullptr : X.c_dqin, first ? dhidden : nullptr, dz, nullptr, nullptr,
+                    c.ctx_dropout, train, seed, 16u * (8 + i), st));
+    }
+  }
+
+  for (int i = c.num_layers - 1; i >= 0; --i) {
+    LayerBufs b = self_bufs(S.layers[i], D);
+    LayerBwdBufs w; w.dr2 = X.dr2; w.dr2m = X.dr2m; w.dh1 = X.dh1; w.dz1 = X.dz1; w.dr1 = X.dr1; w.dctx = X.dctx;
+    w.dq = X.dqkv; w.lddq = 3 * D; w.dk = X.dqkv + D; w.lddk = 3 * D; w.dv = X.dqkv + 2 * D; w.lddv = 3 * D; w.delta = X.delta;
+    const bf16_t* zin = i == 0 ? S.z0 : S.layers[i - 1].z2;
+    const bool fc0 = (i == 0 && c.use_input_fc);
+    if (fc0) RUN(launch_fill_f32(X.cvec, D, 0.f, st));
+    RUN(layer_bwd(c, P, G, L.layers[i], W.layers[i], zin, T, Lseq, zin, T, Lseq, N, lens, b, w, dz, nullptr, 0, dz_other, nullptr, nullptr,
+                  fc0 ? S.h0 : nullptr, fc0 ? X.cvec : nullptr, c.dropout, train, seed, 16u * i, st));
+    bf16_t* t = dz; dz = dz_other; dz_other = t;
+  }
+  // dz now holds: dh0 (input-FC nets: already multiplied by gelu'(h0)) or dz0 (grad wrt LN(x)+pe)
+  if (c.use_input_fc) {
+    RUN(launch_fill_f32(X.Mbuf, (long)D * Din, 0.f, st));
+    { GemmTN t; t.A = dz; t.lda = D; t.B = S.xhat; t.ldb = Din; t.T = T; t.Mo = D; t.No = Din; t.C = X.Mbuf; t.ldc = Din; RUN(launch_gemm_tn(t, st)); }
+    RUN(launch_infc_param_grads(X.Mbuf, P + L.in_w, P + L.n_gain, P + L.n_bias, X.cvec, D, Din, G + L.in_w, G + L.n_gain, G + L.n_bias, st));
+    RUN(launch_axpy_f32(G + L.in_b, X.cvec, D, 1.0f, st));  // db_in += colsum(dh0)
+  } else {
+    LnBwd l; l.dy = dz; l.lddy = D; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.gain = P + L.n_gain; l.R = T; l.D = D;
+    l.dx32 = dfeats; l.lddx32 = Din; l.dgain = G + L.n_gain; l.dbias = G + L.n_bias;
+    if (!dfeats) { l.dx = dz_other; l.lddx = D; }
+    RUN(launch_ln_bwd(l, st));
+  }
+  (void)pe; (void)hidden;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,394 @@
+// Attention kernels for gfx950 with v_mfma_f32_16x16x16_bf16 (d_head = 16*k, k <= 4).
+//
+// Forward / dQ kernels compute S^T = K.Q^T per 16x16 tile so that a lane owns ONE query
+// (lane&15) and 4 consecutive keys per register quad: softmax statistics are lane-local plus two
+// xor-shuffles, and the S^T accumulator layout IS the B-operand layout of the next MFMA
+// (O^T = V^T.P^T, dQ^T = K^T.dS^T) — probabilities never leave registers.
+// The dK/dV kernel uses the mirrored orientation (lane owns one key).
+// K/V (resp. Q/dO) chunks of 64 rows are staged in LDS both row-major and transposed.
+#include "attention.h"
+
+namespace coot {
+
+constexpr int KC = 64;  // rows per staged chunk
+
+template <int DH>
+struct AttnSmem {
+  static constexpr int RP = DH + 8;  // row-major pitch (elements)
+  static constexpr int TP = KC + 8;  // transposed pitch
+};
+
+__device__ __forceinline__ f32x4_t mfma16(s16x4_t a, s16x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ s16x4_t pack4(float a, float b, float c, float d) {
+  unsigned lo = pack2bf(a, b), hi = pack2bf(c, d);
+  s16x4_t r;
+  r[0] = (short)(lo & 0xFFFF); r[1] = (short)(lo >> 16); r[2] = (short)(hi & 0xFFFF); r[3] = (short)(hi >> 16);
+  return r;
+}
+
+// stage `rows` rows (row index r0.., valid while < rmax) of a [*, ld] matrix at column c0 into
+// row-major LDS tile R[KC][RP] and/or transposed tile T[DH][TP]; out-of-range rows are zero.
+template <int DH, bool ROWMAJOR, bool TRANSPOSED>
+__device__ __forceinline__ void stage_chunk(const bf16_t* src, long ld, long rowbase, int r0, int rmax, int c0,
+                                            bf16_t* R, bf16_t* T) {
+  constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP;
+  constexpr int CPR = DH / 8;  // 16-byte chunks per row
+  for (int c = threadIdx.x; c < KC * CPR; c += 256) {
+    const int r = c / CPR, cc = (c % CPR) * 8;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (r0 + r < rmax) v = *reinterpret_cast<const u32x4_t*>(src + (rowbase + r0 + r) * ld + c0 + cc);
+    if (ROWMAJOR) {
+      // RP*2 bytes is a multiple of 16 only when DH % 8 == 0 and (DH+8)*2 % 16 == 0 -> true for DH=16k
+      *reinterpret_cast<u32x4_t*>(&R[r * RP + cc]) = v;
+    }
+    if (TRANSPOSED) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        T[(cc + 2 * j) * TP + r] = (bf16_t)(v[j] & 0xFFFFu);
+        T[(cc + 2 * j + 1) * TP + r] = (bf16_t)(v[j] >> 16);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP, NK = DH / 16;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[KC * RP];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[DH * TP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int Lq = a.Lq, Lk = a.Lk;
+  const int nvalid = (int)a.lens[n];
+  const long qbase = (long)n * Lq, kbase = (long)n * Lk;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int qrow = q0 + lq;
+  const bool qok = qrow < Lq;
+
+  s16x4_t qf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    qf[ks] = s16x4_t{0, 0, 0, 0};
+    if (qok) qf[ks] = *reinterpret_cast<const s16x4_t*>(a.q + (qbase + qrow) * a.ldq + h * DH + ks * 16 + lg * 4);
+  }
+  f32x4_t oacc[NK];
+#pragma unroll
+  for (int dt = 0; dt < NK; ++dt) oacc[dt] = f32x4_t{0, 0, 0, 0};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kc = 0; kc < Lk; kc += KC) {
+    __syncthreads();
+    stage_chunk<DH, true, false>(a.k, a.ldk, kbase, kc, Lk, h * DH, Ks, nullptr);
+    stage_chunk<DH, false, true>(a.v, a.ldv, kbase, kc, Lk, h * DH, nullptr, Vt);
+    __syncthreads();
+    f32x4_t s[4];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = f32x4_t{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        s16x4_t kf = *reinterpret_cast<const s16x4_t*>(&Ks[(kt * 16 + lq) * RP + ks * 16 + lg * 4]);
+        s[kt] = mfma16(kf, qf[ks], s[kt]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kidx = kc + kt * 16 + lg * 4 + i;
+        float v = s[kt][i] * a.scale;
+        if (kidx >= nvalid) v = kMaskFill;   // masked_fill(mask, -INF) (transformer_legacy.py:544)
+        if (kidx >= Lk) v = -INFINITY;       // beyond the padded length: does not exist
+        s[kt][i] = v;
+        cmax = fmaxf(cmax, v);
+      }
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+    const float m_new = fmaxf(m_run, cmax);
+    const float alpha = __expf(m_run - m_new);
+    float csum = 0.f;
+    s16x4_t pf[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      float p[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p[i] = __expf(s[kt][i] - m_new);
+        csum += p[i];
+        if (a.drop.thr) {
+          const int kidx = kc + kt * 16 + lg * 4 + i;
+          unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qrow) * Lk + kidx);
+          p[i] *= drop_scale(a.drop.seed, a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+        }
+      }
+      pf[kt] = pack4(p[0], p[1], p[2], p[3]);
+    }
+    csum += __shfl_xor(csum, 16, 64);
+    csum += __shfl_xor(csum, 32, 64);
+    l_run = l_run * alpha + csum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) oacc[dt][i] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        s16x4_t vf = *reinterpret_cast<const s16x4_t*>(&Vt[(dt * 16 + lq) * TP + kt * 16 + lg * 4]);
+        oacc[dt] = mfma16(vf, pf[kt], oacc[dt]);
+      }
+    }
+  }
+  if (qok) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) {
+      u32x2_t pk = {pack2bf(oacc[dt][0] * inv, oacc[dt][1] * inv), pack2bf(oacc[dt][2] * inv, oacc[dt][3] * inv)};
+      *reinterpret_cast<u32x2_t*>(a.o + (qbase + qrow) * a.ldo + h * DH + dt * 16 + lg * 4) = pk;
+    }
+    if (lg == 0 && a.lse) a.lse[(qbase + qrow) * a.H + h] = m_run + __logf(l_run);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 1: dQ (and delta = rowsum(dO * O)), one wave per 16 queries
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
+  constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP, NK = DH / 16;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[KC * RP];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[KC * RP];
+  __shared__ __attribute__((aligned(16))) bf16_t Kt[DH * TP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int Lq = a.Lq, Lk = a.Lk;
+  const int nvalid = (int)a.lens[n];
+  const long qbase = (long)n * Lq, kbase = (long)n * Lk;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int qrow = q0 + lq;
+  const bool qok = qrow < Lq;
+
+  s16x4_t qf[NK], dof[NK];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    qf[ks] = s16x4_t{0, 0, 0, 0}; dof[ks] = qf[ks];
+    if (qok) {
+      const long off = h * DH + ks * 16 + lg * 4;
+      qf[ks] = *reinterpret_cast<const s16x4_t*>(a.q + (qbase + qrow) * a.ldq + off);
+      dof[ks] = *reinterpret_cast<const s16x4_t*>(a.dout + (qbase + qrow) * a.lddo + off);
+      s16x4_t of = *reinterpret_cast<const s16x4_t*>(a.o + (qbase + qrow) * a.ldo + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dl += bf2f((bf16_t)dof[ks][j]) * bf2f((bf16_t)of[j]);
+    }
+  }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  float lse = 0.f;
+  if (qok) {
+    lse = a.lse[(qbase + qrow) * a.H + h];
+    if (lg == 0) a.delta[(qbase + qrow) * a.H + h] = dl;
+  }
+  f32x4_t dqacc[NK];
+#pragma unroll
+  for (int dt = 0; dt < NK; ++dt) dqacc[dt] = f32x4_t{0, 0, 0, 0};
+
+  for (int kc = 0; kc < Lk; kc += KC) {
+    __syncthreads();
+    stage_chunk<DH, true, true>(a.k, a.ldk, kbase, kc, Lk, h * DH, Ks, Kt);
+    stage_chunk<DH, true, false>(a.v, a.ldv, kbase, kc, Lk, h * DH, Vs, nullptr);
+    __syncthreads();
+    s16x4_t dsf[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4_t s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        s16x4_t kf = *reinterpret_cast<const s16x4_t*>(&Ks[(kt * 16 + lq) * RP + ks * 16 + lg * 4]);
+        s16x4_t vf = *reinterpret_cast<const s16x4_t*>(&Vs[(kt * 16 + lq) * RP + ks * 16 + lg * 4]);
+        s = mfma16(kf, qf[ks], s);
+        dp = mfma16(vf, dof[ks], dp);
+      }
+      float ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kidx = kc + kt * 16 + lg * 4 + i;
+        float sv = s[i] * a.scale;
+        if (kidx >= nvalid) sv = kMaskFill;
+        float p = (kidx < Lk && qok) ? __expf(sv - lse) : 0.f;
+        float dpe = dp[i];
+        if (a.drop.thr) {
+          unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qrow) * Lk + kidx);
+          dpe *= drop_scale(a.drop.seed, a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+        }
+        ds[i] = (kidx < nvalid) ? p * (dpe - dl) * a.scale : 0.f;  // masked_fill blocks the gradient
+      }
+      dsf[kt] = pack4(ds[0], ds[1], ds[2], ds[3]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        s16x4_t ktf = *reinterpret_cast<const s16x4_t*>(&Kt[(dt * 16 + lq) * TP + kt * 16 + lg * 4]);
+        dqacc[dt] = mfma16(ktf, dsf[kt], dqacc[dt]);
+      }
+  }
+  if (qok) {
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) {
+      u32x2_t pk = {pack2bf(dqacc[dt][0], dqacc[dt][1]), pack2bf(dqacc[dt][2], dqacc[dt][3])};
+      *reinterpret_cast<u32x2_t*>(a.dq + (qbase + qrow) * a.lddq + h * DH + dt * 16 + lg * 4) = pk;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 2: dK, dV, one wave per 16 keys, loop over query chunks
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
+  constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP, NK = DH / 16;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[KC * RP];
+  __shared__ __attribute__((aligned(16))) bf16_t dOs[KC * RP];
+  __shared__ __attribute__((aligned(16))) bf16_t Qt[DH * TP];
+  __shared__ __attribute__((aligned(16))) bf16_t dOt[DH * TP];
+  __shared__ float lse_s[KC], delta_s[KC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int Lq = a.Lq, Lk = a.Lk;
+  const int nvalid = (int)a.lens[n];
+  const long qbase = (long)n * Lq, kbase = (long)n * Lk;
+  const int lk = lane & 15, lg = lane >> 4;
+  const int krow = k0 + lk;
+  const bool kin = krow < Lk;
+  const bool kvalid = krow < nvalid;
+
+  s16x4_t kf[NK], vf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    kf[ks] = s16x4_t{0, 0, 0, 0}; vf[ks] = kf[ks];
+    if (kin) {
+      kf[ks] = *reinterpret_cast<const s16x4_t*>(a.k + (kbase + krow) * a.ldk + h * DH + ks * 16 + lg * 4);
+      vf[ks] = *reinterpret_cast<const s16x4_t*>(a.v + (kbase + krow) * a.ldv + h * DH + ks * 16 + lg * 4);
+    }
+  }
+  f32x4_t dkacc[NK], dvacc[NK];
+#pragma unroll
+  for (int dt = 0; dt < NK; ++dt) { dkacc[dt] = f32x4_t{0, 0, 0, 0}; dvacc[dt] = dkacc[dt]; }
+
+  for (int qc = 0; qc < Lq; qc += KC) {
+    __syncthreads();
+    stage_chunk<DH, true, true>(a.q, a.ldq, qbase, qc, Lq, h * DH, Qs, Qt);
+    stage_chunk<DH, true, true>(a.dout, a.lddo, qbase, qc, Lq, h * DH, dOs, dOt);
+    if (threadIdx.x < KC) {
+      const int qr = qc + threadIdx.x;
+      lse_s[threadIdx.x] = qr < Lq ? a.lse[(qbase + qr) * a.H + h] : 0.f;
+      delta_s[threadIdx.x] = qr < Lq ? a.delta[(qbase + qr) * a.H + h] : 0.f;
+    }
+    __syncthreads();
+    s16x4_t pf[4], dsf[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4_t s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        s16x4_t qfr = *reinterpret_cast<const s16x4_t*>(&Qs[(qt * 16 + lk) * RP + ks * 16 + lg * 4]);
+        s16x4_t dofr = *reinterpret_cast<const s16x4_t*>(&dOs[(qt * 16 + lk) * RP + ks * 16 + lg * 4]);
+        s = mfma16(qfr, kf[ks], s);     // s[i]  = S[q = qt*16 + lg*4 + i][key = lk]
+        dp = mfma16(dofr, vf[ks], dp);  // dp[i] = dP[q][key]
+      }
+      float p[4], ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ql = qt * 16 + lg * 4 + i, qr = qc + ql;
+        float sv = s[i] * a.scale;
+        float pv = (kvalid && qr < Lq) ? __expf(sv - lse_s[ql]) : 0.f;
+        float dsc = 1.f;
+        if (a.drop.thr) {
+          unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qr) * Lk + krow);
+          dsc = drop_scale(a.drop.seed, a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+        }
+        p[i] = pv * dsc;
+        ds[i] = pv * (dp[i] * dsc - delta_s[ql]) * a.scale;
+      }
+      pf[qt] = pack4(p[0], p[1], p[2], p[3]);
+      dsf[qt] = pack4(ds[0], ds[1], ds[2], ds[3]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        s16x4_t dotf = *reinterpret_cast<const s16x4_t*>(&dOt[(dt * 16 + lk) * TP + qt * 16 + lg * 4]);
+        s16x4_t qtf = *reinterpret_cast<const s16x4_t*>(&Qt[(dt * 16 + lk) * TP + qt * 16 + lg * 4]);
+        dvacc[dt] = mfma16(pf[qt], dotf, dvacc[dt]);   // [key = lg*4+i][d = dt*16 + lk]
+        dkacc[dt] = mfma16(dsf[qt], qtf, dkacc[dt]);
+      }
+  }
+#pragma unroll
+  for (int dt = 0; dt < NK; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = k0 + lg * 4 + i;
+      if (kr < Lk) {
+        a.dk[(kbase + kr) * a.lddk + h * DH + dt * 16 + lk] = f2bf(dkacc[dt][i]);
+        a.dv[(kbase + kr) * a.lddv + h * DH + dt * 16 + lk] = f2bf(dvacc[dt][i]);
+      }
+    }
+}
+
+template <int DH>
+static int attn_fwd_t(const AttnArgs& a, hipStream_t st) {
+  dim3 grid((a.Lq + 63) / 64, a.H, a.Nseq);
+  hipLaunchKernelGGL(attn_fwd_kernel<DH>, grid, dim3(256), 0, st, a);
+  COOT_CHECK_LAUNCH("attn_fwd");
+  return 0;
+}
+template <int DH>
+static int attn_bwd_t(const AttnArgs& a, hipStream_t st) {
+  dim3 gq((a.Lq + 63) / 64, a.H, a.Nseq);
+  hipLaunchKernelGGL(attn_bwd_q_kernel<DH>, gq, dim3(256), 0, st, a);
+  COOT_CHECK_LAUNCH("attn_bwd_q");
+  dim3 gk((a.Lk + 63) / 64, a.H, a.Nseq);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel<DH>, gk, dim3(256), 0, st, a);
+  COOT_CHECK_LAUNCH("attn_bwd_kv");
+  return 0;
+}
+
+static int attn_check(const AttnArgs& a) {
+  COOT_REQUIRE(a.q && a.k && a.v && a.o && a.lens, "attention: null pointer");
+  COOT_REQUIRE(a.dh % 16 == 0 && a.dh >= 16 && a.dh <= 64, "attention: d_head=%d unsupported (16,32,48,64)", a.dh);
+  COOT_REQUIRE(a.ldq % 4 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0, "attention: strides must be multiples of 8");
+  return 0;
+}
+
+int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
+  if (int rc = attn_check(a)) return rc;
+  if (a.Nseq <= 0 || a.Lq <= 0) return 0;
+  switch (a.dh) {
+    case 16: return attn_fwd_t<16>(a, st);
+    case 32: return attn_fwd_t<32>(a, st);
+    case 48: return attn_fwd_t<48>(a, st);
+    default: return attn_fwd_t<64>(a, st);
+  }
+}
+
+int launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
+  if (int rc = attn_check(a)) return rc;
+  COOT_REQUIRE(a.dout && a.lse && a.delta && a.dq && a.dk && a.dv, "attention bwd: null pointer");
+  COOT_REQUIRE(a.ldq % 8 == 0 && a.lddo % 8 == 0, "attention bwd: strides must be multiples of 8");
+  if (a.Nseq <= 0 || a.Lq <= 0) return 0;
+  switch (a.dh) {
+    case 16: return attn_bwd_t<16>(a, st);
+    case 32: return attn_bwd_t<32>(a, st);
+    case 48: return attn_bwd_t<48>(a, st);
+    default: return attn_bwd_t<64>(a, st);
+  }
+}
+
+}  // namespace coot

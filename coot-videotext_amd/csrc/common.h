@@ -1,0 +1,85 @@
+// Common device helpers for the COOT retrieval hot path on gfx950 (CDNA4, wave64).
+// No CUDA compatibility layer: this code is written for MI355X only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace coot {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits in HBM / LDS
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr float kMaskFill = -32752.0f;  // nntrainer/typext.py:24 (INF), used as -INF mask fill
+constexpr float kLnEps = 1e-6f;         // nntrainer/models/normalizations.py:89
+
+// ---- bf16 <-> f32 (round-to-nearest-even, same as v_cvt_pk_bf16_f32) ----------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+// ---- exact-erf GELU (nn.GELU(), nntrainer/models/activations.py:29-30) and derivative -------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * __expf(-0.5f * x * x) * 0.39894228040143268f;
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based RNG for dropout: one 32-bit draw per (seed, site, element) ---------------
+// (cannot match torch's Philox stream; training parity is statistical)
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned rng_u32(unsigned long long seed, unsigned site, unsigned long long idx) {
+  unsigned a = mix32((unsigned)idx ^ (unsigned)(seed));
+  unsigned b = mix32((unsigned)(idx >> 32) + site * 0x9E3779B9u + (unsigned)(seed >> 32));
+  return mix32(a ^ (b + 0x85ebca6bU + (a << 6) + (a >> 2)));
+}
+// keep-scale: 0 if dropped else 1/(1-p).  thr = p * 2^32
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned site, unsigned long long idx,
+                                            unsigned thr, float inv_keep) {
+  return rng_u32(seed, site, idx) >= thr ? inv_keep : 0.0f;
+}
+
+}  // namespace coot
+
+// ---- host side error plumbing --------------------------------------------------------------
+namespace coot {
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+}  // namespace coot
+
+#define COOT_CHECK_LAUNCH(what)                                   \
+  do {                                                            \
+    int _rc = coot::check_hip(hipGetLastError(), what);           \
+    if (_rc) return _rc;                                          \
+  } while (0)
+
+#define COOT_REQUIRE(cond, ...)                                   \
+  do {                                                            \
+    if (!(cond)) { coot::set_error(__VA_ARGS__); return -2; }     \
+  } while (0)

@@ -1,0 +1,57 @@
+// bf16 MFMA GEMMs for the COOT hot path (gfx950).
+//   gemm_nt : C[M,N]  = epilogue( alpha * X[M,K] . W[N,K]^T )         (all Linear fwd + dX)
+//   gemm_tn : C[Mo,No] += alpha * sum_t A[t,Mo]^T . B[t,No]            (all weight grads, split over t)
+#pragma once
+#include "common.h"
+
+namespace coot {
+
+struct GemmEpi {
+  const float* bias = nullptr;  // [N]
+  float alpha = 1.0f;
+  int act = 0;  // 0 none | 1 v=gelu(v) | 2 v*=gelu'(aux)
+  const bf16_t* aux = nullptr; long ldaux = 0;     // pre-activation for act==2
+  bf16_t* save_pre = nullptr; long ldpre = 0;      // store v before activation (bf16)
+  const bf16_t* res = nullptr; long ldres = 0;     // + residual (bf16)
+  const float* res32 = nullptr; long ldres32 = 0;  // + residual (fp32)
+  const float* pe = nullptr; int pe_L = 1;         // + pe[(row % pe_L) * N + col]
+  const float* rowscale = nullptr; const bf16_t* diag_src = nullptr; long lddiag = 0;  // + rowscale[row]*diag_src[row][col]
+  float* colsum = nullptr;                         // atomicAdd column sums of the final value
+  // dropout applied to (alpha*acc + bias) [act 0/1] or to the final product [act 2]
+  unsigned drop_thr = 0; float drop_inv_keep = 1.0f; unsigned long long drop_seed = 0; unsigned drop_site = 0;
+  long drop_ld = 0;  // element index = row * drop_ld + col (+ z * drop_zoff)
+  void* out = nullptr; long ldc = 0; int out_f32 = 0; int accumulate = 0;
+};
+
+struct GemmNT {
+  const bf16_t* X = nullptr; long ldx = 0;  // [M,K] tokens
+  const bf16_t* W = nullptr; long ldw = 0;  // [N,K] features
+  int M = 0, N = 0, K = 0;
+  const int* M_dev = nullptr;  // optional device-side row count (<= M): tiles beyond it exit
+  // grouped launch: blockIdx.z = g adds these element offsets
+  int groups = 1; long zX = 0, zW = 0, zOut = 0;  // zOut applies to out/aux/save_pre/res/bias/colsum columns
+  GemmEpi epi;
+};
+
+int launch_gemm_nt(const GemmNT& g, hipStream_t stream);
+
+struct GemmTN {
+  const bf16_t* A = nullptr; long lda = 0;  // [T, Mo]
+  const bf16_t* B = nullptr; long ldb = 0;  // [T, No]
+  int T = 0, Mo = 0, No = 0;
+  float alpha = 1.0f;
+  float* C = nullptr; long ldc = 0;  // fp32 [Mo, No], accumulated with atomics
+  int groups = 1; long zA = 0, zB = 0, zC = 0;
+};
+
+int launch_gemm_tn(const GemmTN& g, hipStream_t stream);
+
+// per-launch HIP-event timing of gemm_nt (bench roofline leg)
+void gemm_timing_enable(int on);
+int gemm_timing_collect(int only_big_k, double* ms, double* flops, int* launches);
+
+// 0 = ds_read_b64_tr_b16 fragments (default), 1 = transposing LDS stores (fallback)
+void set_tn_mode(int mode);
+int get_tn_mode();
+
+}  // namespace coot

@@ -1,0 +1,39 @@
+// Loss kernels: L2 normalisation, bidirectional max-margin ranking (ContrastiveLoss),
+// cycle-consistency (CycleConsistencyLoss).  coot/loss_fn.py, coot/trainer_retrieval.py:148-233.
+#pragma once
+#include "common.h"
+
+namespace coot {
+
+// a = v / max(||v||, 1e-12): writes bf16 a [N, lda], bf16 a^T [d, ldt] (zero padded columns), inv_norm [N]
+int launch_l2norm_fwd(const float* v, long ldv, int N, int d, bf16_t* a, long lda, bf16_t* aT, long ldt, float* inv_norm,
+                      hipStream_t st);
+// dv (+)= (da - a <a,da>) * inv_norm ;  a = v * inv_norm
+int launch_l2norm_bwd(const float* da, long ldda, const float* v, long ldv, const float* inv_norm, int N, int d, float* dv,
+                      long lddv, int accumulate, hipStream_t st);
+
+// From S [N, lds] (fp32 similarity):  loss += w/(N*N) * sum_{i!=j} relu(m+S_ij-S_ii) + relu(m+S_ij-S_jj)
+// G [N, ldg] / GT [N, ldg] bf16 = off-diagonal violation counts {0,1,2} (zero diagonal, zero padding),
+// gd[i] += -(w/(N*N)) * (#row violations of i in cost_s + #column violations of i in cost_im)
+int launch_hinge(const float* S, long lds, int N, float margin, float w, float* loss, bf16_t* G, bf16_t* GT, long ldg,
+                 float* gd, hipStream_t st);
+
+struct CycleArgs {
+  const float* clip = nullptr;  // [B, Cc, D] zero padded
+  const float* sent = nullptr;  // [B, Cs, D]
+  const long long* clip_lens = nullptr;  // [B]
+  const long long* sent_lens = nullptr;
+  const long long* idx_clip = nullptr;   // [B] sampled position per video (th.multinomial, loss_fn.py:312)
+  const long long* idx_sent = nullptr;
+  int B = 0, Cc = 0, Cs = 0, D = 0;
+  float weight = 0.f;       // loss_cycle_cons
+  float inv_batch = 0.f;    // 1 / (global batch size)
+  float* loss = nullptr;    // += weight * (L_clip + L_sent) contribution of these B videos
+  float* rows_clip = nullptr;  // optional [B, Cc] per-position losses (deterministic parity target)
+  float* rows_sent = nullptr;  // optional [B, Cs]
+  float* dclip = nullptr;   // [B, Cc, D] += grad (may be null: forward only)
+  float* dsent = nullptr;   // [B, Cs, D]
+};
+int launch_cyclecons(const CycleArgs& a, hipStream_t st);
+
+}  // namespace coot

@@ -1,0 +1,274 @@
+// Loss kernels for gfx950.  The N x N similarity GEMMs run on the MFMA GEMM (gemm.hip); this
+// file holds the wave-shuffle reductions around them and the per-video cycle-consistency kernel.
+#include "loss.h"
+
+namespace coot {
+
+// ---- F.normalize(p=2, dim=1, eps=1e-12) (coot/trainer_retrieval.py:161-166) -------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* v, long ldv, int N, int d, bf16_t* a, long lda, bf16_t* aT,
+                                                         long ldt, float* inv_norm) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) { float x = v[(long)row * ldv + c]; s += x * x; }
+  s = wave_sum(s);
+  const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+  if (lane == 0) inv_norm[row] = inv;
+  for (int c = lane; c < d; c += 64) {
+    bf16_t h = f2bf(v[(long)row * ldv + c] * inv);
+    a[(long)row * lda + c] = h;
+    if (aT) aT[(long)c * ldt + row] = h;
+  }
+}
+int launch_l2norm_fwd(const float* v, long ldv, int N, int d, bf16_t* a, long lda, bf16_t* aT, long ldt, float* inv_norm, hipStream_t st) {
+  COOT_REQUIRE(v && a && inv_norm, "l2norm: null pointer");
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, v, ldv, N, d, a, lda, aT, ldt, inv_norm);
+  COOT_CHECK_LAUNCH("l2norm_fwd");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* da, long ldda, const float* v, long ldv, const float* inv_norm,
+                                                         int N, int d, float* dv, long lddv, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float inv = inv_norm[row];
+  float dot = 0.f;
+  for (int c = lane; c < d; c += 64) dot += v[(long)row * ldv + c] * inv * da[(long)row * ldda + c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < d; c += 64) {
+    const float a = v[(long)row * ldv + c] * inv;
+    const float g = (da[(long)row * ldda + c] - a * dot) * inv;
+    if (accumulate) dv[(long)row * lddv + c] += g; else dv[(long)row * lddv + c] = g;
+  }
+}
+int launch_l2norm_bwd(const float* da, long ldda, const float* v, long ldv, const float* inv_norm, int N, int d, float* dv, long lddv,
+                      int accumulate, hipStream_t st) {
+  COOT_REQUIRE(da && v && inv_norm && dv, "l2norm bwd: null pointer");
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, da, ldda, v, ldv, inv_norm, N, d, dv, lddv, accumulate);
+  COOT_CHECK_LAUNCH("l2norm_bwd");
+  return 0;
+}
+
+// ---- ContrastiveLoss.forward (coot/loss_fn.py:63-100) + its gradient wrt S ---------------------
+// 64 x 64 tiles; thread (ty = tid/64 -> 16 rows each, tx = tid%64 -> column).
+__global__ __launch_bounds__(256) void hinge_kernel(const float* S, long lds, int N, float margin, float w, float* loss, bf16_t* G,
+                                                    bf16_t* GT, long ldg, float* gd) {
+  __shared__ float colcnt[64];
+  __shared__ float rowcnt[64];
+  __shared__ float lsum[4];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  if (threadIdx.x < 64) { colcnt[threadIdx.x] = 0.f; rowcnt[threadIdx.x] = 0.f; }
+  __syncthreads();
+  const int j = j0 + tx;
+  const float djj = j < N ? S[(long)j * lds + j] : 0.f;
+  float part = 0.f, ccnt = 0.f;
+  for (int r = 0; r < 16; ++r) {
+    const int il = ty * 16 + r, i = i0 + il;
+    float g = 0.f;
+    float rc = 0.f;
+    if (i < N && j < N && i != j) {
+      const float s = S[(long)i * lds + j];
+      const float dii = S[(long)i * lds + i];
+      const float cs = margin + s - dii;   // cost_s  (compare with the row's diagonal)
+      const float ci = margin + s - djj;   // cost_im (compare with the column's diagonal)
+      if (cs > 0.f) { part += cs; g += 1.f; rc = 1.f; }
+      if (ci > 0.f) { part += ci; g += 1.f; ccnt += 1.f; }
+    }
+    if (i < N && j < N) {
+      G[(long)i * ldg + j] = f2bf(g);
+      GT[(long)j * ldg + i] = f2bf(g);
+    }
+    rc = wave_sum(rc);  // the 64 lanes of a wave share row i
+    if (tx == 0 && rc != 0.f) atomicAdd(&rowcnt[il], rc);
+  }
+  atomicAdd(&colcnt[tx], ccnt);
+  part = wave_sum(part);
+  if (tx == 0) lsum[ty] = part;
+  __syncthreads();
+  const float sc = w / ((float)N * (float)N);
+  if (threadIdx.x == 0) atomicAdd(loss, (lsum[0] + lsum[1] + lsum[2] + lsum[3]) * sc);
+  if (threadIdx.x < 64) {
+    const int i = i0 + threadIdx.x, jj = j0 + threadIdx.x;
+    if (i < N && rowcnt[threadIdx.x] != 0.f) atomicAdd(gd + i, -sc * rowcnt[threadIdx.x]);
+    if (jj < N && colcnt[threadIdx.x] != 0.f) atomicAdd(gd + jj, -sc * colcnt[threadIdx.x]);
+  }
+}
+int launch_hinge(const float* S, long lds, int N, float margin, float w, float* loss, bf16_t* G, bf16_t* GT, long ldg, float* gd,
+                 hipStream_t st) {
+  COOT_REQUIRE(S && loss && G && GT && gd, "hinge: null pointer");
+  if (N <= 0) return 0;
+  dim3 grid((N + 63) / 64, (N + 63) / 64);
+  hipLaunchKernelGGL(hinge_kernel, grid, dim3(256), 0, st, S, lds, N, margin, w, loss, G, GT, ldg, gd);
+  COOT_CHECK_LAUNCH("hinge");
+  return 0;
+}
+
+// ---- CycleConsistencyLoss (coot/loss_fn.py:143-387), one workgroup per (video, direction) -------
+constexpr int CC_MAXC = 64;   // max clips / sentences per video
+constexpr int CC_NVD = 16;    // D <= 1024
+
+__global__ __launch_bounds__(256) void cyclecons_kernel(CycleArgs a) {
+  __shared__ float dist[CC_MAXC][CC_MAXC + 1];
+  __shared__ float alpha[CC_MAXC][CC_MAXC + 1];
+  __shared__ float beta_sel[CC_MAXC], alpha_sel[CC_MAXC], dd2[CC_MAXC], ddist[CC_MAXC], dalpha[CC_MAXC];
+  __shared__ float wred[4][CC_MAXC];
+  __shared__ float lrow[CC_MAXC];
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = a.D;
+  const float* src = dir == 0 ? a.clip + (long)b * a.Cc * D : a.sent + (long)b * a.Cs * D;
+  const float* tgt = dir == 0 ? a.sent + (long)b * a.Cs * D : a.clip + (long)b * a.Cc * D;
+  const int Csrc = dir == 0 ? a.Cc : a.Cs, Ctgt = dir == 0 ? a.Cs : a.Cc;
+  const int ns = (int)(dir == 0 ? a.clip_lens[b] : a.sent_lens[b]);
+  const int nt = (int)(dir == 0 ? a.sent_lens[b] : a.clip_lens[b]);
+  const float invD = 1.0f / (float)D;
+
+  // (1) proximity = -mean_d (src_i - tgt_j)^2, masked with -INF where source or target is padding
+  for (int pidx = wave; pidx < Csrc * Ctgt; pidx += 4) {
+    const int i = pidx / Ctgt, j = pidx % Ctgt;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) { float t = src[(long)i * D + d] - tgt[(long)j * D + d]; s += t * t; }
+    s = wave_sum(s);
+    if (lane == 0) dist[i][j] = (i < ns && j < nt) ? -s * invD : kMaskFill;
+  }
+  __syncthreads();
+  // (2) alpha = softmax_j
+  if (threadIdx.x < Csrc) {
+    const int i = threadIdx.x;
+    float m = -INFINITY;
+    for (int j = 0; j < Ctgt; ++j) m = fmaxf(m, dist[i][j]);
+    float z = 0.f;
+    for (int j = 0; j < Ctgt; ++j) { float e = __expf(dist[i][j] - m); alpha[i][j] = e; z += e; }
+    const float iz = 1.f / z;
+    for (int j = 0; j < Ctgt; ++j) alpha[i][j] *= iz;
+  }
+  __syncthreads();
+  // (3) soft NN s~_i = sum_j alpha_ij tgt_j (registers), dist2[i][k] = -mean_d (s~_i - src_k)^2 -> dist
+  for (int i = wave; i < Csrc; i += 4) {
+    float nn[CC_NVD];
+#pragma unroll
+    for (int v = 0; v < CC_NVD; ++v) {
+      const int d = lane + 64 * v;
+      float t = 0.f;
+      if (d < D) for (int j = 0; j < Ctgt; ++j) t += alpha[i][j] * tgt[(long)j * D + d];
+      nn[v] = t;
+    }
+    for (int k = 0; k < Csrc; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < CC_NVD; ++v) {
+        const int d = lane + 64 * v;
+        if (d < D) { float t = nn[v] - src[(long)k * D + d]; s += t * t; }
+      }
+      s = wave_sum(s);
+      if (lane == 0) dist[i][k] = (i < ns && k < ns) ? -s * invD : kMaskFill;
+    }
+  }
+  __syncthreads();
+  // (4) beta = softmax_k, mu_i = sum_k beta_ik k, l_i = (mu_i - i)^2 (0 for padded i)
+  const int isel = (int)(dir == 0 ? a.idx_clip[b] : a.idx_sent[b]);
+  if (threadIdx.x < Csrc) {
+    const int i = threadIdx.x;
+    float m = -INFINITY;
+    for (int k = 0; k < Csrc; ++k) m = fmaxf(m, dist[i][k]);
+    float z = 0.f;
+    for (int k = 0; k < Csrc; ++k) z += __expf(dist[i][k] - m);
+    float mu = 0.f;
+    const float iz = 1.f / z;
+    for (int k = 0; k < Csrc; ++k) {
+      const float bk = __expf(dist[i][k] - m) * iz;
+      mu += bk * (float)k;
+      if (i == isel) beta_sel[k] = bk;
+    }
+    const float l = i < ns ? (mu - (float)i) * (mu - (float)i) : 0.f;
+    lrow[i] = l;
+    float* rows = dir == 0 ? a.rows_clip : a.rows_sent;
+    if (rows) rows[(long)b * Csrc + i] = l;
+    if (i == isel) {
+      atomicAdd(a.loss, a.weight * a.inv_batch * l);
+      // d loss / d mu
+      dd2[CC_MAXC - 1] = 0.f;
+      wred[0][0] = a.weight * a.inv_batch * 2.f * (mu - (float)i);
+    }
+    if (i == isel) for (int j = 0; j < Ctgt; ++j) alpha_sel[j] = alpha[i][j];
+  }
+  if (!a.dclip) return;
+  __syncthreads();
+  float* dsrc = dir == 0 ? a.dclip + (long)b * a.Cc * D : a.dsent + (long)b * a.Cs * D;
+  float* dtgt = dir == 0 ? a.dsent + (long)b * a.Cs * D : a.dclip + (long)b * a.Cc * D;
+  const float dmu = wred[0][0];
+  __syncthreads();
+  // ddist2_k = beta_k (dbeta_k - sum beta dbeta), dbeta_k = dmu * k ; zero for masked k
+  if (threadIdx.x == 0) {
+    float sb = 0.f;
+    for (int k = 0; k < Csrc; ++k) sb += beta_sel[k] * dmu * (float)k;
+    for (int k = 0; k < Csrc; ++k) dd2[k] = k < ns ? beta_sel[k] * (dmu * (float)k - sb) : 0.f;
+  }
+  __syncthreads();
+  // per-thread feature slice d = tid + 256*v (D <= 1024)
+  float nn1[4], dnn1[4], cvec[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int d = threadIdx.x + 256 * v;
+    nn1[v] = 0.f; dnn1[v] = 0.f; cvec[v] = 0.f;
+    if (d < D) {
+      cvec[v] = src[(long)isel * D + d];
+      float t = 0.f;
+      for (int j = 0; j < Ctgt; ++j) t += alpha_sel[j] * tgt[(long)j * D + d];
+      nn1[v] = t;
+      float g = 0.f;
+      for (int k = 0; k < Csrc; ++k) {
+        const float diff = t - src[(long)k * D + d];
+        g += dd2[k] * (-2.f * invD) * diff;
+        if (dd2[k] != 0.f) atomicAdd(dsrc + (long)k * D + d, dd2[k] * (2.f * invD) * diff);
+      }
+      dnn1[v] = g;
+    }
+  }
+  // dalpha_j = <tgt_j, dnn1>
+  for (int j = 0; j < Ctgt; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const int d = threadIdx.x + 256 * v; if (d < D) s += tgt[(long)j * D + d] * dnn1[v]; }
+    s = wave_sum(s);
+    if (lane == 0) wred[wave][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sa = 0.f;
+    for (int j = 0; j < Ctgt; ++j) { dalpha[j] = wred[0][j] + wred[1][j] + wred[2][j] + wred[3][j]; sa += alpha_sel[j] * dalpha[j]; }
+    for (int j = 0; j < Ctgt; ++j) ddist[j] = j < nt ? alpha_sel[j] * (dalpha[j] - sa) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int d = threadIdx.x + 256 * v;
+    if (d < D) {
+      float gsel = 0.f;
+      for (int j = 0; j < Ctgt; ++j) {
+        const float diff = cvec[v] - tgt[(long)j * D + d];
+        float gt = alpha_sel[j] * dnn1[v] + ddist[j] * (2.f * invD) * diff;
+        gsel += ddist[j] * (-2.f * invD) * diff;
+        if (gt != 0.f) atomicAdd(dtgt + (long)j * D + d, gt);
+      }
+      atomicAdd(dsrc + (long)isel * D + d, gsel);
+    }
+  }
+}
+
+int launch_cyclecons(const CycleArgs& a, hipStream_t st) {
+  COOT_REQUIRE(a.clip && a.sent && a.clip_lens && a.sent_lens && a.idx_clip && a.idx_sent && a.loss, "cyclecons: null pointer");
+  COOT_REQUIRE(a.Cc <= CC_MAXC && a.Cs <= CC_MAXC && a.D <= 1024, "cyclecons: at most %d clips/sentences per video and D<=1024 (Cc=%d Cs=%d D=%d)", CC_MAXC, a.Cc, a.Cs, a.D);
+  COOT_REQUIRE((a.dclip == nullptr) == (a.dsent == nullptr), "cyclecons: dclip/dsent must both be set or both null");
+  if (a.B <= 0) return 0;
+  hipLaunchKernelGGL(cyclecons_kernel, dim3(a.B, 2), dim3(256), 0, st, a);
+  COOT_CHECK_LAUNCH("cyclecons");
+  return 0;
+}
+
+}  // namespace coot

@@ -1,0 +1,45 @@
+// Pooling / packing kernels: GenPool column softmax ("atn"), TemporalAvgPool ("avg_special"),
+// clip->video packing, small casts.
+#pragma once
+#include "common.h"
+#include "rowops.h"
+
+namespace coot {
+
+struct PoolArgs {
+  const bf16_t* s = nullptr; long lds = 0;   // [N*L, D] pre-softmax scores (dropout2 already applied)
+  const bf16_t* z = nullptr; long ldz = 0;   // [N*L, D] features being pooled
+  const long long* lens = nullptr;           // [N]
+  int N = 0, L = 0, D = 0;
+  float* pooled = nullptr; long ldp = 0;     // [N, D] fp32 (may be a column slice of a wider matrix)
+  float* pooled_copy = nullptr;              // optional dense [N, D] copy kept for the backward
+  float* smax = nullptr; float* ssum = nullptr;  // [N, D] saved softmax statistics
+  DropCfg drop_w;                            // dropout3 on the softmax weights
+  // backward
+  const float* dpooled = nullptr; long lddp = 0;
+  bf16_t* ds = nullptr; long ldds = 0;       // grad wrt the pre-dropout2 scores (bf16)
+  bf16_t* dz = nullptr; long lddz = 0;       // partial grad wrt z (direct path)
+  float* ds_colsum = nullptr;                // [D] atomics (bias grad of the 2nd pooling FC)
+  DropCfg drop_s; long drop_s_ld = 0;        // dropout2 mask (same indexing as the GEMM epilogue)
+};
+int launch_pool_fwd(const PoolArgs& p, hipStream_t stream);
+int launch_pool_bwd(const PoolArgs& p, hipStream_t stream);
+
+// TemporalAvgPool (poolers.py:232-241): sum over ALL L rows / len
+int launch_avgpool_fwd(const bf16_t* z, long ldz, const long long* lens, int N, int L, int D, float* out, long ldo, hipStream_t st);
+// dz[n,l,:] = (dz_add ? dz_add : 0) + dpooled[n,:]/len[n]
+int launch_avgpool_bwd(const float* dpooled, long lddp, const long long* lens, int N, int L, int D, bf16_t* dz, long lddz, hipStream_t st);
+
+// pack loop of encode_visual (coot/model_retrieval.py:121-136)
+int launch_pack_fwd(const float* emb, const long long* counts, int B, int Cmax, int D, float* out, unsigned char* mask,
+                    long long* lens, hipStream_t st);
+// d_emb[ptr+c,:] += d_out[b,c,:]
+int launch_pack_bwd(const float* dout, const long long* counts, int B, int Cmax, int D, float* demb, hipStream_t st);
+
+int launch_cast_bf16_f32(const bf16_t* src, long lds, int R, int C, float* dst, long ldd, hipStream_t st);
+int launch_cast_f32_bf16(const float* src, long lds, int R, int C, bf16_t* dst, long ldd, hipStream_t st);
+// out_f32[r][c] = a_bf16[r][c] + b_bf16[r][c]  (used to merge two grad streams into an fp32 output)
+int launch_add_bf16_to_f32(const bf16_t* a, long lda, const bf16_t* b, long ldb, int R, int C, float* dst, long ldd,
+                           int accumulate, hipStream_t st);
+
+}  // namespace coot

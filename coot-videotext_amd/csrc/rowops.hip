@@ -1,0 +1,310 @@
+// Row-wise kernels for gfx950: one 64-lane wave per row, the row lives in registers,
+// 8/16-byte coalesced loads, wave-shuffle reductions (no LDS, no barriers in the forward).
+#include "rowops.h"
+
+namespace coot {
+
+// ---- row load/store helpers: chunk = 4 consecutive elements ---------------------------------
+__device__ __forceinline__ f32x4_t load4(const void* base, int is_f32, long off) {
+  if (is_f32) return *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(base) + off);
+  u32x2_t u = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(base) + off);
+  return f32x4_t{bflo(u[0]), bfhi(u[0]), bflo(u[1]), bfhi(u[1])};
+}
+__device__ __forceinline__ void store4_bf(bf16_t* p, f32x4_t v) {
+  u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+  *reinterpret_cast<u32x2_t*>(p) = pk;
+}
+
+// LayerNormalization 'layernorm_coot' (nntrainer/models/normalizations.py:98-101):
+//   y = gain * (x - mean) / (std_unbiased + 1e-6) + bias
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.R) return;
+  const int D = p.D, nch = D >> 2;
+  f32x4_t v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + 64 * i;
+    v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (c < nch) v[i] = load4(p.x, p.x_f32, (long)row * p.ldx + c * 4);
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; v[i][j] = d; q += d * d; }
+    }
+  }
+  const float stdv = sqrtf(wave_sum(q) / (float)(D - 1));
+  const float rs = 1.0f / (stdv + kLnEps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + 64 * i;
+    if (c >= nch) continue;
+    const int col = c * 4;
+    f32x4_t y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = v[i][j] * rs;
+      if (p.gain) t = t * p.gain[col + j] + p.bias[col + j];
+      if (p.pe) t += p.pe[(long)(row % p.pe_L) * D + col + j];
+      if (p.drop.thr) t *= drop_scale(p.drop.seed, p.drop.site, (unsigned long long)row * D + col + j, p.drop.thr, p.drop.inv_keep);
+      y[j] = t;
+    }
+    if (p.y) store4_bf(p.y + (long)row * p.ldy + col, y);
+    if (p.y32) *reinterpret_cast<f32x4_t*>(p.y32 + (long)row * p.ldy32 + col) = y;
+  }
+}
+
+int launch_ln_fwd(const LnFwd& p, hipStream_t stream) {
+  COOT_REQUIRE(p.x && (p.y || p.y32), "ln_fwd: null pointer");
+  COOT_REQUIRE(p.D % 4 == 0 && p.D <= 4096 && p.D >= 8 && p.ldx % 4 == 0, "ln_fwd: D=%d unsupported (need D%%4==0, 8<=D<=4096)", p.D);
+  if (p.R <= 0) return 0;
+  dim3 grid((p.R + 3) / 4);
+  if (p.D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, stream, p);
+  else if (p.D <= 2048) hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, dim3(256), 0, stream, p);
+  COOT_CHECK_LAUNCH("ln_fwd");
+  return 0;
+}
+
+// Backward:  xc = x - mean, s = std + eps, h = dy * gain
+//   dx = (h - mean(h))/s - (sum h*xc)/s^2 * xc/((n-1)*std)      [second term 0 where std == 0]
+//   dgain += dy * xc/s ; dbias += dy
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
+  __shared__ float red[3][4][NV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = p.D, nch = D >> 2;
+  f32x4_t ag[NV], ab[NV], ac[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { ag[i] = f32x4_t{0, 0, 0, 0}; ab[i] = ag[i]; ac[i] = ag[i]; }
+  for (int row = blockIdx.x * 4 + wave; row < p.R; row += gridDim.x * 4) {
+    f32x4_t x[NV], dy[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + 64 * i;
+      x[i] = f32x4_t{0, 0, 0, 0}; dy[i] = x[i];
+      if (c < nch) {
+        const int col = c * 4;
+        x[i] = load4(p.x, p.x_f32, (long)row * p.ldx + col);
+        dy[i] = p.dy32 ? *reinterpret_cast<const f32x4_t*>(p.dy32 + (long)row * p.lddy32 + col)
+                       : load4(p.dy, 0, (long)row * p.lddy + col);
+        if (p.dy_add) { f32x4_t t = load4(p.dy_add, 0, (long)row * p.lddy_add + col); dy[i] += t; }
+        if (p.drop.thr) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            dy[i][j] *= drop_scale(p.drop.seed, p.drop.site, (unsigned long long)row * D + col + j, p.drop.thr, p.drop.inv_keep);
+        }
+      }
+      s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f, hs = 0.f, hx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float d = x[i][j] - mean; x[i][j] = d; q += d * d;
+          float h = dy[i][j] * p.gain[c * 4 + j];
+          hs += h; hx += h * d;
+        }
+      }
+    }
+    q = wave_sum(q); hs = wave_sum(hs); hx = wave_sum(hx);
+    const float stdv = sqrtf(q / (float)(D - 1));
+    const float sv = stdv + kLnEps, rs = 1.0f / sv;
+    const float hmean = hs / (float)D;
+    const float k2 = stdv > 0.f ? hx * rs * rs / ((float)(D - 1) * stdv) : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + 64 * i;
+      if (c >= nch) continue;
+      const int col = c * 4;
+      f32x4_t dx, dm;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float h = dy[i][j] * p.gain[col + j];
+        dx[j] = (h - hmean) * rs - k2 * x[i][j];
+        ag[i][j] += dy[i][j] * x[i][j] * rs;
+        ab[i][j] += dy[i][j];
+        float m = dx[j];
+        if (p.dxm && p.dxm_drop.thr)
+          m *= drop_scale(p.dxm_drop.seed, p.dxm_drop.site, (unsigned long long)row * p.dxm_drop_ld + col + j, p.dxm_drop.thr, p.dxm_drop.inv_keep);
+        dm[j] = m;
+        ac[i][j] += m;
+      }
+      if (p.dx) store4_bf(p.dx + (long)row * p.lddx + col, dx);
+      if (p.dx32) *reinterpret_cast<f32x4_t*>(p.dx32 + (long)row * p.lddx32 + col) = dx;
+      if (p.dxm) store4_bf(p.dxm + (long)row * p.lddxm + col, dm);
+    }
+  }
+  // block reduce of the column partials (4 waves), then one atomic per column per block
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int idx = (lane + 64 * i) * 4 + j;
+      red[0][wave][idx] = ag[i][j]; red[1][wave][idx] = ab[i][j]; red[2][wave][idx] = ac[i][j];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    float x = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+    if (p.dgain) atomicAdd(p.dgain + c, g);
+    if (p.dbias) atomicAdd(p.dbias + c, b);
+    if (p.dxcolsum) atomicAdd(p.dxcolsum + c, x);
+  }
+}
+
+int launch_ln_bwd(const LnBwd& p, hipStream_t stream) {
+  COOT_REQUIRE((p.dy || p.dy32) && p.x && p.gain, "ln_bwd: null pointer");
+  COOT_REQUIRE(p.D % 4 == 0 && p.D <= 1024 && p.D >= 8, "ln_bwd: D=%d unsupported (need D%%4==0, 8<=D<=1024)", p.D);
+  if (p.R <= 0) return 0;
+  int blocks = (p.R + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  if (p.D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, stream, p);
+  COOT_CHECK_LAUNCH("ln_bwd");
+  return 0;
+}
+
+// ---- column sums of a bf16 matrix -----------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* x, long ldx, int R, int C, float* out, int rows_per_block) {
+  // thread -> 2 columns (4-byte loads); block covers 512 columns x rows_per_block rows
+  const int col = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (col >= C) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float a = 0.f, b = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    unsigned u = *reinterpret_cast<const unsigned*>(x + (long)r * ldx + col);
+    a += bflo(u); b += bfhi(u);
+  }
+  atomicAdd(out + col, a);
+  if (col + 1 < C) atomicAdd(out + col + 1, b);
+}
+
+int launch_colsum_bf16(const bf16_t* x, long ldx, int R, int C, float* out, hipStream_t stream) {
+  COOT_REQUIRE(x && out && C % 2 == 0 && ldx % 2 == 0, "colsum: bad args");
+  if (R <= 0) return 0;
+  int rpb = 64;
+  dim3 grid((C / 2 + 255) / 256, (R + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, out, rpb);
+  COOT_CHECK_LAUNCH("colsum_bf16");
+  return 0;
+}
+
+// ---- weight cast / transpose (tiny; once per optimizer step) ---------------------------------
+__global__ __launch_bounds__(256) void cast_weight_kernel(const float* src, long lds, int R, int C, bf16_t* dst, long ldd,
+                                                          int transpose, const float* colscale) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) { v = src[(long)r * lds + c]; if (colscale) v *= colscale[c]; }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (!transpose) {
+    for (int i = ty; i < 32; i += 8) {
+      int r = r0 + i, c = c0 + tx;
+      if (r < R && c < C) dst[(long)r * ldd + c] = f2bf(tile[i][tx]);
+    }
+  } else {
+    for (int i = ty; i < 32; i += 8) {
+      int c = c0 + i, r = r0 + tx;
+      if (r < R && c < C) dst[(long)c * ldd + r] = f2bf(tile[tx][i]);
+    }
+  }
+}
+
+int launch_cast_weight(const float* src, long lds, int R, int C, bf16_t* dst, long ldd, int transpose,
+                       const float* colscale, hipStream_t stream) {
+  COOT_REQUIRE(src && dst, "cast_weight: null pointer");
+  dim3 grid((C + 31) / 32, (R + 31) / 32);
+  hipLaunchKernelGGL(cast_weight_kernel, grid, dim3(256), 0, stream, src, lds, R, C, dst, ldd, transpose, colscale);
+  COOT_CHECK_LAUNCH("cast_weight");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void matvec_bias_kernel(const float* W, long ldw, int N, int K, const float* v, const float* b, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += W[(long)n * ldw + k] * v[k];
+  s = wave_sum(s);
+  if (lane == 0) out[n] = s + (b ? b[n] : 0.f);
+}
+
+int launch_matvec_bias(const float* W, long ldw, int N, int K, const float* v, const float* b, float* out, hipStream_t stream) {
+  COOT_REQUIRE(W && v && out, "matvec: null pointer");
+  hipLaunchKernelGGL(matvec_bias_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, ldw, N, K, v, b, out);
+  COOT_CHECK_LAUNCH("matvec_bias");
+  return 0;
+}
+
+// thread per column k, loop over n (N = 384 rows): coalesced along k
+__global__ __launch_bounds__(256) void infc_param_grads_kernel(const float* M, const float* W, const float* g0, const float* b0,
+                                                               const float* c, int N, int K, float* dW, float* dg0, float* db0) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const float g = g0[k], b = b0[k];
+  float sg = 0.f, sb = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float m = M[(long)n * K + k], w = W[(long)n * K + k], cn = c[n];
+    dW[(long)n * K + k] += m * g + cn * b;
+    sg += w * m;
+    sb += cn * w;
+  }
+  dg0[k] += sg;
+  db0[k] += sb;
+}
+
+int launch_infc_param_grads(const float* M, const float* W, const float* g0, const float* b0, const float* c,
+                            int N, int K, float* dW, float* dg0, float* db0, hipStream_t stream) {
+  hipLaunchKernelGGL(infc_param_grads_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, M, W, g0, b0, c, N, K, dW, dg0, db0);
+  COOT_CHECK_LAUNCH("infc_param_grads");
+  return 0;
+}
+
+__global__ void fill_f32_kernel(float* p, long n, float v) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+int launch_fill_f32(float* p, long n, float v, hipStream_t stream) {
+  if (n <= 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, stream, p, n, v);
+  COOT_CHECK_LAUNCH("fill_f32");
+  return 0;
+}
+
+__global__ void axpy_f32_kernel(float* y, const float* x, long n, float a) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+int launch_axpy_f32(float* y, const float* x, long n, float a, hipStream_t stream) {
+  if (n <= 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(axpy_f32_kernel, dim3(blocks), dim3(256), 0, stream, y, x, n, a);
+  COOT_CHECK_LAUNCH("axpy_f32");
+  return 0;
+}
+
+}  // namespace coot

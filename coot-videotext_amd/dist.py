@@ -1,0 +1,104 @@
+"""
+Data-parallel training of the retrieval path: one process per GPU, torch.distributed over RCCL/xGMI
+(backend "nccl" on ROCm; "gloo" in the CPU tests).
+
+The reference only has single-process nn.DataParallel (nntrainer/trainer_base.py:126-129: encoders scattered,
+outputs gathered to GPU 0, loss on the full batch).  Same semantics here, restated for multi-process DP
+(SURVEY 8e):
+  * videos are sharded by rank; all encoder work and the cycle-consistency loss are per video;
+  * ONE packed all-gather of the six embedding sets per step; every rank evaluates the contrastive loss on the
+    FULL gathered batch (mean over the global N^2, identical numerics to one GPU) and keeps the gradient of
+    its own rows — no second collective for the embedding gradients;
+  * global max clips/sentences per video (all-reduce MAX) so every rank pads to the same Cmax — required for
+    reference-exact avg_special pooling;
+  * parameter gradients: all-reduce(SUM) of the four flat gradient arenas (one collective per network,
+    issued on a side stream as soon as backward has produced them).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class _GatherRows(torch.autograd.Function):
+    """all-gather row blocks of possibly different heights; backward = own slice of the incoming gradient
+    (every rank computes the same full loss, so no reduction is needed)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, counts: List[int], rank: int, group):
+        world = len(counts)
+        maxc = max(counts)
+        pad = x.new_zeros((maxc,) + tuple(x.shape[1:]))
+        pad[: x.shape[0]] = x
+        out = x.new_empty((world * maxc,) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+        ctx.counts, ctx.rank, ctx.maxc = counts, rank, maxc
+        if all(c == maxc for c in counts):
+            return out
+        idx = torch.cat([torch.arange(r * maxc, r * maxc + c, device=x.device) for r, c in enumerate(counts)])
+        return out.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        start = sum(ctx.counts[: ctx.rank])
+        return g[start:start + ctx.counts[ctx.rank]].contiguous(), None, None, None
+
+
+def gather_rows(x: torch.Tensor, counts: List[int], rank: int, group=None) -> torch.Tensor:
+    return _GatherRows.apply(x, counts, rank, group)
+
+
+class DataParallelContext:
+    """Holds rank/world and implements the collectives of one training step."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def global_max(self, value: int, device) -> int:
+        t = torch.tensor([int(value)], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def global_counts(self, n: int, device) -> List[int]:
+        t = torch.tensor([int(n)], dtype=torch.int64, device=device)
+        out = torch.empty(self.world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return [int(v) for v in out.tolist()]
+
+    def gather_embeddings(self, vis, txt, clip_counts: Optional[List[int]] = None, vid_counts: Optional[List[int]] = None):
+        """Returns the six full-batch embedding sets (vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx).
+        Row counts per rank may be passed when known on the host (fixed-shape batches) to avoid two tiny
+        all-gathers + host syncs."""
+        dev = vis.vid_emb.device
+        if vid_counts is None:
+            vid_counts = self.global_counts(vis.vid_emb.shape[0], dev)
+        if clip_counts is None:
+            clip_counts = self.global_counts(vis.clip_emb.shape[0], dev)
+        # pack the high-level (per video) sets into one buffer and the low-level (per clip) sets into another:
+        # two collectives instead of six
+        high = torch.cat([vis.vid_emb, txt.par_emb, vis.vid_context, txt.par_context], dim=1)
+        low = torch.cat([vis.clip_emb, txt.sent_emb], dim=1)
+        high_all = gather_rows(high, vid_counts, self.rank, self.group)
+        low_all = gather_rows(low, clip_counts, self.rank, self.group)
+        dg, dl = vis.vid_emb.shape[1], vis.clip_emb.shape[1]
+        vid_emb, par_emb = high_all[:, :dg], high_all[:, dg:2 * dg]
+        vid_ctx, par_ctx = high_all[:, 2 * dg:2 * dg + dl], high_all[:, 2 * dg + dl:]
+        clip_emb, sent_emb = low_all[:, :dl], low_all[:, dl:]
+        return vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx, sum(vid_counts)
+
+    def allreduce_grads(self, flat_grads: List[torch.Tensor], side_stream=None) -> None:
+        """Sum the flat gradient arenas over ranks.  With a side stream the collectives are enqueued there
+        (ordered after the current stream) and the current stream waits for them afterwards."""
+        if side_stream is None:
+            for g in flat_grads:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        side_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side_stream):
+            for g in flat_grads:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        torch.cuda.current_stream().wait_stream(side_stream)

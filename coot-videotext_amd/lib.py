@@ -1,0 +1,125 @@
+"""
+ctypes binding of libcoot_hip.so (C ABI declared in include/coot_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (same convention as the reference, which raises plain Python exceptions,
+e.g. nntrainer/models/transformer_legacy.py:154-156, :252).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcoot_hip.so")
+
+EXPORTS = [
+    "coot_last_error", "coot_version", "coot_set_option", "coot_net_param_numel", "coot_net_param_count",
+    "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights",
+    "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_pack_fwd",
+    "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_cyclecons_fwd_bwd",
+    "coot_gemm_nt", "coot_gemm_tn", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
+    "coot_timing_collect",
+]
+
+
+class NetConfig(C.Structure):
+    """coot_net_config (include/coot_hip.h)."""
+    _fields_ = [("input_dim", C.c_int), ("hidden_dim", C.c_int), ("num_heads", C.c_int), ("ff_dim", C.c_int),
+                ("num_layers", C.c_int), ("use_input_fc", C.c_int), ("use_context", C.c_int),
+                ("ctx_num_layers", C.c_int), ("pooler", C.c_int), ("pool_hidden", C.c_int), ("pool_heads", C.c_int),
+                ("dropout", C.c_float), ("ctx_dropout", C.c_float), ("pool_dropout", C.c_float)]
+
+
+class ContrastiveConfig(C.Structure):
+    """coot_contrastive_config."""
+    _fields_ = [("margin", C.c_float), ("weight_high", C.c_float), ("weight_high_internal", C.c_float),
+                ("weight_low", C.c_float), ("weight_low_internal", C.c_float), ("weight_context", C.c_float),
+                ("weight_context_internal", C.c_float)]
+
+
+_lib = None
+
+
+def build_hint() -> str:
+    return f"build it with: bash {os.path.join(_HERE, 'csrc', 'build.sh')}  (or python -c 'import __graft_entry__ as g; g.build()')"
+
+
+def load():
+    """Load libcoot_hip.so (once).  Raises RuntimeError if it is missing — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"libcoot_hip.so not found at {LIB_PATH}; {build_hint()}")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, sz, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
+    cfgp = C.POINTER(NetConfig)
+    lib.coot_last_error.restype = C.c_char_p
+    lib.coot_last_error.argtypes = []
+    lib.coot_version.restype = i32
+    lib.coot_set_option.argtypes = [C.c_char_p, i32]
+    lib.coot_net_param_numel.restype = i64
+    lib.coot_net_param_numel.argtypes = [cfgp]
+    lib.coot_net_param_count.argtypes = [cfgp]
+    lib.coot_net_param_info.argtypes = [cfgp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
+    lib.coot_net_out_dim.argtypes = [cfgp]
+    lib.coot_net_wpack_bytes.restype = sz
+    lib.coot_net_wpack_bytes.argtypes = [cfgp]
+    lib.coot_net_pack_weights.argtypes = [cfgp, vp, vp, vp]
+    lib.coot_net_saved_bytes.restype = sz
+    lib.coot_net_saved_bytes.argtypes = [cfgp, i32, i32]
+    lib.coot_net_scratch_bytes.restype = sz
+    lib.coot_net_scratch_bytes.argtypes = [cfgp, i32, i32]
+    lib.coot_net_fwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp]
+    lib.coot_net_bwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp]
+    lib.coot_pack_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.coot_pack_bwd.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.coot_contrastive_scratch_bytes.restype = sz
+    lib.coot_contrastive_scratch_bytes.argtypes = [i32, i32, i32, i32]
+    lib.coot_contrastive_fwd_bwd.argtypes = [C.POINTER(ContrastiveConfig), i32, i32, i32, i32] + [vp] * 6 + [vp] + [vp] * 6 + [vp, sz, vp]
+    lib.coot_cyclecons_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp]
+    lib.coot_gemm_nt.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp, i64, i32, vp]
+    lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]
+    lib.coot_ln_fwd.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.coot_attn_fwd.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.coot_probe_tr16.argtypes = [vp, vp]
+    lib.coot_timing_enable.argtypes = [i32]
+    lib.coot_timing_collect.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().coot_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libcoot_hip {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def param_table(cfg: NetConfig) -> Tuple[int, List[Tuple[str, int, Tuple[int, ...]]]]:
+    """(numel, [(state-dict name, offset, shape)]) of the flat fp32 parameter arena."""
+    lib = load()
+    total = lib.coot_net_param_numel(C.byref(cfg))
+    if total < 0:
+        check(-1, "coot_net_param_numel")
+    n = lib.coot_net_param_count(C.byref(cfg))
+    out = []
+    name = C.create_string_buffer(256)
+    off = C.c_int64()
+    shape = (C.c_int64 * 4)()
+    ndim = C.c_int()
+    for i in range(n):
+        check(lib.coot_net_param_info(C.byref(cfg), i, name, 256, C.byref(off), shape, C.byref(ndim)), "coot_net_param_info")
+        out.append((name.value.decode(), int(off.value), tuple(int(shape[j]) for j in range(ndim.value))))
+    return int(total), out

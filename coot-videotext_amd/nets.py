@@ -1,0 +1,250 @@
+"""
+TransformerHip — drop-in for nntrainer.models.TransformerLegacy
+(nntrainer/models/transformer_legacy.py:115-288) backed by libcoot_hip.so.
+
+* Parameters stay ``nn.Parameter``s with the reference's state-dict names and shapes (SURVEY 8a
+  row a2) so checkpoints (``model_N.pth`` = {net_name: state_dict}), ``torch.optim`` and the
+  reference's init (nntrainer/initialization.py:51-111) keep working.  Physically they are views
+  into ONE flat fp32 arena per network, whose layout the C library defines
+  (coot_net_param_info); gradients use the same flat layout.
+* ``forward(features, mask, lengths, hidden_state) -> (pooled, per_token)`` has the reference
+  signature.  All math runs in HIP kernels through the C ABI; PyTorch only owns memory, streams
+  and the autograd graph edges.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import lib as _lib
+from .config import TransformerConfig
+
+
+def sincos_pe(max_len: int, dim: int) -> torch.Tensor:
+    """PositionalEncodingSinCos buffer (nntrainer/models/encoder.py:84-90); note the exponent uses the
+    dim index itself (not index//2)."""
+    pe = torch.zeros(max_len, dim).float()
+    position = torch.arange(0, max_len).unsqueeze(1).float()
+    dimension = torch.arange(0, dim).float()
+    div_term = 10000 ** (2 * dimension / dim)
+    pe[:, 0::2] = torch.sin(position / div_term[0::2])
+    pe[:, 1::2] = torch.cos(position / div_term[1::2])
+    return pe
+
+
+def fill_truncnorm_(t: torch.Tensor, std: float, limit: float = 2.0, generator=None) -> None:
+    """Truncated normal as the reference draws it (nntrainer/utils_torch.py:73-92): 8 candidates per
+    element, first one inside +-limit sigma."""
+    tmp = torch.empty(tuple(t.shape) + (8,)).normal_(generator=generator)
+    valid = (tmp < limit) & (tmp > -limit)
+    _, ind = valid.max(-1, keepdim=True)
+    t.copy_(tmp.gather(-1, ind).squeeze(-1).mul_(std))
+
+
+class TransformerHip(nn.Module):
+    def __init__(self, cfg: TransformerConfig, feature_dim: Optional[int] = None):
+        super().__init__()
+        if feature_dim is not None:
+            assert feature_dim == cfg.input_dim, (feature_dim, cfg.input_dim)
+        self.cfg = cfg
+        self.c_cfg = cfg.to_c()
+        self.numel, self.table = _lib.param_table(self.c_cfg)
+        self.output_dim = cfg.hidden_dim * (2 if cfg.use_context else 1)
+        flat = torch.zeros(self.numel, dtype=torch.float32)
+        self._flat: torch.Tensor = flat
+        self._params: List[nn.Parameter] = []
+        for name, off, shape in self.table:
+            p = nn.Parameter(flat[off:off + math.prod(shape)].view(shape), requires_grad=True)
+            self._register(name, p)
+            self._params.append(p)
+        # non-trainable state-dict entries of the reference
+        self._submodule("embedding").register_buffer("pe", sincos_pe(1000, cfg.hidden_dim))
+        if cfg.pooler == "atn":
+            self._register("pooler.pools.0.genpool_one", nn.Parameter(torch.ones(1), requires_grad=False))
+        self._wpack: Optional[torch.Tensor] = None
+        self._dirty = True
+        self._grad_flat: Optional[torch.Tensor] = None
+        self.call_counter = 0
+        self.init_network(cfg.weight_init_type, cfg.weight_init_std)
+
+    # ---- module tree that reproduces the reference state-dict keys ---------------------------------
+    def _submodule(self, path: str) -> nn.Module:
+        mod: nn.Module = self
+        for part in path.split("."):
+            if part not in mod._modules:
+                mod.add_module(part, nn.Module())
+            mod = mod._modules[part]
+        return mod
+
+    def _register(self, name: str, p: nn.Parameter) -> None:
+        path, leaf = name.rsplit(".", 1) if "." in name else ("", name)
+        (self._submodule(path) if path else self).register_parameter(leaf, p)
+
+    def init_network(self, init_type: str, init_std: float) -> None:
+        """nntrainer/initialization.py:51-111: truncnorm on every weight AND bias, LN gain 1 / bias 0."""
+        if init_type == "none":
+            return
+        assert init_type == "truncnorm", init_type
+        with torch.no_grad():
+            for (name, _, _), p in zip(self.table, self._params):
+                if "layer_normalization" in name or "norm_input." in name:
+                    p.fill_(1.0 if name.endswith("gain") else 0.0)
+                else:
+                    fill_truncnorm_(p, init_std)
+        self._dirty = True
+
+    # ---- flat arena maintenance -----------------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn)
+        self._reflatten()
+        return self
+
+    def _reflatten(self) -> None:
+        dev = self._params[0].device
+        flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for (name, off, shape), p in zip(self.table, self._params):
+                flat[off:off + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + p.numel()].view(shape)
+        self._flat = flat
+        self._wpack = None
+        self._grad_flat = None
+        self._dirty = True
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._dirty = True
+        return out
+
+    def mark_dirty(self) -> None:
+        """Call after an optimizer step: the bf16 weight pack is rebuilt before the next forward."""
+        self._dirty = True
+
+    def bind_flat_grads(self) -> torch.Tensor:
+        """Pre-assign every param.grad as a view of one flat fp32 gradient arena (zeroed), so the
+        autograd accumulation lands in place and a fused optimizer / one all-reduce can use it."""
+        if self._grad_flat is None or self._grad_flat.device != self._flat.device:
+            self._grad_flat = torch.zeros_like(self._flat)
+            for (name, off, shape), p in zip(self.table, self._params):
+                p.grad = self._grad_flat[off:off + p.numel()].view(shape)
+        return self._grad_flat
+
+    def ensure_packed(self) -> torch.Tensor:
+        lib = _lib.load()
+        if self._wpack is None:
+            nbytes = lib.coot_net_wpack_bytes(C.byref(self.c_cfg))
+            self._wpack = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
+            self._dirty = True
+        if self._dirty or self.training:
+            _lib.check(lib.coot_net_pack_weights(C.byref(self.c_cfg), _lib.ptr(self._flat), _lib.ptr(self._wpack),
+                                                 _lib.stream_ptr()), "coot_net_pack_weights")
+            self._dirty = False
+        return self._wpack
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def forward(self, features: torch.Tensor, mask: Optional[torch.Tensor], lengths: torch.Tensor,
+                hidden_state: Optional[torch.Tensor], want_tokens: bool = True, seed: Optional[int] = None):
+        """Reference signature (transformer_legacy.py:200-215).  `mask` (True = padding) must be
+        consistent with `lengths`; the kernels use `lengths`."""
+        if not features.is_cuda:
+            raise RuntimeError("TransformerHip runs on an MI355X only (features must be a cuda tensor); "
+                               "there is no CPU fallback")
+        if self.cfg.use_context and hidden_state is None:
+            raise AssertionError("hidden_state required for use_context (transformer_legacy.py:252)")
+        self.ensure_packed()
+        if seed is None:
+            self.call_counter += 1
+            seed = (torch.initial_seed() * 1000003 + self.call_counter) & 0xFFFFFFFFFFFFFFFF
+        pooled, tokens = _NetFn.apply(self, features, lengths, hidden_state, bool(want_tokens), int(seed), *self._params)
+        return pooled, tokens
+
+
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: TransformerHip, feats, lengths, hidden, want_tokens, seed, *params):
+        lib = _lib.load()
+        cfg = net.c_cfg
+        feats = feats.contiguous().float()
+        lengths = lengths.contiguous().long()
+        N, L, Din = feats.shape
+        assert Din == net.cfg.input_dim, (Din, net.cfg.input_dim)
+        dev = feats.device
+        hid = hidden.contiguous().float() if hidden is not None else None
+        pooled = torch.empty(N, net.output_dim, dtype=torch.float32, device=dev)
+        tokens = torch.empty(N, L, net.cfg.hidden_dim, dtype=torch.float32, device=dev) if want_tokens else None
+        saved = torch.empty(lib.coot_net_saved_bytes(C.byref(cfg), N, L), dtype=torch.uint8, device=dev)
+        train = 1 if net.training else 0
+        pe = net.embedding.pe
+        _lib.check(lib.coot_net_fwd(C.byref(cfg), _lib.ptr(net._flat), _lib.ptr(net._wpack), _lib.ptr(pe), _lib.ptr(feats),
+                                    _lib.ptr(lengths), N, L, _lib.ptr(hid), _lib.ptr(pooled), _lib.ptr(tokens),
+                                    _lib.ptr(saved), saved.numel(), None, 0, train, seed, _lib.stream_ptr()), "coot_net_fwd")
+        ctx.net, ctx.saved, ctx.seed, ctx.train = net, saved, seed, train
+        ctx.feats, ctx.lengths, ctx.hid = feats, lengths, hid
+        ctx.need_dfeats = bool(ctx.needs_input_grad[1])
+        ctx.need_dhid = hidden is not None
+        ctx.mark_non_differentiable(*([tokens] if tokens is not None else []))
+        return pooled, tokens
+
+    @staticmethod
+    def backward(ctx, dpooled, _dtokens):
+        lib = _lib.load()
+        net: TransformerHip = ctx.net
+        cfg = net.c_cfg
+        feats, lengths, hid = ctx.feats, ctx.lengths, ctx.hid
+        N, L, Din = feats.shape
+        dev = feats.device
+        dpooled = dpooled.contiguous().float()
+        gflat = torch.zeros(net.numel, dtype=torch.float32, device=dev)
+        dhid = torch.empty(N, net.cfg.hidden_dim, dtype=torch.float32, device=dev) if ctx.need_dhid else None
+        dfeats = None
+        if ctx.need_dfeats:
+            if net.cfg.use_input_fc:
+                raise RuntimeError("gradient wrt input features is only available for networks without input_fc")
+            dfeats = torch.empty_like(feats)
+        scratch = torch.empty(lib.coot_net_scratch_bytes(C.byref(cfg), N, L), dtype=torch.uint8, device=dev)
+        _lib.check(lib.coot_net_bwd(C.byref(cfg), _lib.ptr(net._flat), _lib.ptr(net._wpack), _lib.ptr(net.embedding.pe),
+                                    _lib.ptr(feats), _lib.ptr(lengths), N, L, _lib.ptr(hid), _lib.ptr(dpooled), _lib.ptr(gflat),
+                                    _lib.ptr(dhid), _lib.ptr(dfeats), _lib.ptr(ctx.saved), ctx.saved.numel(), _lib.ptr(scratch),
+                                    scratch.numel(), ctx.train, ctx.seed, _lib.stream_ptr()), "coot_net_bwd")
+        grads = tuple(gflat[off:off + math.prod(shape)].view(shape) for (_, off, shape) in net.table)
+        return (None, dfeats, None, dhid, None, None) + grads
+
+
+class _PackFn(torch.autograd.Function):
+    """The pack loop of encode_visual/encode_text (coot/model_retrieval.py:121-136)."""
+
+    @staticmethod
+    def forward(ctx, emb, counts, cmax: int):
+        lib = _lib.load()
+        emb = emb.contiguous().float()
+        counts = counts.contiguous().long()
+        B, D = counts.shape[0], emb.shape[1]
+        dev = emb.device
+        out = torch.empty(B, cmax, D, dtype=torch.float32, device=dev)
+        mask = torch.empty(B, cmax, dtype=torch.bool, device=dev)
+        lens = torch.empty(B, dtype=torch.long, device=dev)
+        _lib.check(lib.coot_pack_fwd(_lib.ptr(emb), _lib.ptr(counts), B, cmax, D, _lib.ptr(out), _lib.ptr(mask), _lib.ptr(lens),
+                                     _lib.stream_ptr()), "coot_pack_fwd")
+        ctx.counts, ctx.shape = counts, (emb.shape[0], D, B, cmax)
+        ctx.mark_non_differentiable(mask, lens)
+        return out, mask, lens
+
+    @staticmethod
+    def backward(ctx, dout, _dm, _dl):
+        lib = _lib.load()
+        Nc, D, B, cmax = ctx.shape
+        dout = dout.contiguous().float()
+        demb = torch.zeros(Nc, D, dtype=torch.float32, device=dout.device)
+        _lib.check(lib.coot_pack_bwd(_lib.ptr(dout), _lib.ptr(ctx.counts), B, cmax, D, _lib.ptr(demb), _lib.stream_ptr()),
+                   "coot_pack_bwd")
+        return demb, None, None
+
+
+def pack_by_count(emb: torch.Tensor, counts: torch.Tensor, cmax: Optional[int] = None):
+    if cmax is None:
+        cmax = int(counts.max())  # host sync, as th.max(batch.clip_num) in the reference (:122)
+    return _PackFn.apply(emb, counts, int(cmax))

@@ -1,0 +1,68 @@
+"""Seeded synthetic RetrievalDataBatchTuple generators (ActivityNet / YouCook2 shaped), SURVEY 8d.
+Features ~ N(0,1), zero in padded rows, masks/lengths consistent; generated directly on the device."""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .model_retrieval import RetrievalDataBatchTuple
+
+# fixed-shape workloads of BASELINE.json / SURVEY 8d: (B, C, Lv, Lc, Lp, Ls, Dv, Dt)
+WORKLOADS = {
+    "anet": dict(B=64, C=4, Lv=80, Lc=80, Lp=64, Ls=16, Dv=2048, Dt=1536),
+    "yc2_100m": dict(B=16, C=8, Lv=80, Lc=20, Lp=96, Ls=12, Dv=512, Dt=1536),
+    "yc2_2d3d": dict(B=64, C=8, Lv=80, Lc=20, Lp=96, Ls=12, Dv=4096, Dt=1536),
+}
+
+
+def make_batch(seed: int, B: int, counts: Union[int, Sequence[int]], Lv: int, Lc: int, Lp: int, Ls: int, Dv: int, Dt: int,
+               ragged: bool = False, device="cuda") -> RetrievalDataBatchTuple:
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    counts_t = torch.full((B,), int(counts), dtype=torch.long) if np.isscalar(counts) else torch.as_tensor(counts, dtype=torch.long)
+    Nc = int(counts_t.sum())
+
+    def lens(n, L, lo):
+        if not ragged:
+            return torch.full((n,), L, dtype=torch.long)
+        l = torch.randint(lo, L + 1, (n,), generator=g)
+        l[int(torch.randint(0, n, (1,), generator=g))] = L
+        return l
+
+    dg = torch.Generator(device=device).manual_seed(seed + 1)
+
+    def feats(n, L, D, ln):
+        x = torch.randn(n, L, D, device=device, generator=dg)
+        mask = torch.arange(L, device=device)[None, :] >= ln.to(device)[:, None]
+        x.masked_fill_(mask[:, :, None], 0.0)
+        return x, mask
+
+    vl, pl = lens(B, Lv, max(1, Lv // 4)), lens(B, Lp, max(1, Lp // 4))
+    cl, sl = lens(Nc, Lc, max(1, Lc // 8)), lens(Nc, Ls, max(1, Ls // 4))
+    vf, vm = feats(B, Lv, Dv, vl)
+    pf, pm = feats(B, Lp, Dt, pl)
+    cf, cm = feats(Nc, Lc, Dv, cl)
+    sf, sm = feats(Nc, Ls, Dt, sl)
+    keys = [str(i) for i in range(B)]
+    return RetrievalDataBatchTuple(
+        key=keys, data_key=keys, sentences=[[""]] * B, vid_feat=vf, vid_feat_mask=vm, vid_feat_len=vl.to(device),
+        par_feat=pf, par_feat_mask=pm, par_feat_len=pl.to(device), clip_num=counts_t.to(device), clip_feat=cf,
+        clip_feat_mask=cm, clip_feat_len=cl.to(device), sent_num=counts_t.to(device), sent_feat=sf, sent_feat_mask=sm,
+        sent_feat_len=sl.to(device), max_clip_num=int(counts_t.max()), max_sent_num=int(counts_t.max()))
+
+
+def batch_from_numpy(b: dict, device="cuda") -> RetrievalDataBatchTuple:
+    """dict of numpy arrays (same field names as the batch tuple) -> device batch."""
+    t = {k: torch.as_tensor(np.asarray(v)) for k, v in b.items()}
+    B = len(b["clip_num"])
+    keys = [str(i) for i in range(B)]
+    f = lambda k: t[k].float().to(device)
+    return RetrievalDataBatchTuple(
+        key=keys, data_key=keys, sentences=[[""]] * B, vid_feat=f("vid_feat"), vid_feat_mask=t["vid_feat_mask"].to(device),
+        vid_feat_len=t["vid_feat_len"].to(device), par_feat=f("par_feat"), par_feat_mask=t["par_feat_mask"].to(device),
+        par_feat_len=t["par_feat_len"].to(device), clip_num=t["clip_num"].to(device), clip_feat=f("clip_feat"),
+        clip_feat_mask=t["clip_feat_mask"].to(device), clip_feat_len=t["clip_feat_len"].to(device),
+        sent_num=t["sent_num"].to(device), sent_feat=f("sent_feat"), sent_feat_mask=t["sent_feat_mask"].to(device),
+        sent_feat_len=t["sent_feat_len"].to(device), max_clip_num=int(np.max(b["clip_num"])),
+        max_sent_num=int(np.max(b["sent_num"])))

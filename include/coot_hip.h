@@ -1,0 +1,136 @@
+/*
+ * coot_hip.h — C ABI of libcoot_hip.so: the MI355X (gfx950) implementation of the COOT retrieval
+ * training hot path.  Plain pointers and sizes only; every pointer is DEVICE memory unless stated
+ * otherwise; every call enqueues asynchronously on the given hipStream_t (pass
+ * torch.cuda.current_stream().cuda_stream) and never allocates, frees, synchronises or retains
+ * pointers.  Return value: 0 = ok, negative = error (message via coot_last_error()).
+ *
+ * The reference (simon-ging/coot-videotext) is pure Python/PyTorch and has no FFI for this path;
+ * each entry point names the reference code it replaces (file:line relative to the reference
+ * root) — INTEGRATION.md shows the ctypes binding a maintainer adds.
+ */
+#ifndef COOT_HIP_H
+#define COOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* coot_stream_t; /* hipStream_t */
+
+/* One COOT network = nntrainer/models/transformer_legacy.py:26-97 (TransformerConfig) restricted to
+ * the options the shipped YAMLs use. */
+typedef struct coot_net_config {
+  int input_dim;      /* feature dim fed to norm_input                                    */
+  int hidden_dim;     /* selfatn_config.hidden_dim (d_model)                              */
+  int num_heads;      /* selfatn_config.num_heads                                         */
+  int ff_dim;         /* selfatn_config.pointwise_ff_dim (0 => hidden_dim)                */
+  int num_layers;     /* selfatn_config.num_layers                                        */
+  int use_input_fc;   /* input_fc: Linear(input_dim, hidden_dim) + GELU                   */
+  int use_context;    /* cross-attention context block (global nets)                      */
+  int ctx_num_layers; /* crossatn_config.num_layers                                       */
+  int pooler;         /* 0 = "atn" (GenPool), 1 = "avg_special" (TemporalAvgPool)         */
+  int pool_hidden;    /* pooler_config.hidden_dim (0 => hidden_dim)                       */
+  int pool_heads;     /* pooler_config.num_heads                                          */
+  float dropout;      /* selfatn_config.dropout   (used only when train != 0)             */
+  float ctx_dropout;  /* crossatn_config.dropout                                          */
+  float pool_dropout; /* pooler_config.dropout                                            */
+} coot_net_config;
+
+const char* coot_last_error(void);
+int coot_version(void);
+/* option switches for A/B measurements: "tn_mode" 0 = ds_read_b64_tr_b16 fragments, 1 = transposing LDS stores */
+int coot_set_option(const char* name, int value);
+
+/* ---- parameter layout (flat fp32 arena per network; gradients use the same layout) -----------
+ * Names and shapes are the reference state-dict names, e.g.
+ * "tf.encoder_layers.0.self_attention_layer.sublayer.query_projection.weight". */
+int64_t coot_net_param_numel(const coot_net_config* cfg);
+int coot_net_param_count(const coot_net_config* cfg);
+int coot_net_param_info(const coot_net_config* cfg, int index, char* name, int name_len, int64_t* offset,
+                        int64_t shape[4], int* ndim);
+int coot_net_out_dim(const coot_net_config* cfg);
+
+/* ---- bf16 weight pack (once per optimizer step) ---------------------------------------------- */
+size_t coot_net_wpack_bytes(const coot_net_config* cfg);
+int coot_net_pack_weights(const coot_net_config* cfg, const float* params, void* wpack, coot_stream_t stream);
+
+/* ---- one network forward / backward -----------------------------------------------------------
+ * Replaces TransformerLegacy.forward (nntrainer/models/transformer_legacy.py:200-288) and its
+ * autograd backward.  feats [N, L, input_dim] fp32 zero padded, lengths [N] int64 (valid rows),
+ * hidden [N, hidden_dim] fp32 or NULL, pe = embedding.pe [>=L, hidden_dim] fp32.
+ * pooled [N, out_dim] fp32; per_token [N, L, hidden_dim] fp32 or NULL.
+ * `saved` carries activations from fwd to bwd (coot_net_saved_bytes), `scratch` is temporary
+ * (coot_net_scratch_bytes).  train != 0 enables dropout with the given seed. */
+size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int L);
+size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int L);
+int coot_net_fwd(const coot_net_config* cfg, const float* params, const void* wpack, const float* pe,
+                 const float* feats, const int64_t* lengths, int N, int L, const float* hidden,
+                 float* pooled, float* per_token, void* saved, size_t saved_bytes, void* scratch,
+                 size_t scratch_bytes, int train, uint64_t seed, coot_stream_t stream);
+/* grads: flat fp32 arena, ACCUMULATED (+=).  dhidden [N, hidden_dim] (written) or NULL.
+ * dfeats [N, L, input_dim] fp32 (written; only supported when use_input_fc == 0) or NULL. */
+int coot_net_bwd(const coot_net_config* cfg, const float* params, const void* wpack, const float* pe,
+                 const float* feats, const int64_t* lengths, int N, int L, const float* hidden,
+                 const float* dpooled, float* grads, float* dhidden, float* dfeats, void* saved,
+                 size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed,
+                 coot_stream_t stream);
+
+/* ---- clip -> video packing: the python loop of coot/model_retrieval.py:121-136 ---------------- */
+int coot_pack_fwd(const float* emb, const int64_t* counts, int B, int Cmax, int D, float* out /*[B,Cmax,D]*/,
+                  uint8_t* mask /*[B,Cmax] 1 = pad*/, int64_t* lens /*[B]*/, coot_stream_t stream);
+int coot_pack_bwd(const float* dout, const int64_t* counts, int B, int Cmax, int D, float* demb /* += */,
+                  coot_stream_t stream);
+
+/* ---- losses ------------------------------------------------------------------------------------
+ * compute_total_constrastive_loss (coot/trainer_retrieval.py:148-182) with ContrastiveLoss
+ * (coot/loss_fn.py:63-100): six un-normalised embedding sets, loss accumulated into *loss,
+ * gradients accumulated into d* (all NULL => forward only). */
+typedef struct coot_contrastive_config {
+  float margin;
+  float weight_high, weight_high_internal, weight_low, weight_low_internal, weight_context,
+      weight_context_internal;
+} coot_contrastive_config;
+size_t coot_contrastive_scratch_bytes(int n_high, int n_low, int d_high, int d_low);
+int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low,
+                             const float* vid_emb, const float* par_emb, const float* clip_emb,
+                             const float* sent_emb, const float* vid_ctx, const float* par_ctx, float* loss,
+                             float* d_vid_emb, float* d_par_emb, float* d_clip_emb, float* d_sent_emb,
+                             float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes,
+                             coot_stream_t stream);
+
+/* CycleConsistencyLoss.forward + get_total_loss(num_samples=1) (coot/loss_fn.py:143-319).
+ * idx_* are the th.multinomial draws (one valid position per video).  loss += weight *
+ * inv_batch * sum_b (l_clip[b, idx_clip[b]] + l_sent[b, idx_sent[b]]); rows_* optional [B, C]. */
+int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* clip_lens,
+                           const int64_t* sent_lens, const int64_t* idx_clip, const int64_t* idx_sent, int B,
+                           int Cc, int Cs, int D, float weight, float inv_batch, float* loss, float* rows_clip,
+                           float* rows_sent, float* dclip, float* dsent, coot_stream_t stream);
+
+/* ---- kernel-level entry points (unit tests / microbenchmarks) ---------------------------------- */
+/* C[M,N] (bf16 or fp32) = act(X[M,K] . W[N,K]^T + bias) (+ residual)   (bf16 operands as uint16) */
+int coot_gemm_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, int M, int N, int K, const float* bias,
+                 int act, const void* residual_bf16, int64_t ldres, void* out, int64_t ldc, int out_f32,
+                 coot_stream_t stream);
+/* C[Mo,No] fp32 += sum_t A[t,Mo] * B[t,No] */
+int coot_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int T, int Mo, int No, float* C,
+                 int64_t ldc, coot_stream_t stream);
+int coot_ln_fwd(const float* x, int R, int D, const float* gain, const float* bias, void* y_bf16, float* y_f32,
+                coot_stream_t stream);
+int coot_attn_fwd(const void* qkv, int Nseq, int L, int H, int dh, const int64_t* lens, void* out, float* lse,
+                  coot_stream_t stream);
+/* HIP-event timing of every gemm_nt launch (the dominant kernel) while enabled; collect() synchronises the
+ * recorded events and returns summed duration [ms], algorithmic flops (2*M*N*K) and launch count.
+ * only_big_k != 0 restricts to the input-FC instances (K >= 1024). */
+int coot_timing_enable(int on);
+int coot_timing_collect(int only_big_k, double* ms, double* flops, int* launches);
+/* probe of ds_read_b64_tr_b16: out[64*4] = what each lane reads from a 16x64 bf16 LDS tile holding its own index */
+int coot_probe_tr16(uint16_t* out, coot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COOT_HIP_H */

@@ -1,0 +1,305 @@
+"""Path-level parity on the MI355X: networks, encode_visual/encode_text, losses and gradients through the
+C ABI vs the oracle (exact fp64 and bf16-emulating) and vs the reference-generated golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import coot_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import coot_videotext_amd as cva
+    assert torch.cuda.is_available()
+    cva.lib.load()
+    return torch, cva
+
+
+def _inputs(cfg, N, L, seed, with_ctx):
+    rs = np.random.RandomState(seed)
+    lens = rs.randint(1, L + 1, size=N)
+    lens[0] = L
+    x = rs.randn(N, L, cfg.input_dim)
+    x[np.arange(L)[None, :] >= lens[:, None]] = 0
+    hid = rs.randn(N, cfg.hidden_dim) if with_ctx else None
+    R = rs.randn(N, cfg.hidden_dim * (2 if with_ctx else 1))
+    return x, lens, hid, R
+
+
+SMALL_LOCAL = O.NetConfig(input_dim=40, hidden_dim=64, num_heads=4, ff_dim=64, pool_hidden=128, pool_heads=2)
+SMALL_LOCAL2 = O.NetConfig(input_dim=48, hidden_dim=96, num_heads=2, ff_dim=64, pool_hidden=96, pool_heads=2, num_layers=2)
+SMALL_GLOBAL = O.NetConfig(input_dim=64, hidden_dim=64, num_heads=4, ff_dim=64, use_input_fc=False, use_context=True,
+                           pooler="avg_special")
+ANET_LOCAL = O.NetConfig(input_dim=2048, hidden_dim=384, num_heads=8, ff_dim=384, pool_hidden=768, pool_heads=2)
+ANET_GLOBAL = O.NetConfig(input_dim=384, hidden_dim=384, num_heads=8, ff_dim=384, use_input_fc=False, use_context=True,
+                          pooler="avg_special")
+
+
+@pytest.mark.parametrize("name,cfg,N,L,with_ctx", [
+    ("small_local", SMALL_LOCAL, 5, 7, False), ("small_local_2layer", SMALL_LOCAL2, 4, 70, False),
+    ("small_global", SMALL_GLOBAL, 4, 5, True), ("anet_local", ANET_LOCAL, 6, 80, False),
+    ("anet_global", ANET_GLOBAL, 5, 9, True)])
+def test_net_fwd_bwd(env, name, cfg, N, L, with_ctx):
+    torch, cva = env
+    P = O.make_params(cfg, 11)
+    x, lens, hid, R = _inputs(cfg, N, L, 12, with_ctx)
+    pooled_o, tok_o, cache = O.net_fwd(P, cfg, x, lens, hid)
+    pooled_e, tok_e, _ = O.net_fwd(P, cfg, x, lens, hid, O.BF16)
+    G, dhid_o, dx_o = O.net_bwd(P, cfg, R, cache, need_dfeats=True)
+
+    net = H.make_hip_net(cfg, P).eval()
+    xt = torch.from_numpy(x).float().cuda().requires_grad_(not cfg.use_input_fc)
+    ht = torch.from_numpy(hid).float().cuda().requires_grad_(True) if with_ctx else None
+    mask = torch.from_numpy(np.arange(L)[None, :] >= lens[:, None]).cuda()
+    pooled, tok = net(xt, mask, torch.from_numpy(lens).cuda(), ht)
+    (pooled * torch.from_numpy(R).float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    pg, tg = pooled.detach().cpu().numpy(), tok.detach().cpu().numpy()
+    cos_exact = H.cosine_rows(pg, pooled_o).min()
+    err_emu = H.rel_err(pg, pooled_e)
+    err_tok = H.rel_err(tg, tok_e)
+    print(f"[{name}] pooled: cos vs fp64 oracle {cos_exact:.6f}, rel err vs bf16-emulating oracle {err_emu:.2e}, tokens {err_tok:.2e}")
+    assert cos_exact > 1 - 1e-3            # north_star tolerance
+    assert err_emu < 2e-2 and err_tok < 3e-2  # same rounding points -> much tighter than bf16 drift
+    # gradients (dropout off): cosine per parameter vs the fp64 oracle
+    worst = 1.0
+    for (pname, p) in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = p.grad.detach().cpu().numpy()
+        c = H.cosine_flat(g, G[pname])
+        nr = np.linalg.norm(g) / max(np.linalg.norm(G[pname]), 1e-30)
+        worst = min(worst, c)
+        assert c > 0.995 and 0.97 < nr < 1.03, (name, pname, c, nr)
+    print(f"[{name}] worst parameter-gradient cosine {worst:.5f}")
+    if with_ctx:
+        assert H.cosine_flat(ht.grad.cpu().numpy(), dhid_o) > 0.995
+    if not cfg.use_input_fc:
+        valid = np.arange(L)[None, :] < lens[:, None]
+        assert H.cosine_flat(xt.grad.cpu().numpy()[valid], dx_o[valid]) > 0.995
+
+
+def _full(env, dims, B, counts, Ls, seed, q_tol):
+    torch, cva = env
+    dv, dt, hidden, heads, ff, ph = dims
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], seed + 10 * i) for i in range(4)]
+    b = O.make_batch(seed + 100, B, counts, *Ls, dv, dt, ragged=True, corr=0.5)
+    return cfgs, Ps, b
+
+
+def test_full_path_anet_golden(env, golden_dir):
+    """encode_visual + encode_text + losses + gradients at the paper's ActivityNet dims against the fixture the
+    unmodified reference produced (tests/golden/full_anet.npz)."""
+    torch, cva = env
+    g = dict(np.load(os.path.join(golden_dir, "full_anet.npz")))
+    seed, B, Lv, Lc, Lp, Ls, dv, dt, hidden, heads, ff, ph = [int(v) for v in g["meta"]]
+    cfgs = H.full_cfgs(dv, dt, hidden, heads, ff, ph)
+    Ps = [O.make_params(cfgs[i], seed + 10 * i) for i in range(4)]
+    b = O.make_batch(seed + 100, B, g["counts"], Lv, Lc, Lp, Ls, dv, dt, ragged=True, corr=0.5)
+    cfg, mgr = H.make_manager(cfgs, Ps)
+    mgr.set_all_models_eval()
+    trainer = cva.RetrievalTrainer(cfg, mgr, is_test=True)
+    batch = cva.synthetic.batch_from_numpy(b) if hasattr(cva, "synthetic") else None
+    if batch is None:
+        from importlib import import_module
+        batch = import_module("coot_videotext_amd.synthetic").batch_from_numpy(b)
+    vis = mgr.encode_visual(batch)
+    txt = mgr.encode_text(batch)
+    contr = trainer.compute_total_constrastive_loss(vis, txt)
+    ic = torch.from_numpy(g["cc_idx_clip"]).cuda()
+    isent = torch.from_numpy(g["cc_idx_sent"]).cuda()
+    cc = trainer.compute_cyclecons_loss(vis, txt, ic, isent)
+    (contr + cc).backward()
+    torch.cuda.synchronize()
+    for got, key in ((vis.vid_emb, "vid_emb"), (vis.clip_emb, "clip_emb"), (vis.vid_context, "vid_context"),
+                     (txt.par_emb, "par_emb"), (txt.sent_emb, "sent_emb"), (txt.par_context, "par_context")):
+        cos = H.cosine_rows(got.detach().cpu().numpy(), g[key]).min()
+        print(f"[golden] {key}: min cosine vs reference {cos:.6f}")
+        assert cos > 1 - 1e-3, (key, cos)
+    assert (vis.clip_emb_mask.cpu().numpy() == g["clip_emb_mask"]).all()
+    assert (vis.clip_emb_lens.cpu().numpy() == g["clip_emb_lens"]).all()
+    assert (txt.sent_emb_mask.cpu().numpy() == g["sent_emb_mask"]).all()
+    print(f"[golden] contrastive {float(contr):.5f} vs {float(g['contr_loss']):.5f}; cyclecons {float(cc):.6f} vs {float(g['cc_loss']):.6f}")
+    assert abs(float(contr) - float(g["contr_loss"])) < 2e-2
+    assert abs(float(cc) - float(g["cc_loss"])) < 0.05 * abs(float(g["cc_loss"])) + 1e-4
+    bad = []
+    for k in H.NET_KEYS:
+        for n, p in mgr.model_dict[k].named_parameters():
+            if not p.requires_grad:
+                continue
+            gn = float(g[f"gnorm:{k}:{n}"])
+            sub = p.grad.detach().cpu().numpy().reshape(-1)[::97]
+            c = H.cosine_flat(sub, g[f"gsub:{k}:{n}"])
+            nr = float(np.linalg.norm(p.grad.detach().cpu().numpy())) / max(gn, 1e-30)
+            if not (c > 0.98 and 0.95 < nr < 1.05):
+                bad.append((k, n, round(c, 4), round(nr, 4)))
+    assert not bad, bad
+    # R@K of these embeddings equals the reference's (north_star: +-0.1 R@K)
+    for (a, c2, tag) in ((vis.vid_emb, txt.par_emb, "vp"), (vis.clip_emb, txt.sent_emb, "cs")):
+        e1 = torch.nn.functional.normalize(a.detach()).cpu().numpy()
+        e2 = torch.nn.functional.normalize(c2.detach()).cpu().numpy()
+        r12, r21, s1 = cva.compute_retrieval(e1, e2)
+        got = np.array([r12[k] for k in ("r1", "r5", "r10")] + [r21[k] for k in ("r1", "r5", "r10")])
+        ref = g[f"ret_{tag}"][[0, 1, 2, 6, 7, 8]]
+        assert np.abs(got - ref).max() <= 0.1 + 1e-9, (tag, got, ref)
+
+
+def test_full_path_small_vs_oracle(env):
+    """Ragged small-dim case (d_head 16), all gradients against the fp64 oracle."""
+    torch, cva = env
+    from importlib import import_module
+    syn = import_module("coot_videotext_amd.synthetic")
+    dims = (40, 24, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 21 + 10 * i) for i in range(4)]
+    counts = [2, 1, 3, 2, 5]
+    b = O.make_batch(121, 5, counts, 9, 7, 8, 5, dims[0], dims[1], ragged=True, corr=0.5)
+    rs = np.random.RandomState(3)
+    ic = np.array([rs.randint(0, c) for c in counts])
+    isent = np.array([rs.randint(0, c) for c in counts])
+    vis_o, txt_o, contr_o, cc_o, Gs = H.oracle_full(cfgs, Ps, b, ic, isent)
+    cfg, mgr = H.make_manager(cfgs, Ps)
+    mgr.set_all_models_eval()
+    trainer = cva.RetrievalTrainer(cfg, mgr, is_test=True)
+    batch = syn.batch_from_numpy(b)
+    vis, txt = mgr.encode_visual(batch), mgr.encode_text(batch)
+    contr = trainer.compute_total_constrastive_loss(vis, txt)
+    cc = trainer.compute_cyclecons_loss(vis, txt, torch.from_numpy(ic).cuda(), torch.from_numpy(isent).cuda())
+    (contr + cc).backward()
+    torch.cuda.synchronize()
+    assert H.cosine_rows(vis.vid_emb.detach().cpu().numpy(), vis_o["global_emb"]).min() > 1 - 1e-3
+    assert H.cosine_rows(txt.sent_emb.detach().cpu().numpy(), txt_o["item_emb"]).min() > 1 - 1e-3
+    assert abs(float(contr) - contr_o) < 2e-2 and abs(float(cc) - cc_o) < 0.05 * abs(cc_o) + 1e-4
+    bad = []
+    for i, k in enumerate(H.NET_KEYS):
+        for n, p in mgr.model_dict[k].named_parameters():
+            if p.requires_grad:
+                c = H.cosine_flat(p.grad.detach().cpu().numpy(), Gs[i][n])
+                if c < 0.99:
+                    bad.append((k, n, round(c, 4)))
+    assert not bad, bad
+
+
+def test_losses_vs_oracle(env):
+    torch, cva = env
+    rs = np.random.RandomState(5)
+    nh, nl, dh_, dl = 37, 101, 128, 64
+    E = dict(vid_emb=rs.randn(nh, dh_), par_emb=rs.randn(nh, dh_), clip_emb=rs.randn(nl, dl), sent_emb=rs.randn(nl, dl),
+             vid_context=rs.randn(nh, dl), par_context=rs.randn(nh, dl))
+    for a, b2 in (("vid_emb", "par_emb"), ("clip_emb", "sent_emb"), ("vid_context", "par_context")):
+        E[b2] = 0.7 * E[a] + 0.7 * E[b2]  # correlated -> a realistic mix of violated / satisfied margins
+    w = dict(H.ANET_W, weight_context_internal=0.5)
+    loss_o, dE = O.total_contrastive_loss(E, w, 0.2)
+    cfg = cva.ContrastiveLossConfig(0.2, **{k: v for k, v in w.items()})
+    ts = {k: torch.from_numpy(v).float().cuda().requires_grad_(True) for k, v in E.items()}
+    loss = cva.total_contrastive_loss(cfg, ts["vid_emb"], ts["par_emb"], ts["clip_emb"], ts["sent_emb"], ts["vid_context"], ts["par_context"])
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f"contrastive {float(loss):.6f} vs oracle {loss_o:.6f}")
+    assert abs(float(loss) - loss_o) < 5e-3
+    for k in E:
+        assert H.cosine_flat(ts[k].grad.cpu().numpy(), dE[k]) > 0.995, k
+    # single-term module API on normalised inputs (ContrastiveLoss.forward)
+    a, b2 = O.l2_normalize(E["clip_emb"]), O.l2_normalize(E["sent_emb"])
+    l1, _, _ = O.contrastive_loss(a, b2, 0.2)
+    got = cva.ContrastiveLoss(0.2)(torch.from_numpy(a).float().cuda(), torch.from_numpy(b2).float().cuda())
+    assert abs(float(got) - l1) < 5e-3
+
+    # cycle consistency: per-position rows, sampled loss and gradients
+    B, Cc, Cs, D = 6, 7, 5, 64
+    clens, slens = np.array([7, 3, 1, 5, 2, 6]), np.array([5, 3, 1, 4, 2, 5])
+    clip = rs.randn(B, Cc, D) * 0.3
+    sent = rs.randn(B, Cs, D) * 0.3
+    clip[np.arange(Cc)[None, :] >= clens[:, None]] = 0
+    sent[np.arange(Cs)[None, :] >= slens[:, None]] = 0
+    cv, sv = np.arange(Cc)[None, :] < clens[:, None], np.arange(Cs)[None, :] < slens[:, None]
+    ic, isent = np.array([3, 2, 0, 4, 1, 5]), np.array([4, 0, 0, 3, 1, 2])
+    rows_c, rows_s = O.cycle_consistency_rows(clip, cv, sent, sv), O.cycle_consistency_rows(sent, sv, clip, cv)
+    lc, ls = O.cycle_consistency_loss(clip, cv, sent, sv, ic, isent)
+    dc, ds = O.cycle_consistency_bwd(clip, cv, sent, sv, ic, isent, 0.01)
+    ct = torch.from_numpy(clip).float().cuda().requires_grad_(True)
+    st = torch.from_numpy(sent).float().cuda().requires_grad_(True)
+    loss, rc, rsent = cva.cycle_consistency_loss(ct, torch.from_numpy(clens).cuda(), st, torch.from_numpy(slens).cuda(), 0.01,
+                                                 torch.from_numpy(ic).cuda(), torch.from_numpy(isent).cuda(), want_rows=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.abs(rc.cpu().numpy() - rows_c).max() < 1e-4 * max(1, rows_c.max())
+    assert np.abs(rsent.cpu().numpy() - rows_s).max() < 1e-4 * max(1, rows_s.max())
+    assert abs(float(loss) - 0.01 * (lc + ls)) < 1e-5 + 1e-4 * abs(0.01 * (lc + ls))
+    assert H.rel_err(ct.grad.cpu().numpy(), dc) < 1e-3 and H.rel_err(st.grad.cpu().numpy(), ds) < 1e-3
+
+
+def test_mask_semantics(env, golden_dir):
+    """tests_nntrainer/test_transformers.py:22-79: perturbing masked (padding) inputs must not change the outputs
+    at un-masked positions, nor the pooled embedding of a local network."""
+    torch, cva = env
+    cfg = SMALL_LOCAL
+    P = O.make_params(cfg, 3)
+    x, lens, _, _ = _inputs(cfg, 4, 9, 5, False)
+    net = H.make_hip_net(cfg, P).eval()
+    mask = torch.from_numpy(np.arange(9)[None, :] >= lens[:, None]).cuda()
+    x2 = x.copy()
+    x2[np.arange(9)[None, :] >= lens[:, None]] += 3.0
+    with torch.no_grad():
+        p0, t0 = net(torch.from_numpy(x).float().cuda(), mask, torch.from_numpy(lens).cuda(), None)
+        p1, t1 = net(torch.from_numpy(x2).float().cuda(), mask, torch.from_numpy(lens).cuda(), None)
+    valid = torch.from_numpy(np.arange(9)[None, :] < lens[:, None]).cuda()
+    assert torch.equal(p0, p1)
+    assert torch.equal(t0[valid], t1[valid])
+    assert not torch.equal(t0[~valid], t1[~valid]) or bool((~valid).sum() == 0)
+
+
+def test_train_steps_reduce_loss(env):
+    """A few optimisation steps with dropout ON (train mode) on a fixed synthetic batch: loss goes down and
+    stays finite; eval forward is deterministic."""
+    torch, cva = env
+    from importlib import import_module
+    syn = import_module("coot_videotext_amd.synthetic")
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.05)
+    mgr.set_all_models_train()
+    trainer = cva.RetrievalTrainer(cfg, mgr)
+    batch = syn.make_batch(7, 16, [1, 2, 3, 4] * 4, 12, 10, 9, 6, dims[0], dims[1], ragged=True)
+    losses = [float(trainer.train_step(batch)[0]) for _ in range(30)]
+    print("train losses", [round(l, 4) for l in losses[::5]])
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.05
+    mgr.set_all_models_eval()
+    with torch.no_grad():
+        a = mgr.encode_visual(batch).vid_emb
+        b = mgr.encode_visual(batch).vid_emb
+    assert torch.equal(a, b)
+
+
+def test_dropout_statistics(env):
+    """Train-mode forward differs from eval, different seeds differ, same seed repeats; the mean over many
+    seeds approaches the eval output (inverted dropout is unbiased to first order)."""
+    torch, cva = env
+    cfg = SMALL_LOCAL
+    P = O.make_params(cfg, 3)
+    x, lens, _, _ = _inputs(cfg, 6, 9, 5, False)
+    net = H.make_hip_net(cfg, P, dropout=0.1)
+    xt, lt = torch.from_numpy(x).float().cuda(), torch.from_numpy(lens).cuda()
+    with torch.no_grad():
+        net.eval()
+        pe_, _ = net(xt, None, lt, None)
+        net.train()
+        a, _ = net(xt, None, lt, None, seed=1)
+        a2, _ = net(xt, None, lt, None, seed=1)
+        b, _ = net(xt, None, lt, None, seed=2)
+        acc = torch.zeros_like(a)
+        n = 200
+        for s in range(n):
+            acc += net(xt, None, lt, None, seed=100 + s)[0]
+    assert torch.equal(a, a2) and not torch.equal(a, b) and not torch.equal(a, pe_)
+    dev = float((acc / n - pe_).abs().max() / pe_.abs().max())
+    print("dropout mean deviation", dev)
+    assert dev < 0.1
