@@ -125,3 +125,25 @@ def oracle_full(cfgs, Ps, b, idx_clip, idx_sent, q=O.EXACT, w=ANET_W, margin=0.2
         Gtl, Gtg = O.encode_side_bwd(Ps[2], cfgs[2], Ps[3], cfgs[3], ct, dE["par_emb"], dE["sent_emb"], dE["par_context"], dsr)
         Gs = [Gvl, Gvg, Gtl, Gtg]
     return vis, txt, contr, cc, Gs
+
+
+def grad_report(named_got, ref: dict, cos_min=0.99, ratio_tol=0.05):
+    """Compare parameter gradients with a reference.  Parameters whose true gradient is (numerically) zero
+    (e.g. key-projection bias, 2nd pooling bias: softmax shift invariance) are checked by magnitude only.
+    Returns (bad list, table string)."""
+    rows, bad = [], []
+    scale = max(float(np.linalg.norm(np.asarray(v, np.float64))) for v in ref.values())
+    for name, g in named_got:
+        r = np.asarray(ref[name], np.float64)
+        g = np.asarray(g, np.float64)
+        nr, ng = float(np.linalg.norm(r)), float(np.linalg.norm(g))
+        if nr < 1e-6 * scale:
+            ok = ng < 1e-3 * scale
+            rows.append(f"{name:90s} zero-grad  |got|={ng:.2e} |ref|={nr:.2e} {'ok' if ok else 'BAD'}")
+        else:
+            c = cosine_flat(g, r)
+            ok = c > cos_min and abs(ng / nr - 1) < ratio_tol
+            rows.append(f"{name:90s} cos={c:.5f} ratio={ng / nr:.4f} {'ok' if ok else 'BAD'}")
+        if not ok:
+            bad.append(rows[-1])
+    return bad, "\n".join(rows)

@@ -109,8 +109,8 @@ def test_ln_fwd(env, R, D):
     g, b = (1 + 0.1 * rs.randn(D)).astype(np.float32), (0.1 * rs.randn(D)).astype(np.float32)
     ref = ln_coot(x.astype(np.float64), g, b)
     y = torch.zeros(R, D, dtype=torch.float32, device="cuda")
-    cva.lib.check(lib.coot_ln_fwd(torch.from_numpy(x).cuda().data_ptr(), R, D, torch.from_numpy(g).cuda().data_ptr(),
-                                  torch.from_numpy(b).cuda().data_ptr(), None, y.data_ptr(), _sp(torch)), "ln_fwd")
+    dx, dg, db = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda(), torch.from_numpy(b).cuda()  # keep alive
+    cva.lib.check(lib.coot_ln_fwd(dx.data_ptr(), R, D, dg.data_ptr(), db.data_ptr(), None, y.data_ptr(), _sp(torch)), "ln_fwd")
     torch.cuda.synchronize()
     err = rel_err(y.cpu().numpy(), ref)
     assert err < 1e-5, err
@@ -136,7 +136,8 @@ def test_attn_fwd(env, Nseq, L, H, dh):
     dq = _dev_bf16(torch, qkv.reshape(Nseq * L, 3 * D))
     out = torch.zeros(Nseq * L, D, dtype=torch.int16, device="cuda")
     lse = torch.zeros(Nseq * L, H, dtype=torch.float32, device="cuda")
-    cva.lib.check(lib.coot_attn_fwd(dq.data_ptr(), Nseq, L, H, dh, torch.from_numpy(lens).cuda().data_ptr(), out.data_ptr(),
+    dlens = torch.from_numpy(lens).cuda()
+    cva.lib.check(lib.coot_attn_fwd(dq.data_ptr(), Nseq, L, H, dh, dlens.data_ptr(), out.data_ptr(),
                                     lse.data_ptr(), _sp(torch)), "attn_fwd")
     torch.cuda.synchronize()
     got = from_bf16_bits(out.cpu().numpy().view(np.uint16)).reshape(Nseq, L, D)
