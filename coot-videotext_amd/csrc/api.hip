@@ -169,8 +169,8 @@ struct Saved {
   bf16_t* cq_in = nullptr;
   bf16_t *hp = nullptr, *ap = nullptr, *s = nullptr; float *smax = nullptr, *ssum = nullptr, *pooled = nullptr;
 };
-static void layout_saved(const coot_net_config& c, int N, int Lseq, Arena& A, Saved& S) {
-  const size_t T = (size_t)N * Lseq, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
+static void layout_saved(const coot_net_config& c, int N, long Ttok, Arena& A, Saved& S) {
+  const size_t T = (size_t)Ttok, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
   if (c.use_input_fc) { S.xhat = A.get<bf16_t>(T * c.input_dim); S.h0 = A.get<bf16_t>(T * D); }
   S.z0 = A.get<bf16_t>(T * D);
   for (int i = 0; i < c.num_layers; ++i) {
@@ -203,8 +203,8 @@ struct Scratch {  // backward temporaries
   float *delta, *Mbuf, *cvec;
   bf16_t *c_dq, *c_dkv, *c_d1, *c_d2, *c_dh1, *c_dz1, *c_dr1, *c_dctx, *c_dqin; float* c_delta;
 };
-static void layout_scratch(const coot_net_config& c, int N, int Lseq, Arena& A, Scratch& S) {
-  const size_t T = (size_t)N * Lseq, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
+static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A, Scratch& S) {
+  const size_t T = (size_t)Ttok, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
   S.dzA = A.get<bf16_t>(T * D); S.dzB = A.get<bf16_t>(T * D); S.dr2 = A.get<bf16_t>(T * D); S.dr2m = A.get<bf16_t>(T * D);
   S.dh1 = A.get<bf16_t>(T * F); S.dz1 = A.get<bf16_t>(T * D); S.dr1 = A.get<bf16_t>(T * D); S.dctx = A.get<bf16_t>(T * D);
   S.dqkv = A.get<bf16_t>(T * 3 * D); S.delta = A.get<float>(T * H);
@@ -244,8 +244,44 @@ struct LayerBufs {
   bf16_t *ctx, *r1, *z1, *h1, *a1, *r2, *z2; float* lse;
 };
 
+// A network call processes up to two SEGMENTS of sequences through the same weights (e.g. the 64 whole
+// videos and their 256 clips of one batch, coot/model_retrieval.py:104 and :120): all token-level kernels
+// (GEMMs, LayerNorm, column sums) run once over the concatenated token matrix; only the kernels that see the
+// sequence structure (attention, pooling, positional encoding) are segment aware.
+struct Segs {
+  int n = 1; int N[2] = {0, 0}; int L[2] = {0, 0}; const long long* lens[2] = {nullptr, nullptr};
+  int Ntot() const { return N[0] + (n > 1 ? N[1] : 0); }
+  int T() const { return N[0] * L[0] + (n > 1 ? N[1] * L[1] : 0); }
+};
+
+// self-attention over every segment (rows of segment s start at sum_{s'<s} N*L), or one cross-attention
+// (context block: one query row per sequence) when `cross`
+static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipStream_t st) {
+  if (cross) {
+    COOT_REQUIRE(sg.n == 1, "context networks take a single segment");
+    a.lens = sg.lens[0]; a.Nseq = sg.N[0]; a.Lq = 1; a.Lk = sg.L[0];
+    return bwd ? launch_attn_bwd(a, st) : launch_attn_fwd(a, st);
+  }
+  long row = 0;
+  const AttnArgs base = a;
+  for (int s = 0; s < sg.n; ++s) {
+    a = base;
+    a.q = base.q + row * base.ldq; a.k = base.k + row * base.ldk; a.v = base.v + row * base.ldv; a.o = base.o + row * base.ldo;
+    a.lse = base.lse + row * base.H;
+    if (bwd) {
+      a.dout = base.dout + row * base.lddo; a.delta = base.delta + row * base.H;
+      a.dq = base.dq + row * base.lddq; a.dk = base.dk + row * base.lddk; a.dv = base.dv + row * base.lddv;
+    }
+    a.lens = sg.lens[s]; a.Nseq = sg.N[s]; a.Lq = sg.L[s]; a.Lk = sg.L[s];
+    a.drop.seed = base.drop.seed + (unsigned long long)s * 0x9E3779B97F4A7C15ull;
+    RUN(bwd ? launch_attn_bwd(a, st) : launch_attn_fwd(a, st));
+    row += (long)sg.N[s] * sg.L[s];
+  }
+  return 0;
+}
+
 static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp, const LayerW& lw, const bf16_t* xq, int rows_q,
-                     int Lq, const bf16_t* xkv, int rows_kv, int Lk, int Nseq, const long long* lens, const LayerBufs& b,
+                     const bf16_t* xkv, int rows_kv, const Segs& sg, const LayerBufs& b,
                      float* z2_f32, long ldz2_f32, float pdrop, int train, uint64_t seed, unsigned site_base, hipStream_t st) {
   const int D = c.hidden_dim, F = c.ff_dim, H = c.num_heads, dh = D / H;
   const bool self = (xq == xkv);
@@ -262,9 +298,9 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
     RUN(launch_gemm_nt(g2, st));
   }
   AttnArgs a; a.q = b.q; a.ldq = b.ldq; a.k = b.k; a.ldk = b.ldk; a.v = b.v; a.ldv = b.ldv; a.o = b.ctx; a.ldo = D; a.lse = b.lse;
-  a.lens = lens; a.Nseq = Nseq; a.Lq = Lq; a.Lk = Lk; a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+  a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
   a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
-  RUN(launch_attn_fwd(a, st));
+  RUN(attention_all(a, sg, !self, false, st));
   {
     GemmNT g; g.X = b.ctx; g.ldx = D; g.W = lw.wo_nk; g.ldw = D; g.M = rows_q; g.N = D; g.K = D;
     g.epi.bias = P + lp.bo; g.epi.res = xq; g.epi.ldres = D; g.epi.out = b.r1; g.epi.ldc = D;
@@ -300,7 +336,7 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
 struct LayerBwdBufs { bf16_t *dr2, *dr2m, *dh1, *dz1, *dr1, *dctx, *dq; long lddq; bf16_t* dk; long lddk; bf16_t* dv; long lddv; float* delta; };
 
 static int layer_bwd(const coot_net_config& c, const float* P, float* G, const LayerP& lp, const LayerW& lw, const bf16_t* xq,
-                     int rows_q, int Lq, const bf16_t* xkv, int rows_kv, int Lk, int Nseq, const long long* lens,
+                     int rows_q, const bf16_t* xkv, int rows_kv, const Segs& sg,
                      const LayerBufs& b, const LayerBwdBufs& w, const bf16_t* dz2, const float* dz2_f32, long lddz2_f32,
                      bf16_t* dxq, float* dxq_f32, bf16_t* dxkv_accum, const bf16_t* gelu_aux, float* gelu_colsum, float pdrop,
                      int train, uint64_t seed, unsigned site_base, hipStream_t st) {
@@ -339,10 +375,10 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
   }
   { GemmTN t; t.A = w.dr1; t.lda = D; t.B = b.ctx; t.ldb = D; t.T = rows_q; t.Mo = D; t.No = D; t.C = G + lp.wo; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
   AttnArgs a; a.q = b.q; a.ldq = b.ldq; a.k = b.k; a.ldk = b.ldk; a.v = b.v; a.ldv = b.ldv; a.o = b.ctx; a.ldo = D; a.lse = b.lse;
-  a.lens = lens; a.Nseq = Nseq; a.Lq = Lq; a.Lk = Lk; a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+  a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
   a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
   a.dout = w.dctx; a.lddo = D; a.delta = w.delta; a.dq = w.dq; a.lddq = w.lddq; a.dk = w.dk; a.lddk = w.lddk; a.dv = w.dv; a.lddv = w.lddv;
-  RUN(launch_attn_bwd(a, st));
+  RUN(attention_all(a, sg, !self, true, st));
   if (self) {
     RUN(launch_colsum_bf16(w.dq, 3 * D, rows_q, 3 * D, G + lp.bq, st));
     { GemmTN t; t.A = w.dq; t.lda = 3 * D; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = 3 * D; t.No = D; t.C = G + lp.wqkv; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
@@ -429,19 +465,28 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
   NetLayout L; build_layout(c, L);
   Arena A(wpack, (size_t)-1); WPack W; layout_wpack(c, A, W);
   const int D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
+  PackJobs jobs;
+  auto flush = [&]() -> int { int rc = launch_pack_jobs(P, wpack, jobs, st); jobs.n = 0; return rc; };
+  auto add = [&](int64_t src_off, long lds, int R, int Cc, bf16_t* dst, long ldd, int transpose, int64_t colscale_off) -> int {
+    if (jobs.n == 56) RUN(flush());
+    PackJob& j = jobs.j[jobs.n++];
+    j.src_off = src_off; j.dst_byte_off = (char*)dst - (char*)wpack; j.R = R; j.C = Cc; j.lds = lds; j.ldd = ldd;
+    j.transpose = transpose; j.colscale_off = colscale_off;
+    return 0;
+  };
   if (c.use_input_fc) {
-    RUN(launch_cast_weight(P + L.in_w, Din, D, Din, W.in_w, Din, 0, P + L.n_gain, st));
+    RUN(add(L.in_w, Din, D, Din, W.in_w, Din, 0, L.n_gain));  // W * gain: LN affine folded into the FC
     RUN(launch_matvec_bias(P + L.in_w, Din, D, Din, P + L.n_bias, P + L.in_b, W.in_bias, st));
   }
   auto pack_layer = [&](const LayerP& lp, const LayerW& lw) -> int {
-    RUN(launch_cast_weight(P + lp.wqkv, D, 3 * D, D, lw.wqkv_nk, D, 0, nullptr, st));
-    RUN(launch_cast_weight(P + lp.wqkv, D, 3 * D, D, lw.wqkv_kn, 3 * D, 1, nullptr, st));
-    RUN(launch_cast_weight(P + lp.wo, D, D, D, lw.wo_nk, D, 0, nullptr, st));
-    RUN(launch_cast_weight(P + lp.wo, D, D, D, lw.wo_kn, D, 1, nullptr, st));
-    RUN(launch_cast_weight(P + lp.w1, D, F, D, lw.w1_nk, D, 0, nullptr, st));
-    RUN(launch_cast_weight(P + lp.w1, D, F, D, lw.w1_kn, F, 1, nullptr, st));
-    RUN(launch_cast_weight(P + lp.w2, F, D, F, lw.w2_nk, F, 0, nullptr, st));
-    RUN(launch_cast_weight(P + lp.w2, F, D, F, lw.w2_kn, D, 1, nullptr, st));
+    RUN(add(lp.wqkv, D, 3 * D, D, lw.wqkv_nk, D, 0, -1));
+    RUN(add(lp.wqkv, D, 3 * D, D, lw.wqkv_kn, 3 * D, 1, -1));
+    RUN(add(lp.wo, D, D, D, lw.wo_nk, D, 0, -1));
+    RUN(add(lp.wo, D, D, D, lw.wo_kn, D, 1, -1));
+    RUN(add(lp.w1, D, F, D, lw.w1_nk, D, 0, -1));
+    RUN(add(lp.w1, D, F, D, lw.w1_kn, F, 1, -1));
+    RUN(add(lp.w2, F, D, F, lw.w2_nk, F, 0, -1));
+    RUN(add(lp.w2, F, D, F, lw.w2_kn, D, 1, -1));
     return 0;
   };
   for (int i = 0; i < c.num_layers; ++i) RUN(pack_layer(L.layers[i], W.layers[i]));
@@ -450,59 +495,69 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
     const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
     for (int h = 0; h < H; ++h) {
       // W1[h]: [D, dhp].  nk: rows (h*dhp + e) = W1[h][:, e]  -> [PH, D].  kn: [D, PH] with row d = concat_h W1[h][d][:]
-      RUN(launch_cast_weight(P + L.pw1 + (size_t)h * D * dhp, dhp, D, dhp, W.pw1_nk + (size_t)h * dhp * D, D, 1, nullptr, st));
-      RUN(launch_cast_weight(P + L.pw1 + (size_t)h * D * dhp, dhp, D, dhp, W.pw1_kn + (size_t)h * dhp, PH, 0, nullptr, st));
+      RUN(add(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.pw1_nk + (size_t)h * dhp * D, D, 1, -1));
+      RUN(add(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.pw1_kn + (size_t)h * dhp, PH, 0, -1));
       // W2[h]: [dhp, dop].  nk (fwd): [dop, dhp] per head.  kn (dX): natural [dhp, dop] per head
-      RUN(launch_cast_weight(P + L.pw2 + (size_t)h * dhp * dop, dop, dhp, dop, W.pw2_nk + (size_t)h * dop * dhp, dhp, 1, nullptr, st));
-      RUN(launch_cast_weight(P + L.pw2 + (size_t)h * dhp * dop, dop, dhp, dop, W.pw2_kn + (size_t)h * dhp * dop, dop, 0, nullptr, st));
+      RUN(add(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.pw2_nk + (size_t)h * dop * dhp, dhp, 1, -1));
+      RUN(add(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.pw2_kn + (size_t)h * dhp * dop, dop, 0, -1));
     }
   }
+  RUN(flush());
   return 0;
 }
 
-size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int Lseq) {
+size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int Lseq, int N2, int L2) {
   coot_net_config c; if (norm_cfg(cfg, &c)) return 0;
-  Arena A(nullptr, 0); Saved S; layout_saved(c, N, Lseq, A, S); return A.off + 256;
+  Arena A(nullptr, 0); Saved S; layout_saved(c, N + N2, (long)N * Lseq + (long)N2 * L2, A, S); return A.off + 256;
 }
-size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int Lseq) {
+size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int Lseq, int N2, int L2) {
   coot_net_config c; if (norm_cfg(cfg, &c)) return 0;
-  Arena A(nullptr, 0); Scratch S; layout_scratch(c, N, Lseq, A, S); return A.off + 256;
+  Arena A(nullptr, 0); Scratch S; layout_scratch(c, N + N2, (long)N * Lseq + (long)N2 * L2, A, S); return A.off + 256;
 }
 
 int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, const float* pe, const float* feats,
-                 const int64_t* lengths, int N, int Lseq, const float* hidden, float* pooled, float* per_token, void* saved,
+                 const int64_t* lengths, int N, int Lseq, const float* feats2, const int64_t* lengths2, int N2, int L2,
+                 const float* hidden, float* pooled, float* per_token, void* saved,
                  size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed, coot_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   coot_net_config c; RUN(norm_cfg(cfg, &c));
   COOT_REQUIRE(P && wpack && pe && feats && lengths && pooled && saved, "net_fwd: null pointer");
   COOT_REQUIRE(!c.use_context || hidden, "net_fwd: context network needs hidden state (transformer_legacy.py:252)");
-  COOT_REQUIRE(Lseq <= 1000, "net_fwd: sequence length %d exceeds positional table (max_len 1000)", Lseq);
+  COOT_REQUIRE(Lseq <= 1000 && L2 <= 1000, "net_fwd: sequence length %d exceeds positional table (max_len 1000)", Lseq);
   if (N <= 0) return 0;
+  Segs sg; sg.N[0] = N; sg.L[0] = Lseq; sg.lens[0] = (const long long*)lengths;
+  if (N2 > 0) {
+    COOT_REQUIRE(feats2 && lengths2 && !c.use_context && !per_token, "net_fwd: second segment needs feats2/lengths2 (local networks, no per-token output)");
+    sg.n = 2; sg.N[1] = N2; sg.L[1] = L2; sg.lens[1] = (const long long*)lengths2;
+  }
+  const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
-  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, N, Lseq, AS, S);
+  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.T(), AS, S);
   COOT_REQUIRE(!AS.overflow, "net_fwd: saved buffer too small (%zu < %zu)", saved_bytes, AS.off);
-  const int D = c.hidden_dim, T = N * Lseq, Din = c.input_dim;
-  const long long* lens = (const long long*)lengths;
+  const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim, T0 = N * Lseq;
   const int out_dim = D * (c.use_context ? 2 : 1);
 
   if (c.use_input_fc) {
-    LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T; l.D = Din; l.y = S.xhat; l.ldy = Din;
+    LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T0; l.D = Din; l.y = S.xhat; l.ldy = Din;
     RUN(launch_ln_fwd(l, st));
+    if (sg.n > 1) { l.x = feats2; l.R = T - T0; l.y = S.xhat + (size_t)T0 * Din; RUN(launch_ln_fwd(l, st)); }
     GemmNT g; g.X = S.xhat; g.ldx = Din; g.W = W.in_w; g.ldw = Din; g.M = T; g.N = D; g.K = Din;
     g.epi.bias = W.in_bias; g.epi.act = 1; g.epi.save_pre = S.h0; g.epi.ldpre = D; g.epi.pe = pe; g.epi.pe_L = Lseq;
+    g.epi.pe_T0 = T0; g.epi.pe_L2 = sg.n > 1 ? L2 : Lseq;
     g.epi.out = S.z0; g.epi.ldc = D;
     RUN(launch_gemm_nt(g, st));
   } else {
-    LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T; l.D = Din; l.gain = P + L.n_gain; l.bias = P + L.n_bias;
+    LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T0; l.D = Din; l.gain = P + L.n_gain; l.bias = P + L.n_bias;
     l.pe = pe; l.pe_L = Lseq; l.y = S.z0; l.ldy = D;
     RUN(launch_ln_fwd(l, st));
+    if (sg.n > 1) { l.x = feats2; l.R = T - T0; l.pe_L = L2; l.y = S.z0 + (size_t)T0 * D; RUN(launch_ln_fwd(l, st)); }
   }
   const bf16_t* z = S.z0;
   for (int i = 0; i < c.num_layers; ++i) {
     LayerBufs b = self_bufs(S.layers[i], D);
     const bool last = (i == c.num_layers - 1);
-    RUN(layer_fwd(c, P, L.layers[i], W.layers[i], z, T, Lseq, z, T, Lseq, N, lens, b, last ? per_token : nullptr, D, c.dropout,
+    RUN(layer_fwd(c, P, L.layers[i], W.layers[i], z, T, z, T, sg, b, last ? per_token : nullptr, D, c.dropout,
                   train, seed, 16u * i, st));
     z = S.layers[i].z2;
   }
@@ -512,7 +567,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     for (int i = 0; i < c.ctx_num_layers; ++i) {
       LayerBufs b = ctx_bufs(S.ctx[i], D);
       const bool last = (i == c.ctx_num_layers - 1);
-      RUN(layer_fwd(c, P, L.ctx[i], W.ctx[i], cq, N, 1, z, T, Lseq, N, lens, b, last ? pooled + D : nullptr, out_dim, c.ctx_dropout,
+      RUN(layer_fwd(c, P, L.ctx[i], W.ctx[i], cq, N, z, T, sg, b, last ? pooled + D : nullptr, out_dim, c.ctx_dropout,
                     train, seed, 16u * (8 + i), st));
       cq = S.ctx[i].z2;
     }
@@ -532,18 +587,26 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       epi_drop(g.epi, mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2), D);
       RUN(launch_gemm_nt(g, st));
     }
-    PoolArgs p; p.s = S.s; p.lds = D; p.z = z; p.ldz = D; p.lens = lens; p.N = N; p.L = Lseq; p.D = D; p.pooled = pooled; p.ldp = out_dim;
-    p.pooled_copy = S.pooled; p.smax = S.smax; p.ssum = S.ssum; p.drop_w = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL3);
-    RUN(launch_pool_fwd(p, st));
+    long row = 0; int n0 = 0;
+    for (int sidx = 0; sidx < sg.n; ++sidx) {
+      PoolArgs p; p.s = S.s + row * D; p.lds = D; p.z = z + row * D; p.ldz = D; p.lens = sg.lens[sidx]; p.N = sg.N[sidx]; p.L = sg.L[sidx];
+      p.D = D; p.pooled = pooled + (size_t)n0 * out_dim; p.ldp = out_dim;
+      p.pooled_copy = S.pooled + (size_t)n0 * D; p.smax = S.smax + (size_t)n0 * D; p.ssum = S.ssum + (size_t)n0 * D;
+      p.drop_w = mkdrop(train, c.pool_dropout, seed + 977u * sidx, 16u * 15 + SITE_POOL3);
+      RUN(launch_pool_fwd(p, st));
+      row += (long)sg.N[sidx] * sg.L[sidx]; n0 += sg.N[sidx];
+    }
   } else {
-    RUN(launch_avgpool_fwd(z, D, lens, N, Lseq, D, pooled, out_dim, st));
+    COOT_REQUIRE(sg.n == 1, "avg_special networks take a single segment");
+    RUN(launch_avgpool_fwd(z, D, sg.lens[0], N, Lseq, D, pooled, out_dim, st));
   }
   (void)scratch; (void)scratch_bytes;
   return 0;
 }
 
 int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, const float* pe, const float* feats,
-                 const int64_t* lengths, int N, int Lseq, const float* hidden, const float* dpooled, float* G, float* dhidden,
+                 const int64_t* lengths, int N, int Lseq, const float* feats2, const int64_t* lengths2, int N2, int L2,
+                 const float* hidden, const float* dpooled, float* G, float* dhidden,
                  float* dfeats, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed,
                  coot_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -551,14 +614,20 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   COOT_REQUIRE(P && wpack && feats && lengths && dpooled && G && saved && scratch, "net_bwd: null pointer");
   COOT_REQUIRE(!(dfeats && c.use_input_fc), "net_bwd: dfeats is only available for networks without input_fc");
   if (N <= 0) return 0;
+  Segs sg; sg.N[0] = N; sg.L[0] = Lseq; sg.lens[0] = (const long long*)lengths;
+  if (N2 > 0) {
+    COOT_REQUIRE(feats2 && lengths2 && !c.use_context && !dfeats, "net_bwd: second segment only for local networks");
+    sg.n = 2; sg.N[1] = N2; sg.L[1] = L2; sg.lens[1] = (const long long*)lengths2;
+  }
+  const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
-  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, N, Lseq, AS, S);
+  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.T(), AS, S);
   COOT_REQUIRE(!AS.overflow, "net_bwd: saved buffer too small");
-  Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, N, Lseq, AX, X);
+  Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, Ntot, sg.T(), AX, X);
   COOT_REQUIRE(!AX.overflow, "net_bwd: scratch buffer too small (%zu < %zu)", scratch_bytes, AX.off);
-  const int D = c.hidden_dim, T = N * Lseq, Din = c.input_dim;
-  const long long* lens = (const long long*)lengths;
+  const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim;
+  const long long* lens = sg.lens[0];
   const int out_dim = D * (c.use_context ? 2 : 1);
   const bf16_t* zL = S.layers[c.num_layers - 1].z2;
   bf16_t* dz = X.dzA;     // grad wrt the last layer's output tokens
@@ -566,12 +635,17 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
 
   if (c.pooler == 0) {
     const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
-    PoolArgs p; p.s = S.s; p.lds = D; p.z = zL; p.ldz = D; p.lens = lens; p.N = N; p.L = Lseq; p.D = D;
-    p.pooled = S.pooled; p.ldp = D; p.smax = S.smax; p.ssum = S.ssum;
-    p.drop_w = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL3);
-    p.drop_s = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2); p.drop_s_ld = D;
-    p.dpooled = dpooled; p.lddp = out_dim; p.ds = X.ds; p.ldds = D; p.dz = X.dzp; p.lddz = D; p.ds_colsum = G + L.pb2;
-    RUN(launch_pool_bwd(p, st));
+    long row = 0; int n0 = 0;
+    for (int sidx = 0; sidx < sg.n; ++sidx) {
+      PoolArgs p; p.s = S.s + row * D; p.lds = D; p.z = zL + row * D; p.ldz = D; p.lens = sg.lens[sidx]; p.N = sg.N[sidx]; p.L = sg.L[sidx];
+      p.D = D; p.pooled = S.pooled + (size_t)n0 * D; p.ldp = D; p.smax = S.smax + (size_t)n0 * D; p.ssum = S.ssum + (size_t)n0 * D;
+      p.drop_w = mkdrop(train, c.pool_dropout, seed + 977u * sidx, 16u * 15 + SITE_POOL3);
+      p.drop_s = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2); p.drop_s_ld = D; p.drop_s_row0 = row;
+      p.dpooled = dpooled + (size_t)n0 * out_dim; p.lddp = out_dim; p.ds = X.ds + row * D; p.ldds = D; p.dz = X.dzp + row * D; p.lddz = D;
+      p.ds_colsum = G + L.pb2;
+      RUN(launch_pool_bwd(p, st));
+      row += (long)sg.N[sidx] * sg.L[sidx]; n0 += sg.N[sidx];
+    }
     { GemmTN t; t.A = S.ap; t.lda = PH; t.B = X.ds; t.ldb = D; t.T = T; t.Mo = dhp; t.No = dop; t.C = G + L.pw2; t.ldc = dop;
       t.groups = H; t.zA = dhp; t.zB = dop; t.zC = (long)dhp * dop; RUN(launch_gemm_tn(t, st)); }
     {  // dhp = (ds_h . W2[h]^T) * gelu'(hp) * drop1 ; db1p = colsum
@@ -589,6 +663,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       RUN(launch_gemm_nt(g, st));
     }
   } else {
+    COOT_REQUIRE(sg.n == 1, "avg_special networks take a single segment");
     RUN(launch_avgpool_bwd(dpooled, out_dim, lens, N, Lseq, D, dz, D, st));
   }
 
@@ -601,7 +676,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       const bf16_t* qin = i == 0 ? S.cq_in : S.ctx[i - 1].z2;
       const bool last = (i == c.ctx_num_layers - 1);
       const bool first = (i == 0);
-      RUN(layer_bwd(c, P, G, L.ctx[i], W.ctx[i], qin, N, 1, zL, T, Lseq, N, lens, b, w, last ? nullptr : X.c_dqin,
+      RUN(layer_bwd(c, P, G, L.ctx[i], W.ctx[i], qin, N, zL, T, sg, b, w, last ? nullptr : X.c_dqin,
                     last ? dpooled + D : nullptr, out_dim, first ? nullptr : X.c_dqin, first ? dhidden : nullptr, dz, nullptr, nullptr,
                     c.ctx_dropout, train, seed, 16u * (8 + i), st));
     }
@@ -614,7 +689,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     const bf16_t* zin = i == 0 ? S.z0 : S.layers[i - 1].z2;
     const bool fc0 = (i == 0 && c.use_input_fc);
     if (fc0) RUN(launch_fill_f32(X.cvec, D, 0.f, st));
-    RUN(layer_bwd(c, P, G, L.layers[i], W.layers[i], zin, T, Lseq, zin, T, Lseq, N, lens, b, w, dz, nullptr, 0, dz_other, nullptr, nullptr,
+    RUN(layer_bwd(c, P, G, L.layers[i], W.layers[i], zin, T, zin, T, sg, b, w, dz, nullptr, 0, dz_other, nullptr, nullptr,
                   fc0 ? S.h0 : nullptr, fc0 ? X.cvec : nullptr, c.dropout, train, seed, 16u * i, st));
     bf16_t* t = dz; dz = dz_other; dz_other = t;
   }

@@ -14,7 +14,8 @@ struct GemmEpi {
   bf16_t* save_pre = nullptr; long ldpre = 0;      // store v before activation (bf16)
   const bf16_t* res = nullptr; long ldres = 0;     // + residual (bf16)
   const float* res32 = nullptr; long ldres32 = 0;  // + residual (fp32)
-  const float* pe = nullptr; int pe_L = 1;         // + pe[(row % pe_L) * N + col]
+  const float* pe = nullptr; int pe_L = 1;         // + pe[pos * N + col], pos = row % pe_L (rows < pe_T0)
+  int pe_T0 = 0x7fffffff; int pe_L2 = 1;           //                      pos = (row - pe_T0) % pe_L2 (second segment)
   const float* rowscale = nullptr; const bf16_t* diag_src = nullptr; long lddiag = 0;  // + rowscale[row]*diag_src[row][col]
   float* colsum = nullptr;                         // atomicAdd column sums of the final value
   // dropout applied to (alpha*acc + bias) [act 0/1] or to the final product [act 2]

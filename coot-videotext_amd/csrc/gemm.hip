@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
         for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
       }
       if (e.pe) {
-        const float* pp = e.pe + (long)(row % e.pe_L) * N + col;
+        const int pos = row < e.pe_T0 ? row % e.pe_L : (row - e.pe_T0) % e.pe_L2;
+        const float* pp = e.pe + (long)pos * N + col;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += pp[j];
       }

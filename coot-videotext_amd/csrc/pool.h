@@ -21,6 +21,7 @@ struct PoolArgs {
   bf16_t* dz = nullptr; long lddz = 0;       // partial grad wrt z (direct path)
   float* ds_colsum = nullptr;                // [D] atomics (bias grad of the 2nd pooling FC)
   DropCfg drop_s; long drop_s_ld = 0;        // dropout2 mask (same indexing as the GEMM epilogue)
+  long drop_s_row0 = 0;                      // global row index of this segment's first token
 };
 int launch_pool_fwd(const PoolArgs& p, hipStream_t stream);
 int launch_pool_bwd(const PoolArgs& p, hipStream_t stream);

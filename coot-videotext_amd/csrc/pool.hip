@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs p) {
       ds1 = w1 * (g1 * bfhi(f) * d31 - gp1);
       dz0 = g0 * w0 * d30; dz1 = g1 * w1 * d31;
       if (p.drop_s.thr) {
-        unsigned long long idx = (unsigned long long)(r0 + l) * p.drop_s_ld + c;
+        unsigned long long idx = (unsigned long long)(p.drop_s_row0 + r0 + l) * p.drop_s_ld + c;
         ds0 *= drop_scale(p.drop_s.seed, p.drop_s.site, idx, p.drop_s.thr, p.drop_s.inv_keep);
         ds1 *= drop_scale(p.drop_s.seed, p.drop_s.site, idx + 1, p.drop_s.thr, p.drop_s.inv_keep);
       }

@@ -43,6 +43,11 @@ int launch_colsum_bf16(const bf16_t* x, long ldx, int R, int C, float* out, hipS
 int launch_cast_weight(const float* src, long lds, int R, int C, bf16_t* dst, long ldd, int transpose,
                        const float* colscale, hipStream_t stream);
 
+// many cast/transpose jobs in ONE launch (the whole bf16 weight pack of a network)
+struct PackJob { long src_off; long dst_byte_off; int R, C; long lds, ldd; int transpose; long colscale_off; };
+struct PackJobs { int n = 0; PackJob j[56]; };
+int launch_pack_jobs(const float* P, void* wpack, const PackJobs& jobs, hipStream_t stream);
+
 // out[n] = b[n] + sum_k W[n,k] * v[k]   (tiny mat-vec; used for the folded input-FC bias)
 int launch_matvec_bias(const float* W, long ldw, int N, int K, const float* v, const float* b, float* out,
                        hipStream_t stream);

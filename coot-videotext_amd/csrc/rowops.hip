@@ -240,6 +240,47 @@ int launch_cast_weight(const float* src, long lds, int R, int C, bf16_t* dst, lo
   return 0;
 }
 
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const float* P, char* wpack, PackJobs jobs) {
+  __shared__ float tile[32][33];
+  const PackJob& jb = jobs.j[blockIdx.y];
+  const int tiles_x = (jb.C + 31) / 32, tiles_y = (jb.R + 31) / 32;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x % tiles_x) * 32, r0 = (blockIdx.x / tiles_x) * 32;
+  const float* src = P + jb.src_off;
+  const float* colscale = jb.colscale_off >= 0 ? P + jb.colscale_off : nullptr;
+  bf16_t* dst = reinterpret_cast<bf16_t*>(wpack + jb.dst_byte_off);
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < jb.R && c < jb.C) { v = src[(long)r * jb.lds + c]; if (colscale) v *= colscale[c]; }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (!jb.transpose) {
+    for (int i = ty; i < 32; i += 8) {
+      int r = r0 + i, c = c0 + tx;
+      if (r < jb.R && c < jb.C) dst[(long)r * jb.ldd + c] = f2bf(tile[i][tx]);
+    }
+  } else {
+    for (int i = ty; i < 32; i += 8) {
+      int c = c0 + i, r = r0 + tx;
+      if (r < jb.R && c < jb.C) dst[(long)c * jb.ldd + r] = f2bf(tile[tx][i]);
+    }
+  }
+}
+int launch_pack_jobs(const float* P, void* wpack, const PackJobs& jobs, hipStream_t stream) {
+  if (jobs.n <= 0) return 0;
+  int max_tiles = 1;
+  for (int i = 0; i < jobs.n; ++i) {
+    int t = ((jobs.j[i].C + 31) / 32) * ((jobs.j[i].R + 31) / 32);
+    if (t > max_tiles) max_tiles = t;
+  }
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3(max_tiles, jobs.n), dim3(256), 0, stream, P, (char*)wpack, jobs);
+  COOT_CHECK_LAUNCH("pack_jobs");
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void matvec_bias_kernel(const float* W, long ldw, int N, int K, const float* v, const float* b, float* out) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -257,26 +298,27 @@ int launch_matvec_bias(const float* W, long ldw, int N, int K, const float* v, c
   return 0;
 }
 
-// thread per column k, loop over n (N = 384 rows): coalesced along k
+// thread = one column k for a slab of 32 rows n: coalesced along k; dg0/db0 partials via atomics
 __global__ __launch_bounds__(256) void infc_param_grads_kernel(const float* M, const float* W, const float* g0, const float* b0,
                                                                const float* c, int N, int K, float* dW, float* dg0, float* db0) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= K) return;
+  const int n0 = blockIdx.y * 32, n1 = min(N, n0 + 32);
   const float g = g0[k], b = b0[k];
   float sg = 0.f, sb = 0.f;
-  for (int n = 0; n < N; ++n) {
+  for (int n = n0; n < n1; ++n) {
     const float m = M[(long)n * K + k], w = W[(long)n * K + k], cn = c[n];
     dW[(long)n * K + k] += m * g + cn * b;
     sg += w * m;
     sb += cn * w;
   }
-  dg0[k] += sg;
-  db0[k] += sb;
+  atomicAdd(dg0 + k, sg);
+  atomicAdd(db0 + k, sb);
 }
 
 int launch_infc_param_grads(const float* M, const float* W, const float* g0, const float* b0, const float* c,
                             int N, int K, float* dW, float* dg0, float* db0, hipStream_t stream) {
-  hipLaunchKernelGGL(infc_param_grads_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, M, W, g0, b0, c, N, K, dW, dg0, db0);
+  hipLaunchKernelGGL(infc_param_grads_kernel, dim3((K + 255) / 256, (N + 31) / 32), dim3(256), 0, stream, M, W, g0, b0, c, N, K, dW, dg0, db0);
   COOT_CHECK_LAUNCH("infc_param_grads");
   return 0;
 }

@@ -69,11 +69,11 @@ def load():
     lib.coot_net_wpack_bytes.argtypes = [cfgp]
     lib.coot_net_pack_weights.argtypes = [cfgp, vp, vp, vp]
     lib.coot_net_saved_bytes.restype = sz
-    lib.coot_net_saved_bytes.argtypes = [cfgp, i32, i32]
+    lib.coot_net_saved_bytes.argtypes = [cfgp, i32, i32, i32, i32]
     lib.coot_net_scratch_bytes.restype = sz
-    lib.coot_net_scratch_bytes.argtypes = [cfgp, i32, i32]
-    lib.coot_net_fwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp]
-    lib.coot_net_bwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp]
+    lib.coot_net_scratch_bytes.argtypes = [cfgp, i32, i32, i32, i32]
+    lib.coot_net_fwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp]
+    lib.coot_net_bwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp]
     lib.coot_pack_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.coot_pack_bwd.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.coot_contrastive_scratch_bytes.restype = sz

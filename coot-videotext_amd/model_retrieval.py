@@ -142,8 +142,9 @@ class RetrievalModelManager:
     # ---- coot/model_retrieval.py:86-197 --------------------------------------------------------------------
     def _encode(self, net_local, net_global, ctx_feat, ctx_mask, ctx_len, item_feat, item_mask, item_len, item_num,
                 cmax: Optional[int]):
-        context, _ = net_local(ctx_feat, ctx_mask, ctx_len, None, want_tokens=False)
-        item_emb, _ = net_local(item_feat, item_mask, item_len, None, want_tokens=False)
+        # both passes through the local network share one call (same weights): every GEMM / LayerNorm launch
+        # covers the video-level AND the clip-level tokens
+        context, item_emb = net_local.forward_pair(ctx_feat, ctx_len, item_feat, item_len)
         if cmax is None:
             cmax = int(torch.max(item_num))
         if self.global_max_fn is not None:

@@ -68,6 +68,7 @@ class TransformerHip(nn.Module):
         self._wpack: Optional[torch.Tensor] = None
         self._dirty = True
         self._grad_flat: Optional[torch.Tensor] = None
+        self.accumulate_into_flat = False  # set by RetrievalTrainer.train_step (see _NetFn.backward)
         self.call_counter = 0
         self.init_network(cfg.weight_init_type, cfg.weight_init_std)
 
@@ -133,16 +134,23 @@ class TransformerHip(nn.Module):
                 p.grad = self._grad_flat[off:off + p.numel()].view(shape)
         return self._grad_flat
 
+    def _param_version(self) -> int:
+        return sum(p._version for p in self._params)
+
     def ensure_packed(self) -> torch.Tensor:
+        """(Re)build the bf16 weight pack when the fp32 parameters changed (in-place optimizer updates bump the
+        tensors' version counters) — once per optimizer step, two kernel launches."""
         lib = _lib.load()
         if self._wpack is None:
             nbytes = lib.coot_net_wpack_bytes(C.byref(self.c_cfg))
             self._wpack = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
             self._dirty = True
-        if self._dirty or self.training:
+        ver = self._param_version()
+        if self._dirty or ver != getattr(self, "_packed_version", None):
             _lib.check(lib.coot_net_pack_weights(C.byref(self.c_cfg), _lib.ptr(self._flat), _lib.ptr(self._wpack),
                                                  _lib.stream_ptr()), "coot_net_pack_weights")
             self._dirty = False
+            self._packed_version = ver
         return self._wpack
 
     # ---- forward ----------------------------------------------------------------------------------------
@@ -150,6 +158,18 @@ class TransformerHip(nn.Module):
                 hidden_state: Optional[torch.Tensor], want_tokens: bool = True, seed: Optional[int] = None):
         """Reference signature (transformer_legacy.py:200-215).  `mask` (True = padding) must be
         consistent with `lengths`; the kernels use `lengths`."""
+        pooled, tokens = self._run(features, lengths, None, None, hidden_state, want_tokens, seed)
+        return pooled, tokens
+
+    def forward_pair(self, features: torch.Tensor, lengths: torch.Tensor, features2: torch.Tensor, lengths2: torch.Tensor,
+                     seed: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Two sets of sequences through the same weights in ONE call (video frames + clip frames of a batch,
+        coot/model_retrieval.py:104,:120).  Returns (pooled_1 [N1, D], pooled_2 [N2, D])."""
+        pooled, _ = self._run(features, lengths, features2, lengths2, None, False, seed)
+        n1 = features.shape[0]
+        return pooled[:n1], pooled[n1:]
+
+    def _run(self, features, lengths, features2, lengths2, hidden_state, want_tokens, seed):
         if not features.is_cuda:
             raise RuntimeError("TransformerHip runs on an MI355X only (features must be a cuda tensor); "
                                "there is no CPU fallback")
@@ -159,31 +179,38 @@ class TransformerHip(nn.Module):
         if seed is None:
             self.call_counter += 1
             seed = (torch.initial_seed() * 1000003 + self.call_counter) & 0xFFFFFFFFFFFFFFFF
-        pooled, tokens = _NetFn.apply(self, features, lengths, hidden_state, bool(want_tokens), int(seed), *self._params)
-        return pooled, tokens
+        return _NetFn.apply(self, features, lengths, features2, lengths2, hidden_state, bool(want_tokens), int(seed),
+                            *self._params)
 
 
 class _NetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net: TransformerHip, feats, lengths, hidden, want_tokens, seed, *params):
+    def forward(ctx, net: TransformerHip, feats, lengths, feats2, lengths2, hidden, want_tokens, seed, *params):
         lib = _lib.load()
         cfg = net.c_cfg
         feats = feats.contiguous().float()
         lengths = lengths.contiguous().long()
         N, L, Din = feats.shape
         assert Din == net.cfg.input_dim, (Din, net.cfg.input_dim)
+        N2 = L2 = 0
+        if feats2 is not None:
+            feats2 = feats2.contiguous().float()
+            lengths2 = lengths2.contiguous().long()
+            N2, L2, Din2 = feats2.shape
+            assert Din2 == Din
         dev = feats.device
         hid = hidden.contiguous().float() if hidden is not None else None
-        pooled = torch.empty(N, net.output_dim, dtype=torch.float32, device=dev)
+        pooled = torch.empty(N + N2, net.output_dim, dtype=torch.float32, device=dev)
         tokens = torch.empty(N, L, net.cfg.hidden_dim, dtype=torch.float32, device=dev) if want_tokens else None
-        saved = torch.empty(lib.coot_net_saved_bytes(C.byref(cfg), N, L), dtype=torch.uint8, device=dev)
+        saved = torch.empty(lib.coot_net_saved_bytes(C.byref(cfg), N, L, N2, L2), dtype=torch.uint8, device=dev)
         train = 1 if net.training else 0
         pe = net.embedding.pe
         _lib.check(lib.coot_net_fwd(C.byref(cfg), _lib.ptr(net._flat), _lib.ptr(net._wpack), _lib.ptr(pe), _lib.ptr(feats),
-                                    _lib.ptr(lengths), N, L, _lib.ptr(hid), _lib.ptr(pooled), _lib.ptr(tokens),
-                                    _lib.ptr(saved), saved.numel(), None, 0, train, seed, _lib.stream_ptr()), "coot_net_fwd")
+                                    _lib.ptr(lengths), N, L, _lib.ptr(feats2), _lib.ptr(lengths2), N2, L2, _lib.ptr(hid),
+                                    _lib.ptr(pooled), _lib.ptr(tokens), _lib.ptr(saved), saved.numel(), None, 0, train, seed,
+                                    _lib.stream_ptr()), "coot_net_fwd")
         ctx.net, ctx.saved, ctx.seed, ctx.train = net, saved, seed, train
-        ctx.feats, ctx.lengths, ctx.hid = feats, lengths, hid
+        ctx.feats, ctx.lengths, ctx.hid, ctx.feats2, ctx.lengths2 = feats, lengths, hid, feats2, lengths2
         ctx.need_dfeats = bool(ctx.needs_input_grad[1])
         ctx.need_dhid = hidden is not None
         ctx.mark_non_differentiable(*([tokens] if tokens is not None else []))
@@ -194,24 +221,32 @@ class _NetFn(torch.autograd.Function):
         lib = _lib.load()
         net: TransformerHip = ctx.net
         cfg = net.c_cfg
-        feats, lengths, hid = ctx.feats, ctx.lengths, ctx.hid
+        feats, lengths, hid, feats2, lengths2 = ctx.feats, ctx.lengths, ctx.hid, ctx.feats2, ctx.lengths2
         N, L, Din = feats.shape
+        N2, L2 = (feats2.shape[0], feats2.shape[1]) if feats2 is not None else (0, 0)
         dev = feats.device
         dpooled = dpooled.contiguous().float()
-        gflat = torch.zeros(net.numel, dtype=torch.float32, device=dev)
+        # gradient sink: the network's persistent flat arena (train_step; param.grad are views of it) or a
+        # fresh zeroed arena whose views are returned to autograd (generic drop-in use)
+        direct = net.accumulate_into_flat and net._grad_flat is not None
+        gflat = net._grad_flat if direct else torch.zeros(net.numel, dtype=torch.float32, device=dev)
         dhid = torch.empty(N, net.cfg.hidden_dim, dtype=torch.float32, device=dev) if ctx.need_dhid else None
         dfeats = None
         if ctx.need_dfeats:
             if net.cfg.use_input_fc:
                 raise RuntimeError("gradient wrt input features is only available for networks without input_fc")
             dfeats = torch.empty_like(feats)
-        scratch = torch.empty(lib.coot_net_scratch_bytes(C.byref(cfg), N, L), dtype=torch.uint8, device=dev)
+        scratch = torch.empty(lib.coot_net_scratch_bytes(C.byref(cfg), N, L, N2, L2), dtype=torch.uint8, device=dev)
         _lib.check(lib.coot_net_bwd(C.byref(cfg), _lib.ptr(net._flat), _lib.ptr(net._wpack), _lib.ptr(net.embedding.pe),
-                                    _lib.ptr(feats), _lib.ptr(lengths), N, L, _lib.ptr(hid), _lib.ptr(dpooled), _lib.ptr(gflat),
-                                    _lib.ptr(dhid), _lib.ptr(dfeats), _lib.ptr(ctx.saved), ctx.saved.numel(), _lib.ptr(scratch),
-                                    scratch.numel(), ctx.train, ctx.seed, _lib.stream_ptr()), "coot_net_bwd")
-        grads = tuple(gflat[off:off + math.prod(shape)].view(shape) for (_, off, shape) in net.table)
-        return (None, dfeats, None, dhid, None, None) + grads
+                                    _lib.ptr(feats), _lib.ptr(lengths), N, L, _lib.ptr(feats2), _lib.ptr(lengths2), N2, L2,
+                                    _lib.ptr(hid), _lib.ptr(dpooled), _lib.ptr(gflat), _lib.ptr(dhid), _lib.ptr(dfeats),
+                                    _lib.ptr(ctx.saved), ctx.saved.numel(), _lib.ptr(scratch), scratch.numel(), ctx.train,
+                                    ctx.seed, _lib.stream_ptr()), "coot_net_bwd")
+        if direct:
+            grads = (None,) * len(net.table)
+        else:
+            grads = tuple(gflat[off:off + math.prod(shape)].view(shape) for (_, off, shape) in net.table)
+        return (None, dfeats, None, None, None, dhid, None, None) + grads
 
 
 class _PackFn(torch.autograd.Function):

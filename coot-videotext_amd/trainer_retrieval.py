@@ -84,8 +84,9 @@ class RetrievalTrainer:
         caller's choice).  With ``self.dp`` set (dist.DataParallelContext) the batch is this rank's shard."""
         nets = list(self.model_mgr.model_dict.values())
         flat_grads = [net.bind_flat_grads() for net in nets]
-        for g in flat_grads:
+        for net, g in zip(nets, flat_grads):
             g.zero_()
+            net.accumulate_into_flat = True  # backward kernels accumulate straight into the flat arenas
         visual_data = self.model_mgr.encode_visual(batch)
         text_data = self.model_mgr.encode_text(batch)
         dp = getattr(self, "dp", None)
@@ -104,6 +105,8 @@ class RetrievalTrainer:
                     loss_fn.sample_cycle_indices(text_data.sent_emb_lens, self.cc_generator), global_batch=global_b)
         loss = contr_loss + cc_loss
         loss.backward()
+        for net in nets:
+            net.accumulate_into_flat = False
         if dp is not None:
             dp.allreduce_grads(flat_grads, getattr(self, "comm_stream", None))
         self.optimizer.step()

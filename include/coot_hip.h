@@ -65,16 +65,21 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* params, void*
  * pooled [N, out_dim] fp32; per_token [N, L, hidden_dim] fp32 or NULL.
  * `saved` carries activations from fwd to bwd (coot_net_saved_bytes), `scratch` is temporary
  * (coot_net_scratch_bytes).  train != 0 enables dropout with the given seed. */
-size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int L);
-size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int L);
+size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int L, int N2, int L2);
+size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int L, int N2, int L2);
+/* Optional SECOND SEGMENT (feats2 [N2, L2, input_dim], lengths2 [N2]; N2 = 0 / NULL when unused): a second set
+ * of sequences pushed through the same network in the same call (the reference calls net_video_local twice
+ * per step, coot/model_retrieval.py:104 and :120).  pooled then holds N + N2 rows (segment 1 first). */
 int coot_net_fwd(const coot_net_config* cfg, const float* params, const void* wpack, const float* pe,
-                 const float* feats, const int64_t* lengths, int N, int L, const float* hidden,
+                 const float* feats, const int64_t* lengths, int N, int L, const float* feats2,
+                 const int64_t* lengths2, int N2, int L2, const float* hidden,
                  float* pooled, float* per_token, void* saved, size_t saved_bytes, void* scratch,
                  size_t scratch_bytes, int train, uint64_t seed, coot_stream_t stream);
 /* grads: flat fp32 arena, ACCUMULATED (+=).  dhidden [N, hidden_dim] (written) or NULL.
  * dfeats [N, L, input_dim] fp32 (written; only supported when use_input_fc == 0) or NULL. */
 int coot_net_bwd(const coot_net_config* cfg, const float* params, const void* wpack, const float* pe,
-                 const float* feats, const int64_t* lengths, int N, int L, const float* hidden,
+                 const float* feats, const int64_t* lengths, int N, int L, const float* feats2,
+                 const int64_t* lengths2, int N2, int L2, const float* hidden,
                  const float* dpooled, float* grads, float* dhidden, float* dfeats, void* saved,
                  size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed,
                  coot_stream_t stream);
