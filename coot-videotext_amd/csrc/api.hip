@@ -200,7 +200,7 @@ static void layout_saved(const coot_net_config& c, int N, long Ttok, Arena& A, S
 
 struct Scratch {  // backward temporaries
   bf16_t *dzA, *dzB, *dr2, *dr2m, *dh1, *dz1, *dr1, *dctx, *dqkv, *ds, *dhp, *dzp;
-  float *delta, *Mbuf, *cvec;
+  float *delta, *Mbuf, *cvec, *tn_ws; size_t tn_ws_floats;
   bf16_t *c_dq, *c_dkv, *c_d1, *c_d2, *c_dh1, *c_dz1, *c_dr1, *c_dctx, *c_dqin; float* c_delta;
 };
 static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A, Scratch& S) {
@@ -211,6 +211,17 @@ static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A,
   S.ds = nullptr; S.dhp = nullptr; S.dzp = nullptr; S.Mbuf = nullptr; S.cvec = nullptr;
   if (c.pooler == 0) { S.ds = A.get<bf16_t>(T * D); S.dhp = A.get<bf16_t>(T * c.pool_hidden); S.dzp = A.get<bf16_t>(T * D); }
   if (c.use_input_fc) { S.Mbuf = A.get<float>(D * c.input_dim); S.cvec = A.get<float>(D); }
+  {
+    size_t w = gemm_tn_workspace_floats((int)T, 3 * (int)D, (int)D, 1);
+    auto mx = [&](size_t v) { if (v > w) w = v; };
+    mx(gemm_tn_workspace_floats((int)T, (int)D, (int)F, 1)); mx(gemm_tn_workspace_floats((int)T, (int)F, (int)D, 1));
+    if (c.use_input_fc) mx(gemm_tn_workspace_floats((int)T, (int)D, c.input_dim, 1));
+    if (c.pooler == 0) {
+      const int Hh = c.pool_heads, dhp = c.pool_hidden / Hh, dop = (int)D / Hh;
+      mx(gemm_tn_workspace_floats((int)T, dhp, dop, Hh)); mx(gemm_tn_workspace_floats((int)T, (int)D, dhp, Hh));
+    }
+    S.tn_ws_floats = w; S.tn_ws = A.get<float>(w);
+  }
   if (c.use_context) {
     const size_t n = N;
     S.c_dq = A.get<bf16_t>(n * D); S.c_dkv = A.get<bf16_t>(T * 2 * D); S.c_d1 = A.get<bf16_t>(n * D); S.c_d2 = A.get<bf16_t>(n * D);
@@ -626,6 +637,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   COOT_REQUIRE(!AS.overflow, "net_bwd: saved buffer too small");
   Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, Ntot, sg.T(), AX, X);
   COOT_REQUIRE(!AX.overflow, "net_bwd: scratch buffer too small (%zu < %zu)", scratch_bytes, AX.off);
+  struct TnWs { TnWs(float* p, size_t n) { set_tn_default_workspace(p, n); } ~TnWs() { set_tn_default_workspace(nullptr, 0); } } tnws(X.tn_ws, X.tn_ws_floats);
   const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim;
   const long long* lens = sg.lens[0];
   const int out_dim = D * (c.use_context ? 2 : 1);

@@ -158,9 +158,11 @@ int coot_gemm_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, int M, 
   g.epi.out_f32 = out_f32;
   return launch_gemm_nt(g, (hipStream_t)stream);
 }
+size_t coot_gemm_tn_workspace_bytes(int T, int Mo, int No) { return gemm_tn_workspace_floats(T, Mo, No, 1) * sizeof(float); }
 int coot_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int T, int Mo, int No, float* C, int64_t ldc,
-                 coot_stream_t stream) {
+                 void* workspace, size_t workspace_bytes, coot_stream_t stream) {
   GemmTN t; t.A = (const bf16_t*)A; t.lda = lda; t.B = (const bf16_t*)B; t.ldb = ldb; t.T = T; t.Mo = Mo; t.No = No; t.C = C; t.ldc = ldc;
+  t.ws = (float*)workspace; t.ws_floats = workspace_bytes / sizeof(float);
   return launch_gemm_tn(t, (hipStream_t)stream);
 }
 int coot_ln_fwd(const float* x, int R, int D, const float* gain, const float* bias, void* y_bf16, float* y_f32, coot_stream_t stream) {

@@ -43,9 +43,13 @@ struct GemmTN {
   float alpha = 1.0f;
   float* C = nullptr; long ldc = 0;  // fp32 [Mo, No], accumulated with atomics
   int groups = 1; long zA = 0, zB = 0, zC = 0;
+  float* ws = nullptr; size_t ws_floats = 0;  // optional split-reduction workspace (else the thread's default / atomics)
 };
 
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream);
+size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups);
+// default workspace used by launch_gemm_tn when GemmTN::ws is null (set by the orchestrator for one call)
+void set_tn_default_workspace(float* ws, size_t floats);
 
 // per-launch HIP-event timing of gemm_nt (bench roofline leg)
 void gemm_timing_enable(int on);

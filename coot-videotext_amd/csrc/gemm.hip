@@ -1,12 +1,15 @@
 // bf16 MFMA GEMM kernels for gfx950 (wave64, v_mfma_f32_16x16x32_bf16).
 //
-// Tile: BM tokens x 128 features x 64 K per step, 256 threads = 4 waves (2 x 2), each wave
-// owns (BM/2) x 64 of the output as 16x16 MFMA fragments.  The WEIGHT rows are the MFMA
-// A-operand and the TOKEN rows the B-operand, so one lane's 4 accumulator registers are 4
-// consecutive output features of one token -> 8/16-byte epilogue stores.
-// Operands go HBM -> registers -> LDS (register staged, double-buffered LDS, one barrier per
-// K step); rows are padded to 80 elements (160 B) which makes every ds_read_b128 fragment read
-// bank-conflict free (checked against the gfx950 lane-group table).
+// Main loop: tile BM tokens x 128 features x 64 K per step, 256 threads = 4 waves (2 x 2), each wave owns
+// (BM/2) x 64 of the output as 16x16 MFMA fragments.  Operands go HBM -> registers -> LDS (register staged,
+// double-buffered LDS, one barrier per K step); rows are padded to 80 elements (160 B) which makes every
+// ds_read_b128 fragment read bank-conflict free (checked against the gfx950 lane-group table).
+//
+// Epilogue: the fp32 accumulator tile is staged through LDS (the operand buffers are dead by then) so that
+// every global access of the fused epilogue (bias, residual, saved pre-activation, GELU', output) is a
+// 16-byte, row-contiguous access: a lane owns 8 consecutive features of one token.  The straightforward
+// "store what the MFMA layout gives you" epilogue (8-byte stores in 32-byte runs) cost more than the K loop
+// at K = 384 (profiles/README.md).
 #include "gemm.h"
 
 namespace coot {
@@ -14,6 +17,7 @@ namespace coot {
 constexpr int BN = 128;
 constexpr int BK = 64;
 constexpr int PITCH = BK + 16;  // elements; 160 B rows
+constexpr int CPITCH = BN + 4;  // floats; epilogue staging tile rows (528 B: conflict-free b128 writes)
 
 __device__ __forceinline__ u32x4_t load16_guard(const bf16_t* p, bool ok) {
   u32x4_t z = {0u, 0u, 0u, 0u};
@@ -21,13 +25,92 @@ __device__ __forceinline__ u32x4_t load16_guard(const bf16_t* p, bool ok) {
   return z;
 }
 
+__device__ __forceinline__ void unpack8(u32x4_t u, float* v) {
+  v[0] = bflo(u[0]); v[1] = bfhi(u[0]); v[2] = bflo(u[1]); v[3] = bfhi(u[1]);
+  v[4] = bflo(u[2]); v[5] = bfhi(u[2]); v[6] = bflo(u[3]); v[7] = bfhi(u[3]);
+}
+__device__ __forceinline__ u32x4_t pack8(const float* v) {
+  return u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+
+// Fused epilogue on 8 consecutive features [col, col+8) of token `row`; v = raw accumulators.
+__device__ __forceinline__ void epilogue8(const GemmEpi& e, float* v, int row, int col, long zo, int N, const float* bias8) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + bias8[j];
+  float dsc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dsc[j] = 1.f;
+  if (e.drop_thr) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      dsc[j] = drop_scale(e.drop_seed, e.drop_site, (unsigned long long)row * e.drop_ld + zo + col + j, e.drop_thr, e.drop_inv_keep);
+    if (e.act != 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= dsc[j];
+    }
+  }
+  if (e.save_pre) *reinterpret_cast<u32x4_t*>(e.save_pre + (long)row * e.ldpre + zo + col) = pack8(v);
+  if (e.act == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+  }
+  if (e.pe) {
+    const int pos = row < e.pe_T0 ? row % e.pe_L : (row - e.pe_T0) % e.pe_L2;
+    const f32x4_t* pp = reinterpret_cast<const f32x4_t*>(e.pe + (long)pos * N + col);
+    f32x4_t p0 = pp[0], p1 = pp[1];
+    v[0] += p0[0]; v[1] += p0[1]; v[2] += p0[2]; v[3] += p0[3]; v[4] += p1[0]; v[5] += p1[1]; v[6] += p1[2]; v[7] += p1[3];
+  }
+  if (e.res) {
+    float r[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(e.res + (long)row * e.ldres + zo + col), r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += r[j];
+  }
+  if (e.res32) {
+    const f32x4_t* rp = reinterpret_cast<const f32x4_t*>(e.res32 + (long)row * e.ldres32 + zo + col);
+    f32x4_t r0 = rp[0], r1 = rp[1];
+    v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3]; v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
+  }
+  if (e.rowscale) {
+    const float rsv = e.rowscale[row];
+    float d[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(e.diag_src + (long)row * e.lddiag + col), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += rsv * d[j];
+  }
+  if (e.act == 2) {  // backward through GELU (and its dropout), after the residual adds
+    float a[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(e.aux + (long)row * e.ldaux + zo + col), a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]) * dsc[j];
+  }
+  if (e.out_f32) {
+    f32x4_t* op = reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.out) + (long)row * e.ldc + zo + col);
+    if (e.accumulate) {
+      f32x4_t o0 = op[0], o1 = op[1];
+      op[0] = f32x4_t{o0[0] + v[0], o0[1] + v[1], o0[2] + v[2], o0[3] + v[3]};
+      op[1] = f32x4_t{o1[0] + v[4], o1[1] + v[5], o1[2] + v[6], o1[3] + v[7]};
+    } else {
+      op[0] = f32x4_t{v[0], v[1], v[2], v[3]};
+      op[1] = f32x4_t{v[4], v[5], v[6], v[7]};
+    }
+  } else {
+    *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(e.out) + (long)row * e.ldc + zo + col) = pack8(v);
+  }
+}
+
 template <int BM>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
-  constexpr int TM = BM / 32;      // token fragments per wave
+  constexpr int TM = BM / 32;        // token fragments per wave
   constexpr int XCH = BM * 8 / 256;  // 16-byte chunks per thread for the token tile
   constexpr int WCH = BN * 8 / 256;
-  __shared__ __attribute__((aligned(16))) bf16_t Xs[2][BM * PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t Ws[2][BN * PITCH];
+  constexpr int OPER_ELEMS = 2 * (BM + BN) * PITCH;                  // bf16 elements of the two double-buffered operands
+  constexpr int STAGE_ELEMS = BM * CPITCH * 2;                        // fp32 staging tile, in bf16 units
+  constexpr int SMEM_ELEMS = OPER_ELEMS > STAGE_ELEMS ? OPER_ELEMS : STAGE_ELEMS;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_ELEMS];
+  bf16_t* Xs = smem;                       // [2][BM * PITCH]
+  bf16_t* Ws = smem + 2 * BM * PITCH;      // [2][BN * PITCH]
+  float* Cs = reinterpret_cast<float*>(smem);  // [BM][CPITCH] (after the K loop)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -58,12 +141,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
       int c = tid + 256 * i, r = c >> 3, kc = (c & 7) * 8;
-      *reinterpret_cast<u32x4_t*>(&Xs[buf][r * PITCH + kc]) = xr[i];
+      *reinterpret_cast<u32x4_t*>(&Xs[buf * BM * PITCH + r * PITCH + kc]) = xr[i];
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       int c = tid + 256 * i, r = c >> 3, kc = (c & 7) * 8;
-      *reinterpret_cast<u32x4_t*>(&Ws[buf][r * PITCH + kc]) = wr[i];
+      *reinterpret_cast<u32x4_t*>(&Ws[buf * BN * PITCH + r * PITCH + kc]) = wr[i];
     }
   };
 
@@ -81,15 +164,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
+    const bf16_t* xb = Xs + buf * BM * PITCH;
+    const bf16_t* wb = Ws + buf * BN * PITCH;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       bf16x8_t xf[TM], wf[4];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        xf[a] = *reinterpret_cast<const bf16x8_t*>(&Xs[buf][(wm * (BM / 2) + a * 16 + frow) * PITCH + kk * 32 + fk]);
+        xf[a] = *reinterpret_cast<const bf16x8_t*>(&xb[(wm * (BM / 2) + a * 16 + frow) * PITCH + kk * 32 + fk]);
 #pragma unroll
       for (int b = 0; b < 4; ++b)
-        wf[b] = *reinterpret_cast<const bf16x8_t*>(&Ws[buf][(wn * 64 + b * 16 + frow) * PITCH + kk * 32 + fk]);
+        wf[b] = *reinterpret_cast<const bf16x8_t*>(&wb[(wn * 64 + b * 16 + frow) * PITCH + kk * 32 + fk]);
+      // weights = MFMA A operand, tokens = B operand: acc[a][b][j] = C[token a*16 + (lane&15)][feature b*16 + (lane>>4)*4 + j]
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -100,102 +186,51 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds token (lane&15) x 4 consecutive features ((lane>>4)*4 .. +3) ----
+  // ---- stage the accumulator tile through LDS: [BM][128] fp32 -------------------------------------------
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int r = wm * (BM / 2) + a * 16 + (lane & 15), c = wn * 64 + b * 16 + (lane >> 4) * 4;
+      *reinterpret_cast<f32x4_t*>(&Cs[r * CPITCH + c]) = acc[a][b];
+    }
+  __syncthreads();
+
+  // ---- fused epilogue, lane = 8 consecutive features of one token ---------------------------------------
   const GemmEpi& e = g.epi;
   const long zo = z * g.zOut;
-  float cs[4][4];
+  const int cch = tid & 15, rg = tid >> 4;
+  const int col = col0 + cch * 8;
+  const bool cok = col < N;  // N % 8 == 0 (launcher)
+  float bias8[8], csum[8];
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int j = 0; j < 8; ++j) { bias8[j] = 0.f; csum[j] = 0.f; }
+  if (cok && e.bias) {
+    const f32x4_t* bp = reinterpret_cast<const f32x4_t*>(e.bias + zo + col);
+    f32x4_t b0 = bp[0], b1 = bp[1];
+    bias8[0] = b0[0]; bias8[1] = b0[1]; bias8[2] = b0[2]; bias8[3] = b0[3];
+    bias8[4] = b1[0]; bias8[5] = b1[1]; bias8[6] = b1[2]; bias8[7] = b1[3];
+  }
+#pragma unroll 2
+  for (int i = 0; i < BM / 16; ++i) {
+    const int rl = rg + 16 * i, row = row0 + rl;
+    if (!cok || row >= M) continue;
+    float v[8];
+    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(&Cs[rl * CPITCH + cch * 8]);
+    const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(&Cs[rl * CPITCH + cch * 8 + 4]);
+    v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
+    epilogue8(e, v, row, col, zo, N, bias8);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cs[b][j] = 0.f;
-
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    const int row = row0 + wm * (BM / 2) + a * 16 + (lane & 15);
-    const bool rok = row < M;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int col = col0 + wn * 64 + b * 16 + (lane >> 4) * 4;
-      if (!rok || col >= N) continue;  // N % 4 == 0 is required by the launcher
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] * e.alpha;
-      if (e.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += e.bias[zo + col + j];
-      }
-      float dsc[4] = {1.f, 1.f, 1.f, 1.f};
-      if (e.drop_thr) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          dsc[j] = drop_scale(e.drop_seed, e.drop_site, (unsigned long long)row * e.drop_ld + zo + col + j,
-                              e.drop_thr, e.drop_inv_keep);
-        if (e.act != 2) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= dsc[j];
-        }
-      }
-      if (e.save_pre) {
-        u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *reinterpret_cast<u32x2_t*>(e.save_pre + (long)row * e.ldpre + zo + col) = pk;
-      }
-      if (e.act == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
-      }
-      if (e.pe) {
-        const int pos = row < e.pe_T0 ? row % e.pe_L : (row - e.pe_T0) % e.pe_L2;
-        const float* pp = e.pe + (long)pos * N + col;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += pp[j];
-      }
-      if (e.res) {
-        u32x2_t rx = *reinterpret_cast<const u32x2_t*>(e.res + (long)row * e.ldres + zo + col);
-        v[0] += bflo(rx[0]); v[1] += bfhi(rx[0]); v[2] += bflo(rx[1]); v[3] += bfhi(rx[1]);
-      }
-      if (e.res32) {
-        const float* rp = e.res32 + (long)row * e.ldres32 + zo + col;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += rp[j];
-      }
-      if (e.rowscale) {
-        const float rsv = e.rowscale[row];
-        u32x2_t dx = *reinterpret_cast<const u32x2_t*>(e.diag_src + (long)row * e.lddiag + col);
-        v[0] += rsv * bflo(dx[0]); v[1] += rsv * bfhi(dx[0]); v[2] += rsv * bflo(dx[1]); v[3] += rsv * bfhi(dx[1]);
-      }
-      if (e.act == 2) {  // backward through GELU (and its dropout): applied after the residual adds
-        u32x2_t ax = *reinterpret_cast<const u32x2_t*>(e.aux + (long)row * e.ldaux + zo + col);
-        v[0] *= gelu_grad_f(bflo(ax[0])) * dsc[0];
-        v[1] *= gelu_grad_f(bfhi(ax[0])) * dsc[1];
-        v[2] *= gelu_grad_f(bflo(ax[1])) * dsc[2];
-        v[3] *= gelu_grad_f(bfhi(ax[1])) * dsc[3];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cs[b][j] += v[j];
-      if (e.out_f32) {
-        float* op = reinterpret_cast<float*>(e.out) + (long)row * e.ldc + zo + col;
-        if (e.accumulate) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) op[j] += v[j];
-        } else {
-          *reinterpret_cast<f32x4_t*>(op) = f32x4_t{v[0], v[1], v[2], v[3]};
-        }
-      } else {
-        u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(e.out) + (long)row * e.ldc + zo + col) = pk;
-      }
-    }
+    for (int j = 0; j < 8; ++j) csum[j] += v[j];
   }
   if (e.colsum) {
+    // lanes l, l+16, l+32, l+48 of a wave hold the same feature chunk
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int col = col0 + wn * 64 + b * 16 + (lane >> 4) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float s = cs[b][j];
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-        if ((lane & 15) == 0 && col + j < N) atomicAdd(e.colsum + zo + col + j, s);
-      }
+    for (int j = 0; j < 8; ++j) {
+      float s = csum[j];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 16 && cok) atomicAdd(e.colsum + zo + col + j, s);
     }
   }
 }
@@ -230,9 +265,12 @@ static TimingSlot* timing_begin(const GemmNT& g, hipStream_t stream) {
 
 int launch_gemm_nt(const GemmNT& g, hipStream_t stream) {
   COOT_REQUIRE(g.X && g.W && g.epi.out, "gemm_nt: null operand");
-  COOT_REQUIRE(g.K % 8 == 0 && g.ldx % 8 == 0 && g.ldw % 8 == 0, "gemm_nt: K/ldx/ldw must be multiples of 8 (K=%d ldx=%ld ldw=%ld)", g.K, g.ldx, g.ldw);
-  COOT_REQUIRE(g.N % 4 == 0 && g.epi.ldc % 4 == 0 && g.zOut % 4 == 0, "gemm_nt: N/ldc must be multiples of 4 (N=%d ldc=%ld)", g.N, g.epi.ldc);
+  COOT_REQUIRE(g.K % 8 == 0 && g.ldx % 8 == 0 && g.ldw % 8 == 0 && g.zX % 8 == 0 && g.zW % 8 == 0,
+               "gemm_nt: K/ldx/ldw must be multiples of 8 (K=%d ldx=%ld ldw=%ld)", g.K, g.ldx, g.ldw);
+  COOT_REQUIRE(g.N % 8 == 0 && g.epi.ldc % 8 == 0 && g.zOut % 8 == 0, "gemm_nt: N/ldc must be multiples of 8 (N=%d ldc=%ld)", g.N, g.epi.ldc);
   COOT_REQUIRE(!(g.epi.accumulate && !g.epi.out_f32), "gemm_nt: accumulate needs fp32 out");
+  COOT_REQUIRE(g.epi.ldres % 8 == 0 && g.epi.ldaux % 8 == 0 && g.epi.ldpre % 8 == 0 && g.epi.ldres32 % 4 == 0 && g.epi.lddiag % 8 == 0,
+               "gemm_nt: epilogue strides must be multiples of 8");
   if (g.M <= 0 || g.N <= 0) return 0;
   const int nb = (g.N + BN - 1) / BN;
   // small-M problems: halve the token tile to get more workgroups onto the 256 CUs
@@ -252,32 +290,36 @@ int launch_gemm_nt(const GemmNT& g, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------
 // TN: C[Mo,No] += alpha * sum_t A[t,Mo] * B[t,No]   (reduction over the row index)
-// Both operands are loaded row-major ([t][col], coalesced along col) and the MFMA fragments are
-// formed either with the LDS transpose read ds_read_b64_tr_b16 (mode 0) or from a transposed
-// LDS image written with 2-byte stores (mode 1, fallback).
+// Both operands are loaded row-major ([t][col], coalesced along col) and the MFMA fragments are formed
+// either with the LDS transpose read ds_read_b64_tr_b16 (mode 0) or from a transposed LDS image written
+// with 2-byte stores (mode 1, fallback).  The t range is split over workgroups; each split writes its fp32
+// partial tile to a workspace with coalesced 16-byte stores and a second kernel reduces the splits into C
+// (cross-XCD fp32 atomics were the bottleneck of the one-pass version; they remain as the no-workspace path).
 // ---------------------------------------------------------------------------------------------
-constexpr int TN_BT = 64;           // t rows per step
-constexpr int TN_BC = 128;          // columns per operand tile
+constexpr int TN_BT = 64;             // t rows per step
+constexpr int TN_BC = 128;            // columns per operand tile
 constexpr int TN_PITCH = TN_BC + 16;  // mode 0: [t][col], 288-byte rows (8 consecutive rows -> 64 distinct banks)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split) {
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split, int splits, float* ws) {
   // mode 0: As[t][col] (pitch TN_PITCH).  mode 1: At[col][t] (pitch PITCH).
   constexpr int ASZ = MODE == 0 ? TN_BT * TN_PITCH : TN_BC * PITCH;
-  __shared__ __attribute__((aligned(16))) bf16_t As[2][ASZ];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[2][ASZ];
+  constexpr int OPER_ELEMS = 4 * ASZ;
+  constexpr int STAGE_ELEMS = TN_BC * CPITCH * 2;
+  constexpr int SMEM_ELEMS = OPER_ELEMS > STAGE_ELEMS ? OPER_ELEMS : STAGE_ELEMS;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_ELEMS];
+  bf16_t* As = smem;            // [2][ASZ]
+  bf16_t* Bs = smem + 2 * ASZ;  // [2][ASZ]
+  float* Cs = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int z = blockIdx.z % g.groups, split = blockIdx.z / g.groups;
   const int m0 = blockIdx.y * TN_BC, n0 = blockIdx.x * TN_BC;
   const int t_begin = split * t_per_split;
   const int t_end = min(g.T, t_begin + t_per_split);
-  if (t_begin >= t_end) return;
   const bf16_t* A = g.A + z * g.zA;
   const bf16_t* B = g.B + z * g.zB;
-  float* C = g.C + z * g.zC;
 
-  // tile = 64 rows x 128 cols = 1024 chunks of 16 B; 4 per thread per operand
   u32x4_t ar[4], br[4];
   auto gload = [&](int t0) {
 #pragma unroll
@@ -293,15 +335,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split)
     for (int i = 0; i < 4; ++i) {
       int c = tid + 256 * i, r = c >> 4, cc = (c & 15) * 8;
       if (MODE == 0) {
-        *reinterpret_cast<u32x4_t*>(&As[buf][r * TN_PITCH + cc]) = ar[i];
-        *reinterpret_cast<u32x4_t*>(&Bs[buf][r * TN_PITCH + cc]) = br[i];
+        *reinterpret_cast<u32x4_t*>(&As[buf * ASZ + r * TN_PITCH + cc]) = ar[i];
+        *reinterpret_cast<u32x4_t*>(&Bs[buf * ASZ + r * TN_PITCH + cc]) = br[i];
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          As[buf][(cc + 2 * j) * PITCH + r] = (bf16_t)(ar[i][j] & 0xFFFFu);
-          As[buf][(cc + 2 * j + 1) * PITCH + r] = (bf16_t)(ar[i][j] >> 16);
-          Bs[buf][(cc + 2 * j) * PITCH + r] = (bf16_t)(br[i][j] & 0xFFFFu);
-          Bs[buf][(cc + 2 * j + 1) * PITCH + r] = (bf16_t)(br[i][j] >> 16);
+          As[buf * ASZ + (cc + 2 * j) * PITCH + r] = (bf16_t)(ar[i][j] & 0xFFFFu);
+          As[buf * ASZ + (cc + 2 * j + 1) * PITCH + r] = (bf16_t)(ar[i][j] >> 16);
+          Bs[buf * ASZ + (cc + 2 * j) * PITCH + r] = (bf16_t)(br[i][j] & 0xFFFFu);
+          Bs[buf * ASZ + (cc + 2 * j + 1) * PITCH + r] = (bf16_t)(br[i][j] >> 16);
         }
       }
     }
@@ -313,14 +355,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nsteps = (t_end - t_begin + TN_BT - 1) / TN_BT;
-  gload(t_begin);
-  sstore(0);
+  const int nsteps = t_begin < t_end ? (t_end - t_begin + TN_BT - 1) / TN_BT : 0;
+  if (nsteps > 0) {
+    gload(t_begin);
+    sstore(0);
+  }
   __syncthreads();
   const int grp = lane >> 4, p = lane & 15;
   for (int st = 0; st < nsteps; ++st) {
     const int buf = st & 1;
     if (st + 1 < nsteps) gload(t_begin + (st + 1) * TN_BT);
+    const bf16_t* ab = As + buf * ASZ;
+    const bf16_t* bb = Bs + buf * ASZ;
 #pragma unroll
     for (int ks = 0; ks < TN_BT / 32; ++ks) {
       bf16x8_t af[4], bfr[4];
@@ -330,31 +376,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split)
         // lane p of a 16-lane group supplies the 8-byte row chunk [t = base + (p>>2)][c0 + (p&3)*4 .. +3]
         const int trow = ks * 32 + 4 * grp + (p >> 2);
         const int tcol = (p & 3) * 4;
+        typedef short s16x8_t __attribute__((ext_vector_type(8)));
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const bf16_t* pa = &As[buf][trow * TN_PITCH + wm * 64 + a * 16 + tcol];
+          const bf16_t* pa = &ab[trow * TN_PITCH + wm * 64 + a * 16 + tcol];
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pa));
           s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pa + 16 * TN_PITCH));
-          typedef short s16x8_t __attribute__((ext_vector_type(8)));
           s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           af[a] = __builtin_bit_cast(bf16x8_t, v);
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const bf16_t* pb = &Bs[buf][trow * TN_PITCH + wn * 64 + b * 16 + tcol];
+          const bf16_t* pb = &bb[trow * TN_PITCH + wn * 64 + b * 16 + tcol];
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb));
           s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb + 16 * TN_PITCH));
-          typedef short s16x8_t __attribute__((ext_vector_type(8)));
           s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           bfr[b] = __builtin_bit_cast(bf16x8_t, v);
         }
       } else {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-          af[a] = *reinterpret_cast<const bf16x8_t*>(&As[buf][(wm * 64 + a * 16 + p) * PITCH + ks * 32 + grp * 8]);
+          af[a] = *reinterpret_cast<const bf16x8_t*>(&ab[(wm * 64 + a * 16 + p) * PITCH + ks * 32 + grp * 8]);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          bfr[b] = *reinterpret_cast<const bf16x8_t*>(&Bs[buf][(wn * 64 + b * 16 + p) * PITCH + ks * 32 + grp * 8]);
+          bfr[b] = *reinterpret_cast<const bf16x8_t*>(&bb[(wn * 64 + b * 16 + p) * PITCH + ks * 32 + grp * 8]);
       }
       // MFMA-A = B-matrix columns (output col), MFMA-B = A-matrix columns (output row):
       // lane reg j = C[row = m0 + wm*64 + a*16 + (lane&15)][col = n0 + wn*64 + b*16 + (lane>>4)*4 + j]
@@ -367,44 +412,105 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split)
     if (st + 1 < nsteps) sstore(buf ^ 1);
     __syncthreads();
   }
+  if (ws == nullptr) {  // one-pass path: fp32 atomics straight into C
+    float* C = g.C + z * g.zC;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int row = m0 + wm * 64 + a * 16 + (lane & 15);
-    if (row >= g.Mo) continue;
+    for (int a = 0; a < 4; ++a) {
+      const int row = m0 + wm * 64 + a * 16 + (lane & 15);
+      if (row >= g.Mo) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = n0 + wn * 64 + b * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col + j < g.No) atomicAdd(C + (long)row * g.ldc + col + j, acc[a][b][j] * g.alpha);
+      }
+    }
+    return;
+  }
+  // two-pass path: partial tile -> LDS -> coalesced 16-byte stores into ws[split][group][Mo][No]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int col = n0 + wn * 64 + b * 16 + (lane >> 4) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (col + j < g.No) atomicAdd(C + (long)row * g.ldc + col + j, acc[a][b][j] * g.alpha);
+      const int r = wm * 64 + a * 16 + (lane & 15), c = wn * 64 + b * 16 + (lane >> 4) * 4;
+      *reinterpret_cast<f32x4_t*>(&Cs[r * CPITCH + c]) = acc[a][b];
+    }
+  __syncthreads();
+  float* wsp = ws + ((long)split * g.groups + z) * g.Mo * g.No;
+  const int c4 = (tid & 31) * 4, rg = tid >> 5;  // 32 lanes x float4 = one 128-column row
+  if (n0 + c4 < g.No) {
+#pragma unroll 4
+    for (int i = 0; i < TN_BC / 8; ++i) {
+      const int rl = rg + 8 * i, row = m0 + rl;
+      if (row < g.Mo) *reinterpret_cast<f32x4_t*>(wsp + (long)row * g.No + n0 + c4) = *reinterpret_cast<const f32x4_t*>(&Cs[rl * CPITCH + c4]);
     }
   }
 }
 
+// C[z][m][n] += alpha * sum_s ws[s][z][m][n]
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTN g, int splits, const float* ws) {
+  const long per = (long)g.Mo * g.No;
+  const long total4 = per * g.groups / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    const int z = (int)(e / per);
+    const long r = e % per;
+    const int m = (int)(r / g.No), n = (int)(r % g.No);
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < splits; ++sp) s += *reinterpret_cast<const f32x4_t*>(ws + ((long)sp * g.groups + z) * per + r);
+    float* c = g.C + z * g.zC + (long)m * g.ldc + n;
+    c[0] += s[0] * g.alpha; c[1] += s[1] * g.alpha; c[2] += s[2] * g.alpha; c[3] += s[3] * g.alpha;
+  }
+}
+
+static thread_local float* g_tn_ws = nullptr;
+static thread_local size_t g_tn_ws_floats = 0;
+void set_tn_default_workspace(float* ws, size_t floats) { g_tn_ws = ws; g_tn_ws_floats = floats; }
 static int g_tn_mode = 0;
 void set_tn_mode(int mode) { g_tn_mode = mode ? 1 : 0; }
 int get_tn_mode() { return g_tn_mode; }
+
+static int tn_splits(int T, int Mo, int No, int groups) {
+  const int tiles = ((Mo + TN_BC - 1) / TN_BC) * ((No + TN_BC - 1) / TN_BC) * groups;
+  // split the t reduction so that about one workgroup per CU exists; each split handles >= 256 rows
+  int splits = (288 + tiles - 1) / tiles;
+  const int max_splits = (T + 4 * TN_BT - 1) / (4 * TN_BT);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups) {
+  return (size_t)tn_splits(T, Mo, No, groups) * groups * Mo * No;
+}
 
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
   COOT_REQUIRE(g.A && g.B && g.C, "gemm_tn: null operand");
   COOT_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.Mo % 8 == 0 && g.No % 8 == 0 && g.zA % 8 == 0 && g.zB % 8 == 0,
                "gemm_tn: lda/ldb/Mo/No must be multiples of 8 (Mo=%d No=%d lda=%ld ldb=%ld)", g.Mo, g.No, g.lda, g.ldb);
   if (g.T <= 0 || g.Mo <= 0 || g.No <= 0) return 0;
-  const int tiles = ((g.Mo + TN_BC - 1) / TN_BC) * ((g.No + TN_BC - 1) / TN_BC) * g.groups;
-  // split the t reduction so that ~512 workgroups exist; each split handles a multiple of 64 rows
-  int splits = (512 + tiles - 1) / tiles;
-  const int max_splits = (g.T + 4 * TN_BT - 1) / (4 * TN_BT);  // >= 256 rows per split
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  int splits = tn_splits(g.T, g.Mo, g.No, g.groups);
   int t_per_split = (g.T + splits - 1) / splits;
   t_per_split = (t_per_split + TN_BT - 1) / TN_BT * TN_BT;
   splits = (g.T + t_per_split - 1) / t_per_split;
+  float* ws = nullptr;
+  const size_t need = (size_t)splits * g.groups * g.Mo * g.No;
+  if (g.ws && need <= g.ws_floats) ws = g.ws;
+  else if (!g.ws && g_tn_ws && need <= g_tn_ws_floats) ws = g_tn_ws;
   dim3 grid((g.No + TN_BC - 1) / TN_BC, (g.Mo + TN_BC - 1) / TN_BC, g.groups * splits);
   if (g_tn_mode == 0)
-    hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, dim3(256), 0, stream, g, t_per_split);
+    hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, dim3(256), 0, stream, g, t_per_split, splits, ws);
   else
-    hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, stream, g, t_per_split);
+    hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, stream, g, t_per_split, splits, ws);
   COOT_CHECK_LAUNCH("gemm_tn");
+  if (ws) {
+    const long total4 = (long)g.Mo * g.No * g.groups / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g, splits, ws);
+    COOT_CHECK_LAUNCH("gemm_tn_reduce");
+  }
   return 0;
 }
 

@@ -19,7 +19,7 @@ EXPORTS = [
     "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights",
     "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_pack_fwd",
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_cyclecons_fwd_bwd",
-    "coot_gemm_nt", "coot_gemm_tn", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
+    "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect",
 ]
 
@@ -81,7 +81,9 @@ def load():
     lib.coot_contrastive_fwd_bwd.argtypes = [C.POINTER(ContrastiveConfig), i32, i32, i32, i32] + [vp] * 6 + [vp] + [vp] * 6 + [vp, sz, vp]
     lib.coot_cyclecons_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp]
     lib.coot_gemm_nt.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp, i64, i32, vp]
-    lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp]
+    lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, sz, vp]
+    lib.coot_gemm_tn_workspace_bytes.restype = sz
+    lib.coot_gemm_tn_workspace_bytes.argtypes = [i32, i32, i32]
     lib.coot_ln_fwd.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.coot_attn_fwd.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.coot_probe_tr16.argtypes = [vp, vp]

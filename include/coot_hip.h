@@ -120,9 +120,11 @@ int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* 
 int coot_gemm_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, int M, int N, int K, const float* bias,
                  int act, const void* residual_bf16, int64_t ldres, void* out, int64_t ldc, int out_f32,
                  coot_stream_t stream);
-/* C[Mo,No] fp32 += sum_t A[t,Mo] * B[t,No] */
+/* C[Mo,No] fp32 += sum_t A[t,Mo] * B[t,No].  workspace (coot_gemm_tn_workspace_bytes) selects the two-pass
+ * split reduction; NULL falls back to fp32 atomics. */
+size_t coot_gemm_tn_workspace_bytes(int T, int Mo, int No);
 int coot_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int T, int Mo, int No, float* C,
-                 int64_t ldc, coot_stream_t stream);
+                 int64_t ldc, void* workspace, size_t workspace_bytes, coot_stream_t stream);
 int coot_ln_fwd(const float* x, int R, int D, const float* gain, const float* bias, void* y_bf16, float* y_f32,
                 coot_stream_t stream);
 int coot_attn_fwd(const void* qkv, int Nseq, int L, int H, int dh, const int64_t* lens, void* out, float* lse,

@@ -75,9 +75,9 @@ def test_gemm_nt(env, M, N, K, act, use_res, out_f32):
     assert err < (2e-5 if out_f32 else 6e-3), err
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode,use_ws", [(0, True), (0, False), (1, True)])
 @pytest.mark.parametrize("T,Mo,No", [(64, 128, 128), (1000, 384, 384), (5000, 384, 2048), (333, 200, 72)])
-def test_gemm_tn(env, mode, T, Mo, No):
+def test_gemm_tn(env, mode, use_ws, T, Mo, No):
     torch, cva, lib = env
     rs = np.random.RandomState(T + Mo + No)
     A = rs.randn(T, Mo).astype(np.float32)
@@ -89,13 +89,15 @@ def test_gemm_tn(env, mode, T, Mo, No):
     dC = torch.from_numpy(C0.copy()).cuda()
     cva.lib.check(lib.coot_set_option(b"tn_mode", mode))
     try:
-        cva.lib.check(lib.coot_gemm_tn(dA.data_ptr(), Mo, dB.data_ptr(), No, T, Mo, No, dC.data_ptr(), No, _sp(torch)), "gemm_tn")
+        ws = torch.empty(lib.coot_gemm_tn_workspace_bytes(T, Mo, No) if use_ws else 0, dtype=torch.uint8, device="cuda")
+        cva.lib.check(lib.coot_gemm_tn(dA.data_ptr(), Mo, dB.data_ptr(), No, T, Mo, No, dC.data_ptr(), No,
+                                       ws.data_ptr() if use_ws else None, ws.numel(), _sp(torch)), "gemm_tn")
         torch.cuda.synchronize()
     finally:
         lib.coot_set_option(b"tn_mode", 0)
     got = dC.cpu().numpy() - C0
     err = rel_err(got, ref)
-    print(f"gemm_tn mode={mode} T={T} {Mo}x{No} rel_err={err:.2e}")
+    print(f"gemm_tn mode={mode} ws={use_ws} T={T} {Mo}x{No} rel_err={err:.2e}")
     assert err < 2e-5, err
 
 
