@@ -136,6 +136,7 @@ def main():
     last = None
     for _ in range(args.steps):
         last = step()
+    host_issue = time.perf_counter() - t0  # CPU time to enqueue K steps (informational)
     barrier()
     elapsed = time.perf_counter() - t0
     if dp is not None:
@@ -185,7 +186,7 @@ def main():
                        "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
                        "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",
                        "final_loss": round(loss_val, 5)},
-            "per_gpu": round(value / world, 1),
+            "per_gpu": round(value / world, 1), "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
             "algorithmic_tflops_per_s": round((fwd_flops if args.eval else train_flops) * world / (ms_per_step * 1e-3) / 1e12, 2),
         }
         if roofline is not None:

@@ -200,7 +200,7 @@ static void layout_saved(const coot_net_config& c, int N, long Ttok, Arena& A, S
 
 struct Scratch {  // backward temporaries
   bf16_t *dzA, *dzB, *dr2, *dr2m, *dh1, *dz1, *dr1, *dctx, *dqkv, *ds, *dhp, *dzp;
-  float *delta, *Mbuf, *cvec, *tn_ws; size_t tn_ws_floats;
+  float *delta, *Mbuf, *cvec, *tn_ws; size_t tn_ws_floats; float* part_ws; size_t part_floats;
   bf16_t *c_dq, *c_dkv, *c_d1, *c_d2, *c_dh1, *c_dz1, *c_dr1, *c_dctx, *c_dqin; float* c_delta;
 };
 static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A, Scratch& S) {
@@ -221,6 +221,10 @@ static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A,
       mx(gemm_tn_workspace_floats((int)T, dhp, dop, Hh)); mx(gemm_tn_workspace_floats((int)T, (int)D, dhp, Hh));
     }
     S.tn_ws_floats = w; S.tn_ws = A.get<float>(w);
+  }
+  {
+    size_t widest = 3 * D; if (F > widest) widest = F; if ((size_t)c.pool_hidden > widest) widest = c.pool_hidden;
+    S.part_floats = (T / 64 + 1024) * widest; S.part_ws = A.get<float>(S.part_floats);
   }
   if (c.use_context) {
     const size_t n = N;
@@ -638,6 +642,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, Ntot, sg.T(), AX, X);
   COOT_REQUIRE(!AX.overflow, "net_bwd: scratch buffer too small (%zu < %zu)", scratch_bytes, AX.off);
   struct TnWs { TnWs(float* p, size_t n) { set_tn_default_workspace(p, n); } ~TnWs() { set_tn_default_workspace(nullptr, 0); } } tnws(X.tn_ws, X.tn_ws_floats);
+  struct PartWs { PartWs(float* p, size_t n) { set_partials_workspace(p, n); } ~PartWs() { set_partials_workspace(nullptr, 0); } } partws(X.part_ws, X.part_floats);
   const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim;
   const long long* lens = sg.lens[0];
   const int out_dim = D * (c.use_context ? 2 : 1);

@@ -17,7 +17,8 @@ struct GemmEpi {
   const float* pe = nullptr; int pe_L = 1;         // + pe[pos * N + col], pos = row % pe_L (rows < pe_T0)
   int pe_T0 = 0x7fffffff; int pe_L2 = 1;           //                      pos = (row - pe_T0) % pe_L2 (second segment)
   const float* rowscale = nullptr; const bf16_t* diag_src = nullptr; long lddiag = 0;  // + rowscale[row]*diag_src[row][col]
-  float* colsum = nullptr;                         // atomicAdd column sums of the final value
+  float* colsum = nullptr;                         // += column sums of the final value (bias gradients)
+  float* colsum_ws = nullptr; long ld_colsum_ws = 0;  // internal: per-row-block partials (set by the launcher)
   // dropout applied to (alpha*acc + bias) [act 0/1] or to the final product [act 2]
   unsigned drop_thr = 0; float drop_inv_keep = 1.0f; unsigned long long drop_seed = 0; unsigned drop_site = 0;
   long drop_ld = 0;  // element index = row * drop_ld + col (+ z * drop_zoff)

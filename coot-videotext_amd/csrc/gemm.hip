@@ -11,6 +11,7 @@
 // "store what the MFMA layout gives you" epilogue (8-byte stores in 32-byte runs) cost more than the K loop
 // at K = 384 (profiles/README.md).
 #include "gemm.h"
+#include "rowops.h"
 
 namespace coot {
 
@@ -230,7 +231,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
       float s = csum[j];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (lane < 16 && cok) atomicAdd(e.colsum + zo + col + j, s);
+      csum[j] = s;
+    }
+    if (e.colsum_ws) {  // one partial row per row-block, reduced by reduce_partials_kernel (no atomics)
+      __syncthreads();
+      float* red = Cs;  // [4][128]
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave * 128 + cch * 8 + j] = csum[j];
+      }
+      __syncthreads();
+      if (tid < 128 && col0 + tid < N)
+        e.colsum_ws[(long)blockIdx.y * e.ld_colsum_ws + zo + col0 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+    } else if (lane < 16 && cok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(e.colsum + zo + col + j, csum[j]);
     }
   }
 }
@@ -263,7 +278,8 @@ static TimingSlot* timing_begin(const GemmNT& g, hipStream_t stream) {
   return s;
 }
 
-int launch_gemm_nt(const GemmNT& g, hipStream_t stream) {
+int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
+  GemmNT g = g_in;
   COOT_REQUIRE(g.X && g.W && g.epi.out, "gemm_nt: null operand");
   COOT_REQUIRE(g.K % 8 == 0 && g.ldx % 8 == 0 && g.ldw % 8 == 0 && g.zX % 8 == 0 && g.zW % 8 == 0,
                "gemm_nt: K/ldx/ldw must be multiples of 8 (K=%d ldx=%ld ldw=%ld)", g.K, g.ldx, g.ldw);
@@ -275,16 +291,24 @@ int launch_gemm_nt(const GemmNT& g, hipStream_t stream) {
   const int nb = (g.N + BN - 1) / BN;
   // small-M problems: halve the token tile to get more workgroups onto the 256 CUs
   const long blocks128 = (long)((g.M + 127) / 128) * nb * g.groups;
+  const bool big = blocks128 >= 384;
+  const int row_blocks = big ? (g.M + 127) / 128 : (g.M + 63) / 64;
+  const int ccols = g.groups > 1 ? (int)(g.groups * g.zOut) : g.N;
+  if (g.epi.colsum) {
+    g.epi.colsum_ws = partials_workspace((size_t)row_blocks * ccols);
+    g.epi.ld_colsum_ws = ccols;
+  }
   TimingSlot* ts = timing_begin(g, stream);
-  if (blocks128 >= 384) {
-    dim3 grid(nb, (g.M + 127) / 128, g.groups);
+  if (big) {
+    dim3 grid(nb, row_blocks, g.groups);
     hipLaunchKernelGGL(gemm_nt_kernel<128>, grid, dim3(256), 0, stream, g);
   } else {
-    dim3 grid(nb, (g.M + 63) / 64, g.groups);
+    dim3 grid(nb, row_blocks, g.groups);
     hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, stream, g);
   }
   if (ts) hipEventRecord(ts->b, stream);
   COOT_CHECK_LAUNCH("gemm_nt");
+  if (g.epi.colsum_ws) return launch_reduce_partials(g.epi.colsum_ws, row_blocks, ccols, ccols, g.epi.colsum, stream);
   return 0;
 }
 

@@ -19,7 +19,8 @@ struct PoolArgs {
   const float* dpooled = nullptr; long lddp = 0;
   bf16_t* ds = nullptr; long ldds = 0;       // grad wrt the pre-dropout2 scores (bf16)
   bf16_t* dz = nullptr; long lddz = 0;       // partial grad wrt z (direct path)
-  float* ds_colsum = nullptr;                // [D] atomics (bias grad of the 2nd pooling FC)
+  float* ds_colsum = nullptr;                // [D] (bias grad of the 2nd pooling FC)
+  float* part_ws = nullptr;                  // internal: [N][D] partials
   DropCfg drop_s; long drop_s_ld = 0;        // dropout2 mask (same indexing as the GEMM epilogue)
   long drop_s_row0 = 0;                      // global row index of this segment's first token
 };

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs p) {
     *reinterpret_cast<unsigned*>(p.ds + (r0 + l) * p.ldds + c) = pack2bf(ds0, ds1);
     *reinterpret_cast<unsigned*>(p.dz + (r0 + l) * p.lddz + c) = pack2bf(dz0, dz1);
   }
-  if (p.ds_colsum) { atomicAdd(p.ds_colsum + c, cs0); atomicAdd(p.ds_colsum + c + 1, cs1); }
+  if (p.part_ws) { p.part_ws[(long)n * p.D + c] = cs0; p.part_ws[(long)n * p.D + c + 1] = cs1; }
+  else if (p.ds_colsum) { atomicAdd(p.ds_colsum + c, cs0); atomicAdd(p.ds_colsum + c + 1, cs1); }
 }
 
 static int pool_check(const PoolArgs& p) {
@@ -96,12 +97,15 @@ int launch_pool_fwd(const PoolArgs& p, hipStream_t st) {
   COOT_CHECK_LAUNCH("pool_fwd");
   return 0;
 }
-int launch_pool_bwd(const PoolArgs& p, hipStream_t st) {
+int launch_pool_bwd(const PoolArgs& p_in, hipStream_t st) {
+  PoolArgs p = p_in;
   if (int rc = pool_check(p)) return rc;
   COOT_REQUIRE(p.dpooled && p.ds && p.dz && p.smax && p.ssum, "pool bwd: null pointer");
   if (p.N <= 0) return 0;
+  p.part_ws = p.ds_colsum ? partials_workspace((size_t)p.N * p.D) : nullptr;
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(p.N, (p.D / 2 + 255) / 256), dim3(256), 0, st, p);
   COOT_CHECK_LAUNCH("pool_bwd");
+  if (p.part_ws) return launch_reduce_partials(p.part_ws, p.N, p.D, p.D, p.ds_colsum, st);
   return 0;
 }
 

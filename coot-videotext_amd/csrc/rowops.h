@@ -31,7 +31,8 @@ struct LnBwd {
   bf16_t* dxm = nullptr; long lddxm = 0;       // dx * dropmask(dxm_drop) (for a preceding Linear->Dropout)
   DropCfg dxm_drop; long dxm_drop_ld = 0;
   float* dgain = nullptr; float* dbias = nullptr;  // atomics, [D]
-  float* dxcolsum = nullptr;                       // atomics, [D]: colsum of dxm (if set) else dx
+  float* dxcolsum = nullptr;                       // [D]: colsum of dxm (if set) else dx
+  float* part_ws = nullptr;                        // internal: [blocks][3][D] partials (set by the launcher)
   DropCfg drop;                                    // dropout that was applied to the LN output in fwd
 };
 int launch_ln_bwd(const LnBwd& p, hipStream_t stream);
@@ -56,6 +57,14 @@ int launch_matvec_bias(const float* W, long ldw, int N, int K, const float* v, c
 //   dW[n,k] += M[n,k]*g[k] + c[n]*b0[k];  dg[k] += sum_n W[n,k]*M[n,k];  db0[k] += sum_n c[n]*W[n,k]
 int launch_infc_param_grads(const float* M, const float* W, const float* g0, const float* b0, const float* c,
                             int N, int K, float* dW, float* dg0, float* db0, hipStream_t stream);
+
+// ---- contention-free column reductions ---------------------------------------------------------------
+// Producers write per-workgroup partial sums into a stream-ordered scratch region instead of issuing hundreds of
+// fp32 atomics onto the same few addresses (cross-XCD atomics serialise at the memory side: a 40 us GEMM became
+// 265 us, profiles/README.md); out[c] += sum_p ws[p*ld + c] is then one tiny kernel.
+void set_partials_workspace(float* ws, size_t floats);   // thread-local, set by the orchestrator per call
+float* partials_workspace(size_t need_floats);            // nullptr if not available / too small
+int launch_reduce_partials(const float* ws, int nparts, long ld, int C, float* out, hipStream_t stream);
 
 int launch_fill_f32(float* p, long n, float v, hipStream_t stream);
 // y += a * x

@@ -75,6 +75,56 @@ int launch_ln_fwd(const LnFwd& p, hipStream_t stream) {
   return 0;
 }
 
+#define RUN_RED(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+static thread_local float* g_part_ws = nullptr;
+static thread_local size_t g_part_floats = 0;
+void set_partials_workspace(float* ws, size_t floats) { g_part_ws = ws; g_part_floats = floats; }
+float* partials_workspace(size_t need) { return (g_part_ws && need <= g_part_floats) ? g_part_ws : nullptr; }
+
+// out_k[c] += sum_p ws[p*ld + k*seg + c] for up to three outputs k (seg columns each).
+// grid = (column blocks of 64, part chunks): every block sums <= 64 parts (16 independent loads per thread), the
+// few chunks per column are combined with atomics (<= 8 adds per address: no contention to speak of).
+struct ReduceOuts { float* out[3]; int nout; int seg; };
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* ws, int nparts, long ld, int C, ReduceOuts ro, int parts_per_chunk) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+  const int p0 = blockIdx.y * parts_per_chunk, p1 = min(nparts, p0 + parts_per_chunk);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int p = p0 + pg;
+    for (; p + 12 < p1; p += 16) {
+      s0 += ws[(long)p * ld + c]; s1 += ws[(long)(p + 4) * ld + c]; s2 += ws[(long)(p + 8) * ld + c]; s3 += ws[(long)(p + 12) * ld + c];
+    }
+    for (; p < p1; p += 4) s0 += ws[(long)p * ld + c];
+  }
+  red[pg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pg == 0 && c < C) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const int k = c / ro.seg;
+    float* o = ro.out[k];
+    if (o) {
+      if (gridDim.y == 1) o[c - k * ro.seg] += v; else atomicAdd(o + (c - k * ro.seg), v);
+    }
+  }
+}
+static int launch_reduce_multi(const float* ws, int nparts, long ld, ReduceOuts ro, hipStream_t stream) {
+  const int C = ro.nout * ro.seg;
+  if (C <= 0 || nparts <= 0) return 0;
+  int chunks = (nparts + 63) / 64;
+  if (chunks > 8) chunks = 8;
+  const int ppc = (nparts + chunks - 1) / chunks;
+  chunks = (nparts + ppc - 1) / ppc;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, stream, ws, nparts, ld, C, ro, ppc);
+  COOT_CHECK_LAUNCH("reduce_partials");
+  return 0;
+}
+int launch_reduce_partials(const float* ws, int nparts, long ld, int C, float* out, hipStream_t stream) {
+  ReduceOuts ro; ro.out[0] = out; ro.out[1] = nullptr; ro.out[2] = nullptr; ro.nout = 1; ro.seg = C;
+  return launch_reduce_multi(ws, nparts, ld, ro, stream);
+}
+
 // Backward:  xc = x - mean, s = std + eps, h = dy * gain
 //   dx = (h - mean(h))/s - (sum h*xc)/s^2 * xc/((n-1)*std)      [second term 0 where std == 0]
 //   dgain += dy * xc/s ; dbias += dy
@@ -162,26 +212,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
     float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
     float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
     float x = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
-    if (p.dgain) atomicAdd(p.dgain + c, g);
-    if (p.dbias) atomicAdd(p.dbias + c, b);
-    if (p.dxcolsum) atomicAdd(p.dxcolsum + c, x);
+    if (p.part_ws) {
+      float* w = p.part_ws + (long)blockIdx.x * 3 * D;
+      w[c] = g; w[D + c] = b; w[2 * D + c] = x;
+    } else {
+      if (p.dgain) atomicAdd(p.dgain + c, g);
+      if (p.dbias) atomicAdd(p.dbias + c, b);
+      if (p.dxcolsum) atomicAdd(p.dxcolsum + c, x);
+    }
   }
 }
 
-int launch_ln_bwd(const LnBwd& p, hipStream_t stream) {
+int launch_ln_bwd(const LnBwd& p_in, hipStream_t stream) {
+  LnBwd p = p_in;
   COOT_REQUIRE((p.dy || p.dy32) && p.x && p.gain, "ln_bwd: null pointer");
   COOT_REQUIRE(p.D % 4 == 0 && p.D <= 1024 && p.D >= 8, "ln_bwd: D=%d unsupported (need D%%4==0, 8<=D<=1024)", p.D);
   if (p.R <= 0) return 0;
   int blocks = (p.R + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 256) blocks = 256;
+  p.part_ws = partials_workspace((size_t)blocks * 3 * p.D);
   if (p.D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, stream, p);
   COOT_CHECK_LAUNCH("ln_bwd");
+  if (p.part_ws) {  // dgain | dbias | colsum(dx) in one launch
+    ReduceOuts ro; ro.out[0] = p.dgain; ro.out[1] = p.dbias; ro.out[2] = p.dxcolsum; ro.nout = 3; ro.seg = p.D;
+    RUN_RED(launch_reduce_multi(p.part_ws, blocks, 3L * p.D, ro, stream));
+  }
   return 0;
 }
 
 // ---- column sums of a bf16 matrix -----------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* x, long ldx, int R, int C, float* out, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* x, long ldx, int R, int C, float* out, int rows_per_block, float* part) {
   // thread -> 2 columns (4-byte loads); block covers 512 columns x rows_per_block rows
   const int col = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (col >= C) return;
@@ -191,6 +252,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* x, long 
     unsigned u = *reinterpret_cast<const unsigned*>(x + (long)r * ldx + col);
     a += bflo(u); b += bfhi(u);
   }
+  if (part) { part[(long)blockIdx.y * C + col] = a; if (col + 1 < C) part[(long)blockIdx.y * C + col + 1] = b; return; }
   atomicAdd(out + col, a);
   if (col + 1 < C) atomicAdd(out + col + 1, b);
 }
@@ -200,8 +262,10 @@ int launch_colsum_bf16(const bf16_t* x, long ldx, int R, int C, float* out, hipS
   if (R <= 0) return 0;
   int rpb = 64;
   dim3 grid((C / 2 + 255) / 256, (R + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, out, rpb);
+  float* part = partials_workspace((size_t)grid.y * C);
+  hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, out, rpb, part);
   COOT_CHECK_LAUNCH("colsum_bf16");
+  if (part) return launch_reduce_partials(part, (int)grid.y, C, C, out, stream);
   return 0;
 }
 

@@ -76,6 +76,35 @@ class RetrievalTrainer:
         return loss_fn.cycle_consistency_loss(visual_data.clip_emb_reshape, visual_data.clip_emb_lens,
                                               text_data.sent_emb_reshape, text_data.sent_emb_lens, w, idx_clip, idx_sent)
 
+    # ---- video side and text side are independent until the loss: run them on two HIP streams -------------------
+    overlap_sides = True
+
+    def encode_both(self, batch: RetrievalDataBatchTuple):
+        """encode_visual and encode_text (coot/trainer_retrieval.py:265-266) on two side streams so the small
+        text-side kernels fill the CUs the video side leaves idle.  Autograd replays each backward node on the
+        stream its forward ran on, so the backward passes overlap the same way."""
+        if not (self.overlap_sides and batch.vid_feat.is_cuda):
+            return self.model_mgr.encode_visual(batch), self.model_mgr.encode_text(batch)
+        if getattr(self, "_side_streams", None) is None:
+            self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        main = torch.cuda.current_stream()
+        sv, st = self._side_streams
+        sv.wait_stream(main)
+        st.wait_stream(main)
+        with torch.cuda.stream(sv):
+            visual_data = self.model_mgr.encode_visual(batch)
+        with torch.cuda.stream(st):
+            text_data = self.model_mgr.encode_text(batch)
+        main.wait_stream(sv)
+        main.wait_stream(st)
+        return visual_data, text_data
+
+    def _join_side_streams(self) -> None:
+        if getattr(self, "_side_streams", None) is not None:
+            main = torch.cuda.current_stream()
+            for s in self._side_streams:
+                main.wait_stream(s)
+
     # ---- one optimisation step (coot/trainer_retrieval.py:253-291) ---------------------------------------
     def train_step(self, batch: RetrievalDataBatchTuple, vid_counts=None, clip_counts=None
                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -87,8 +116,7 @@ class RetrievalTrainer:
         for net, g in zip(nets, flat_grads):
             g.zero_()
             net.accumulate_into_flat = True  # backward kernels accumulate straight into the flat arenas
-        visual_data = self.model_mgr.encode_visual(batch)
-        text_data = self.model_mgr.encode_text(batch)
+        visual_data, text_data = self.encode_both(batch)
         dp = getattr(self, "dp", None)
         if dp is None:
             contr_loss = self.compute_total_constrastive_loss(visual_data, text_data)
@@ -105,6 +133,7 @@ class RetrievalTrainer:
                     loss_fn.sample_cycle_indices(text_data.sent_emb_lens, self.cc_generator), global_batch=global_b)
         loss = contr_loss + cc_loss
         loss.backward()
+        self._join_side_streams()
         for net in nets:
             net.accumulate_into_flat = False
         if dp is not None:
