@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
+    ap.add_argument("--mode", default="native", choices=["native", "autograd", "graph"],
+                    help="native: one C call per step (default); autograd: torch autograd Functions; graph: autograd step in a HIP graph")
     return ap.parse_args()
 
 
@@ -121,8 +123,12 @@ def main():
     else:
         mgr.set_all_models_train()
 
-        def step():
-            return trainer.train_step(batch, vid_counts, clip_counts)[0]
+        mode = args.mode if world == 1 else "autograd"  # multi-GPU: autograd path with torch.distributed collectives
+
+        def step(graph=None):
+            if mode == "native" and graph is None:
+                return trainer.train_step_native(batch)[0]
+            return trainer.train_step(batch, vid_counts, clip_counts, use_graph=(mode == "graph") if graph is None else graph)[0]
 
     def barrier():
         if dp is not None:
@@ -154,7 +160,7 @@ def main():
         nst = max(2, min(5, args.steps))
         lib.coot_timing_enable(1)
         for _ in range(nst):
-            step()
+            step(False) if not args.eval else step()
         torch.cuda.synchronize()
         ms, fl, n = C.c_double(), C.c_double(), C.c_int()
         cva.lib.check(lib.coot_timing_collect(0, C.byref(ms), C.byref(fl), C.byref(n)), "timing_collect")
@@ -185,6 +191,7 @@ def main():
                                    f"Lc=Lv={w['Lc']}, Ls={w['Ls']}, Lp={w['Lp']}, Dv={w['Dv']}, Dt={w['Dt']}, d_model=384",
                        "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
                        "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",
+                       "launch": "eval" if args.eval else (args.mode if world == 1 else "autograd"),
                        "final_loss": round(loss_val, 5)},
             "per_gpu": round(value / world, 1), "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
             "algorithmic_tflops_per_s": round((fwd_flops if args.eval else train_flops) * world / (ms_per_step * 1e-3) / 1e12, 2),

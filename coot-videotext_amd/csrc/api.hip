@@ -234,6 +234,7 @@ static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A,
   }
 }
 
+static thread_local const unsigned long long* g_seed_dev = nullptr;  // device base seed of the current call
 static DropCfg mkdrop(int train, float p, uint64_t seed, unsigned site) {
   DropCfg d;
   if (train && p > 0.f) {
@@ -241,12 +242,12 @@ static DropCfg mkdrop(int train, float p, uint64_t seed, unsigned site) {
     d.thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     if (d.thr == 0) d.thr = 1;
     d.inv_keep = 1.0f / (1.0f - p);
-    d.seed = seed; d.site = site;
+    d.seed = seed; d.site = site; d.seed_ptr = g_seed_dev;
   }
   return d;
 }
 static void epi_drop(GemmEpi& e, const DropCfg& d, long ld) {
-  e.drop_thr = d.thr; e.drop_inv_keep = d.inv_keep; e.drop_seed = d.seed; e.drop_site = d.site; e.drop_ld = ld;
+  e.drop_thr = d.thr; e.drop_inv_keep = d.inv_keep; e.drop_seed = d.seed; e.drop_seed_ptr = d.seed_ptr; e.drop_site = d.site; e.drop_ld = ld;
 }
 enum { SITE_ATTN = 1, SITE_POSTLN = 2, SITE_FF1 = 3, SITE_FF2 = 4, SITE_POOL1 = 5, SITE_POOL2 = 6, SITE_POOL3 = 7 };
 
@@ -533,8 +534,10 @@ size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int Lseq, int N
 int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, const float* pe, const float* feats,
                  const int64_t* lengths, int N, int Lseq, const float* feats2, const int64_t* lengths2, int N2, int L2,
                  const float* hidden, float* pooled, float* per_token, void* saved,
-                 size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed, coot_stream_t stream) {
+                 size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed, const uint64_t* seed_dev,
+                 coot_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  struct SeedScope { SeedScope(const uint64_t* p) { g_seed_dev = (const unsigned long long*)p; } ~SeedScope() { g_seed_dev = nullptr; } } seedscope(seed_dev);
   coot_net_config c; RUN(norm_cfg(cfg, &c));
   COOT_REQUIRE(P && wpack && pe && feats && lengths && pooled && saved, "net_fwd: null pointer");
   COOT_REQUIRE(!c.use_context || hidden, "net_fwd: context network needs hidden state (transformer_legacy.py:252)");
@@ -623,8 +626,9 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
                  const int64_t* lengths, int N, int Lseq, const float* feats2, const int64_t* lengths2, int N2, int L2,
                  const float* hidden, const float* dpooled, float* G, float* dhidden,
                  float* dfeats, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed,
-                 coot_stream_t stream) {
+                 const uint64_t* seed_dev, coot_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  struct SeedScope { SeedScope(const uint64_t* p) { g_seed_dev = (const unsigned long long*)p; } ~SeedScope() { g_seed_dev = nullptr; } } seedscope(seed_dev);
   coot_net_config c; RUN(norm_cfg(cfg, &c));
   COOT_REQUIRE(P && wpack && feats && lengths && dpooled && G && saved && scratch, "net_bwd: null pointer");
   COOT_REQUIRE(!(dfeats && c.use_input_fc), "net_bwd: dfeats is only available for networks without input_fc");

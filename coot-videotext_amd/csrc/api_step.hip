@@ -1,0 +1,280 @@
+// C-ABI, part 3: the whole retrieval training step as native code (coot/trainer_retrieval.py:253-291):
+// forward of both sides on two HIP streams, losses, backward, fused Adam — one C call per step (or four phase
+// calls when torch.distributed collectives sit between the phases).  No Python, no autograd bookkeeping and no
+// allocator traffic between the ~350 kernel launches of a step: the step was host-bound (9.5 us per launch from
+// Python, hipGraph replay no better on ROCm 7: ~8 us per node) — from C a launch costs ~3.5 us.
+#include <string.h>
+
+#include "../../include/coot_hip.h"
+#include "common.h"
+#include "pool.h"
+#include "rowops.h"
+
+using namespace coot;
+
+#define RUN(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+namespace {
+
+struct Bump {
+  char* base; size_t cap; size_t off = 0; bool overflow = false;
+  Bump(void* b, size_t c) : base((char*)b), cap(c) {}
+  void* get(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    char* p = base ? base + off : nullptr;
+    off += bytes;
+    if (base && off > cap) overflow = true;
+    return p;
+  }
+  template <typename T> T* arr(size_t n) { return (T*)get(n * sizeof(T)); }
+};
+
+struct StepWs {
+  void *saved_lv, *saved_gv, *saved_lt, *saved_gt; size_t sz_lv, sz_gv, sz_lt, sz_gt;
+  void *scratch_v, *scratch_t; size_t sz_sv, sz_st;
+  void* loss_scratch; size_t sz_loss;
+  // embeddings (this rank) and their gradients — used by the single-call step
+  float *local_v, *local_t, *glob_v, *glob_t, *resh_v, *resh_t;
+  float *d_local_v, *d_local_t, *d_glob_v, *d_glob_t, *d_resh_v, *d_resh_t;
+  float *dhid_v, *dhid_t, *dfeat_v, *dfeat_t;
+  unsigned char *mask_v, *mask_t; long long *lens_v, *lens_t, *idx;
+  float* zero_begin; size_t zero_bytes;  // gradient buffers that must start at 0, contiguous
+};
+
+inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+void layout_step(const coot_step_config& c, const coot_step_dims& d, Bump& A, StepWs& W) {
+  const size_t D = c.net[0].hidden_dim;
+  W.sz_lv = coot_net_saved_bytes(&c.net[0], d.B, d.Lv, d.Nc, d.Lc);
+  W.sz_gv = coot_net_saved_bytes(&c.net[1], d.B, d.Cmax_clip, 0, 0);
+  W.sz_lt = coot_net_saved_bytes(&c.net[2], d.B, d.Lp, d.Nc, d.Ls);
+  W.sz_gt = coot_net_saved_bytes(&c.net[3], d.B, d.Cmax_sent, 0, 0);
+  W.saved_lv = A.get(W.sz_lv); W.saved_gv = A.get(W.sz_gv); W.saved_lt = A.get(W.sz_lt); W.saved_gt = A.get(W.sz_gt);
+  W.sz_sv = max2(coot_net_scratch_bytes(&c.net[0], d.B, d.Lv, d.Nc, d.Lc), coot_net_scratch_bytes(&c.net[1], d.B, d.Cmax_clip, 0, 0));
+  W.sz_st = max2(coot_net_scratch_bytes(&c.net[2], d.B, d.Lp, d.Nc, d.Ls), coot_net_scratch_bytes(&c.net[3], d.B, d.Cmax_sent, 0, 0));
+  W.scratch_v = A.get(W.sz_sv); W.scratch_t = A.get(W.sz_st);
+  W.sz_loss = coot_contrastive_scratch_bytes(d.B, d.Nc, 2 * (int)D, (int)D);
+  W.loss_scratch = A.get(W.sz_loss);
+  const size_t nl = (size_t)(d.B + d.Nc) * D, ng = (size_t)d.B * 2 * D;
+  const size_t nrv = (size_t)d.B * d.Cmax_clip * D, nrt = (size_t)d.B * d.Cmax_sent * D;
+  W.local_v = A.arr<float>(nl); W.local_t = A.arr<float>(nl); W.glob_v = A.arr<float>(ng); W.glob_t = A.arr<float>(ng);
+  W.resh_v = A.arr<float>(nrv); W.resh_t = A.arr<float>(nrt);
+  W.dhid_v = A.arr<float>((size_t)d.B * D); W.dhid_t = A.arr<float>((size_t)d.B * D);
+  W.dfeat_v = A.arr<float>(nrv); W.dfeat_t = A.arr<float>(nrt);
+  W.mask_v = A.arr<unsigned char>((size_t)d.B * d.Cmax_clip); W.mask_t = A.arr<unsigned char>((size_t)d.B * d.Cmax_sent);
+  W.lens_v = A.arr<long long>(d.B); W.lens_t = A.arr<long long>(d.B); W.idx = A.arr<long long>(2 * (size_t)d.B);
+  // one contiguous block of gradient buffers zeroed with a single memset per step
+  A.get(0);
+  const size_t z0 = (A.off + 255) & ~(size_t)255;
+  W.d_local_v = A.arr<float>(nl); W.d_local_t = A.arr<float>(nl); W.d_glob_v = A.arr<float>(ng); W.d_glob_t = A.arr<float>(ng);
+  W.d_resh_v = A.arr<float>(nrv); W.d_resh_t = A.arr<float>(nrt);
+  W.zero_begin = (float*)(A.base ? A.base + z0 : nullptr);
+  W.zero_bytes = A.off - z0;
+}
+
+int check_cfg(const coot_step_config& c) {
+  const int D = c.net[0].hidden_dim;
+  COOT_REQUIRE(c.net[1].hidden_dim == D && c.net[2].hidden_dim == D && c.net[3].hidden_dim == D, "step: the four networks must share hidden_dim");
+  COOT_REQUIRE(c.net[0].use_input_fc && c.net[2].use_input_fc && !c.net[0].use_context && !c.net[2].use_context &&
+               c.net[0].pooler == 0 && c.net[2].pooler == 0, "step: local networks = input_fc + atn pooler, no context");
+  COOT_REQUIRE(!c.net[1].use_input_fc && !c.net[3].use_input_fc && c.net[1].use_context && c.net[3].use_context &&
+               c.net[1].input_dim == D && c.net[3].input_dim == D, "step: global networks = context networks on the local output dim");
+  return 0;
+}
+
+// fork/join between the caller's main stream and the two side streams
+struct StreamJoin {
+  hipEvent_t ev[3]; bool made = false;
+  int init() {
+    if (made) return 0;
+    for (int i = 0; i < 3; ++i) RUN(check_hip(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "hipEventCreate"));
+    made = true; return 0;
+  }
+  int fork(hipStream_t main, hipStream_t a, hipStream_t b) {
+    RUN(init());
+    RUN(check_hip(hipEventRecord(ev[0], main), "eventRecord"));
+    RUN(check_hip(hipStreamWaitEvent(a, ev[0], 0), "streamWait"));
+    RUN(check_hip(hipStreamWaitEvent(b, ev[0], 0), "streamWait"));
+    return 0;
+  }
+  int join(hipStream_t main, hipStream_t a, hipStream_t b) {
+    RUN(check_hip(hipEventRecord(ev[1], a), "eventRecord"));
+    RUN(check_hip(hipEventRecord(ev[2], b), "eventRecord"));
+    RUN(check_hip(hipStreamWaitEvent(main, ev[1], 0), "streamWait"));
+    RUN(check_hip(hipStreamWaitEvent(main, ev[2], 0), "streamWait"));
+    return 0;
+  }
+};
+thread_local StreamJoin g_join;
+
+// one side (video or text): local(ctx segment + item segment) -> pack -> global
+int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, int gi, const float* ctx_feat, const int64_t* ctx_len,
+                 int Lctx, const float* item_feat, const int64_t* item_len, int Litem, const int64_t* item_num, int Cmax,
+                 const coot_step_dims& d, float* local_out, float* glob_out, float* resh, unsigned char* mask, long long* lens,
+                 void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, int train, uint64_t seed, hipStream_t st) {
+  const int D = c.net[0].hidden_dim;
+  RUN(coot_net_pack_weights(&c.net[li], b.params[li], b.wpack[li], st));
+  RUN(coot_net_pack_weights(&c.net[gi], b.params[gi], b.wpack[gi], st));
+  RUN(coot_net_fwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
+                   nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, nullptr, st));
+  RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
+  RUN(coot_net_fwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0,
+                   local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi, nullptr, st));
+  return 0;
+}
+
+// backward of one side.  d_local [B+Nc, D]: in = loss gradients wrt (context | item embeddings), d_glob [B, 2D],
+// d_resh [B, Cmax, D] = cycle-consistency gradient wrt the packed tensor.
+int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li, int gi, const float* ctx_feat, const int64_t* ctx_len,
+                  int Lctx, const float* item_feat, const int64_t* item_len, int Litem, const int64_t* item_num, int Cmax,
+                  const coot_step_dims& d, const float* local_out, const float* resh, float* d_local, const float* d_glob,
+                  const float* d_resh, float* dhid, float* dfeat, void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, void* scratch,
+                  size_t sz_scratch, int train, uint64_t seed, hipStream_t st) {
+  const int D = c.net[0].hidden_dim;
+  RUN(coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
+                   b.grads[gi], dhid, dfeat, saved_g, sz_g, scratch, sz_scratch, train, seed + 11 * gi, nullptr, st));
+  RUN(launch_axpy_f32(d_local, dhid, (long)d.B * D, 1.0f, st));                               // context grad += dhidden
+  RUN(launch_pack_bwd(dfeat, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));  // item grads += unpack(global input grad)
+  if (d_resh) RUN(launch_pack_bwd(d_resh, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));
+  RUN(coot_net_bwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem, nullptr,
+                   d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_scratch, train, seed + 11 * li, nullptr, st));
+  return 0;
+}
+
+// idx[b] uniform in [0, len[b])  — th.multinomial(mask, 1) of coot/loss_fn.py:306-314 on the device
+__global__ void sample_idx_kernel(const long long* lens_a, const long long* lens_b, int B, unsigned long long seed, long long* idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * B) return;
+  const long long len = i < B ? lens_a[i] : lens_b[i - B];
+  const unsigned r = rng_u32(seed, 0xCCu, (unsigned long long)i);
+  long long v = (long long)(((unsigned long long)r * (unsigned long long)len) >> 32);
+  idx[i] = v < len ? v : len - 1;
+}
+
+// torch.optim.Adam (coupled L2 weight decay, nntrainer/optimization.py:45-74); bias corrections precomputed on the host
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, const float* decay, long n, float lr,
+                                                   float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      f32x4_t pp = *reinterpret_cast<f32x4_t*>(p + i), gg = *reinterpret_cast<const f32x4_t*>(g + i);
+      f32x4_t mm = *reinterpret_cast<f32x4_t*>(m + i), vv = *reinterpret_cast<f32x4_t*>(v + i);
+      f32x4_t dd = decay ? *reinterpret_cast<const f32x4_t*>(decay + i) : f32x4_t{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gj = gg[j] + wd * dd[j] * pp[j];
+        mm[j] = b1 * mm[j] + (1.f - b1) * gj;
+        vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+        pp[j] -= lr * inv_bc1 * mm[j] / (sqrtf(vv[j]) * inv_sqrt_bc2 + eps);
+      }
+      *reinterpret_cast<f32x4_t*>(p + i) = pp; *reinterpret_cast<f32x4_t*>(m + i) = mm; *reinterpret_cast<f32x4_t*>(v + i) = vv;
+    } else {
+      for (long k = i; k < n; ++k) {
+        const float gj = g[k] + wd * (decay ? decay[k] : 1.f) * p[k];
+        m[k] = b1 * m[k] + (1.f - b1) * gj;
+        v[k] = b2 * v[k] + (1.f - b2) * gj * gj;
+        p[k] -= lr * inv_bc1 * m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream) {
+  COOT_REQUIRE(params && grads && m && v && step >= 1, "adam: bad arguments");
+  if (n <= 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, decay_mask, (long)n, lr, beta1, beta2,
+                     eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+  COOT_CHECK_LAUNCH("adam");
+  return 0;
+}
+
+size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_dims* dims) {
+  Bump A(nullptr, 0); StepWs W; layout_step(*cfg, *dims, A, W); return A.off + 512;
+}
+
+int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, const coot_step_batch* x, const coot_step_dims* d,
+                      float* local_v, float* local_t, float* glob_v, float* glob_t, float* resh_v, float* resh_t, void* workspace,
+                      size_t workspace_bytes, int train, uint64_t seed, coot_stream_t main_s, coot_stream_t side_v, coot_stream_t side_t) {
+  RUN(check_cfg(*cfg));
+  Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
+  COOT_REQUIRE(!A.overflow, "step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
+  hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
+  RUN(g_join.fork(sm, sv, st));
+  RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
+                   local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv));
+  RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
+                   local_t, glob_t, resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st));
+  RUN(g_join.join(sm, sv, st));
+  return 0;
+}
+
+int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* b, const coot_step_batch* x, const coot_step_dims* d,
+                       const float* local_v, const float* local_t, const float* resh_v, const float* resh_t, float* d_local_v,
+                       float* d_local_t, const float* d_glob_v, const float* d_glob_t, const float* d_resh_v, const float* d_resh_t,
+                       void* workspace, size_t workspace_bytes, int train, uint64_t seed, coot_stream_t main_s, coot_stream_t side_v,
+                       coot_stream_t side_t) {
+  RUN(check_cfg(*cfg));
+  Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
+  COOT_REQUIRE(!A.overflow, "step: workspace too small");
+  hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
+  RUN(g_join.fork(sm, sv, st));
+  RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d, local_v,
+                    resh_v, d_local_v, d_glob_v, d_resh_v, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, W.scratch_v,
+                    W.sz_sv, train, seed, sv));
+  RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, local_t,
+                    resh_t, d_local_t, d_glob_t, d_resh_t, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, W.scratch_t,
+                    W.sz_st, train, seed + 1000, st));
+  RUN(g_join.join(sm, sv, st));
+  return 0;
+}
+
+int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, const coot_step_batch* x, const coot_step_dims* d,
+                    float* losses, void* workspace, size_t workspace_bytes, int train, uint64_t seed, int64_t step, int do_optimizer,
+                    coot_stream_t main_s, coot_stream_t side_v, coot_stream_t side_t) {
+  RUN(check_cfg(*cfg));
+  COOT_REQUIRE(losses, "train_step: losses pointer");
+  Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
+  COOT_REQUIRE(!A.overflow, "train_step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
+  hipStream_t sm = (hipStream_t)main_s;
+  const int D = cfg->net[0].hidden_dim;
+  // zero: parameter gradients (4 arenas), embedding gradients (one block), the three loss words
+  for (int i = 0; i < 4; ++i)
+    RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), sm), "memset grads"));
+  RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, sm), "memset embedding grads"));
+  RUN(check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), sm), "memset losses"));
+  RUN(coot_step_forward(cfg, b, x, d, W.local_v, W.local_t, W.glob_v, W.glob_t, W.resh_v, W.resh_t, workspace, workspace_bytes, train, seed,
+                        main_s, side_v, side_t));
+  // losses on the main stream: contrastive -> losses[1], cycle-consistency -> losses[2]
+  RUN(coot_contrastive_fwd_bwd(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
+                               W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
+                               W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
+                               W.sz_loss, main_s));
+  if (cfg->cc_weight != 0.f) {
+    hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * d->B + 255) / 256), dim3(256), 0, sm, (const long long*)x->clip_num,
+                       (const long long*)x->sent_num, d->B, (unsigned long long)seed, W.idx);
+    COOT_CHECK_LAUNCH("sample_idx");
+    RUN(coot_cyclecons_fwd_bwd(W.resh_v, W.resh_t, x->clip_num, x->sent_num, (const int64_t*)W.idx, (const int64_t*)(W.idx + d->B), d->B,
+                               d->Cmax_clip, d->Cmax_sent, D, cfg->cc_weight, 1.0f / (float)d->B, losses + 2, nullptr, nullptr, W.d_resh_v,
+                               W.d_resh_t, main_s));
+  }
+  RUN(launch_axpy_f32(losses, losses + 1, 1, 1.0f, sm));
+  RUN(launch_axpy_f32(losses, losses + 2, 1, 1.0f, sm));
+  RUN(coot_step_backward(cfg, b, x, d, W.local_v, W.local_t, W.resh_v, W.resh_t, W.d_local_v, W.d_local_t, W.d_glob_v, W.d_glob_t,
+                         cfg->cc_weight != 0.f ? W.d_resh_v : nullptr, cfg->cc_weight != 0.f ? W.d_resh_t : nullptr, workspace,
+                         workspace_bytes, train, seed, main_s, side_v, side_t));
+  if (do_optimizer)
+    for (int i = 0; i < 4; ++i)
+      RUN(coot_adam_step(b->params[i], b->grads[i], b->adam_m[i], b->adam_v[i], b->decay_mask[i], coot_net_param_numel(&cfg->net[i]),
+                         cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, step, main_s));
+  return 0;
+}
+
+}  // extern "C"

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         if (a.drop.thr) {
           const int kidx = kc + kt * 16 + lg * 4 + i;
           unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qrow) * Lk + kidx);
-          p[i] *= drop_scale(a.drop.seed, a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          p[i] *= drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
         }
       }
       pf[kt] = pack4(p[0], p[1], p[2], p[3]);
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
         float dpe = dp[i];
         if (a.drop.thr) {
           unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qrow) * Lk + kidx);
-          dpe *= drop_scale(a.drop.seed, a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          dpe *= drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
         }
         ds[i] = (kidx < nvalid) ? p * (dpe - dl) * a.scale : 0.f;  // masked_fill blocks the gradient
       }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
         float dsc = 1.f;
         if (a.drop.thr) {
           unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qr) * Lk + krow);
-          dsc = drop_scale(a.drop.seed, a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          dsc = drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
         }
         p[i] = pv * dsc;
         ds[i] = pv * (dp[i] * dsc - delta_s[ql]) * a.scale;

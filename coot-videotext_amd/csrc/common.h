@@ -68,6 +68,11 @@ __device__ __forceinline__ unsigned rng_u32(unsigned long long seed, unsigned si
   unsigned b = mix32((unsigned)(idx >> 32) + site * 0x9E3779B9u + (unsigned)(seed >> 32));
   return mix32(a ^ (b + 0x85ebca6bU + (a << 6) + (a >> 2)));
 }
+// effective seed = host salt + *device base seed (the device word advances once per training step, so a captured
+// HIP graph draws fresh masks on every replay)
+__device__ __forceinline__ unsigned long long eff_seed(unsigned long long salt, const unsigned long long* base) {
+  return salt + (base ? *base : 0ull);
+}
 // keep-scale: 0 if dropped else 1/(1-p).  thr = p * 2^32
 __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned site, unsigned long long idx,
                                             unsigned thr, float inv_keep) {

@@ -21,6 +21,7 @@ struct GemmEpi {
   float* colsum_ws = nullptr; long ld_colsum_ws = 0;  // internal: per-row-block partials (set by the launcher)
   // dropout applied to (alpha*acc + bias) [act 0/1] or to the final product [act 2]
   unsigned drop_thr = 0; float drop_inv_keep = 1.0f; unsigned long long drop_seed = 0; unsigned drop_site = 0;
+  const unsigned long long* drop_seed_ptr = nullptr;
   long drop_ld = 0;  // element index = row * drop_ld + col (+ z * drop_zoff)
   void* out = nullptr; long ldc = 0; int out_f32 = 0; int accumulate = 0;
 };

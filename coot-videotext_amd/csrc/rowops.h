@@ -6,6 +6,7 @@ namespace coot {
 
 struct DropCfg {
   unsigned thr = 0; float inv_keep = 1.0f; unsigned long long seed = 0; unsigned site = 0;
+  const unsigned long long* seed_ptr = nullptr;  // device base seed added to `seed`
 };
 
 struct LnFwd {

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
       float t = v[i][j] * rs;
       if (p.gain) t = t * p.gain[col + j] + p.bias[col + j];
       if (p.pe) t += p.pe[(long)(row % p.pe_L) * D + col + j];
-      if (p.drop.thr) t *= drop_scale(p.drop.seed, p.drop.site, (unsigned long long)row * D + col + j, p.drop.thr, p.drop.inv_keep);
+      if (p.drop.thr) t *= drop_scale(eff_seed(p.drop.seed, p.drop.seed_ptr), p.drop.site, (unsigned long long)row * D + col + j, p.drop.thr, p.drop.inv_keep);
       y[j] = t;
     }
     if (p.y) store4_bf(p.y + (long)row * p.ldy + col, y);
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         if (p.drop.thr) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            dy[i][j] *= drop_scale(p.drop.seed, p.drop.site, (unsigned long long)row * D + col + j, p.drop.thr, p.drop.inv_keep);
+            dy[i][j] *= drop_scale(eff_seed(p.drop.seed, p.drop.seed_ptr), p.drop.site, (unsigned long long)row * D + col + j, p.drop.thr, p.drop.inv_keep);
         }
       }
       s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         ab[i][j] += dy[i][j];
         float m = dx[j];
         if (p.dxm && p.dxm_drop.thr)
-          m *= drop_scale(p.dxm_drop.seed, p.dxm_drop.site, (unsigned long long)row * p.dxm_drop_ld + col + j, p.dxm_drop.thr, p.dxm_drop.inv_keep);
+          m *= drop_scale(eff_seed(p.dxm_drop.seed, p.dxm_drop.seed_ptr), p.dxm_drop.site, (unsigned long long)row * p.dxm_drop_ld + col + j, p.dxm_drop.thr, p.dxm_drop.inv_keep);
         dm[j] = m;
         ac[i][j] += m;
       }

@@ -20,7 +20,8 @@ EXPORTS = [
     "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_pack_fwd",
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
-    "coot_timing_collect",
+    "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
+    "coot_adam_step",
 ]
 
 
@@ -37,6 +38,25 @@ class ContrastiveConfig(C.Structure):
     _fields_ = [("margin", C.c_float), ("weight_high", C.c_float), ("weight_high_internal", C.c_float),
                 ("weight_low", C.c_float), ("weight_low_internal", C.c_float), ("weight_context", C.c_float),
                 ("weight_context_internal", C.c_float)]
+
+
+class StepConfig(C.Structure):
+    """coot_step_config."""
+    _fields_ = [("net", NetConfig * 4), ("contr", ContrastiveConfig), ("cc_weight", C.c_float), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+class StepDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "Nc", "Lv", "Lc", "Lp", "Ls", "Cmax_clip", "Cmax_sent")]
+
+
+class StepBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p * 4) for n in ("params", "grads", "wpack", "adam_m", "adam_v", "decay_mask", "pe")]
+
+
+class StepBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("vid_feat", "clip_feat", "par_feat", "sent_feat", "vid_len", "clip_len",
+                                          "par_len", "sent_len", "clip_num", "sent_num")]
 
 
 _lib = None
@@ -72,8 +92,8 @@ def load():
     lib.coot_net_saved_bytes.argtypes = [cfgp, i32, i32, i32, i32]
     lib.coot_net_scratch_bytes.restype = sz
     lib.coot_net_scratch_bytes.argtypes = [cfgp, i32, i32, i32, i32]
-    lib.coot_net_fwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp]
-    lib.coot_net_bwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp]
+    lib.coot_net_fwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp, vp]
+    lib.coot_net_bwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp, vp]
     lib.coot_pack_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.coot_pack_bwd.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.coot_contrastive_scratch_bytes.restype = sz
@@ -89,6 +109,13 @@ def load():
     lib.coot_probe_tr16.argtypes = [vp, vp]
     lib.coot_timing_enable.argtypes = [i32]
     lib.coot_timing_collect.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]
+    scp, sdp, sbp, sxp = C.POINTER(StepConfig), C.POINTER(StepDims), C.POINTER(StepBuffers), C.POINTER(StepBatch)
+    lib.coot_step_workspace_bytes.restype = sz
+    lib.coot_step_workspace_bytes.argtypes = [scp, sdp]
+    lib.coot_train_step.argtypes = [scp, sbp, sxp, sdp, vp, vp, sz, i32, u64, i64, i32, vp, vp, vp]
+    lib.coot_step_forward.argtypes = [scp, sbp, sxp, sdp] + [vp] * 6 + [vp, sz, i32, u64, vp, vp, vp]
+    lib.coot_step_backward.argtypes = [scp, sbp, sxp, sdp] + [vp] * 10 + [vp, sz, i32, u64, vp, vp, vp]
+    lib.coot_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp]
     _lib = lib
     return lib
 

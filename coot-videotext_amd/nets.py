@@ -69,6 +69,7 @@ class TransformerHip(nn.Module):
         self._dirty = True
         self._grad_flat: Optional[torch.Tensor] = None
         self.accumulate_into_flat = False  # set by RetrievalTrainer.train_step (see _NetFn.backward)
+        self.seed_dev: Optional[torch.Tensor] = None  # device int64 base seed (advanced once per step by the trainer)
         self.call_counter = 0
         self.init_network(cfg.weight_init_type, cfg.weight_init_std)
 
@@ -208,7 +209,7 @@ class _NetFn(torch.autograd.Function):
         _lib.check(lib.coot_net_fwd(C.byref(cfg), _lib.ptr(net._flat), _lib.ptr(net._wpack), _lib.ptr(pe), _lib.ptr(feats),
                                     _lib.ptr(lengths), N, L, _lib.ptr(feats2), _lib.ptr(lengths2), N2, L2, _lib.ptr(hid),
                                     _lib.ptr(pooled), _lib.ptr(tokens), _lib.ptr(saved), saved.numel(), None, 0, train, seed,
-                                    _lib.stream_ptr()), "coot_net_fwd")
+                                    _lib.ptr(net.seed_dev), _lib.stream_ptr()), "coot_net_fwd")
         ctx.net, ctx.saved, ctx.seed, ctx.train = net, saved, seed, train
         ctx.feats, ctx.lengths, ctx.hid, ctx.feats2, ctx.lengths2 = feats, lengths, hid, feats2, lengths2
         ctx.need_dfeats = bool(ctx.needs_input_grad[1])
@@ -241,7 +242,7 @@ class _NetFn(torch.autograd.Function):
                                     _lib.ptr(feats), _lib.ptr(lengths), N, L, _lib.ptr(feats2), _lib.ptr(lengths2), N2, L2,
                                     _lib.ptr(hid), _lib.ptr(dpooled), _lib.ptr(gflat), _lib.ptr(dhid), _lib.ptr(dfeats),
                                     _lib.ptr(ctx.saved), ctx.saved.numel(), _lib.ptr(scratch), scratch.numel(), ctx.train,
-                                    ctx.seed, _lib.stream_ptr()), "coot_net_bwd")
+                                    ctx.seed, _lib.ptr(net.seed_dev), _lib.stream_ptr()), "coot_net_bwd")
         if direct:
             grads = (None,) * len(net.table)
         else:

@@ -13,14 +13,17 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import torch
 
+import ctypes as C
+
+from . import lib as _lib
 from . import loss_fn
-from .config import RetrievalConfig
+from .config import RetrievalConfig, RetrievalNetworksConst
 from .model_retrieval import (RetrievalDataBatchTuple, RetrievalModelManager, RetrievalTextEmbTuple,
                               RetrievalVisualEmbTuple)
 from .retrieval import compute_retrieval
 
 
-def make_optimizer(cfg_opt, params) -> torch.optim.Optimizer:
+def make_optimizer(cfg_opt, params, capturable: bool = False) -> torch.optim.Optimizer:
     """nntrainer/optimization.py:45-74 for name == 'adam': Adam(lr, betas=(momentum, adam_beta2), eps,
     weight_decay * decay_mult per parameter).  Parameters are grouped by decay_mult (same update rule,
     fewer groups)."""
@@ -34,7 +37,7 @@ def make_optimizer(cfg_opt, params) -> torch.optim.Optimizer:
     param_groups = [{"params": ps, "weight_decay": w, "lr": lr} for w, ps in groups.items()]
     return torch.optim.Adam(param_groups, lr=lr, betas=(float(cfg_opt.momentum), float(cfg_opt.adam_beta2)),
                             eps=float(cfg_opt.adam_eps), amsgrad=bool(getattr(cfg_opt, "adam_amsgrad", False)),
-                            foreach=True)
+                            foreach=True, capturable=capturable)
 
 
 class RetrievalTrainer:
@@ -48,7 +51,8 @@ class RetrievalTrainer:
         self.optimizer = None
         if not is_test:
             params, _names, _flat = model_mgr.get_all_params()
-            self.optimizer = make_optimizer(cfg.optimizer, params)
+            on_gpu = any(p.is_cuda for p in _flat)
+            self.optimizer = make_optimizer(cfg.optimizer, params, capturable=on_gpu)  # capturable: HIP-graph safe
         self.cc_generator: Optional[torch.Generator] = None
         self.total_step = 0
 
@@ -106,12 +110,55 @@ class RetrievalTrainer:
                 main.wait_stream(s)
 
     # ---- one optimisation step (coot/trainer_retrieval.py:253-291) ---------------------------------------
-    def train_step(self, batch: RetrievalDataBatchTuple, vid_counts=None, clip_counts=None
+    def train_step(self, batch: RetrievalDataBatchTuple, vid_counts=None, clip_counts=None, use_graph: bool = False
                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """forward + losses + backward (+ gradient all-reduce) + optimizer step; returns (loss, contr_loss,
         cc_loss) as 0-dim device tensors (no host sync; the reference's per-step .item() logging is the
-        caller's choice).  With ``self.dp`` set (dist.DataParallelContext) the batch is this rank's shard."""
+        caller's choice).  With ``self.dp`` set (dist.DataParallelContext) the batch is this rank's shard.
+        use_graph=True replays the whole step as ONE captured HIP graph (captured on first use for this batch's
+        shapes; a new batch of the same shapes is copied into the captured input buffers)."""
+        if not use_graph:
+            return self._step_impl(batch, vid_counts, clip_counts)
+        g = getattr(self, "_graph", None)
+        if g is None or not self._graph_matches(batch):
+            self._capture(batch, vid_counts, clip_counts)
+        elif batch is not self._graph_batch:
+            for name, value in batch.__dict__.items():
+                if torch.is_tensor(value):
+                    getattr(self._graph_batch, name).copy_(value, non_blocking=True)
+        self._graph.replay()
+        self.total_step += 1
+        return self._graph_out
+
+    def _graph_matches(self, batch) -> bool:
+        ref = self._graph_batch
+        return all((not torch.is_tensor(v)) or (v.shape == getattr(ref, k).shape) for k, v in batch.__dict__.items()) \
+            and batch.max_clip_num == ref.max_clip_num and batch.max_sent_num == ref.max_sent_num
+
+    def _capture(self, batch, vid_counts, clip_counts, warmup: int = 3) -> None:
+        """Whole-step capture: eager warm-up on a side stream (allocator, RCCL, lazy inits), then one capture."""
+        if batch.max_clip_num is None or batch.max_sent_num is None:
+            raise RuntimeError("graph capture needs batch.max_clip_num / max_sent_num on the host (no device sync inside a graph)")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step_impl(batch, vid_counts, clip_counts)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph_batch = batch
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._step_impl(batch, vid_counts, clip_counts)
+        self._graph, self._graph_out = graph, out
+
+    def _step_impl(self, batch, vid_counts=None, clip_counts=None):
         nets = list(self.model_mgr.model_dict.values())
+        if getattr(self, "_seed_dev", None) is None:
+            self._seed_dev = torch.zeros(1, dtype=torch.int64, device=batch.vid_feat.device)
+            for net in nets:
+                net.seed_dev = self._seed_dev
+        self._seed_dev += 1  # device-side dropout seed: advances on every step, also under graph replay
         flat_grads = [net.bind_flat_grads() for net in nets]
         for net, g in zip(nets, flat_grads):
             g.zero_()
@@ -140,8 +187,94 @@ class RetrievalTrainer:
             dp.allreduce_grads(flat_grads, getattr(self, "comm_stream", None))
         self.optimizer.step()
         self.model_mgr.mark_weights_dirty()
-        self.total_step += 1
+        if not torch.cuda.is_current_stream_capturing():
+            self.total_step += 1
         return loss.detach(), contr_loss.detach(), (cc_loss.detach() if torch.is_tensor(cc_loss) else torch.zeros_like(loss))
+
+    # ---- native step: the whole optimisation step sequenced inside libcoot_hip.so ---------------------------------
+    def _native_setup(self, batch: RetrievalDataBatchTuple):
+        lib = _lib.load()
+        nets = [self.model_mgr.model_dict[k] for k in RetrievalNetworksConst.values()]
+        dev = batch.vid_feat.device
+        st = getattr(self, "_native", None)
+        if st is None:
+            st = type("NativeState", (), {})()
+            st.nets = nets
+            st.cfg = _lib.StepConfig()
+            for i, net in enumerate(nets):
+                st.cfg.net[i] = net.c_cfg
+                net.bind_flat_grads()
+                net.ensure_packed()
+            st.cfg.contr = self.loss_cfg.to_c()
+            st.cfg.cc_weight = float(self.cfg.train.loss_cycle_cons)
+            o = self.cfg.optimizer
+            st.cfg.lr, st.cfg.beta1, st.cfg.beta2 = float(o.lr), float(o.momentum), float(o.adam_beta2)
+            st.cfg.eps, st.cfg.weight_decay = float(o.adam_eps), float(o.weight_decay)
+            wd_bias = bool(getattr(o, "weight_decay_for_bias", False))
+            st.m = [torch.zeros_like(n._flat) for n in nets]
+            st.v = [torch.zeros_like(n._flat) for n in nets]
+            st.decay = []
+            for n in nets:  # decay_mult = 0 for biases when weight_decay_for_bias (model_manager_base.py:152-154, sic)
+                mask = torch.ones_like(n._flat)
+                for (name, off, shape) in n.table:
+                    if wd_bias and "bias" in name:
+                        mask[off:off + int(np.prod(shape))] = 0.0
+                st.decay.append(mask)
+            st.bufs = _lib.StepBuffers()
+            st.losses = torch.zeros(3, dtype=torch.float32, device=dev)
+            st.streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            st.step = 0
+            st.dims_key = None
+            self._native = st
+        for i, n in enumerate(nets):  # arenas move when a module is re-flattened (.cuda()/load): refresh every call
+            st.bufs.params[i], st.bufs.grads[i], st.bufs.wpack[i] = n._flat.data_ptr(), n._grad_flat.data_ptr(), n._wpack.data_ptr()
+            st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i] = st.m[i].data_ptr(), st.v[i].data_ptr(), st.decay[i].data_ptr()
+            st.bufs.pe[i] = n.embedding.pe.data_ptr()
+        if batch.max_clip_num is None or batch.max_sent_num is None:
+            batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
+        key = (batch.vid_feat.shape, batch.clip_feat.shape, batch.par_feat.shape, batch.sent_feat.shape, batch.max_clip_num, batch.max_sent_num)
+        if key != st.dims_key:
+            B, Lv, _ = batch.vid_feat.shape
+            Nc, Lc, _ = batch.clip_feat.shape
+            st.dims = _lib.StepDims(B, Nc, Lv, Lc, batch.par_feat.shape[1], batch.sent_feat.shape[1], batch.max_clip_num, batch.max_sent_num)
+            assert batch.sent_feat.shape[0] == Nc and batch.par_feat.shape[0] == B
+            st.ws = torch.empty(lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims)), dtype=torch.uint8, device=dev)
+            st.dims_key = key
+        x = _lib.StepBatch()
+        for f in ("vid_feat", "clip_feat", "par_feat", "sent_feat"):
+            t_ = getattr(batch, f)
+            assert t_.dtype == torch.float32 and t_.is_contiguous(), f
+            setattr(x, f, t_.data_ptr())
+        for f, src in (("vid_len", "vid_feat_len"), ("clip_len", "clip_feat_len"), ("par_len", "par_feat_len"),
+                       ("sent_len", "sent_feat_len"), ("clip_num", "clip_num"), ("sent_num", "sent_num")):
+            t_ = getattr(batch, src)
+            assert t_.dtype == torch.int64 and t_.is_contiguous(), src
+            setattr(x, f, t_.data_ptr())
+        return st, x
+
+    def train_step_native(self, batch: RetrievalDataBatchTuple, do_optimizer: bool = True, seed: Optional[int] = None):
+        """One optimisation step as ONE call into libcoot_hip.so (coot_train_step): forward of both sides on two
+        HIP streams, losses, backward, fused Adam — no Python between the kernel launches.  Returns views of the
+        device loss vector (total, contrastive, cycle-consistency).  Single-GPU path; Adam state is the library's
+        (flat moment arenas), the learning rate is read from self.optimizer's first param group on every call so the
+        reference's LR schedulers keep working."""
+        lib = _lib.load()
+        st, x = self._native_setup(batch)
+        if self.optimizer is not None:
+            st.cfg.lr = float(self.optimizer.param_groups[0]["lr"])
+        if do_optimizer:
+            st.step += 1
+        if seed is None:
+            seed = (torch.initial_seed() * 1000003 + 7919 * (self.total_step + 1)) & 0xFFFFFFFFFFFFFFFF
+        train = 1 if self.model_mgr.is_train else 0
+        main = torch.cuda.current_stream()
+        _lib.check(lib.coot_train_step(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(st.dims), st.losses.data_ptr(),
+                                       st.ws.data_ptr(), st.ws.numel(), train, int(seed), max(st.step, 1), int(do_optimizer),
+                                       main.cuda_stream, st.streams[0].cuda_stream, st.streams[1].cuda_stream), "coot_train_step")
+        if do_optimizer:
+            self.model_mgr.mark_weights_dirty()
+        self.total_step += 1
+        return st.losses[0], st.losses[1], st.losses[2]
 
     # ---- validation (coot/trainer_retrieval.py:312-477, metrics part) ---------------------------------------
     @torch.no_grad()

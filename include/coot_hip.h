@@ -74,15 +74,18 @@ int coot_net_fwd(const coot_net_config* cfg, const float* params, const void* wp
                  const float* feats, const int64_t* lengths, int N, int L, const float* feats2,
                  const int64_t* lengths2, int N2, int L2, const float* hidden,
                  float* pooled, float* per_token, void* saved, size_t saved_bytes, void* scratch,
-                 size_t scratch_bytes, int train, uint64_t seed, coot_stream_t stream);
-/* grads: flat fp32 arena, ACCUMULATED (+=).  dhidden [N, hidden_dim] (written) or NULL.
+                 size_t scratch_bytes, int train, uint64_t seed, const uint64_t* seed_dev, coot_stream_t stream);
+/* Dropout (train != 0) draws from a counter-based generator keyed by (seed + *seed_dev, site, element); seed_dev
+ * is an optional DEVICE word the caller advances once per step — with it a captured HIP graph of the step draws new
+ * masks on every replay; forward and backward of one step must see the same value.
+ * grads: flat fp32 arena, ACCUMULATED (+=).  dhidden [N, hidden_dim] (written) or NULL.
  * dfeats [N, L, input_dim] fp32 (written; only supported when use_input_fc == 0) or NULL. */
 int coot_net_bwd(const coot_net_config* cfg, const float* params, const void* wpack, const float* pe,
                  const float* feats, const int64_t* lengths, int N, int L, const float* feats2,
                  const int64_t* lengths2, int N2, int L2, const float* hidden,
                  const float* dpooled, float* grads, float* dhidden, float* dfeats, void* saved,
                  size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed,
-                 coot_stream_t stream);
+                 const uint64_t* seed_dev, coot_stream_t stream);
 
 /* ---- clip -> video packing: the python loop of coot/model_retrieval.py:121-136 ---------------- */
 int coot_pack_fwd(const float* emb, const int64_t* counts, int B, int Cmax, int D, float* out /*[B,Cmax,D]*/,
@@ -114,6 +117,50 @@ int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* 
                            const int64_t* sent_lens, const int64_t* idx_clip, const int64_t* idx_sent, int B,
                            int Cc, int Cs, int D, float weight, float inv_batch, float* loss, float* rows_clip,
                            float* rows_sent, float* dclip, float* dsent, coot_stream_t stream);
+
+/* ---- the whole training step as native code (coot/trainer_retrieval.py:253-291) -------------------------------
+ * Networks are indexed 0 = net_video_local, 1 = net_video_global, 2 = net_text_local, 3 = net_text_global
+ * (coot/configs_retrieval.py:182-189).  All buffers are caller-owned device memory. */
+typedef struct coot_step_config {
+  coot_net_config net[4];
+  coot_contrastive_config contr;
+  float cc_weight;                               /* train.loss_cycle_cons                                    */
+  float lr, beta1, beta2, eps, weight_decay;     /* Adam as built by nntrainer/optimization.py:45-74          */
+} coot_step_config;
+typedef struct coot_step_dims { int B, Nc, Lv, Lc, Lp, Ls, Cmax_clip, Cmax_sent; } coot_step_dims;
+typedef struct coot_step_buffers {
+  float* params[4]; float* grads[4]; void* wpack[4];       /* flat arenas (coot_net_param_info layout), bf16 pack */
+  float* adam_m[4]; float* adam_v[4];                      /* Adam moments, same layout                            */
+  const float* decay_mask[4];                              /* 1.0 / 0.0 per element (decay_mult), or NULL = all 1  */
+  const float* pe[4];                                      /* embedding.pe tables                                  */
+} coot_step_buffers;
+typedef struct coot_step_batch {                           /* RetrievalDataBatchTuple (coot/dataset_retrieval.py:64-102) */
+  const float *vid_feat, *clip_feat, *par_feat, *sent_feat;
+  const int64_t *vid_len, *clip_len, *par_len, *sent_len, *clip_num, *sent_num;
+} coot_step_batch;
+size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_dims* dims);
+/* One optimisation step in one call: grads zeroed, both sides encoded on side_v / side_t, contrastive +
+ * cycle-consistency losses (cycle indices drawn on the device), backward, Adam (if do_optimizer; `step` is the 1-based
+ * step count for the bias correction).  losses[3] = {total, contrastive, cycle-consistency} (device, overwritten). */
+int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
+                    const coot_step_dims* dims, float* losses, void* workspace, size_t workspace_bytes, int train,
+                    uint64_t seed, int64_t step, int do_optimizer, coot_stream_t main_stream, coot_stream_t side_v,
+                    coot_stream_t side_t);
+/* The same step split in phases, for data parallel training where torch.distributed collectives (all-gather of the
+ * embeddings, all-reduce of the gradients) sit between them.  local_* = [B + Nc, D] (context rows first, then
+ * clip / sentence embeddings), glob_* = [B, 2D], resh_* = [B, Cmax, D] (packed + zero padded). */
+int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
+                      const coot_step_dims* dims, float* local_v, float* local_t, float* glob_v, float* glob_t,
+                      float* resh_v, float* resh_t, void* workspace, size_t workspace_bytes, int train, uint64_t seed,
+                      coot_stream_t main_stream, coot_stream_t side_v, coot_stream_t side_t);
+int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
+                       const coot_step_dims* dims, const float* local_v, const float* local_t, const float* resh_v,
+                       const float* resh_t, float* d_local_v, float* d_local_t, const float* d_glob_v,
+                       const float* d_glob_t, const float* d_resh_v, const float* d_resh_t, void* workspace,
+                       size_t workspace_bytes, int train, uint64_t seed, coot_stream_t main_stream, coot_stream_t side_v,
+                       coot_stream_t side_t);
+int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream);
 
 /* ---- kernel-level entry points (unit tests / microbenchmarks) ---------------------------------- */
 /* C[M,N] (bf16 or fp32) = act(X[M,K] . W[N,K]^T + bias) (+ residual)   (bf16 operands as uint16) */
