@@ -353,8 +353,43 @@ def test_native_step_matches_autograd_path(env):
             # +-lr noise updates from Adam's normalisation in BOTH implementations; they are not comparable
             if float(nb._grad_flat[off:off + n].abs().max()) < 1e-5 * gmax:
                 continue
-            d = float((na._flat[off:off + n] - nb._flat[off:off + n]).abs().max())
-            assert d < 2e-4, (name, d)
+            # Adam divides by sqrt(v): an element whose gradient is in the round-off noise of both implementations
+            # moves by up to +-lr per step in either, so compare element-wise where the gradient is significant and
+            # bound everything else by the 3-step worst case (opposite signs: 2 * 3 * lr)
+            diff = (na._flat[off:off + n] - nb._flat[off:off + n]).abs()
+            sig = nb._grad_flat[off:off + n].abs() > 1e-2 * gmax
+            if bool(sig.any()):
+                d = float(diff[sig].max())
+                assert d < 2e-4, (name, d)
+            assert float(diff.max()) <= 6.1e-3, (name, float(diff.max()))
+
+
+def test_fused_adam_matches_torch_adam(env):
+    """coot_adam_step on identical gradients vs torch.optim.Adam (coupled weight decay with a per-element decay mask =
+    the reference's bias decay_mult 0, nntrainer/optimization.py:45-74, model_manager_base.py:152-154)."""
+    torch, cva = env
+    lib = cva.lib.load()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n = 100003
+    p0 = torch.randn(n, generator=g) * 0.05
+    mask = (torch.arange(n) % 7 != 0).float()
+    pa = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    # torch side: two groups (decay / no decay) over one flat tensor is not expressible, so emulate with two tensors
+    idx_d, idx_n = mask.bool().cuda(), ~mask.bool().cuda()
+    pd_, pn_ = torch.nn.Parameter(p0.cuda()[idx_d].clone()), torch.nn.Parameter(p0.cuda()[idx_n].clone())
+    opt = torch.optim.Adam([dict(params=[pd_], weight_decay=2e-5), dict(params=[pn_], weight_decay=0.0)], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    dm = mask.cuda()
+    for step in range(1, 6):
+        gr = (torch.randn(n, generator=g) * (0.1 ** (step % 3))).cuda()
+        pd_.grad, pn_.grad = gr[idx_d].clone(), gr[idx_n].clone()
+        opt.step()
+        cva.lib.check(lib.coot_adam_step(pa.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), dm.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8,
+                                         2e-5, step, torch.cuda.current_stream().cuda_stream), "adam")
+        torch.cuda.synchronize()
+    ref = torch.empty(n, device="cuda")
+    ref[idx_d], ref[idx_n] = pd_.data, pn_.data
+    assert float((pa - ref).abs().max()) < 2e-6
 
 
 def test_native_step_trains_with_dropout_and_cycle_loss(env):
