@@ -50,6 +50,21 @@ def gather_rows(x: torch.Tensor, counts: List[int], rank: int, group=None) -> to
     return _GatherRows.apply(x, counts, rank, group)
 
 
+def gather_rows_nograd(x: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    """The collective of gather_rows without autograd (native step: gradients are sliced by the caller)."""
+    world, maxc = len(counts), max(counts)
+    if x.shape[0] != maxc:
+        pad = x.new_zeros((maxc,) + tuple(x.shape[1:]))
+        pad[: x.shape[0]] = x
+        x = pad
+    out = x.new_empty((world * maxc,) + tuple(x.shape[1:]))
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    if all(c == maxc for c in counts):
+        return out
+    idx = torch.cat([torch.arange(r * maxc, r * maxc + c, device=x.device) for r, c in enumerate(counts)])
+    return out.index_select(0, idx)
+
+
 class DataParallelContext:
     """Holds rank/world and implements the collectives of one training step."""
 
@@ -62,6 +77,12 @@ class DataParallelContext:
         t = torch.tensor([int(value)], dtype=torch.int32, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
+
+    def global_max_pair(self, a: int, b: int, device) -> Tuple[int, int]:
+        t = torch.tensor([int(a), int(b)], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        v = t.tolist()
+        return int(v[0]), int(v[1])
 
     def global_counts(self, n: int, device) -> List[int]:
         t = torch.tensor([int(n)], dtype=torch.int64, device=device)

@@ -252,13 +252,17 @@ class RetrievalTrainer:
             setattr(x, f, t_.data_ptr())
         return st, x
 
-    def train_step_native(self, batch: RetrievalDataBatchTuple, do_optimizer: bool = True, seed: Optional[int] = None):
+    def train_step_native(self, batch: RetrievalDataBatchTuple, do_optimizer: bool = True, seed: Optional[int] = None,
+                          vid_counts=None, clip_counts=None):
         """One optimisation step as ONE call into libcoot_hip.so (coot_train_step): forward of both sides on two
         HIP streams, losses, backward, fused Adam — no Python between the kernel launches.  Returns views of the
-        device loss vector (total, contrastive, cycle-consistency).  Single-GPU path; Adam state is the library's
+        device loss vector (total, contrastive, cycle-consistency).  With ``self.dp`` set the step runs as native phases
+        with the RCCL collectives between them (_train_step_native_dp).  Adam state is the library's
         (flat moment arenas), the learning rate is read from self.optimizer's first param group on every call so the
         reference's LR schedulers keep working."""
         lib = _lib.load()
+        if getattr(self, "dp", None) is not None:
+            return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts)
         st, x = self._native_setup(batch)
         if self.optimizer is not None:
             st.cfg.lr = float(self.optimizer.param_groups[0]["lr"])
@@ -272,6 +276,103 @@ class RetrievalTrainer:
                                        st.ws.data_ptr(), st.ws.numel(), train, int(seed), max(st.step, 1), int(do_optimizer),
                                        main.cuda_stream, st.streams[0].cuda_stream, st.streams[1].cuda_stream), "coot_train_step")
         if do_optimizer:
+            self.model_mgr.mark_weights_dirty()
+        self.total_step += 1
+        return st.losses[0], st.losses[1], st.losses[2]
+
+    def _train_step_native_dp(self, batch, do_optimizer=True, seed=None, vid_counts=None, clip_counts=None):
+        """Data-parallel native step: this rank's videos through coot_step_forward (C, two streams), ONE
+        packed all-gather per embedding level over RCCL, the contrastive loss on the full gathered batch (every rank
+        keeps the gradient rows of its own videos — no collective for embedding gradients), the per-video
+        cycle-consistency loss scaled by 1 / global batch, coot_step_backward (C), all-reduce(SUM) of the flat gradient
+        arenas, fused Adam.  Same kernels and the same C sequencing as the single-GPU native step."""
+        import torch.distributed as dist
+        lib = _lib.load()
+        dp = self.dp
+        dev = batch.vid_feat.device
+        if not getattr(batch, "global_max_synced", False):
+            if batch.max_clip_num is None or batch.max_sent_num is None:
+                batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
+            batch.max_clip_num, batch.max_sent_num = dp.global_max_pair(batch.max_clip_num, batch.max_sent_num, dev)
+            batch.global_max_synced = True
+        st, x = self._native_setup(batch)
+        if self.optimizer is not None:
+            st.cfg.lr = float(self.optimizer.param_groups[0]["lr"])
+        if do_optimizer:
+            st.step += 1
+        if seed is None:
+            seed = (torch.initial_seed() * 1000003 + 7919 * (self.total_step + 1) + 104729 * dp.rank) & 0xFFFFFFFFFFFFFFFF
+        train = 1 if self.model_mgr.is_train else 0
+        d = st.dims
+        B, Nc, D = d.B, d.Nc, st.cfg.net[0].hidden_dim
+        if vid_counts is None:
+            vid_counts = dp.global_counts(B, dev)
+        if clip_counts is None:
+            clip_counts = dp.global_counts(Nc, dev)
+        key = (st.dims_key, tuple(vid_counts), tuple(clip_counts))
+        if getattr(st, "dp_key", None) != key:
+            f32 = dict(dtype=torch.float32, device=dev)
+            st.emb = [torch.empty(B + Nc, D, **f32), torch.empty(B + Nc, D, **f32), torch.empty(B, 2 * D, **f32), torch.empty(B, 2 * D, **f32),
+                      torch.empty(B, d.Cmax_clip, D, **f32), torch.empty(B, d.Cmax_sent, D, **f32)]
+            st.demb = [torch.zeros_like(t) for t in st.emb]
+            gb, gn = sum(vid_counts), sum(clip_counts)
+            st.sets = [torch.empty(gb, 2 * D, **f32), torch.empty(gb, 2 * D, **f32), torch.empty(gn, D, **f32), torch.empty(gn, D, **f32),
+                       torch.empty(gb, D, **f32), torch.empty(gb, D, **f32)]
+            st.dsets = [torch.zeros_like(t) for t in st.sets]
+            st.loss_scratch = torch.empty(lib.coot_contrastive_scratch_bytes(gb, gn, 2 * D, D), dtype=torch.uint8, device=dev)
+            st.dp_key = key
+        local_v, local_t, glob_v, glob_t, resh_v, resh_t = st.emb
+        main = torch.cuda.current_stream()
+        sv, stt = st.streams
+        for n in st.nets:
+            n._grad_flat.zero_()
+        for g in st.demb + st.dsets:
+            g.zero_()
+        st.losses.zero_()
+        ws, wsn = st.ws.data_ptr(), st.ws.numel()
+        _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *[t.data_ptr() for t in st.emb], ws, wsn,
+                                         train, int(seed), main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_forward")
+        # ---- exchange: two packed all-gathers (per-video sets, per-clip sets) --------------------------------------
+        high = torch.cat([glob_v, glob_t, local_v[:B], local_t[:B]], dim=1)
+        low = torch.cat([local_v[B:], local_t[B:]], dim=1)
+        from .dist import gather_rows_nograd
+        high_all = gather_rows_nograd(high, vid_counts, dp.group)
+        low_all = gather_rows_nograd(low, clip_counts, dp.group)
+        st.sets[0].copy_(high_all[:, :2 * D]); st.sets[1].copy_(high_all[:, 2 * D:4 * D])
+        st.sets[4].copy_(high_all[:, 4 * D:5 * D]); st.sets[5].copy_(high_all[:, 5 * D:])
+        st.sets[2].copy_(low_all[:, :D]); st.sets[3].copy_(low_all[:, D:])
+        sp = main.cuda_stream
+        _lib.check(lib.coot_contrastive_fwd_bwd(C.byref(st.cfg.contr), sum(vid_counts), sum(clip_counts), 2 * D, D,
+                                                *[t.data_ptr() for t in st.sets], st.losses[1:2].data_ptr(),
+                                                *[t.data_ptr() for t in st.dsets], st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
+                   "coot_contrastive_fwd_bwd")
+        v0, c0 = sum(vid_counts[:dp.rank]), sum(clip_counts[:dp.rank])
+        d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t = st.demb
+        d_glob_v.copy_(st.dsets[0][v0:v0 + B]); d_glob_t.copy_(st.dsets[1][v0:v0 + B])
+        d_local_v[B:].copy_(st.dsets[2][c0:c0 + Nc]); d_local_t[B:].copy_(st.dsets[3][c0:c0 + Nc])
+        d_local_v[:B].copy_(st.dsets[4][v0:v0 + B]); d_local_t[:B].copy_(st.dsets[5][v0:v0 + B])
+        use_cc = st.cfg.cc_weight != 0.0
+        if use_cc:
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+            idx_c = loss_fn.sample_cycle_indices(batch.clip_num, g)
+            idx_s = loss_fn.sample_cycle_indices(batch.sent_num, g)
+            _lib.check(lib.coot_cyclecons_fwd_bwd(resh_v.data_ptr(), resh_t.data_ptr(), batch.clip_num.data_ptr(), batch.sent_num.data_ptr(),
+                                                  idx_c.data_ptr(), idx_s.data_ptr(), B, d.Cmax_clip, d.Cmax_sent, D, float(st.cfg.cc_weight),
+                                                  1.0 / float(sum(vid_counts)), st.losses[2:3].data_ptr(), None, None, d_resh_v.data_ptr(),
+                                                  d_resh_t.data_ptr(), sp), "coot_cyclecons_fwd_bwd")
+        _lib.check(lib.coot_step_backward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), local_v.data_ptr(), local_t.data_ptr(),
+                                          resh_v.data_ptr(), resh_t.data_ptr(), d_local_v.data_ptr(), d_local_t.data_ptr(), d_glob_v.data_ptr(),
+                                          d_glob_t.data_ptr(), d_resh_v.data_ptr() if use_cc else None, d_resh_t.data_ptr() if use_cc else None,
+                                          ws, wsn, train, int(seed), main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_backward")
+        # cycle-consistency is a per-rank partial sum of a global mean: reduce it with the gradients (one extra word)
+        dp.allreduce_grads([n._grad_flat for n in st.nets] + [st.losses[2:3]], getattr(self, "comm_stream", None))
+        st.losses[0:1].copy_(st.losses[1:2] + st.losses[2:3])
+        if do_optimizer:
+            for i, n in enumerate(st.nets):
+                _lib.check(lib.coot_adam_step(st.bufs.params[i], st.bufs.grads[i], st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i],
+                                              n.numel, st.cfg.lr, st.cfg.beta1, st.cfg.beta2, st.cfg.eps, st.cfg.weight_decay, max(st.step, 1), sp),
+                           "coot_adam_step")
             self.model_mgr.mark_weights_dirty()
         self.total_step += 1
         return st.losses[0], st.losses[1], st.losses[2]

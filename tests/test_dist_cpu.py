@@ -63,6 +63,12 @@ def _worker(rank, world, port, counts_v, counts_c, out):
     # helpers
     assert dp.global_max(3 + rank, "cpu") == 3 + world - 1
     assert dp.global_counts(counts_c[rank], "cpu") == list(counts_c)
+    assert dp.global_max_pair(3 + rank, 10 - rank, "cpu") == (3 + world - 1, 10)
+    # the collective of the native data-parallel step (no autograd): ragged row blocks arrive in rank order
+    rows = torch.arange(counts_c[rank] * 2, dtype=torch.float32).view(-1, 2) + 100 * rank
+    allrows = cdist.gather_rows_nograd(rows, list(counts_c))
+    exp = torch.cat([torch.arange(c * 2, dtype=torch.float32).view(-1, 2) + 100 * r for r, c in enumerate(counts_c)])
+    assert torch.equal(allrows, exp)
     if rank == 0:
         # single-process reference on the full batch
         torch.manual_seed(0)

@@ -405,3 +405,49 @@ def test_native_step_trains_with_dropout_and_cycle_loss(env):
     losses = [o[0] for o in out]
     assert all(np.isfinite(losses)) and all(abs(o[0] - o[1] - o[2]) < 1e-5 for o in out) and all(o[2] >= 0 for o in out)
     assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.05
+
+
+def test_native_dp_step_matches_single_gpu_native(env):
+    """The data-parallel native step (phase calls + RCCL collectives, here a 1-rank nccl group) must produce the same
+    gradients, losses and updated parameters as the single-call native step (dropout 0, no cycle loss => no RNG)."""
+    torch, cva = env
+    import torch.distributed as dist
+    from coot_videotext_amd import dist as cdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dims = (64, 48, 64, 4, 64, 128)
+        cfgs = H.full_cfgs(*dims)
+        Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+        counts = [1, 2, 3, 4, 2, 1]
+        batch = cva.synthetic.make_batch(7, 6, counts, 12, 10, 9, 6, dims[0], dims[1], ragged=True)
+        cfg_a, mgr_a = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+        cfg_b, mgr_b = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+        mgr_a.set_all_models_train(); mgr_b.set_all_models_train()
+        ta, tb = cva.RetrievalTrainer(cfg_a, mgr_a), cva.RetrievalTrainer(cfg_b, mgr_b)
+        tb.dp = cdist.DataParallelContext()
+        tb.comm_stream = torch.cuda.Stream()
+        for it in range(3):
+            la = ta.train_step_native(batch)
+            lb = tb.train_step_native(batch, vid_counts=[6], clip_counts=[sum(counts)])
+            torch.cuda.synchronize()
+            assert abs(float(la[0]) - float(lb[0])) < 1e-5 * max(1.0, abs(float(la[0]))), (it, float(la[0]), float(lb[0]))
+            for na, nb in zip(mgr_a.model_dict.values(), mgr_b.model_dict.values()):
+                ga, gb = na._grad_flat, nb._grad_flat
+                assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-10
+                assert float((na._flat - nb._flat).abs().max()) <= 1e-6
+        # with the cycle loss and dropout on: runs, finite, and the loss decomposes
+        cfg_c, mgr_c = H.make_manager(cfgs, Ps, dropout=0.05, cc_weight=0.01)
+        mgr_c.set_all_models_train()
+        tc = cva.RetrievalTrainer(cfg_c, mgr_c)
+        tc.dp = cdist.DataParallelContext()
+        l = tc.train_step_native(batch)
+        torch.cuda.synchronize()
+        assert all(np.isfinite(float(v)) for v in l) and float(l[2]) > 0
+        assert abs(float(l[0]) - float(l[1]) - float(l[2])) < 1e-6
+    finally:
+        if own_pg:
+            dist.destroy_process_group()

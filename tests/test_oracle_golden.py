@@ -194,3 +194,28 @@ def test_bf16_round_is_rne():
     import torch
     ref = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
     assert (O.bf16_round(x) == ref).all()
+
+
+def test_torch_cpu_port_matches_numpy_oracle():
+    """oracle/coot_torch_cpu.py (the PyTorch-CPU restatement timed as bench.py's cpu_baseline) against the numpy oracle,
+    which the tests above pin to the reference-generated fixtures: embeddings, both losses and every parameter
+    gradient of the full path (ragged batch, cycle loss on)."""
+    from oracle import coot_torch_cpu as T
+    from tests import helpers as H
+    dims = (40, 32, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 21 + i) for i in range(4)]
+    counts = [2, 1, 3, 2]
+    b = O.make_batch(5, 4, counts, 11, 9, 8, 6, dims[0], dims[1], ragged=True)
+    ic, isent = np.array([1, 0, 2, 0]), np.array([0, 0, 1, 1])
+    vis_o, txt_o, contr_o, cc_o, Gs = H.oracle_full(cfgs, Ps, b, ic, isent)
+    Pt = [T.to_torch_params(P) for P in Ps]
+    vis, txt, contr, cc = T.full_step(cfgs, Pt, b, ic, isent, H.ANET_W, 0.2, 0.01)
+    for k in ("global_emb", "item_emb", "context"):
+        assert np.abs(vis[k].detach().numpy() - vis_o[k]).max() < 2e-4 * max(1.0, np.abs(vis_o[k]).max())
+        assert np.abs(txt[k].detach().numpy() - txt_o[k]).max() < 2e-4 * max(1.0, np.abs(txt_o[k]).max())
+    assert abs(float(contr) - contr_o) < 1e-4 * max(1.0, abs(contr_o))
+    assert abs(float(cc) - cc_o) < 1e-4 * max(1e-3, abs(cc_o))
+    for P, G in zip(Pt, Gs):
+        bad, table = H.grad_report([(n, P[n].grad.numpy()) for n in G if P[n].grad is not None], G, cos_min=0.9999, ratio_tol=1e-3)
+        assert not bad, "\n".join(bad)
