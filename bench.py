@@ -83,6 +83,19 @@ def cpu_baseline(w, budget_s=20.0):
         opt.step()
 
     one()  # warm-up
+    # intra-op threads: all cores is NOT the fastest setting for these op sizes on a many-core host (oversubscription);
+    # probe a few counts with one step each and time the best one ("cores" = the threads actually used)
+    ncpu = os.cpu_count() or 1
+    best_n, best_t = torch.get_num_threads(), None
+    for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(n)
+        one()
+        t0 = time.perf_counter()
+        one()
+        t = time.perf_counter() - t0
+        if best_t is None or t < best_t:
+            best_n, best_t = n, t
+    torch.set_num_threads(best_n)
     times = []
     t_all = time.perf_counter()
     while len(times) < 3 or (time.perf_counter() - t_all < budget_s and len(times) < 50):
