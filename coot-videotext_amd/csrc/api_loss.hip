@@ -25,60 +25,6 @@ struct Bump {
     return (T*)p;
   }
 };
-inline int pad8(int n) { return (n + 7) & ~7; }
-
-struct EmbSet {  // one normalised embedding set
-  const float* v; float* dv; int N, d;
-  bf16_t *a, *aT; float *inv, *da;
-};
-struct LossScratch {
-  EmbSet e[6];
-  float* S; bf16_t *G, *GT; float* gd;
-};
-// sets: 0 vid_emb 1 par_emb (n_high, d_high) | 2 clip_emb 3 sent_emb (n_low, d_low) | 4 vid_ctx 5 par_ctx (n_high, d_low)
-void layout_loss(int n_high, int n_low, int d_high, int d_low, Bump& A, LossScratch& L) {
-  const int Ns[6] = {n_high, n_high, n_low, n_low, n_high, n_high};
-  const int ds[6] = {d_high, d_high, d_low, d_low, d_low, d_low};
-  for (int i = 0; i < 6; ++i) {
-    EmbSet& e = L.e[i]; e.N = Ns[i]; e.d = ds[i];
-    e.a = A.get<bf16_t>((size_t)pad8(e.N) * e.d); e.aT = A.get<bf16_t>((size_t)e.d * pad8(e.N));
-    e.inv = A.get<float>(e.N); e.da = A.get<float>((size_t)e.N * e.d);
-  }
-  const int nmax = n_high > n_low ? n_high : n_low, np = pad8(nmax);
-  L.S = A.get<float>((size_t)nmax * np); L.G = A.get<bf16_t>((size_t)nmax * np); L.GT = A.get<bf16_t>((size_t)nmax * np);
-  L.gd = A.get<float>(nmax);
-}
-
-// one ContrastiveLoss term w * L(A, B): loss, dA, dB
-int contrastive_term(LossScratch& L, int ia, int ib, float w, float margin, float* loss, bool bwd, hipStream_t st) {
-  EmbSet& A = L.e[ia]; EmbSet& B = L.e[ib];
-  const int N = A.N, d = A.d, np = pad8(N);
-  {
-    // S [N, np]: the normalised sets are stored with pad8(N) zero rows, so columns >= N come out 0
-    GemmNT g; g.X = A.a; g.ldx = d; g.W = B.a; g.ldw = d; g.M = N; g.N = np; g.K = d;
-    g.epi.out = L.S; g.epi.ldc = np; g.epi.out_f32 = 1;
-    RUN(launch_gemm_nt(g, st));
-  }
-  RUN(check_hip(hipMemsetAsync(L.G, 0, (size_t)N * np * sizeof(bf16_t), st), "memset G"));
-  RUN(check_hip(hipMemsetAsync(L.GT, 0, (size_t)N * np * sizeof(bf16_t), st), "memset GT"));
-  RUN(check_hip(hipMemsetAsync(L.gd, 0, (size_t)N * sizeof(float), st), "memset gd"));
-  RUN(launch_hinge(L.S, np, N, margin, w, loss, L.G, L.GT, np, L.gd, st));
-  if (!bwd) return 0;
-  const float alpha = w / ((float)N * (float)N);
-  {  // dA += alpha * G . b + gd * b
-    GemmNT g; g.X = L.G; g.ldx = np; g.W = B.aT; g.ldw = np; g.M = N; g.N = d; g.K = np;
-    g.epi.alpha = alpha; g.epi.rowscale = L.gd; g.epi.diag_src = B.a; g.epi.lddiag = d;
-    g.epi.out = A.da; g.epi.ldc = d; g.epi.out_f32 = 1; g.epi.accumulate = 1;
-    RUN(launch_gemm_nt(g, st));
-  }
-  {  // dB += alpha * G^T . a + gd * a
-    GemmNT g; g.X = L.GT; g.ldx = np; g.W = A.aT; g.ldw = np; g.M = N; g.N = d; g.K = np;
-    g.epi.alpha = alpha; g.epi.rowscale = L.gd; g.epi.diag_src = A.a; g.epi.lddiag = d;
-    g.epi.out = B.da; g.epi.ldc = d; g.epi.out_f32 = 1; g.epi.accumulate = 1;
-    RUN(launch_gemm_nt(g, st));
-  }
-  return 0;
-}
 }  // namespace
 
 extern "C" {
@@ -92,7 +38,7 @@ int coot_pack_bwd(const float* dout, const int64_t* counts, int B, int Cmax, int
 }
 
 size_t coot_contrastive_scratch_bytes(int n_high, int n_low, int d_high, int d_low) {
-  Bump A(nullptr, 0); LossScratch L; layout_loss(n_high, n_low, d_high, d_low, A, L); return A.off + 256;
+  return contrastive_fused_scratch_bytes(n_high, n_low, d_high, d_low);
 }
 
 int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low, const float* vid_emb,
@@ -102,42 +48,15 @@ int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int
                              coot_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   COOT_REQUIRE(cfg && vid_emb && par_emb && clip_emb && sent_emb && vid_ctx && par_ctx && loss && scratch, "contrastive: null pointer");
-  COOT_REQUIRE(d_high % 8 == 0 && d_low % 8 == 0, "contrastive: embedding dims must be multiples of 8");
   const bool bwd = d_vid_emb != nullptr;
   COOT_REQUIRE(!bwd || (d_par_emb && d_clip_emb && d_sent_emb && d_vid_ctx && d_par_ctx), "contrastive: gradient pointers must be all set or all null");
-  Bump A(scratch, scratch_bytes); LossScratch L; layout_loss(n_high, n_low, d_high, d_low, A, L);
-  COOT_REQUIRE(!A.overflow, "contrastive: scratch too small (%zu < %zu)", scratch_bytes, A.off);
   const float* vs[6] = {vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx};
   float* dvs[6] = {d_vid_emb, d_par_emb, d_clip_emb, d_sent_emb, d_vid_ctx, d_par_ctx};
-  for (int i = 0; i < 6; ++i) {
-    EmbSet& e = L.e[i]; e.v = vs[i]; e.dv = dvs[i];
-    RUN(check_hip(hipMemsetAsync(e.aT, 0, (size_t)e.d * pad8(e.N) * sizeof(bf16_t), st), "memset aT"));
-    RUN(check_hip(hipMemsetAsync(e.a, 0, (size_t)pad8(e.N) * e.d * sizeof(bf16_t), st), "memset a"));
-    RUN(launch_l2norm_fwd(e.v, e.d, e.N, e.d, e.a, e.d, e.aT, pad8(e.N), e.inv, st));
-    if (bwd) RUN(check_hip(hipMemsetAsync(e.da, 0, (size_t)e.N * e.d * sizeof(float), st), "memset da"));
-  }
   // coot/trainer_retrieval.py:168-182 (note :181 weights the context cluster term with weight_low_internal)
-  if (cfg->weight_high != 0.f) RUN(contrastive_term(L, 0, 1, cfg->weight_high, cfg->margin, loss, bwd, st));
-  if (cfg->weight_low != 0.f) RUN(contrastive_term(L, 2, 3, cfg->weight_low, cfg->margin, loss, bwd, st));
-  if (cfg->weight_context != 0.f) RUN(contrastive_term(L, 4, 5, cfg->weight_context, cfg->margin, loss, bwd, st));
-  if (cfg->weight_high_internal != 0.f) {
-    RUN(contrastive_term(L, 0, 0, 0.5f * cfg->weight_high_internal, cfg->margin, loss, bwd, st));
-    RUN(contrastive_term(L, 1, 1, 0.5f * cfg->weight_high_internal, cfg->margin, loss, bwd, st));
-  }
-  if (cfg->weight_low_internal != 0.f) {
-    RUN(contrastive_term(L, 2, 2, 0.5f * cfg->weight_low_internal, cfg->margin, loss, bwd, st));
-    RUN(contrastive_term(L, 3, 3, 0.5f * cfg->weight_low_internal, cfg->margin, loss, bwd, st));
-  }
-  if (cfg->weight_context_internal != 0.f) {
-    RUN(contrastive_term(L, 4, 4, 0.5f * cfg->weight_low_internal, cfg->margin, loss, bwd, st));
-    RUN(contrastive_term(L, 5, 5, 0.5f * cfg->weight_low_internal, cfg->margin, loss, bwd, st));
-  }
-  if (bwd)
-    for (int i = 0; i < 6; ++i) {
-      EmbSet& e = L.e[i];
-      RUN(launch_l2norm_bwd(e.da, e.d, e.v, e.d, e.inv, e.N, e.d, e.dv, e.d, 1, st));
-    }
-  return 0;
+  const float w_pair[3] = {cfg->weight_high, cfg->weight_low, cfg->weight_context};
+  const float w_self[3] = {0.5f * cfg->weight_high_internal, 0.5f * cfg->weight_low_internal,
+                           cfg->weight_context_internal != 0.f ? 0.5f * cfg->weight_low_internal : 0.f};
+  return launch_contrastive_fused(vs, dvs, n_high, n_low, d_high, d_low, w_pair, w_self, cfg->margin, loss, scratch, scratch_bytes, st);
 }
 
 int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* clip_lens, const int64_t* sent_lens,

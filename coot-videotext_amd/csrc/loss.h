@@ -36,4 +36,11 @@ struct CycleArgs {
 };
 int launch_cyclecons(const CycleArgs& a, hipStream_t st);
 
+// compute_total_constrastive_loss in three launches (loss_fused.hip).  v / dv: the six sets in the order vid_emb, par_emb,
+// clip_emb, sent_emb, vid_ctx, par_ctx (dv all null = forward only; gradients are ACCUMULATED).  w_pair[p] / w_self[p]:
+// alignment / cluster weight of pair p (high, low, context); w_self already carries the 1/2 of compute_cluster_loss.
+size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_low);
+int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
+                             const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st);
+
 }  // namespace coot

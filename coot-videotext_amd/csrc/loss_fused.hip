@@ -1,0 +1,320 @@
+// compute_total_constrastive_loss (coot/trainer_retrieval.py:148-182) in THREE launches.
+//
+// The step's loss section used to be ~80 launches of tiny kernels and memsets on the critical path (0.75 ms,
+// profiles/r01b).  Restated so that every quantity is produced exactly once, by the workgroup that owns it:
+//   1. cl_norm_kernel   one wave per row i of a PAIR of sets (vid|par, clip|sent, vid_ctx|par_ctx): F.normalize of both
+//                       rows (bf16 a [Np, d] and transposed a^T [d, Np], zero padded), inv-norms, and the three diagonals
+//                       <a_i,b_i>, <a_i,a_i>, <b_i,b_i> the hinge terms compare against.
+//   2. cl_half_kernel   one workgroup per (half-term, 16 rows).  ContrastiveLoss (coot/loss_fn.py:63-100) has the
+//                       symmetric form  G_ij = [m + S_ij - S_ii > 0] + [m + S_ij - S_jj > 0]  (i != j), so the gradient
+//                       wrt B of L(A, B) is the "A-side" gradient of the swapped problem (S' = B A^T): every term is
+//                       two half-terms, each computing a 16 x N strip of S on the MFMA (operands straight from L2),
+//                       the hinge + violation counts in registers, G (exact small integers in bf16) in LDS, and
+//                       dX_strip = G_strip . Y on the MFMA again.  No atomics: per-strip loss partials, per-row
+//                       violation counts and dX strips go to per-half-term buffers.
+//   3. cl_finish_kernel one wave per row of each set: sums the half-term strips + the diagonal term
+//                       (gd_i = -(c1_i(A,B) + c1_i(B,A))), F.normalize backward, accumulates into d_emb; block 0 adds the
+//                       loss partials in a fixed order (deterministic).
+#include "loss.h"
+
+namespace coot {
+
+struct ClPair { const float* va; const float* vb; bf16_t *a, *b, *aT, *bT; float *inva, *invb; float *dab, *daa, *dbb; int N, Np, d; };
+struct ClNormArgs { ClPair p[3]; int row0[4]; };
+
+__global__ __launch_bounds__(256) void cl_norm_kernel(ClNormArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grow >= A.row0[3]) return;
+  const int pi = grow >= A.row0[2] ? 2 : (grow >= A.row0[1] ? 1 : 0);
+  const ClPair& P = A.p[pi];
+  const int row = grow - A.row0[pi], d = P.d;
+  if (row >= P.N) {  // zero padding rows / columns (the MFMA strips read them)
+    for (int c = lane; c < d; c += 64) {
+      P.a[(long)row * d + c] = 0; P.b[(long)row * d + c] = 0;
+      P.aT[(long)c * P.Np + row] = 0; P.bT[(long)c * P.Np + row] = 0;
+    }
+    return;
+  }
+  float sa = 0.f, sb = 0.f;
+  for (int c = lane; c < d; c += 64) { const float x = P.va[(long)row * d + c], y = P.vb[(long)row * d + c]; sa += x * x; sb += y * y; }
+  sa = wave_sum(sa); sb = wave_sum(sb);
+  const float ia = 1.0f / fmaxf(sqrtf(sa), 1e-12f), ib = 1.0f / fmaxf(sqrtf(sb), 1e-12f);
+  float dab = 0.f, daa = 0.f, dbb = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const bf16_t ha = f2bf(P.va[(long)row * d + c] * ia), hb = f2bf(P.vb[(long)row * d + c] * ib);
+    P.a[(long)row * d + c] = ha; P.b[(long)row * d + c] = hb;
+    P.aT[(long)c * P.Np + row] = ha; P.bT[(long)c * P.Np + row] = hb;
+    const float fa = bf2f(ha), fb = bf2f(hb);
+    dab += fa * fb; daa += fa * fa; dbb += fb * fb;
+  }
+  dab = wave_sum(dab); daa = wave_sum(daa); dbb = wave_sum(dbb);
+  if (lane == 0) { P.inva[row] = ia; P.invb[row] = ib; P.dab[row] = dab; P.daa[row] = daa; P.dbb[row] = dbb; }
+}
+
+constexpr int CL_MAX_HALF = 12;
+struct ClHalf {
+  const bf16_t* X; const bf16_t* Y; const bf16_t* YT;  // X [Np, d], Y [Np, d], Y^T [d, Np]
+  const float* diag;                                   // [N]  S_ii of this term
+  float* dX;                                           // [N, d]   sum_{j != i} G_ij y_j   (unscaled)
+  float* c1;                                           // [N]      #{j : m + S_ij - S_ii > 0}
+  float* loss_part;                                    // [nblk]   sum of hinge values of the strip (only if primary)
+  int N, Np, d, blk0, primary;
+};
+struct ClHalfArgs { ClHalf h[CL_MAX_HALF]; int nh; int nblk; float margin; };
+
+constexpr int CL_GP = 8;  // G strip pitch padding (elements)
+
+__global__ __launch_bounds__(256) void cl_half_kernel(ClHalfArgs A) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t Gs[];  // [16][Np32 + CL_GP]
+  __shared__ float c1s[16];
+  __shared__ float lred[4];
+  int hi = 0;
+  for (int t = 1; t < A.nh; ++t) if ((int)blockIdx.x >= A.h[t].blk0) hi = t;
+  const ClHalf& H = A.h[hi];
+  const int rb = blockIdx.x - H.blk0, i0 = rb * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = H.N, Np = H.Np, d = H.d, Np32 = (Np + 31) & ~31, gp = Np32 + CL_GP;
+  if (tid < 16) c1s[tid] = 0.f;
+  __syncthreads();
+  // ---- S strip: wave w takes column blocks w, w+4, ...; X (A operand, m = row i), Y (B operand, n = column j) ----
+  const int kbs = d / 32;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bf16_t* xrow = H.X + (long)(i0 + l15) * d + l4 * 8;
+  float di[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int i = i0 + l4 * 4 + r; di[r] = i < N ? H.diag[i] : 0.f; }
+  float lsum = 0.f, c1r[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int cb = wave; cb * 16 < Np; cb += 4) {
+    const bf16_t* yrow = H.Y + (long)(cb * 16 + l15) * d + l4 * 8;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kb = 0; kb < kbs; ++kb) {
+      const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xrow + kb * 32);
+      const bf16x8_t yf = *reinterpret_cast<const bf16x8_t*>(yrow + kb * 32);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc, 0, 0, 0);
+    }
+    // acc[r] = S[i0 + l4*4 + r][cb*16 + l15]
+    const int j = cb * 16 + l15;
+    const float dj = j < N ? H.diag[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + l4 * 4 + r;
+      float g = 0.f;
+      if (i < N && j < N && i != j) {
+        const float cs = A.margin + acc[r] - di[r];
+        const float ci = A.margin + acc[r] - dj;
+        if (cs > 0.f) { lsum += cs; g += 1.f; c1r[r] += 1.f; }
+        if (ci > 0.f) { lsum += ci; g += 1.f; }
+      }
+      Gs[(l4 * 4 + r) * gp + j] = f2bf(g);
+    }
+  }
+  // zero the K padding of the strip (columns Np .. Np32)
+  for (int c = Np + tid; c < Np32; c += 256)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Gs[r * gp + c] = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = c1r[r];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    if (l15 == 0 && v != 0.f) atomicAdd(&c1s[l4 * 4 + r], v);  // exact small integers: order independent
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) lred[wave] = lsum;
+  __syncthreads();
+  if (tid < 16 && i0 + tid < N) H.c1[i0 + tid] = c1s[tid];
+  if (tid == 0 && H.primary) H.loss_part[rb] = lred[0] + lred[1] + lred[2] + lred[3];
+  // ---- dX strip [16, d] = G strip [16, Np] . Y [Np, d]: A operand = G (LDS), B operand = Y^T rows (k contiguous) ----
+  const int nf = d / 16;
+  for (int f0 = wave; f0 < nf; f0 += 4 * 3) {
+    f32x4_t acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb * 32 < Np32; ++kb) {
+      const int kk = kb * 32 + l4 * 8;
+      const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(&Gs[l15 * gp + kk]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int f = f0 + 4 * q;
+        if (f < nf) {
+          bf16x8_t yf = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (kk < Np) yf = *reinterpret_cast<const bf16x8_t*>(H.YT + (long)(f * 16 + l15) * Np + kk);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, yf, acc[q], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int f = f0 + 4 * q;
+      if (f < nf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + l4 * 4 + r;
+          if (i < N) H.dX[(long)i * d + f * 16 + l15] = acc[q][r];
+        }
+      }
+    }
+  }
+}
+
+// per set: up to 3 contributions  coef * dX_h[i] + dcoef * (c1_p[i] + c1_q[i]) * other[i]   (other = bf16 normalised rows)
+struct ClContrib { const float* dX; float coef; const float* c1p; const float* c1q; float dcoef; const bf16_t* other; };
+struct ClSet { const float* v; const float* inv; float* dv; int N, d, nc, row0; ClContrib c[3]; };
+struct ClFinishArgs { ClSet s[6]; int rows; const float* loss_part[CL_MAX_HALF]; int loss_n[CL_MAX_HALF]; float loss_coef[CL_MAX_HALF]; int nl; float* loss; };
+
+__global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
+  const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // fixed summation order: deterministic loss value
+    float tot = 0.f;
+    for (int t = 0; t < A.nl; ++t) {
+      float s = 0.f;
+      for (int b = 0; b < A.loss_n[t]; ++b) s += A.loss_part[t][b];
+      tot += s * A.loss_coef[t];
+    }
+    *A.loss += tot;
+  }
+  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grow >= A.rows) return;
+  int si = 0;
+#pragma unroll
+  for (int t = 1; t < 6; ++t) if (grow >= A.s[t].row0) si = t;
+  const ClSet& S = A.s[si];
+  if (!S.dv) return;
+  const int row = grow - S.row0, d = S.d;
+  const float inv = S.inv[row];
+  float gdc[3];
+  for (int t = 0; t < S.nc; ++t) gdc[t] = -S.c[t].dcoef * (S.c[t].c1p[row] + S.c[t].c1q[row]);
+  auto grad_at = [&](int c) {
+    float g = 0.f;
+    for (int t = 0; t < S.nc; ++t) g += S.c[t].coef * S.c[t].dX[(long)row * d + c] + gdc[t] * bf2f(S.c[t].other[(long)row * d + c]);
+    return g;
+  };
+  float dot = 0.f;
+  for (int c = lane; c < d; c += 64) dot += S.v[(long)row * d + c] * inv * grad_at(c);
+  dot = wave_sum(dot);
+  for (int c = lane; c < d; c += 64) {
+    const float a = S.v[(long)row * d + c] * inv;
+    S.dv[(long)row * d + c] += (grad_at(c) - a * dot) * inv;
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+namespace {
+inline int pad16(int n) { return (n + 15) & ~15; }
+struct FBump {
+  char* base; size_t cap; size_t off = 0; bool overflow = false;
+  FBump(void* b, size_t c) : base((char*)b), cap(c) {}
+  template <typename T> T* get(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    char* p = base ? base + off : nullptr;
+    off += n * sizeof(T);
+    if (base && off > cap) overflow = true;
+    return (T*)p;
+  }
+};
+struct PairBufs { bf16_t *a, *b, *aT, *bT; float *inva, *invb, *dab, *daa, *dbb; };
+struct HalfBufs { float *dX, *c1, *lp; };
+struct FusedLayout { PairBufs p[3]; HalfBufs h[CL_MAX_HALF]; };
+// half-term order: for pair p (0 high, 1 low, 2 ctx): 4p+0 = (A,B) primary, 4p+1 = (B,A), 4p+2 = (A,A), 4p+3 = (B,B)
+void layout_fused(int n_high, int n_low, int d_high, int d_low, FBump& A, FusedLayout& L) {
+  const int Ns[3] = {n_high, n_low, n_high}, ds[3] = {d_high, d_low, d_low};
+  for (int p = 0; p < 3; ++p) {
+    const size_t Np = pad16(Ns[p]), d = ds[p];
+    L.p[p].a = A.get<bf16_t>(Np * d); L.p[p].b = A.get<bf16_t>(Np * d); L.p[p].aT = A.get<bf16_t>(Np * d); L.p[p].bT = A.get<bf16_t>(Np * d);
+    L.p[p].inva = A.get<float>(Np); L.p[p].invb = A.get<float>(Np); L.p[p].dab = A.get<float>(Np); L.p[p].daa = A.get<float>(Np);
+    L.p[p].dbb = A.get<float>(Np);
+    for (int q = 0; q < 4; ++q) {
+      HalfBufs& h = L.h[4 * p + q];
+      h.dX = A.get<float>(Np * d); h.c1 = A.get<float>(Np); h.lp = A.get<float>(Np / 16 + 1);
+    }
+  }
+}
+}  // namespace
+
+size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_low) {
+  FBump A(nullptr, 0); FusedLayout L; layout_fused(n_high, n_low, d_high, d_low, A, L); return A.off + 256;
+}
+
+// weights: w_pair[p] (alignment), w_self[p] (already includes the 1/2 of compute_cluster_loss)
+int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
+                             const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st) {
+  {
+    const bool hi_on = w_pair[0] != 0.f || w_self[0] != 0.f, lo_on = w_pair[1] != 0.f || w_self[1] != 0.f || w_pair[2] != 0.f || w_self[2] != 0.f;
+    COOT_REQUIRE((!hi_on || d_high % 32 == 0) && (!lo_on || d_low % 32 == 0), "contrastive: embedding dims must be multiples of 32 (%d, %d)", d_high, d_low);
+  }
+  FBump B(scratch, scratch_bytes); FusedLayout L; layout_fused(n_high, n_low, d_high, d_low, B, L);
+  COOT_REQUIRE(!B.overflow, "contrastive: scratch too small (%zu < %zu)", scratch_bytes, B.off);
+  const int Ns[3] = {n_high, n_low, n_high}, ds[3] = {d_high, d_low, d_low};
+  const bool bwd = dv[0] != nullptr;
+  ClNormArgs na; int rows = 0;
+  for (int p = 0; p < 3; ++p) {
+    ClPair& P = na.p[p]; const PairBufs& b = L.p[p];
+    P.va = v[2 * p]; P.vb = v[2 * p + 1]; P.a = b.a; P.b = b.b; P.aT = b.aT; P.bT = b.bT; P.inva = b.inva; P.invb = b.invb;
+    P.dab = b.dab; P.daa = b.daa; P.dbb = b.dbb; P.N = Ns[p]; P.Np = pad16(Ns[p]); P.d = ds[p];
+    na.row0[p] = rows; rows += P.Np;
+  }
+  na.row0[3] = rows;
+  hipLaunchKernelGGL(cl_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, na);
+  COOT_CHECK_LAUNCH("cl_norm");
+  ClHalfArgs ha; ha.nh = 0; ha.margin = margin; int nblk = 0, maxNp = 0;
+  ClFinishArgs fa; fa.nl = 0; fa.loss = loss;
+  int hidx[3][4];
+  for (int p = 0; p < 3; ++p) {
+    const PairBufs& b = L.p[p];
+    const int N = Ns[p], Np = pad16(N), d = ds[p];
+    for (int q = 0; q < 4; ++q) {
+      hidx[p][q] = -1;
+      const bool on = q < 2 ? (w_pair[p] != 0.f) : (w_self[p] != 0.f);
+      if (!on || N <= 0) continue;
+      if (q == 1 && !bwd) continue;  // the swapped half only provides the gradient wrt B (and its violation counts)
+      ClHalf& H = ha.h[ha.nh];
+      const HalfBufs& hb = L.h[4 * p + q];
+      H.X = (q == 0 || q == 2) ? b.a : b.b;
+      H.Y = (q == 0 || q == 3) ? b.b : b.a;
+      H.YT = (q == 0 || q == 3) ? b.bT : b.aT;
+      H.diag = q < 2 ? b.dab : (q == 2 ? b.daa : b.dbb);
+      H.dX = hb.dX; H.c1 = hb.c1; H.loss_part = hb.lp; H.N = N; H.Np = Np; H.d = d; H.blk0 = nblk; H.primary = (q != 1);
+      if (H.primary) {
+        fa.loss_part[fa.nl] = hb.lp; fa.loss_n[fa.nl] = Np / 16; fa.loss_coef[fa.nl] = (q == 0 ? w_pair[p] : w_self[p]) / ((float)N * (float)N);
+        ++fa.nl;
+      }
+      hidx[p][q] = ha.nh++;
+      nblk += Np / 16;
+      if (Np > maxNp) maxNp = Np;
+    }
+  }
+  ha.nblk = nblk;
+  if (nblk > 0) {
+    const size_t smem = (size_t)16 * (((maxNp + 31) & ~31) + CL_GP) * sizeof(bf16_t);
+    COOT_REQUIRE(smem <= 150 * 1024, "contrastive: batch of %d rows exceeds the LDS strip (max ~4600)", maxNp);
+    hipLaunchKernelGGL(cl_half_kernel, dim3(nblk), dim3(256), smem, st, ha);
+    COOT_CHECK_LAUNCH("cl_half");
+  }
+  // finish: per set contributions
+  int frows = 0;
+  for (int s = 0; s < 6; ++s) {
+    const int p = s / 2, isb = s & 1;
+    ClSet& S = fa.s[s]; const PairBufs& b = L.p[p];
+    S.v = v[s]; S.inv = isb ? b.invb : b.inva; S.dv = bwd ? dv[s] : nullptr; S.N = Ns[p]; S.d = ds[p]; S.nc = 0; S.row0 = frows;
+    frows += Ns[p];
+    if (!bwd) continue;
+    const float n2 = (float)Ns[p] * (float)Ns[p];
+    if (hidx[p][0] >= 0) {  // alignment term: this set's half + diagonal (c1 of both orientations) against the other set's rows
+      ClContrib& c = S.c[S.nc++];
+      c.dX = L.h[4 * p + (isb ? 1 : 0)].dX; c.coef = w_pair[p] / n2; c.c1p = L.h[4 * p].c1; c.c1q = L.h[4 * p + 1].c1;
+      c.dcoef = w_pair[p] / n2; c.other = isb ? b.a : b.b;
+    }
+    if (hidx[p][2 + isb] >= 0) {  // cluster term L(A, A): gradient = 2 * (G . A) with diagonal -2 c1
+      ClContrib& c = S.c[S.nc++];
+      c.dX = L.h[4 * p + 2 + isb].dX; c.coef = 2.f * w_self[p] / n2; c.c1p = L.h[4 * p + 2 + isb].c1; c.c1q = c.c1p;
+      c.dcoef = 2.f * w_self[p] / n2; c.other = isb ? b.b : b.a;  // diagonal of G + G^T: -2 c1 each
+    }
+  }
+  fa.rows = frows;
+  hipLaunchKernelGGL(cl_finish_kernel, dim3((frows + 3) / 4 > 0 ? (frows + 3) / 4 : 1), dim3(256), 0, st, fa);
+  COOT_CHECK_LAUNCH("cl_finish");
+  return 0;
+}
+
+}  // namespace coot
