@@ -10,6 +10,7 @@
 #include "../../include/coot_hip.h"
 #include "attention.h"
 #include "common.h"
+#include "fused.h"
 #include "gemm.h"
 #include "loss.h"
 #include "pool.h"
@@ -129,13 +130,22 @@ static void build_layout(const coot_net_config& c, NetLayout& L) {
 }
 
 // ---- bf16 weight pack layout ----------------------------------------------------------------------
-struct LayerW { bf16_t *wqkv_nk, *wqkv_kn, *wo_nk, *wo_kn, *w1_nk, *w1_kn, *w2_nk, *w2_kn; };
+struct LayerW {
+  bf16_t *wqkv_nk, *wqkv_kn, *wo_nk, *wo_kn, *w1_nk, *w1_kn, *w2_nk, *w2_kn;
+  bf16_t *f_wo = nullptr, *f_w1 = nullptr, *f_w2 = nullptr;  // P48 packs of the fused chains (fused.h), d_model = 384 only
+};
 struct WPack {
   bf16_t* in_w = nullptr;     // [D, Din]  = W * gain (LN affine folded)
   float* in_bias = nullptr;   // [D]       = b + W . norm_bias
   std::vector<LayerW> layers, ctx;
   bf16_t *pw1_nk = nullptr, *pw1_kn = nullptr, *pw2_nk = nullptr, *pw2_kn = nullptr;
+  bf16_t *f_pw1 = nullptr, *f_pw2 = nullptr;  // P48: [768 x 384] (head-major rows), 2 x [192 x 384]
 };
+// the fused token-tile chains are specialised for the shipped model width
+static bool fused_layer_ok(const coot_net_config& c) { return c.hidden_dim == FZ_D && c.ff_dim == FZ_D; }
+static bool fused_pool_ok(const coot_net_config& c) {
+  return fused_layer_ok(c) && c.pooler == 0 && c.pool_hidden == 2 * FZ_D && c.pool_heads == 2;
+}
 static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
   const size_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
   if (c.use_input_fc) { W.in_w = A.get<bf16_t>(D * Din); W.in_bias = A.get<float>(D); }
@@ -145,6 +155,7 @@ static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
     w.wo_nk = A.get<bf16_t>(D * D); w.wo_kn = A.get<bf16_t>(D * D);
     w.w1_nk = A.get<bf16_t>(F * D); w.w1_kn = A.get<bf16_t>(F * D);
     w.w2_nk = A.get<bf16_t>(F * D); w.w2_kn = A.get<bf16_t>(F * D);
+    if (fused_layer_ok(c)) { w.f_wo = A.get<bf16_t>(D * D); w.f_w1 = A.get<bf16_t>(F * D); w.f_w2 = A.get<bf16_t>(F * D); }
     return w;
   };
   for (int i = 0; i < c.num_layers; ++i) W.layers.push_back(lay());
@@ -153,6 +164,7 @@ static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
     const size_t PH = c.pool_hidden;
     W.pw1_nk = A.get<bf16_t>(PH * D); W.pw1_kn = A.get<bf16_t>(PH * D);
     W.pw2_nk = A.get<bf16_t>(PH * (D / c.pool_heads)); W.pw2_kn = A.get<bf16_t>(PH * (D / c.pool_heads));
+    if (fused_pool_ok(c)) { W.f_pw1 = A.get<bf16_t>(PH * D); W.f_pw2 = A.get<bf16_t>(PH * (D / c.pool_heads)); }
   }
 }
 
@@ -241,7 +253,8 @@ static DropCfg mkdrop(int train, float p, uint64_t seed, unsigned site) {
     double t = (double)p * 4294967296.0;
     d.thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     if (d.thr == 0) d.thr = 1;
-    d.inv_keep = 1.0f / (1.0f - p);
+    if (d.thr < 65536u) d.thr = 65536u;  // 16-bit compare (common.h): p quantised to 1/65536, inv_keep from the quantised value
+    d.inv_keep = (float)(1.0 / (1.0 - (double)(d.thr >> 16) / 65536.0));
     d.seed = seed; d.site = site; d.seed_ptr = g_seed_dev;
   }
   return d;
@@ -296,9 +309,14 @@ static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipSt
   return 0;
 }
 
+// GenPool score MLP fused behind the last encoder layer (fused path only)
+struct PoolFuse { const bf16_t *pw1, *pw2; const float *pb1, *pb2; bf16_t *hp, *ap, *s; DropCfg d1, d2; };
+static int g_use_fused = 1;  // coot_set_option("fused", 0/1): A/B switch between the fused chains and the per-op kernels
+
 static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp, const LayerW& lw, const bf16_t* xq, int rows_q,
                      const bf16_t* xkv, int rows_kv, const Segs& sg, const LayerBufs& b,
-                     float* z2_f32, long ldz2_f32, float pdrop, int train, uint64_t seed, unsigned site_base, hipStream_t st) {
+                     float* z2_f32, long ldz2_f32, float pdrop, int train, uint64_t seed, unsigned site_base, hipStream_t st,
+                     const PoolFuse* pool = nullptr) {
   const int D = c.hidden_dim, F = c.ff_dim, H = c.num_heads, dh = D / H;
   const bool self = (xq == xkv);
   if (self) {
@@ -317,6 +335,19 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
   a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
   a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
   RUN(attention_all(a, sg, !self, false, st));
+  if (lw.f_wo && g_use_fused) {  // out-proj ... LN2 (and the GenPool score MLP) as ONE launch over token tiles
+    PostAttnFwd f; f.T = rows_q; f.ctx = b.ctx; f.xres = xq; f.wo = lw.f_wo; f.w1 = lw.f_w1; f.w2 = lw.f_w2;
+    f.bo = P + lp.bo; f.ln1g = P + lp.ln1g; f.ln1b = P + lp.ln1b; f.b1 = P + lp.b1; f.b2 = P + lp.b2; f.ln2g = P + lp.ln2g; f.ln2b = P + lp.ln2b;
+    f.r1 = b.r1; f.z1 = b.z1; f.h1 = b.h1; f.a1 = b.a1; f.r2 = b.r2; f.z2 = b.z2; f.z2_f32 = z2_f32; f.ldz2_f32 = ldz2_f32;
+    f.d_postln = mkdrop(train, pdrop, seed, site_base + SITE_POSTLN); f.d_ff1 = mkdrop(train, pdrop, seed, site_base + SITE_FF1);
+    f.d_ff2 = mkdrop(train, pdrop, seed, site_base + SITE_FF2);
+    if (pool) {
+      f.do_pool = 1; f.pw1 = pool->pw1; f.pw2 = pool->pw2; f.pb1 = pool->pb1; f.pb2 = pool->pb2; f.hp = pool->hp; f.ap = pool->ap; f.s = pool->s;
+      f.d_pool1 = pool->d1; f.d_pool2 = pool->d2;
+    }
+    return launch_post_attn_fwd(f, st);
+  }
+  COOT_REQUIRE(!pool, "layer_fwd: fused pooling requested on the unfused path");
   {
     GemmNT g; g.X = b.ctx; g.ldx = D; g.W = lw.wo_nk; g.ldw = D; g.M = rows_q; g.N = D; g.K = D;
     g.epi.bias = P + lp.bo; g.epi.res = xq; g.epi.ldres = D; g.epi.out = b.r1; g.epi.ldc = D;
@@ -446,6 +477,7 @@ const char* coot_last_error(void) { return coot::g_err; }
 int coot_version(void) { return 1; }
 int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
+  if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
   set_error("unknown option %s", name);
   return -2;
 }
@@ -487,7 +519,13 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
     if (jobs.n == 56) RUN(flush());
     PackJob& j = jobs.j[jobs.n++];
     j.src_off = src_off; j.dst_byte_off = (char*)dst - (char*)wpack; j.R = R; j.C = Cc; j.lds = lds; j.ldd = ldd;
-    j.transpose = transpose; j.colscale_off = colscale_off;
+    j.transpose = transpose; j.p48 = 0; j.colscale_off = colscale_off;
+    return 0;
+  };
+  // logical [N, K] = src (transpose == 0) or src^T (transpose == 1), written in the P48 layout of the fused kernels
+  auto add48 = [&](int64_t src_off, long lds, int R, int Cc, bf16_t* dst, int transpose) -> int {
+    RUN(add(src_off, lds, R, Cc, dst, 0, transpose, -1));
+    jobs.j[jobs.n - 1].p48 = 1;
     return 0;
   };
   if (c.use_input_fc) {
@@ -503,6 +541,11 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
     RUN(add(lp.w1, D, F, D, lw.w1_kn, F, 1, -1));
     RUN(add(lp.w2, F, D, F, lw.w2_nk, F, 0, -1));
     RUN(add(lp.w2, F, D, F, lw.w2_kn, D, 1, -1));
+    if (lw.f_wo) {
+      RUN(add48(lp.wo, D, D, D, lw.f_wo, 0));
+      RUN(add48(lp.w1, D, F, D, lw.f_w1, 0));
+      RUN(add48(lp.w2, F, D, F, lw.f_w2, 0));
+    }
     return 0;
   };
   for (int i = 0; i < c.num_layers; ++i) RUN(pack_layer(L.layers[i], W.layers[i]));
@@ -516,6 +559,10 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
       // W2[h]: [dhp, dop].  nk (fwd): [dop, dhp] per head.  kn (dX): natural [dhp, dop] per head
       RUN(add(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.pw2_nk + (size_t)h * dop * dhp, dhp, 1, -1));
       RUN(add(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.pw2_kn + (size_t)h * dhp * dop, dop, 0, -1));
+      if (W.f_pw1) {  // logical [n = pool feature e][k = d] = W1[h]^T, [n = o][k = e] = W2[h]^T
+        RUN(add48(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.f_pw1 + (size_t)h * dhp * D, 1));
+        RUN(add48(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.f_pw2 + (size_t)h * dop * dhp, 1));
+      }
     }
   }
   RUN(flush());
@@ -572,11 +619,17 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     if (sg.n > 1) { l.x = feats2; l.R = T - T0; l.pe_L = L2; l.y = S.z0 + (size_t)T0 * D; RUN(launch_ln_fwd(l, st)); }
   }
   const bf16_t* z = S.z0;
+  const bool pool_fused = g_use_fused && fused_pool_ok(c) && W.f_pw1 && !c.use_context;
   for (int i = 0; i < c.num_layers; ++i) {
     LayerBufs b = self_bufs(S.layers[i], D);
     const bool last = (i == c.num_layers - 1);
+    PoolFuse pf;
+    if (last && pool_fused) {
+      pf.pw1 = W.f_pw1; pf.pw2 = W.f_pw2; pf.pb1 = P + L.pb1; pf.pb2 = P + L.pb2; pf.hp = S.hp; pf.ap = S.ap; pf.s = S.s;
+      pf.d1 = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL1); pf.d2 = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2);
+    }
     RUN(layer_fwd(c, P, L.layers[i], W.layers[i], z, T, z, T, sg, b, last ? per_token : nullptr, D, c.dropout,
-                  train, seed, 16u * i, st));
+                  train, seed, 16u * i, st, (last && pool_fused) ? &pf : nullptr));
     z = S.layers[i].z2;
   }
   if (c.use_context) {
@@ -592,13 +645,13 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   }
   if (c.pooler == 0) {
     const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
-    {
+    if (!pool_fused) {
       GemmNT g; g.X = z; g.ldx = D; g.W = W.pw1_nk; g.ldw = D; g.M = T; g.N = PH; g.K = D;
       g.epi.bias = P + L.pb1; g.epi.act = 1; g.epi.save_pre = S.hp; g.epi.ldpre = PH; g.epi.out = S.ap; g.epi.ldc = PH;
       epi_drop(g.epi, mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL1), PH);
       RUN(launch_gemm_nt(g, st));
     }
-    {
+    if (!pool_fused) {
       GemmNT g; g.X = S.ap; g.ldx = PH; g.W = W.pw2_nk; g.ldw = dhp; g.M = T; g.N = dop; g.K = dhp;
       g.groups = H; g.zX = dhp; g.zW = (long)dop * dhp; g.zOut = dop;
       g.epi.bias = P + L.pb2; g.epi.out = S.s; g.epi.ldc = D;

@@ -73,10 +73,34 @@ __device__ __forceinline__ unsigned rng_u32(unsigned long long seed, unsigned si
 __device__ __forceinline__ unsigned long long eff_seed(unsigned long long salt, const unsigned long long* base) {
   return salt + (base ? *base : 0ull);
 }
-// keep-scale: 0 if dropped else 1/(1-p).  thr = p * 2^32
+// Dropout masks.  The first version drew one rng_u32 (3 x mix32 = 6 integer multiplies) per element: ~100 SIMD cycles
+// per 64 elements, which made the mask generation of one encoder layer cost more than its MFMAs (profiles/README.md).
+// Now: key = f(seed, site) once per call site; ONE mix32 per PAIR of consecutive elements (2 q, 2 q + 1), 16 bits each,
+// compared with the 16-bit threshold thr >> 16 (mkdrop() quantises p to 1/65536 and derives 1/(1-p) from the quantised
+// value, so E[mask * inv_keep] = 1 exactly).  Element index < 2^33.
+__device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned site) {
+  return mix32((unsigned)seed ^ mix32((unsigned)(seed >> 32) + site * 0x9E3779B9u));
+}
+__device__ __forceinline__ unsigned drop_pair(unsigned key, unsigned long long idx) { return mix32((unsigned)(idx >> 1) ^ key); }
+// keep-scale of one element: 0 if dropped else 1/(1-p)
 __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned site, unsigned long long idx,
                                             unsigned thr, float inv_keep) {
-  return rng_u32(seed, site, idx) >= thr ? inv_keep : 0.0f;
+  const unsigned h = drop_pair(drop_key(seed, site), idx);
+  const unsigned u = (idx & 1ull) ? (h >> 16) : (h & 0xFFFFu);
+  return u >= (thr >> 16) ? inv_keep : 0.0f;
+}
+// keep-scales of N consecutive elements starting at an EVEN index (N even): N / 2 hashes
+template <int N>
+__device__ __forceinline__ void drop_scales(unsigned long long seed, unsigned site, unsigned long long idx0, unsigned thr,
+                                            float inv_keep, float* sc) {
+  const unsigned key = drop_key(seed, site), t16 = thr >> 16;
+  const unsigned q0 = (unsigned)(idx0 >> 1);
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const unsigned h = mix32((q0 + j) ^ key);
+    sc[2 * j] = (h & 0xFFFFu) >= t16 ? inv_keep : 0.0f;
+    sc[2 * j + 1] = (h >> 16) >= t16 ? inv_keep : 0.0f;
+  }
 }
 
 }  // namespace coot

@@ -1,0 +1,42 @@
+// Fused token-tile chains of the COOT encoder layer for d_model = 384 (every shipped config).
+//
+// One workgroup (8 waves) owns a tile of BT tokens.  The tile lives in LDS as a bf16 [BT, 384] matrix (800-byte rows:
+// conflict-free ds_read_b128 fragment reads on gfx950) and is the MFMA "token" operand of a CHAIN of 384-wide Linear
+// layers; the weights are streamed straight from L2 into registers in a fragment-major layout ("P48": the 1 KB a
+// wave needs for one 16x32 weight fragment is contiguous, the fragments of the 48 output columns a wave owns follow
+// each other).  Between two GEMMs the fp32 accumulators go through a small fp32 LDS staging buffer so that every
+// elementwise neighbour (bias, dropout, saved pre-activations, GELU, residual, LayerNorm) runs on 16-byte row-contiguous
+// chunks — all global traffic of the chain is coalesced, nothing is re-read from HBM between the Linear layers.
+#pragma once
+#include "common.h"
+#include "rowops.h"
+
+namespace coot {
+
+constexpr int FZ_D = 384;
+
+// element offset of logical W[n][k] (n = output feature, k = reduction index, K = reduction length) in the P48 layout
+__host__ __device__ inline long p48_offset(int n, int k, int K) {
+  const int g = n / 48, b = (n % 48) / 16, r = n % 16, kb = k / 32, q = (k % 32) / 8, e = k % 8;
+  return ((((long)g * (K / 32) + kb) * 3 + b) * 64 + (q * 16 + r)) * 8 + e;
+}
+
+// out-proj + residual + LN1 + FF1 + GELU + FF2 + residual + LN2 (+ GenPool FC1 + GELU + FC2) of one encoder layer,
+// forward (nntrainer/models/transformer_legacy.py:420-467, :582-605; poolers.py:156-190).  Writes exactly the tensors
+// the unfused path saves for the backward pass.
+struct PostAttnFwd {
+  int T = 0;
+  const bf16_t* ctx = nullptr;   // [T, 384] attention output (heads concatenated)
+  const bf16_t* xres = nullptr;  // [T, 384] sublayer input (residual)
+  const bf16_t *wo = nullptr, *w1 = nullptr, *w2 = nullptr, *pw1 = nullptr, *pw2 = nullptr;  // P48 packs
+  const float *bo = nullptr, *ln1g = nullptr, *ln1b = nullptr, *b1 = nullptr, *b2 = nullptr, *ln2g = nullptr, *ln2b = nullptr,
+              *pb1 = nullptr, *pb2 = nullptr;
+  bf16_t *r1 = nullptr, *z1 = nullptr, *h1 = nullptr, *a1 = nullptr, *r2 = nullptr, *z2 = nullptr;
+  float* z2_f32 = nullptr; long ldz2_f32 = 0;
+  int do_pool = 0;
+  bf16_t *hp = nullptr, *ap = nullptr, *s = nullptr;  // [T, 768], [T, 768], [T, 384]
+  DropCfg d_postln, d_ff1, d_ff2, d_pool1, d_pool2;
+};
+int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st);
+
+}  // namespace coot

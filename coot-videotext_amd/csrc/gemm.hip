@@ -42,9 +42,7 @@ __device__ __forceinline__ void epilogue8(const GemmEpi& e, float* v, int row, i
 #pragma unroll
   for (int j = 0; j < 8; ++j) dsc[j] = 1.f;
   if (e.drop_thr) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      dsc[j] = drop_scale(eff_seed(e.drop_seed, e.drop_seed_ptr), e.drop_site, (unsigned long long)row * e.drop_ld + zo + col + j, e.drop_thr, e.drop_inv_keep);
+    drop_scales<8>(eff_seed(e.drop_seed, e.drop_seed_ptr), e.drop_site, (unsigned long long)row * e.drop_ld + zo + col, e.drop_thr, e.drop_inv_keep, dsc);
     if (e.act != 2) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= dsc[j];

@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
     z0 += e0; z1 += e1;
     if (p.drop_w.thr) {
       unsigned long long idx = (unsigned long long)(r0 + l) * p.D + c;
-      e0 *= drop_scale(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, idx, p.drop_w.thr, p.drop_w.inv_keep);
-      e1 *= drop_scale(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, idx + 1, p.drop_w.thr, p.drop_w.inv_keep);
+      float sc[2];
+      drop_scales<2>(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, idx, p.drop_w.thr, p.drop_w.inv_keep, sc);
+      e0 *= sc[0]; e1 *= sc[1];
     }
     a0 += e0 * bflo(f); a1 += e1 * bfhi(f);
   }
@@ -65,16 +66,18 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs p) {
       float d30 = 1.f, d31 = 1.f;
       if (p.drop_w.thr) {
         unsigned long long idx = (unsigned long long)(r0 + l) * p.D + c;
-        d30 = drop_scale(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, idx, p.drop_w.thr, p.drop_w.inv_keep);
-        d31 = drop_scale(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, idx + 1, p.drop_w.thr, p.drop_w.inv_keep);
+        float sc[2];
+        drop_scales<2>(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, idx, p.drop_w.thr, p.drop_w.inv_keep, sc);
+        d30 = sc[0]; d31 = sc[1];
       }
       ds0 = w0 * (g0 * bflo(f) * d30 - gp0);
       ds1 = w1 * (g1 * bfhi(f) * d31 - gp1);
       dz0 = g0 * w0 * d30; dz1 = g1 * w1 * d31;
       if (p.drop_s.thr) {
         unsigned long long idx = (unsigned long long)(p.drop_s_row0 + r0 + l) * p.drop_s_ld + c;
-        ds0 *= drop_scale(eff_seed(p.drop_s.seed, p.drop_s.seed_ptr), p.drop_s.site, idx, p.drop_s.thr, p.drop_s.inv_keep);
-        ds1 *= drop_scale(eff_seed(p.drop_s.seed, p.drop_s.seed_ptr), p.drop_s.site, idx + 1, p.drop_s.thr, p.drop_s.inv_keep);
+        float sc[2];
+        drop_scales<2>(eff_seed(p.drop_s.seed, p.drop_s.seed_ptr), p.drop_s.site, idx, p.drop_s.thr, p.drop_s.inv_keep, sc);
+        ds0 *= sc[0]; ds1 *= sc[1];
       }
       cs0 += ds0; cs1 += ds1;
     }

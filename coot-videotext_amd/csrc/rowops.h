@@ -46,7 +46,9 @@ int launch_cast_weight(const float* src, long lds, int R, int C, bf16_t* dst, lo
                        const float* colscale, hipStream_t stream);
 
 // many cast/transpose jobs in ONE launch (the whole bf16 weight pack of a network)
-struct PackJob { long src_off; long dst_byte_off; int R, C; long lds, ldd; int transpose; long colscale_off; };
+// p48 != 0: the destination is the fragment-major "P48" layout of the fused kernels (fused.h: p48_offset) of the logical
+// matrix [n][k] = dst row, dst column (after the optional transpose); ldd is ignored.
+struct PackJob { long src_off; long dst_byte_off; int R, C; long lds, ldd; int transpose; int p48; long colscale_off; };
 struct PackJobs { int n = 0; PackJob j[56]; };
 int launch_pack_jobs(const float* P, void* wpack, const PackJobs& jobs, hipStream_t stream);
 

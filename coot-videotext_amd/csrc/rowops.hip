@@ -1,6 +1,7 @@
 // Row-wise kernels for gfx950: one 64-lane wave per row, the row lives in registers,
 // 8/16-byte coalesced loads, wave-shuffle reductions (no LDS, no barriers in the forward).
 #include "rowops.h"
+#include "fused.h"
 
 namespace coot {
 
@@ -55,8 +56,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
       float t = v[i][j] * rs;
       if (p.gain) t = t * p.gain[col + j] + p.bias[col + j];
       if (p.pe) t += p.pe[(long)(row % p.pe_L) * D + col + j];
-      if (p.drop.thr) t *= drop_scale(eff_seed(p.drop.seed, p.drop.seed_ptr), p.drop.site, (unsigned long long)row * D + col + j, p.drop.thr, p.drop.inv_keep);
       y[j] = t;
+    }
+    if (p.drop.thr) {
+      float sc[4];
+      drop_scales<4>(eff_seed(p.drop.seed, p.drop.seed_ptr), p.drop.site, (unsigned long long)row * D + col, p.drop.thr, p.drop.inv_keep, sc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] *= sc[j];
     }
     if (p.y) store4_bf(p.y + (long)row * p.ldy + col, y);
     if (p.y32) *reinterpret_cast<f32x4_t*>(p.y32 + (long)row * p.ldy32 + col) = y;
@@ -150,9 +156,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
                        : load4(p.dy, 0, (long)row * p.lddy + col);
         if (p.dy_add) { f32x4_t t = load4(p.dy_add, 0, (long)row * p.lddy_add + col); dy[i] += t; }
         if (p.drop.thr) {
+          float sc[4];
+          drop_scales<4>(eff_seed(p.drop.seed, p.drop.seed_ptr), p.drop.site, (unsigned long long)row * D + col, p.drop.thr, p.drop.inv_keep, sc);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            dy[i][j] *= drop_scale(eff_seed(p.drop.seed, p.drop.seed_ptr), p.drop.site, (unsigned long long)row * D + col + j, p.drop.thr, p.drop.inv_keep);
+          for (int j = 0; j < 4; ++j) dy[i][j] *= sc[j];
         }
       }
       s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
@@ -182,15 +189,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
       if (c >= nch) continue;
       const int col = c * 4;
       f32x4_t dx, dm;
+      float msc[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.dxm && p.dxm_drop.thr)
+        drop_scales<4>(eff_seed(p.dxm_drop.seed, p.dxm_drop.seed_ptr), p.dxm_drop.site, (unsigned long long)row * p.dxm_drop_ld + col, p.dxm_drop.thr,
+                       p.dxm_drop.inv_keep, msc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float h = dy[i][j] * p.gain[col + j];
         dx[j] = (h - hmean) * rs - k2 * x[i][j];
         ag[i][j] += dy[i][j] * x[i][j] * rs;
         ab[i][j] += dy[i][j];
-        float m = dx[j];
-        if (p.dxm && p.dxm_drop.thr)
-          m *= drop_scale(eff_seed(p.dxm_drop.seed, p.dxm_drop.seed_ptr), p.dxm_drop.site, (unsigned long long)row * p.dxm_drop_ld + col + j, p.dxm_drop.thr, p.dxm_drop.inv_keep);
+        const float m = dx[j] * msc[j];
         dm[j] = m;
         ac[i][j] += m;
       }
@@ -324,12 +333,12 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const float* P, char* wp
   if (!jb.transpose) {
     for (int i = ty; i < 32; i += 8) {
       int r = r0 + i, c = c0 + tx;
-      if (r < jb.R && c < jb.C) dst[(long)r * jb.ldd + c] = f2bf(tile[i][tx]);
+      if (r < jb.R && c < jb.C) dst[jb.p48 ? p48_offset(r, c, jb.C) : (long)r * jb.ldd + c] = f2bf(tile[i][tx]);
     }
   } else {
     for (int i = ty; i < 32; i += 8) {
       int c = c0 + i, r = r0 + tx;
-      if (r < jb.R && c < jb.C) dst[(long)c * jb.ldd + r] = f2bf(tile[tx][i]);
+      if (r < jb.R && c < jb.C) dst[jb.p48 ? p48_offset(c, r, jb.R) : (long)c * jb.ldd + r] = f2bf(tile[tx][i]);
     }
   }
 }

@@ -456,3 +456,37 @@ def test_native_dp_step_matches_single_gpu_native(env):
     finally:
         if own_pg:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,cfg,N,L,with_ctx,train", [
+    ("anet_local", ANET_LOCAL, 7, 80, False, False), ("anet_local_train", ANET_LOCAL, 5, 37, False, True),
+    ("anet_global", ANET_GLOBAL, 40, 9, True, False)])
+def test_fused_chain_matches_per_op_kernels(env, name, cfg, N, L, with_ctx, train):
+    """The fused token-tile chains (fused.hip: out-proj ... LN2 + GenPool score MLP in one launch) against the per-op
+    kernels they replace, same inputs / weights / dropout seed: the two paths have the same rounding points, so pooled
+    outputs, per-token outputs and every parameter gradient agree to fp32 summation-order noise of bf16 tensors."""
+    torch, cva = env
+    lib = cva.lib.load()
+    P = O.make_params(cfg, 31)
+    x, lens, hid, R = _inputs(cfg, N, L, 32, with_ctx)
+    res = []
+    for fused in (0, 1):
+        cva.lib.check(lib.coot_set_option(b"fused", fused))
+        net = H.make_hip_net(cfg, P, dropout=0.1 if train else 0.0)
+        net.train(train)
+        xt = torch.from_numpy(x).float().cuda()
+        ht = torch.from_numpy(hid).float().cuda().requires_grad_(True) if with_ctx else None
+        mask = torch.from_numpy(np.arange(L)[None, :] >= lens[:, None]).cuda()
+        pooled, tok = net(xt, mask, torch.from_numpy(lens).cuda(), ht, seed=1234)
+        (pooled * torch.from_numpy(R).float().cuda()).sum().backward()
+        torch.cuda.synchronize()
+        res.append((pooled.detach().cpu().numpy(), tok.detach().cpu().numpy(),
+                    {n: p.grad.detach().cpu().numpy() for n, p in net.named_parameters() if p.requires_grad}))
+    cva.lib.check(lib.coot_set_option(b"fused", 1))
+    (p0, t0, g0), (p1, t1, g1) = res
+    ep, et = H.rel_err(p1, p0), H.rel_err(t1, t0)
+    print(f"[{name}] fused vs per-op: pooled rel err {ep:.2e}, tokens {et:.2e}")
+    assert ep < 5e-3 and et < 5e-3
+    # key-projection bias: the true gradient is zero (softmax shift invariance), both paths hold round-off noise there
+    bad, table = H.grad_report([(n, g) for n, g in g1.items() if "key_projection.bias" not in n], g0, cos_min=0.999, ratio_tol=0.01)
+    assert not bad, "\n".join(bad)
