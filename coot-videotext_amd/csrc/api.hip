@@ -311,7 +311,9 @@ static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipSt
 
 // GenPool score MLP fused behind the last encoder layer (fused path only)
 struct PoolFuse { const bf16_t *pw1, *pw2; const float *pb1, *pb2; bf16_t *hp, *ap, *s; DropCfg d1, d2; };
-static int g_use_fused = 1;  // coot_set_option("fused", 0/1): A/B switch between the fused chains and the per-op kernels
+static int g_use_fused = 1;
+static int g_fz_debug = 0;
+static int g_fused_min_rows = 1024;  // below this many tokens the per-op kernels win (one or two tiles cannot fill the chip)  // coot_set_option("fused", 0/1): A/B switch between the fused chains and the per-op kernels
 
 static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp, const LayerW& lw, const bf16_t* xq, int rows_q,
                      const bf16_t* xkv, int rows_kv, const Segs& sg, const LayerBufs& b,
@@ -335,7 +337,7 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
   a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
   a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
   RUN(attention_all(a, sg, !self, false, st));
-  if (lw.f_wo && g_use_fused) {  // out-proj ... LN2 (and the GenPool score MLP) as ONE launch over token tiles
+  if (lw.f_wo && g_use_fused && (rows_q >= g_fused_min_rows || pool)) {  // out-proj ... LN2 (and the GenPool score MLP) as ONE launch over token tiles
     PostAttnFwd f; f.T = rows_q; f.ctx = b.ctx; f.xres = xq; f.wo = lw.f_wo; f.w1 = lw.f_w1; f.w2 = lw.f_w2;
     f.bo = P + lp.bo; f.ln1g = P + lp.ln1g; f.ln1b = P + lp.ln1b; f.b1 = P + lp.b1; f.b2 = P + lp.b2; f.ln2g = P + lp.ln2g; f.ln2b = P + lp.ln2b;
     f.r1 = b.r1; f.z1 = b.z1; f.h1 = b.h1; f.a1 = b.a1; f.r2 = b.r2; f.z2 = b.z2; f.z2_f32 = z2_f32; f.ldz2_f32 = ldz2_f32;
@@ -345,6 +347,7 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
       f.do_pool = 1; f.pw1 = pool->pw1; f.pw2 = pool->pw2; f.pb1 = pool->pb1; f.pb2 = pool->pb2; f.hp = pool->hp; f.ap = pool->ap; f.s = pool->s;
       f.d_pool1 = pool->d1; f.d_pool2 = pool->d2;
     }
+    f.debug = g_fz_debug;
     return launch_post_attn_fwd(f, st);
   }
   COOT_REQUIRE(!pool, "layer_fwd: fused pooling requested on the unfused path");
@@ -478,6 +481,8 @@ int coot_version(void) { return 1; }
 int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
+  if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
+  if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   set_error("unknown option %s", name);
   return -2;
 }
@@ -619,7 +624,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     if (sg.n > 1) { l.x = feats2; l.R = T - T0; l.pe_L = L2; l.y = S.z0 + (size_t)T0 * D; RUN(launch_ln_fwd(l, st)); }
   }
   const bf16_t* z = S.z0;
-  const bool pool_fused = g_use_fused && fused_pool_ok(c) && W.f_pw1 && !c.use_context;
+  const bool pool_fused = g_use_fused && fused_pool_ok(c) && W.f_pw1 && !c.use_context && T >= g_fused_min_rows;
   for (int i = 0; i < c.num_layers; ++i) {
     LayerBufs b = self_bufs(S.layers[i], D);
     const bool last = (i == c.num_layers - 1);

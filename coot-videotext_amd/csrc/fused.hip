@@ -109,17 +109,28 @@ __device__ __forceinline__ void load_tile(bf16_t* As, const bf16_t* src, long ld
 // token (all global traffic 16-byte, row contiguous) -> bf16 back into the LDS tile (the next GEMM's operand).
 //   pre(row, col)          -> P      issue the chunk's global loads (all chunks of a round first: latencies overlap)
 //   fn(row, col, v[8], P)            elementwise math + global stores; leaves the tile values in v
-template <int RF, typename PreF, typename Fn>
-__device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16_t* As, int row0, int T, const float* bias, PreF pre, Fn fn) {
-  constexpr int RR = RF >= 2 ? 32 : 16, FR = RR / 16, ROUNDS = 16 * RF / RR, CH = RR * 48, IT = (CH + NTHR - 1) / NTHR;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // a thread meets the same IT column chunks in every round: their bias is loaded once, ahead of the barriers
-  float bs[IT][8];
+// bias chunks of the columns a thread meets in every epilogue round (issue the loads BEFORE the GEMM pass)
+template <int NCH, int IT>
+__device__ __forceinline__ void load_bias(const float* bias, float (&bs)[IT][8]) {
 #pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int c = tid + NTHR * i, ch = c % 48;
-    load8f(bias + ch * 8, bs[i]);
-  }
+  for (int i = 0; i < IT; ++i) load8f(bias + ((threadIdx.x + NTHR * i) % NCH) * 8, bs[i]);
+}
+
+template <int RF, typename PreF, typename Fn>
+__device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16_t* As, int row0, int T, const float (&bs)[3][8], PreF pre, Fn fn,
+                                         int dbg = 0) {
+  constexpr int RR = RF >= 2 ? 32 : 16, FR = RR / 16, ROUNDS = 16 * RF / RR, CH = RR * 48, IT = (CH + NTHR - 1) / NTHR;
+  static_assert(IT <= 3, "bias registers");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  decltype(pre(0, 0)) pv[2][IT];
+  auto issue_pre = [&](int r, decltype(pre(0, 0)) (&dst)[IT]) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = tid + NTHR * i, rl = c / 48, ch = c - rl * 48, row = row0 + r * RR + rl;
+      if (c < CH && row < T) dst[i] = pre(row, ch * 8);
+    }
+  };
+  issue_pre(0, pv[0]);
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     __syncthreads();  // staging free again; (r == 0) every wave is done reading the tile in the GEMM
@@ -128,12 +139,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16
 #pragma unroll
       for (int b = 0; b < 3; ++b)
         *reinterpret_cast<f32x4_t*>(&Stg[(a2 * 16 + (lane & 15)) * SPITCH + wave * 48 + b * 16 + (lane >> 4) * 4]) = acc[r * FR + a2][b];
-    decltype(pre(0, 0)) pv[IT];
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int c = tid + NTHR * i, rl = c / 48, ch = c - rl * 48, row = row0 + r * RR + rl;
-      if (c < CH && row < T) pv[i] = pre(row, ch * 8);
-    }
+    if (r + 1 < ROUNDS) issue_pre(r + 1, pv[(r + 1) & 1]);  // the next round's global loads fly during this round
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -143,7 +149,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16
         load8f(&Stg[rl * SPITCH + ch * 8], v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bs[i][j];
-        if (row < T) fn(row, ch * 8, v, pv[i]);
+        if (row < T) { if (!(dbg & 2)) fn(row, ch * 8, v, pv[r & 1][i]); }
         else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -158,16 +164,11 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16
 // The same for a 192-column GEMM computed as 2 row halves x 4 column groups (wave = 4 rh + cg), accumulators
 // acc[RF / 2][3]; results are not written back to the tile.
 template <int RF, typename PreF, typename Fn>
-__device__ __forceinline__ void epilogue_half(f32x4_t (&acc)[RF / 2][3], float* Stg, int row0, int T, const float* bias, PreF pre, Fn fn) {
+__device__ __forceinline__ void epilogue_half(f32x4_t (&acc)[RF / 2][3], float* Stg, int row0, int T, const float (&bs)[2][8], PreF pre, Fn fn, int dbg = 0) {
   static_assert(RF >= 4 && RF % 4 == 0, "row halves of whole 32-row rounds");
   constexpr int RR = 32, ROUNDS = 16 * RF / RR, HR = ROUNDS / 2, CH = RR * 24, IT = (CH + NTHR - 1) / NTHR;
+  static_assert(IT == 2, "bias registers");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cg = wave & 3, rh = wave >> 2;
-  float bs[IT][8];
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int c = tid + NTHR * i, ch = c % 24;
-    load8f(bias + ch * 8, bs[i]);
-  }
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     __syncthreads();
@@ -193,7 +194,7 @@ __device__ __forceinline__ void epilogue_half(f32x4_t (&acc)[RF / 2][3], float* 
         load8f(&Stg[rl * SPITCH + ch * 8], v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bs[i][j];
-        fn(row, ch * 8, v, pv[i]);
+        if (!(dbg & 2)) fn(row, ch * 8, v, pv[i]);
       }
     }
   }
@@ -285,9 +286,11 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   // ---- attention output projection + residual -> r1 ------------------------------------------------------------
   load_tile<RF>(As, p.ctx, FZ_D, 0, row0, T);
   __syncthreads();
+  float bs[3][8];
+  load_bias<48, 3>(p.bo, bs);
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
-  epilogue<RF>(acc, Stg, As, row0, T, p.bo,
+  if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
+  epilogue<RF>(acc, Stg, As, row0, T, bs,
       [&](int row, int col) { return PreRes{gld16(p.xres, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr) {
         float r[8];
@@ -295,14 +298,15 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
         gst16(p.r1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
-      });
+      }, p.debug);
   // ---- LN1 (+ dropout) -> z1 ---------------------------------------------------------------------------------------
-  ln_tile<RF>(As, p.ln1g, p.ln1b, row0, T, p.z1, nullptr, 0, p.d_postln);
+  if (!(p.debug & 4)) ln_tile<RF>(As, p.ln1g, p.ln1b, row0, T, p.z1, nullptr, 0, p.d_postln);
   __syncthreads();
   // ---- FF1: Linear -> Dropout -> GELU ------------------------------------------------------------------------------
+  load_bias<48, 3>(p.b1, bs);
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
-  epilogue<RF>(acc, Stg, As, row0, T, p.b1, [&](int, int) { return PreNone{}; },
+  if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
+  epilogue<RF>(acc, Stg, As, row0, T, bs, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&) {
         if (p.d_ff1.thr) {
           float sc[8];
@@ -314,11 +318,12 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
         gst16(p.a1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
-      });
+      }, p.debug);
   // ---- FF2: Linear -> Dropout, + residual z1 -> r2 -----------------------------------------------------------------
+  load_bias<48, 3>(p.b2, bs);
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
-  epilogue<RF>(acc, Stg, As, row0, T, p.b2,
+  if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
+  epilogue<RF>(acc, Stg, As, row0, T, bs,
       [&](int row, int col) { return PreRes{gld16(p.z1, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr) {
         float r[8];
@@ -332,11 +337,11 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
         gst16(p.r2, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
-      });
+      }, p.debug);
   // ---- LN2 -> z2 ------------------------------------------------------------------------------------------------------
   {
     DropCfg none;
-    ln_tile<RF>(As, p.ln2g, p.ln2b, row0, T, p.z2, p.z2_f32, p.ldz2_f32, none);
+    if (!(p.debug & 4)) ln_tile<RF>(As, p.ln2g, p.ln2b, row0, T, p.z2, p.z2_f32, p.ldz2_f32, none);
   }
   __syncthreads();
   if constexpr (RF >= 4) {
@@ -348,9 +353,10 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
         load_tile<RF>(As, p.z2, FZ_D, 0, row0, T);
         __syncthreads();
       }
+      load_bias<48, 3>(p.pb1 + h * FZ_D, bs);
       zero_acc<RF>(acc);
-      gemm_pass<RF, 12>(As, p.pw1 + (h * 8 + wave) * GSZ, acc, lane);
-      epilogue<RF>(acc, Stg, As, row0, T, p.pb1 + h * FZ_D, [&](int, int) { return PreNone{}; },
+      if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.pw1 + (h * 8 + wave) * GSZ, acc, lane);
+      epilogue<RF>(acc, Stg, As, row0, T, bs, [&](int, int) { return PreNone{}; },
           [&](int row, int col, float (&v)[8], const PreNone&) {
             if (p.d_pool1.thr) {
               float sc[8];
@@ -362,12 +368,14 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
             gst16(p.ap, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u, pack8(v));
-          });
+          }, p.debug);
       // FC2 of head h: 192 output columns = 4 column groups x 2 row halves
       f32x4_t acc2[RF / 2][3];
+      float bs2[2][8];
+      load_bias<24, 2>(p.pb2 + h * (FZ_D / 2), bs2);
       zero_acc<RF / 2>(acc2);
-      gemm_pass<RF / 2, 12>(As + (wave >> 2) * (BT / 2) * APITCH, p.pw2 + (h * 4 + (wave & 3)) * GSZ, acc2, lane);
-      epilogue_half<RF>(acc2, Stg, row0, T, p.pb2 + h * (FZ_D / 2), [&](int, int) { return PreNone{}; },
+      if (!(p.debug & 1)) gemm_pass<RF / 2, 12>(As + (wave >> 2) * (BT / 2) * APITCH, p.pw2 + (h * 4 + (wave & 3)) * GSZ, acc2, lane);
+      epilogue_half<RF>(acc2, Stg, row0, T, bs2, [&](int, int) { return PreNone{}; },
           [&](int row, int col, float (&v)[8], const PreNone&) {
             if (p.d_pool2.thr) {
               float sc[8];
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
               for (int j = 0; j < 8; ++j) v[j] *= sc[j];
             }
             gst16(p.s, (unsigned)(row * FZ_D + h * (FZ_D / 2) + col) * 2u, pack8(v));
-          });
+          }, p.debug);
     }
   }
 }

@@ -237,9 +237,12 @@ int launch_ln_bwd(const LnBwd& p_in, hipStream_t stream) {
   COOT_REQUIRE((p.dy || p.dy32) && p.x && p.gain, "ln_bwd: null pointer");
   COOT_REQUIRE(p.D % 4 == 0 && p.D <= 1024 && p.D >= 8, "ln_bwd: D=%d unsupported (need D%%4==0, 8<=D<=1024)", p.D);
   if (p.R <= 0) return 0;
+  // one wave per row and a dependent load -> reduce -> store chain per row: the kernel is latency bound, so give every
+  // wave only a few rows (256 blocks = 25 rows per wave at T = 25600 ran at 0.3 TB/s)
   int blocks = (p.R + 3) / 4;
-  if (blocks > 256) blocks = 256;
+  if (blocks > 1024) blocks = 1024;
   p.part_ws = partials_workspace((size_t)blocks * 3 * p.D);
+  if (!p.part_ws && blocks > 256) { blocks = 256; p.part_ws = partials_workspace((size_t)blocks * 3 * p.D); }
   if (p.D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, stream, p);
   COOT_CHECK_LAUNCH("ln_bwd");
