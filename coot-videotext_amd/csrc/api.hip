@@ -313,6 +313,7 @@ static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipSt
 struct PoolFuse { const bf16_t *pw1, *pw2; const float *pb1, *pb2; bf16_t *hp, *ap, *s; DropCfg d1, d2; };
 static int g_use_fused = 1;
 static int g_fz_debug = 0;
+static unsigned long long* g_fz_tstamps = nullptr;
 static int g_fused_min_rows = 1024;  // below this many tokens the per-op kernels win (one or two tiles cannot fill the chip)  // coot_set_option("fused", 0/1): A/B switch between the fused chains and the per-op kernels
 
 static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp, const LayerW& lw, const bf16_t* xq, int rows_q,
@@ -347,7 +348,7 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
       f.do_pool = 1; f.pw1 = pool->pw1; f.pw2 = pool->pw2; f.pb1 = pool->pb1; f.pb2 = pool->pb2; f.hp = pool->hp; f.ap = pool->ap; f.s = pool->s;
       f.d_pool1 = pool->d1; f.d_pool2 = pool->d2;
     }
-    f.debug = g_fz_debug;
+    f.debug = g_fz_debug; f.tstamps = g_fz_tstamps;
     return launch_post_attn_fwd(f, st);
   }
   COOT_REQUIRE(!pool, "layer_fwd: fused pooling requested on the unfused path");
@@ -478,6 +479,7 @@ extern "C" {
 
 const char* coot_last_error(void) { return coot::g_err; }
 int coot_version(void) { return 1; }
+int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)dev_u64; return 0; }
 int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }

@@ -19,30 +19,41 @@ constexpr float kLnEps = 1e-6f;         // nntrainer/models/normalizations.py:89
 
 // ---- bf16 <-> f32 (round-to-nearest-even, same as v_cvt_pk_bf16_f32) ----------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16 pairs: the gfx950 hardware conversion (v_cvt_pk_bf16_f32, round to nearest even).  The software form
+// (add 0x7FFF + lsb, shift) costs 5 VALU ops per element — with two or three bf16 stores per element in the fused
+// epilogues that was a third of their instruction count.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.0f) & 0xFFFFu); }
 __device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
 // ---- erf GELU (nn.GELU(), nntrainer/models/activations.py:29-30) and derivative -----------------------
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off class) — one exp + one rcp instead
-// of libm's branchy erff, which costs as much as the whole GEMM epilogue around it.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.0f - poly * __expf(-ax * ax);
-  return copysignf(r, x);
+// Phi(x) = 0.5 erfc(-x / sqrt 2) with erfc by Abramowitz-Stegun 7.1.25 (|error| <= 2.5e-5 on erf, two orders below the
+// bf16 resolution of the stored activations): for z = |x| / sqrt 2, erfc(z) = t (a1 + t (a2 + t a3)) exp(-z^2),
+// t = 1 / (1 + 0.47047 z).  One v_rcp_f32 + one v_exp_f32 + 8 full-rate ops; exp(-x^2 / 2) is shared with the
+// derivative's density term.  The elementwise work of a fused layer is VALU-issue bound (profiles/README.md), so
+// these counts matter as much as the MFMA schedule.
+struct GeluParts { float h; float e; };  // h = 0.5 erfc(|x| / sqrt 2) = Phi(-|x|),  e = exp(-x^2 / 2)
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044f);                 // exp(-x^2/2) = 2^(-x^2/2 * log2 e)
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.33267266f, 1.0f));        // 0.47047 / sqrt 2
+  const float poly = t * (0.1740121f + t * (-0.0479399f + t * 0.3739278f));        // 0.5 * (a1, a2, a3)
+  return GeluParts{poly * e, e};
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_f(float x) {
+  const GeluParts g = gelu_parts(x);
+  const float xh = x * g.h;
+  return x >= 0.0f ? x - xh : xh;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f)) + x * __expf(-0.5f * x * x) * 0.39894228040143268f;
+  const GeluParts g = gelu_parts(x);
+  const float phi_cdf = x >= 0.0f ? 1.0f - g.h : g.h;
+  return fmaf(x * g.e, 0.39894228040143268f, phi_cdf);
 }
 
 // ---- wave64 reductions ---------------------------------------------------------------------

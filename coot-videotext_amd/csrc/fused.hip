@@ -43,6 +43,11 @@ __device__ __forceinline__ void gst16(void* base, unsigned boff, u32x4_t v) {
   *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(base) + boff) = v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter (s_waitcnt
+// vmcnt(0)): inside the epilogue rounds that made every round wait for the previous round's global STORES to be
+// acknowledged and for the next round's prefetched loads to land — the rounds ran at one memory round trip each.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int RF>
 __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RF][3]) {
 #pragma unroll
@@ -120,7 +125,7 @@ template <int RF, typename PreF, typename Fn>
 __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16_t* As, int row0, int T, const float (&bs)[3][8], PreF pre, Fn fn,
                                          int dbg = 0) {
   constexpr int RR = RF >= 2 ? 32 : 16, FR = RR / 16, ROUNDS = 16 * RF / RR, CH = RR * 48, IT = (CH + NTHR - 1) / NTHR;
-  static_assert(IT <= 3, "bias registers");
+  static_assert(IT <= 3 && ROUNDS <= 4, "bias registers / round switch");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   decltype(pre(0, 0)) pv[2][IT];
   auto issue_pre = [&](int r, decltype(pre(0, 0)) (&dst)[IT]) {
@@ -131,16 +136,31 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16
     }
   };
   issue_pre(0, pv[0]);
-#pragma unroll
+  // The round loop is NOT unrolled (only the accumulator -> staging copy depends on the round, through a switch): unrolling
+  // it quadruples the elementwise code of every epilogue and the kernel (190 KB) then streams its own instructions
+  // from L2 — three times the 64 KB instruction cache two CUs share.
+#pragma unroll 1
   for (int r = 0; r < ROUNDS; ++r) {
-    __syncthreads();  // staging free again; (r == 0) every wave is done reading the tile in the GEMM
+    lds_barrier();  // staging free again; (r == 0) every wave is done reading the tile in the GEMM
+    float* sw = &Stg[(lane & 15) * SPITCH + wave * 48 + (lane >> 4) * 4];
+    auto put = [&](auto rc) {
+      constexpr int R = decltype(rc)::value;
 #pragma unroll
-    for (int a2 = 0; a2 < FR; ++a2)
+      for (int a2 = 0; a2 < FR; ++a2)
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
-        *reinterpret_cast<f32x4_t*>(&Stg[(a2 * 16 + (lane & 15)) * SPITCH + wave * 48 + b * 16 + (lane >> 4) * 4]) = acc[r * FR + a2][b];
-    if (r + 1 < ROUNDS) issue_pre(r + 1, pv[(r + 1) & 1]);  // the next round's global loads fly during this round
-    __syncthreads();
+        for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + a2 * 16 * SPITCH + b * 16) = acc[R * FR + a2][b];
+    };
+    switch (r) {
+      case 0: put(std::integral_constant<int, 0>{}); break;
+      case 1: if constexpr (ROUNDS > 1) put(std::integral_constant<int, 1>{}); break;
+      case 2: if constexpr (ROUNDS > 2) put(std::integral_constant<int, 2>{}); break;
+      default: if constexpr (ROUNDS > 3) put(std::integral_constant<int, 3>{}); break;
+    }
+    const int par = r & 1;
+    if (r + 1 < ROUNDS) {  // the next round's global loads fly during this round
+      if (par) issue_pre(r + 1, pv[0]); else issue_pre(r + 1, pv[1]);
+    }
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int c = tid + NTHR * i, rl = c / 48, ch = c - rl * 48, row = row0 + r * RR + rl;
@@ -149,7 +169,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16
         load8f(&Stg[rl * SPITCH + ch * 8], v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bs[i][j];
-        if (row < T) { if (!(dbg & 2)) fn(row, ch * 8, v, pv[r & 1][i]); }
+        if (row < T) { if (!(dbg & 2)) fn(row, ch * 8, v, par ? pv[1][i] : pv[0][i]); }
         else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -158,7 +178,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // The same for a 192-column GEMM computed as 2 row halves x 4 column groups (wave = 4 rh + cg), accumulators
@@ -169,15 +189,20 @@ __device__ __forceinline__ void epilogue_half(f32x4_t (&acc)[RF / 2][3], float* 
   constexpr int RR = 32, ROUNDS = 16 * RF / RR, HR = ROUNDS / 2, CH = RR * 24, IT = (CH + NTHR - 1) / NTHR;
   static_assert(IT == 2, "bias registers");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cg = wave & 3, rh = wave >> 2;
-#pragma unroll
+#pragma unroll 1
   for (int r = 0; r < ROUNDS; ++r) {
-    __syncthreads();
+    lds_barrier();
     if (rh == r / HR) {
+      float* sw = &Stg[(lane & 15) * SPITCH + cg * 48 + (lane >> 4) * 4];
+      auto put = [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
 #pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2)
+        for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
-          *reinterpret_cast<f32x4_t*>(&Stg[(a2 * 16 + (lane & 15)) * SPITCH + cg * 48 + b * 16 + (lane >> 4) * 4]) = acc[(r % HR) * 2 + a2][b];
+          for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + a2 * 16 * SPITCH + b * 16) = acc[R * 2 + a2][b];
+      };
+      static_assert(HR == 2, "two rounds per row half");
+      if (r % HR == 0) put(std::integral_constant<int, 0>{}); else put(std::integral_constant<int, 1>{});
     }
     decltype(pre(0, 0)) pv[IT];
 #pragma unroll
@@ -185,7 +210,7 @@ __device__ __forceinline__ void epilogue_half(f32x4_t (&acc)[RF / 2][3], float* 
       const int c = tid + NTHR * i, rl = c / 24, ch = c - rl * 24, row = row0 + r * RR + rl;
       if (c < CH && row < T) pv[i] = pre(row, ch * 8);
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int c = tid + NTHR * i, rl = c / 24, ch = c - rl * 24, row = row0 + r * RR + rl;
@@ -198,7 +223,7 @@ __device__ __forceinline__ void epilogue_half(f32x4_t (&acc)[RF / 2][3], float* 
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // sum over the 16 lanes of a DPP row (full-rate VALU, no LDS crossbar): every lane of the row receives the total
@@ -282,14 +307,19 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * BT, T = p.T;
   f32x4_t acc[RF][3];
+  int tsn = 0;
+  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  stamp();
 
   // ---- attention output projection + residual -> r1 ------------------------------------------------------------
   load_tile<RF>(As, p.ctx, FZ_D, 0, row0, T);
   __syncthreads();
+  stamp();
   float bs[3][8];
   load_bias<48, 3>(p.bo, bs);
   zero_acc<RF>(acc);
   if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
+  stamp();
   epilogue<RF>(acc, Stg, As, row0, T, bs,
       [&](int row, int col) { return PreRes{gld16(p.xres, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr) {
@@ -299,13 +329,16 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
         for (int j = 0; j < 8; ++j) v[j] += r[j];
         gst16(p.r1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
       }, p.debug);
+  stamp();
   // ---- LN1 (+ dropout) -> z1 ---------------------------------------------------------------------------------------
   if (!(p.debug & 4)) ln_tile<RF>(As, p.ln1g, p.ln1b, row0, T, p.z1, nullptr, 0, p.d_postln);
   __syncthreads();
+  stamp();
   // ---- FF1: Linear -> Dropout -> GELU ------------------------------------------------------------------------------
   load_bias<48, 3>(p.b1, bs);
   zero_acc<RF>(acc);
   if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
+  stamp();
   epilogue<RF>(acc, Stg, As, row0, T, bs, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&) {
         if (p.d_ff1.thr) {
@@ -319,6 +352,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
         gst16(p.a1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
       }, p.debug);
+  stamp();
   // ---- FF2: Linear -> Dropout, + residual z1 -> r2 -----------------------------------------------------------------
   load_bias<48, 3>(p.b2, bs);
   zero_acc<RF>(acc);
@@ -338,16 +372,18 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
         for (int j = 0; j < 8; ++j) v[j] += r[j];
         gst16(p.r2, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
       }, p.debug);
+  stamp();
   // ---- LN2 -> z2 ------------------------------------------------------------------------------------------------------
   {
     DropCfg none;
     if (!(p.debug & 4)) ln_tile<RF>(As, p.ln2g, p.ln2b, row0, T, p.z2, p.z2_f32, p.ldz2_f32, none);
   }
   __syncthreads();
+  stamp();
   if constexpr (RF >= 4) {
     if (!p.do_pool) return;
     // ---- GenPool scores (poolers.py:171-181): per head h, a = GELU(dropout(z W1[h] + b1[h])), s = dropout(a W2[h] + b2[h]) ----
-#pragma unroll
+#pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       if (h == 1) {  // the tile holds a_0 now: bring z2 back (just written, L2 resident)
         load_tile<RF>(As, p.z2, FZ_D, 0, row0, T);
@@ -385,6 +421,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
             }
             gst16(p.s, (unsigned)(row * FZ_D + h * (FZ_D / 2) + col) * 2u, pack8(v));
           }, p.debug);
+      stamp();
     }
   }
 }

@@ -44,6 +44,8 @@ const char* coot_last_error(void);
 int coot_version(void);
 /* option switches for A/B measurements: "tn_mode" 0 = ds_read_b64_tr_b16 fragments, 1 = transposing LDS stores */
 int coot_set_option(const char* name, int value);
+/* profiling aid: device buffer (>= 64 x uint64) receiving s_memtime stamps of block 0 of the fused chain kernels (NULL = off) */
+int coot_debug_timestamps(void* dev_u64);
 
 /* ---- parameter layout (flat fp32 arena per network; gradients use the same layout) -----------
  * Names and shapes are the reference state-dict names, e.g.
