@@ -181,8 +181,11 @@ struct Saved {
   bf16_t* cq_in = nullptr;
   bf16_t *hp = nullptr, *ap = nullptr, *s = nullptr; float *smax = nullptr, *ssum = nullptr, *pooled = nullptr;
 };
-static void layout_saved(const coot_net_config& c, int N, long Ttok, Arena& A, Saved& S) {
-  const size_t T = (size_t)Ttok, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
+static void layout_saved(const coot_net_config& c, int N_in, long Ttok, Arena& A, Saved& S) {
+  // Every activation is allocated in whole 128-row tiles: the fused token-tile chains (fused.hip) read and write whole
+  // tiles without row bounds checks; rows past T / N hold don't-care values that no kernel consumes.
+  const size_t T = ((size_t)Ttok + 127) & ~(size_t)127, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
+  const size_t N = ((size_t)N_in + 127) & ~(size_t)127;
   if (c.use_input_fc) { S.xhat = A.get<bf16_t>(T * c.input_dim); S.h0 = A.get<bf16_t>(T * D); }
   S.z0 = A.get<bf16_t>(T * D);
   for (int i = 0; i < c.num_layers; ++i) {
@@ -348,7 +351,7 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
       f.do_pool = 1; f.pw1 = pool->pw1; f.pw2 = pool->pw2; f.pb1 = pool->pb1; f.pb2 = pool->pb2; f.hp = pool->hp; f.ap = pool->ap; f.s = pool->s;
       f.d_pool1 = pool->d1; f.d_pool2 = pool->d2;
     }
-    f.debug = g_fz_debug; f.tstamps = g_fz_tstamps;
+    f.tstamps = g_fz_tstamps;
     return launch_post_attn_fwd(f, st);
   }
   COOT_REQUIRE(!pool, "layer_fwd: fused pooling requested on the unfused path");

@@ -37,7 +37,6 @@ struct PostAttnFwd {
   bf16_t *hp = nullptr, *ap = nullptr, *s = nullptr;  // [T, 768], [T, 768], [T, 384]
   DropCfg d_postln, d_ff1, d_ff2, d_pool1, d_pool2;
   unsigned long long* tstamps = nullptr;  // profiling aid: s_memtime stamps of block 0 at the phase boundaries
-  int debug = 0;  // profiling aid (coot_set_option("fz_debug")): 1 skip GEMM passes, 2 skip elementwise functors, 4 skip LayerNorm
 };
 int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st);
 

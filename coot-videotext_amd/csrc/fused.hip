@@ -92,28 +92,24 @@ __device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f3
   }
 }
 
-// global bf16 [T, ld] rows [row0, row0 + 16 RF), columns [col0, col0 + 384) -> LDS tile (rows >= T: zeros)
+// global bf16 [., ld] rows [row0, row0 + 16 RF), columns [col0, col0 + 384) -> LDS tile (whole tiles are allocated)
 template <int RF>
-__device__ __forceinline__ void load_tile(bf16_t* As, const bf16_t* src, long ld, int col0, int row0, int T) {
+__device__ __forceinline__ void load_tile(bf16_t* As, const bf16_t* src, long ld, int col0, int row0) {
   constexpr int CH = 16 * RF * 48, IT = (CH + NTHR - 1) / NTHR;
   u32x4_t v[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int c = threadIdx.x + NTHR * i, rl = c / 48, ch = c - rl * 48;
     v[i] = u32x4_t{0u, 0u, 0u, 0u};
-    if (c < CH && row0 + rl < T) v[i] = gld16(src, (unsigned)((row0 + rl) * (int)ld + col0 + ch * 8) * 2u);
+    if (CH % NTHR == 0 || c < CH) v[i] = gld16(src, (unsigned)((row0 + rl) * (int)ld + col0 + ch * 8) * 2u);
   }
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int c = threadIdx.x + NTHR * i, rl = c / 48, ch = c - rl * 48;
-    if (c < CH) *reinterpret_cast<u32x4_t*>(&As[rl * APITCH + ch * 8]) = v[i];
+    if (CH % NTHR == 0 || c < CH) *reinterpret_cast<u32x4_t*>(&As[rl * APITCH + ch * 8]) = v[i];
   }
 }
 
-// Accumulators -> fp32 staging (32 rows per round) -> per-chunk elementwise functor on 8 consecutive features of one
-// token (all global traffic 16-byte, row contiguous) -> bf16 back into the LDS tile (the next GEMM's operand).
-//   pre(row, col)          -> P      issue the chunk's global loads (all chunks of a round first: latencies overlap)
-//   fn(row, col, v[8], P)            elementwise math + global stores; leaves the tile values in v
 // bias chunks of the columns a thread meets in every epilogue round (issue the loads BEFORE the GEMM pass)
 template <int NCH, int IT>
 __device__ __forceinline__ void load_bias(const float* bias, float (&bs)[IT][8]) {
@@ -121,106 +117,91 @@ __device__ __forceinline__ void load_bias(const float* bias, float (&bs)[IT][8])
   for (int i = 0; i < IT; ++i) load8f(bias + ((threadIdx.x + NTHR * i) % NCH) * 8, bs[i]);
 }
 
-template <int RF, typename PreF, typename Fn>
-__device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF][3], float* Stg, bf16_t* As, int row0, int T, const float (&bs)[3][8], PreF pre, Fn fn,
-                                         int dbg = 0) {
-  constexpr int RR = RF >= 2 ? 32 : 16, FR = RR / 16, ROUNDS = 16 * RF / RR, CH = RR * 48, IT = (CH + NTHR - 1) / NTHR;
-  static_assert(IT <= 3 && ROUNDS <= 4, "bias registers / round switch");
+// Accumulators -> fp32 staging (32 rows per round) -> per-chunk elementwise functor on 8 consecutive features of one
+// token (all global traffic 16-byte, row contiguous) -> bf16 back into the LDS tile (the next GEMM's operand).
+//   pre(row, col)          -> P      issue the chunk's global loads (one round ahead: they fly during the previous round)
+//   fn(row, col, v[8], P)            elementwise math + global stores; leaves the tile values in v
+// No row bounds checks: every tensor the chains touch is allocated in whole 128-row tiles (api.hip: layout_saved), rows
+// past T hold don't-care values that stay in their own rows.  The three chunk bodies of a round are branch free, so the
+// scheduler interleaves them (the epilogues are latency/issue bound: 2 waves per SIMD).
+// The round loop is NOT unrolled (only the accumulator -> staging copy depends on the round, through a switch): unrolled,
+// the kernel was 190 KB of straight-line code, three times the instruction cache two CUs share.
+template <int RF, int NCG, typename PreF, typename Fn>
+__device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float* Stg, bf16_t* As, int row0, const float* bias_lds,
+                                         PreF pre, Fn fn, bool to_lds) {
+  // NCG = 8: 384 output columns, wave = column group, all rows; a round = 32 rows x 384 columns.
+  // NCG = 4: 192 output columns, wave = 4 * row half + column group; a round = 64 rows x 192 columns, staged as two
+  //          32-row groups side by side (staging columns 0..191 and 192..383), so the tile pass is the same 3 chunks/thread.
+  constexpr int RR = RF >= 2 ? 32 : 16, FR = RR / 16, RPR = (NCG == 8 ? RR : 2 * RR), ROUNDS = 16 * RF / RPR, CH = RR * 48, IT = CH / NTHR;
+  static_assert(CH % NTHR == 0 && IT == 3 && ROUNDS <= 4 && (NCG == 8 || (NCG == 4 && ROUNDS == 2 && RF == 8)), "tile pass geometry");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  decltype(pre(0, 0)) pv[2][IT];
-  auto issue_pre = [&](int r, decltype(pre(0, 0)) (&dst)[IT]) {
+  const int cg = wave % NCG, rh = wave / NCG;
+  int rl[IT], col[IT];
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int c = tid + NTHR * i, rl = c / 48, ch = c - rl * 48, row = row0 + r * RR + rl;
-      if (c < CH && row < T) dst[i] = pre(row, ch * 8);
-    }
-  };
-  issue_pre(0, pv[0]);
-  // The round loop is NOT unrolled (only the accumulator -> staging copy depends on the round, through a switch): unrolling
-  // it quadruples the elementwise code of every epilogue and the kernel (190 KB) then streams its own instructions
-  // from L2 — three times the 64 KB instruction cache two CUs share.
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + NTHR * i, r_ = c / 48, ch = c - r_ * 48;
+    if constexpr (NCG == 8) { rl[i] = r_; col[i] = ch * 8; }
+    else { rl[i] = r_ + (ch >= 24 ? 32 : 0); col[i] = (ch >= 24 ? ch - 24 : ch) * 8; }
+  }
+  using P = decltype(pre(0, 0));
+  P pv[2][IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) pv[0][i] = pre(row0 + rl[i], col[i]);
+  float* sw = &Stg[(lane & 15) * SPITCH + cg * 48 + (lane >> 4) * 4];
 #pragma unroll 1
   for (int r = 0; r < ROUNDS; ++r) {
     lds_barrier();  // staging free again; (r == 0) every wave is done reading the tile in the GEMM
-    float* sw = &Stg[(lane & 15) * SPITCH + wave * 48 + (lane >> 4) * 4];
-    auto put = [&](auto rc) {
-      constexpr int R = decltype(rc)::value;
-#pragma unroll
-      for (int a2 = 0; a2 < FR; ++a2)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + a2 * 16 * SPITCH + b * 16) = acc[R * FR + a2][b];
-    };
-    switch (r) {
-      case 0: put(std::integral_constant<int, 0>{}); break;
-      case 1: if constexpr (ROUNDS > 1) put(std::integral_constant<int, 1>{}); break;
-      case 2: if constexpr (ROUNDS > 2) put(std::integral_constant<int, 2>{}); break;
-      default: if constexpr (ROUNDS > 3) put(std::integral_constant<int, 3>{}); break;
-    }
-    const int par = r & 1;
-    if (r + 1 < ROUNDS) {  // the next round's global loads fly during this round
-      if (par) issue_pre(r + 1, pv[0]); else issue_pre(r + 1, pv[1]);
-    }
-    lds_barrier();
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int c = tid + NTHR * i, rl = c / 48, ch = c - rl * 48, row = row0 + r * RR + rl;
-      if (c < CH) {
-        float v[8];
-        load8f(&Stg[rl * SPITCH + ch * 8], v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bs[i][j];
-        if (row < T) { if (!(dbg & 2)) fn(row, ch * 8, v, par ? pv[1][i] : pv[0][i]); }
-        else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        }
-        *reinterpret_cast<u32x4_t*>(&As[(r * RR + rl) * APITCH + ch * 8]) = pack8(v);
-      }
-    }
-  }
-  lds_barrier();
-}
-
-// The same for a 192-column GEMM computed as 2 row halves x 4 column groups (wave = 4 rh + cg), accumulators
-// acc[RF / 2][3]; results are not written back to the tile.
-template <int RF, typename PreF, typename Fn>
-__device__ __forceinline__ void epilogue_half(f32x4_t (&acc)[RF / 2][3], float* Stg, int row0, int T, const float (&bs)[2][8], PreF pre, Fn fn, int dbg = 0) {
-  static_assert(RF >= 4 && RF % 4 == 0, "row halves of whole 32-row rounds");
-  constexpr int RR = 32, ROUNDS = 16 * RF / RR, HR = ROUNDS / 2, CH = RR * 24, IT = (CH + NTHR - 1) / NTHR;
-  static_assert(IT == 2, "bias registers");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cg = wave & 3, rh = wave >> 2;
-#pragma unroll 1
-  for (int r = 0; r < ROUNDS; ++r) {
-    lds_barrier();
-    if (rh == r / HR) {
-      float* sw = &Stg[(lane & 15) * SPITCH + cg * 48 + (lane >> 4) * 4];
+    if constexpr (NCG == 8) {
       auto put = [&](auto rc) {
         constexpr int R = decltype(rc)::value;
+        if constexpr (R < ROUNDS) {
 #pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2)
+          for (int a2 = 0; a2 < FR; ++a2)
 #pragma unroll
-          for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + a2 * 16 * SPITCH + b * 16) = acc[R * 2 + a2][b];
+            for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + a2 * 16 * SPITCH + b * 16) = acc[R * FR + a2][b];
+        }
       };
-      static_assert(HR == 2, "two rounds per row half");
-      if (r % HR == 0) put(std::integral_constant<int, 0>{}); else put(std::integral_constant<int, 1>{});
-    }
-    decltype(pre(0, 0)) pv[IT];
+      switch (r) {
+        case 0: put(std::integral_constant<int, 0>{}); break;
+        case 1: put(std::integral_constant<int, 1>{}); break;
+        case 2: put(std::integral_constant<int, 2>{}); break;
+        default: put(std::integral_constant<int, 3>{}); break;
+      }
+    } else {
+      if (rh == r) {
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int c = tid + NTHR * i, rl = c / 24, ch = c - rl * 24, row = row0 + r * RR + rl;
-      if (c < CH && row < T) pv[i] = pre(row, ch * 8);
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + (a & 1) * 16 * SPITCH + (a >> 1) * 192 + b * 16) = acc[a][b];
+      }
+    }
+    const int par = r & 1, rbase = row0 + r * RPR;
+    if (r + 1 < ROUNDS) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const P nx = pre(rbase + RPR + rl[i], col[i]);
+        if (par) pv[0][i] = nx; else pv[1][i] = nx;
+      }
     }
     lds_barrier();
+    float v[IT][8], bs[IT][8];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      const int c = tid + NTHR * i, rl = c / 24, ch = c - rl * 24, row = row0 + r * RR + rl;
-      if (c < CH && row < T) {
-        float v[8];
-        load8f(&Stg[rl * SPITCH + ch * 8], v);
+      load8f(&Stg[(rl[i] & 31) * SPITCH + col[i] + (rl[i] >= 32 ? 192 : 0)], v[i]);
+      load8f(bias_lds + col[i], bs[i]);  // the chain's bias vectors live in LDS (loaded once per workgroup)
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bs[i][j];
-        if (!(dbg & 2)) fn(row, ch * 8, v, pv[i]);
-      }
+    for (int i = 0; i < IT; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] += bs[i][j];
+      fn(rbase + rl[i], col[i], v[i], par ? pv[1][i] : pv[0][i]);
+      // one chunk body at a time (8 independent elements give the VALU enough ILP): letting the scheduler interleave the
+      // three bodies triples their temporaries while the accumulators of the later rounds are still live -> spills
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (to_lds) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) *reinterpret_cast<u32x4_t*>(&As[(r * RPR + rl[i]) * APITCH + col[i]]) = pack8(v[i]);
     }
   }
   lds_barrier();
@@ -241,7 +222,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // COOT LayerNorm (nntrainer/models/normalizations.py:98-101) of every tile row, in place.  Wave w owns rows
 // [2 RF w, 2 RF w + 2 RF); 16 lanes share a row (4 rows per wave in flight): lane j holds the three 8-element chunks at
 // columns 8 j, 128 + 8 j, 256 + 8 j (16-byte LDS / global accesses), reductions are 4 DPP steps.
-template <int RF>
+template <int RF, bool DROP, bool OUT32>
 __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const float* bias, int row0, int T, bf16_t* out, float* out32,
                                         long ld32, const DropCfg& drop) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
@@ -249,10 +230,11 @@ __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const flo
   float gn[3][8], bi[3][8];
 #pragma unroll
   for (int m = 0; m < 3; ++m) { load8f(gain + m * 128 + j16 * 8, gn[m]); load8f(bias + m * 128 + j16 * 8, bi[m]); }
+  unsigned long long seed = 0;
+  if constexpr (DROP) seed = eff_seed(drop.seed, drop.seed_ptr);
 #pragma unroll
   for (int it = 0; it < ITR; ++it) {
-    const int rw = it * 4 + g;
-    if (RW % 4 != 0 && rw >= RW) break;
+    const int rw = (RW >= 4) ? it * 4 + g : (g < RW ? g : 0);  // RF = 1: two rows per wave, lanes 32..63 repeat row 0
     const int rl = wave * RW + rw, row = row0 + rl;
     bf16_t* ar = As + rl * APITCH + j16 * 8;
     float x[3][8];
@@ -275,17 +257,17 @@ __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const flo
       float y[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) y[e] = x[m][e] * rs * gn[m][e] + bi[m][e];
-      if (drop.thr) {
+      if constexpr (DROP) {
         float sc[8];
-        drop_scales<8>(eff_seed(drop.seed, drop.seed_ptr), drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, drop.thr, drop.inv_keep, sc);
+        drop_scales<8>(seed, drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, drop.thr, drop.inv_keep, sc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] *= sc[e];
       }
       const u32x4_t o = pack8(y);
       *reinterpret_cast<u32x4_t*>(ar + m * 128) = o;
-      if (row < T) {
-        if (out) gst16(out, (unsigned)(row * FZ_D + m * 128 + j16 * 8) * 2u, o);
-        if (out32) {
+      gst16(out, (unsigned)(row * FZ_D + m * 128 + j16 * 8) * 2u, o);
+      if constexpr (OUT32) {
+        if (row < T) {
           float* o32 = out32 + (long)row * ld32 + m * 128 + j16 * 8;
           *reinterpret_cast<f32x4_t*>(o32) = f32x4_t{y[0], y[1], y[2], y[3]};
           *reinterpret_cast<f32x4_t*>(o32 + 4) = f32x4_t{y[4], y[5], y[6], y[7]};
@@ -298,29 +280,46 @@ __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const flo
 struct PreNone {};
 struct PreRes { u32x4_t res; };
 
-template <int RF>
+template <bool DROP>
+__device__ __forceinline__ void apply_drop(const DropCfg& d, unsigned long long idx0, float (&v)[8]) {
+  if constexpr (DROP) {
+    float sc[8];
+    drop_scales<8>(eff_seed(d.seed, d.seed_ptr), d.site, idx0, d.thr, d.inv_keep, sc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= sc[j];
+  }
+}
+
+template <int RF, bool DROP>
 __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   constexpr int BT = 16 * RF, RR = RF >= 2 ? 32 : 16;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4];
+  // LDS: token tile | fp32 staging | 7 parameter vectors of 384 floats (bo, b1, b2, ln1 gain/bias, ln2 gain/bias; the
+  // first three slots are re-used for the pooling biases once the encoder layer is done) = 162,816 B of the 160 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4 + 7 * FZ_D * 4];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);
   float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
+  float* Bsm = reinterpret_cast<float*>(smem + BT * APITCH * 2 + RR * SPITCH * 4);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * BT, T = p.T;
   f32x4_t acc[RF][3];
+  {
+    const float* vecs[7] = {p.bo, p.b1, p.b2, p.ln1g, p.ln1b, p.ln2g, p.ln2b};
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (threadIdx.x < FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm + k * FZ_D)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(vecs[k])[threadIdx.x];
+  }
   int tsn = 0;
   auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
   stamp();
 
   // ---- attention output projection + residual -> r1 ------------------------------------------------------------
-  load_tile<RF>(As, p.ctx, FZ_D, 0, row0, T);
+  load_tile<RF>(As, p.ctx, FZ_D, 0, row0);
   __syncthreads();
   stamp();
-  float bs[3][8];
-  load_bias<48, 3>(p.bo, bs);
   zero_acc<RF>(acc);
-  if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
+  gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
   stamp();
-  epilogue<RF>(acc, Stg, As, row0, T, bs,
+  epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 0 * FZ_D,
       [&](int row, int col) { return PreRes{gld16(p.xres, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr) {
         float r[8];
@@ -328,99 +327,79 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
         gst16(p.r1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
-      }, p.debug);
+      }, true);
   stamp();
   // ---- LN1 (+ dropout) -> z1 ---------------------------------------------------------------------------------------
-  if (!(p.debug & 4)) ln_tile<RF>(As, p.ln1g, p.ln1b, row0, T, p.z1, nullptr, 0, p.d_postln);
+  ln_tile<RF, DROP, false>(As, Bsm + 3 * FZ_D, Bsm + 4 * FZ_D, row0, T, p.z1, nullptr, 0, p.d_postln);
   __syncthreads();
   stamp();
   // ---- FF1: Linear -> Dropout -> GELU ------------------------------------------------------------------------------
-  load_bias<48, 3>(p.b1, bs);
   zero_acc<RF>(acc);
-  if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
+  gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
   stamp();
-  epilogue<RF>(acc, Stg, As, row0, T, bs, [&](int, int) { return PreNone{}; },
+  epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 1 * FZ_D, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&) {
-        if (p.d_ff1.thr) {
-          float sc[8];
-          drop8(p.d_ff1, (unsigned long long)row * FZ_D + col, sc);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= sc[j];
-        }
+        apply_drop<DROP>(p.d_ff1, (unsigned long long)row * FZ_D + col, v);
         gst16(p.h1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
         gst16(p.a1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
-      }, p.debug);
+      }, true);
   stamp();
   // ---- FF2: Linear -> Dropout, + residual z1 -> r2 -----------------------------------------------------------------
-  load_bias<48, 3>(p.b2, bs);
   zero_acc<RF>(acc);
-  if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
-  epilogue<RF>(acc, Stg, As, row0, T, bs,
+  gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 2 * FZ_D,
       [&](int row, int col) { return PreRes{gld16(p.z1, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr) {
         float r[8];
         unpack8(pr.res, r);
-        if (p.d_ff2.thr) {
-          float sc[8];
-          drop8(p.d_ff2, (unsigned long long)row * FZ_D + col, sc);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= sc[j];
-        }
+        apply_drop<DROP>(p.d_ff2, (unsigned long long)row * FZ_D + col, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
         gst16(p.r2, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
-      }, p.debug);
+      }, true);
   stamp();
   // ---- LN2 -> z2 ------------------------------------------------------------------------------------------------------
   {
     DropCfg none;
-    if (!(p.debug & 4)) ln_tile<RF>(As, p.ln2g, p.ln2b, row0, T, p.z2, p.z2_f32, p.ldz2_f32, none);
+    if (p.z2_f32) ln_tile<RF, false, true>(As, Bsm + 5 * FZ_D, Bsm + 6 * FZ_D, row0, T, p.z2, p.z2_f32, p.ldz2_f32, none);
+    else ln_tile<RF, false, false>(As, Bsm + 5 * FZ_D, Bsm + 6 * FZ_D, row0, T, p.z2, nullptr, 0, none);
   }
   __syncthreads();
   stamp();
   if constexpr (RF >= 4) {
     if (!p.do_pool) return;
+    // pooling biases into the (now dead) bias slots 0..2: pb1 [768] | pb2 [384]
+    if (threadIdx.x < 2 * FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(p.pb1)[threadIdx.x];
+    else if (threadIdx.x < 3 * FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(p.pb2)[threadIdx.x - 2 * FZ_D / 4];
+    __syncthreads();
     // ---- GenPool scores (poolers.py:171-181): per head h, a = GELU(dropout(z W1[h] + b1[h])), s = dropout(a W2[h] + b2[h]) ----
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       if (h == 1) {  // the tile holds a_0 now: bring z2 back (just written, L2 resident)
-        load_tile<RF>(As, p.z2, FZ_D, 0, row0, T);
+        load_tile<RF>(As, p.z2, FZ_D, 0, row0);
         __syncthreads();
       }
-      load_bias<48, 3>(p.pb1 + h * FZ_D, bs);
       zero_acc<RF>(acc);
-      if (!(p.debug & 1)) gemm_pass<RF, 12>(As, p.pw1 + (h * 8 + wave) * GSZ, acc, lane);
-      epilogue<RF>(acc, Stg, As, row0, T, bs, [&](int, int) { return PreNone{}; },
+      gemm_pass<RF, 12>(As, p.pw1 + (h * 8 + wave) * GSZ, acc, lane);
+      epilogue<RF, 8>(acc, Stg, As, row0, Bsm + h * FZ_D, [&](int, int) { return PreNone{}; },
           [&](int row, int col, float (&v)[8], const PreNone&) {
-            if (p.d_pool1.thr) {
-              float sc[8];
-              drop8(p.d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, sc);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] *= sc[j];
-            }
+            apply_drop<DROP>(p.d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
             gst16(p.hp, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u, pack8(v));
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
             gst16(p.ap, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u, pack8(v));
-          }, p.debug);
+          }, true);
       // FC2 of head h: 192 output columns = 4 column groups x 2 row halves
       f32x4_t acc2[RF / 2][3];
-      float bs2[2][8];
-      load_bias<24, 2>(p.pb2 + h * (FZ_D / 2), bs2);
       zero_acc<RF / 2>(acc2);
-      if (!(p.debug & 1)) gemm_pass<RF / 2, 12>(As + (wave >> 2) * (BT / 2) * APITCH, p.pw2 + (h * 4 + (wave & 3)) * GSZ, acc2, lane);
-      epilogue_half<RF>(acc2, Stg, row0, T, bs2, [&](int, int) { return PreNone{}; },
+      gemm_pass<RF / 2, 12>(As + (wave >> 2) * (BT / 2) * APITCH, p.pw2 + (h * 4 + (wave & 3)) * GSZ, acc2, lane);
+      epilogue<RF, 4>(acc2, Stg, As, row0, Bsm + 2 * FZ_D + h * (FZ_D / 2), [&](int, int) { return PreNone{}; },
           [&](int row, int col, float (&v)[8], const PreNone&) {
-            if (p.d_pool2.thr) {
-              float sc[8];
-              drop8(p.d_pool2, (unsigned long long)row * FZ_D + h * (FZ_D / 2) + col, sc);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] *= sc[j];
-            }
+            apply_drop<DROP>(p.d_pool2, (unsigned long long)row * FZ_D + h * (FZ_D / 2) + col, v);
             gst16(p.s, (unsigned)(row * FZ_D + h * (FZ_D / 2) + col) * 2u, pack8(v));
-          }, p.debug);
+          }, false);
       stamp();
     }
   }
@@ -433,7 +412,13 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
                p.h1 && p.a1 && p.r2 && p.z2, "post_attn_fwd: null pointer");
   COOT_REQUIRE(!p.do_pool || (p.pw1 && p.pw2 && p.pb1 && p.pb2 && p.hp && p.ap && p.s), "post_attn_fwd: pooling pointers");
   if (p.T <= 0) return 0;
-  hipLaunchKernelGGL(post_attn_fwd_kernel<8>, dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+  const bool drop = p.d_postln.thr || p.d_ff1.thr || p.d_ff2.thr || p.d_pool1.thr || p.d_pool2.thr;
+  if (drop) {
+    COOT_REQUIRE(p.d_postln.thr && p.d_ff1.thr && p.d_ff2.thr && (!p.do_pool || (p.d_pool1.thr && p.d_pool2.thr)), "post_attn_fwd: dropout on some sites only");
+    hipLaunchKernelGGL((post_attn_fwd_kernel<8, true>), dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((post_attn_fwd_kernel<8, false>), dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+  }
   COOT_CHECK_LAUNCH("post_attn_fwd");
   return 0;
 }
