@@ -59,6 +59,8 @@ int gemm_timing_collect(int only_big_k, double* ms, double* flops, int* launches
 
 // 0 = ds_read_b64_tr_b16 fragments (default), 1 = transposing LDS stores (fallback)
 void set_tn_mode(int mode);
+// 1 (default): M <= 512 problems use the direct-from-L2 small-M kernel; 0: always the LDS-staged kernel (A/B switch)
+void set_gemm_small(int on);
 int get_tn_mode();
 
 }  // namespace coot

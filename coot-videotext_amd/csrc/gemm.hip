@@ -248,9 +248,136 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-M variant (global networks: 64..512 token rows; the step's critical path is a chain of ~80 such GEMMs).
+// The LDS-staged kernel above runs its 6..18 k-steps as a dependent load -> LDS -> MFMA chain on a handful of
+// workgroups: 10..15 us for a microsecond of work.  Here a wave owns a 16-token x (16 NF)-feature tile and takes its
+// MFMA fragments straight from global memory (the operands are L2 resident), up to 6 k-steps of loads in flight at
+// once, no LDS, no barriers: ~2 memory round trips per launch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epilogue4(const GemmEpi& e, float* v, int row, int col, long zo, int N, const float* bias4) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = v[j] * e.alpha + bias4[j];
+  float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+  if (e.drop_thr) {
+    drop_scales<4>(eff_seed(e.drop_seed, e.drop_seed_ptr), e.drop_site, (unsigned long long)row * e.drop_ld + zo + col, e.drop_thr, e.drop_inv_keep, dsc);
+    if (e.act != 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= dsc[j];
+    }
+  }
+  auto ld4 = [](const bf16_t* p, float* r) {
+    const u32x2_t u = *reinterpret_cast<const u32x2_t*>(p);
+    r[0] = bflo(u[0]); r[1] = bfhi(u[0]); r[2] = bflo(u[1]); r[3] = bfhi(u[1]);
+  };
+  auto st4 = [](bf16_t* p, const float* r) { *reinterpret_cast<u32x2_t*>(p) = u32x2_t{pack2bf(r[0], r[1]), pack2bf(r[2], r[3])}; };
+  if (e.save_pre) st4(e.save_pre + (long)row * e.ldpre + zo + col, v);
+  if (e.act == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+  }
+  if (e.pe) {
+    const int pos = row < e.pe_T0 ? row % e.pe_L : (row - e.pe_T0) % e.pe_L2;
+    const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(e.pe + (long)pos * N + col);
+    v[0] += p0[0]; v[1] += p0[1]; v[2] += p0[2]; v[3] += p0[3];
+  }
+  if (e.res) {
+    float r[4];
+    ld4(e.res + (long)row * e.ldres + zo + col, r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += r[j];
+  }
+  if (e.res32) {
+    const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(e.res32 + (long)row * e.ldres32 + zo + col);
+    v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
+  }
+  if (e.rowscale) {
+    const float rsv = e.rowscale[row];
+    float d[4];
+    ld4(e.diag_src + (long)row * e.lddiag + col, d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += rsv * d[j];
+  }
+  if (e.act == 2) {
+    float a[4];
+    ld4(e.aux + (long)row * e.ldaux + zo + col, a);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(a[j]) * dsc[j];
+  }
+  if (e.out_f32) {
+    f32x4_t* op = reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(e.out) + (long)row * e.ldc + zo + col);
+    if (e.accumulate) { const f32x4_t o0 = op[0]; op[0] = f32x4_t{o0[0] + v[0], o0[1] + v[1], o0[2] + v[2], o0[3] + v[3]}; }
+    else op[0] = f32x4_t{v[0], v[1], v[2], v[3]};
+  } else {
+    st4(reinterpret_cast<bf16_t*>(e.out) + (long)row * e.ldc + zo + col, v);
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmNT g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int z = blockIdx.z;
+  const int M = g.M_dev ? min(g.M, *g.M_dev) : g.M, N = g.N, K = g.K;
+  const int row0 = blockIdx.y * 16, col0 = (blockIdx.x * 4 + wave) * 16 * NF;
+  if (row0 >= M || col0 >= N) return;
+  const bf16_t* X = g.X + z * g.zX;
+  const bf16_t* W = g.W + z * g.zW;
+  const int xr = min(row0 + l15, M - 1);  // rows past M are computed on a clamped row and never stored
+  const bf16_t* xp = X + (long)xr * g.ldx + l4 * 8;
+  const bf16_t* wp[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) wp[f] = W + (long)min(col0 + f * 16 + l15, N - 1) * g.ldw + l4 * 8;
+  f32x4_t acc[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  constexpr int KS = 6;  // k-steps of loads in flight
+  for (int k0 = 0; k0 < K; k0 += 32 * KS) {
+    bf16x8_t xf[KS], wf[NF][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = k0 + s * 32 + l4 * 8;
+      const bool ok = k < K;  // K % 8 == 0: a lane's 8 elements are all inside or all outside
+      xf[s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) xf[s] = *reinterpret_cast<const bf16x8_t*>(xp + k0 + s * 32);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        wf[f][s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) wf[f][s] = *reinterpret_cast<const bf16x8_t*>(wp[f] + k0 + s * 32);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f][s], xf[s], acc[f], 0, 0, 0);
+  }
+  // acc[f][j] = C[token row0 + l15][feature col0 + 16 f + 4 l4 + j]
+  const GemmEpi& e = g.epi;
+  const long zo = z * g.zOut;
+  const int row = row0 + l15;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int col = col0 + f * 16 + l4 * 4;
+    const bool ok = row < M && col < N;  // N % 8 == 0 and col % 4 == 0: a lane's 4 features are all inside or all outside
+    float v[4] = {acc[f][0], acc[f][1], acc[f][2], acc[f][3]};
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok && e.bias) { const f32x4_t b = *reinterpret_cast<const f32x4_t*>(e.bias + zo + col); b4[0] = b[0]; b4[1] = b[1]; b4[2] = b[2]; b4[3] = b[3]; }
+    if (ok) epilogue4(e, v, row, col, zo, N, b4);
+    if (e.colsum) {  // 16 tokens of this wave share a feature: reduce over l15, one atomic per feature (<= M/16 adds per address)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = ok ? v[j] : 0.f;
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        if (l15 == 0 && col < N) atomicAdd(e.colsum + zo + col + j, s);
+      }
+    }
+  }
+}
+
 // ---- optional per-launch timing with HIP events (bench.py roofline leg) -------------------------------
 struct TimingSlot { hipEvent_t a, b; double flops; int big_k; };
 static int g_timing_on = 0;
+static int g_small_on = 1;
+void set_gemm_small(int on) { g_small_on = on; }
 static TimingSlot g_slots[8192];
 static int g_nslots = 0, g_slots_created = 0;
 void gemm_timing_enable(int on) { g_timing_on = on; g_nslots = 0; }
@@ -286,6 +413,20 @@ int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
   COOT_REQUIRE(g.epi.ldres % 8 == 0 && g.epi.ldaux % 8 == 0 && g.epi.ldpre % 8 == 0 && g.epi.ldres32 % 4 == 0 && g.epi.lddiag % 8 == 0,
                "gemm_nt: epilogue strides must be multiples of 8");
   if (g.M <= 0 || g.N <= 0) return 0;
+  if (g.M <= 512 && g_small_on) {  // global networks / loss strips: direct-from-L2 fragments, no LDS
+    TimingSlot* ts = timing_begin(g, stream);
+    g.epi.colsum_ws = nullptr;
+    if ((long)((g.M + 15) / 16) * ((g.N + 31) / 32) >= 512) {
+      dim3 grid((g.N + 4 * 32 - 1) / (4 * 32), (g.M + 15) / 16, g.groups);
+      hipLaunchKernelGGL(gemm_nt_small_kernel<2>, grid, dim3(256), 0, stream, g);
+    } else {
+      dim3 grid((g.N + 4 * 16 - 1) / (4 * 16), (g.M + 15) / 16, g.groups);
+      hipLaunchKernelGGL(gemm_nt_small_kernel<1>, grid, dim3(256), 0, stream, g);
+    }
+    if (ts) hipEventRecord(ts->b, stream);
+    COOT_CHECK_LAUNCH("gemm_nt_small");
+    return 0;
+  }
   const int nb = (g.N + BN - 1) / BN;
   // small-M problems: halve the token tile to get more workgroups onto the 256 CUs
   const long blocks128 = (long)((g.M + 127) / 128) * nb * g.groups;
