@@ -342,8 +342,273 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short self-attention (L <= 128 keys = queries; every sequence of the shipped configs: 80 frames, <= 64 words, <= 27
+// clips): ONE workgroup per (sequence, head), one wave per 16 queries / keys.  K, V (and Q, dO in the backward) of the
+// head are staged once, row-major, with 16-byte copies; the transposed MFMA operands (V^T, K^T, Q^T, dO^T) are
+// formed by the LDS transpose read ds_read_b64_tr_b16 — no transposed LDS images, no 2-byte LDS writes.  All score
+// tiles of a wave stay in registers: single-pass softmax, and the backward is one launch that produces dQ, dK and dV
+// (dK^T / dV^T orientation: a lane owns 4 consecutive head channels of one key: 8-byte stores).
+// The chunked kernels above (64 queries per workgroup, 64-key chunks, three launches for the backward) ran the
+// 80-frame sequences at 2 workgroups per head with 3/8 of the waves idle and re-staged K/V per workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int SH_MAXW = 8;  // waves per workgroup = ceil(L / 16)
+
+__device__ __forceinline__ s16x4_t tr16(const bf16_t* tile, int pitch, int lane) {
+  // tile -> element (row 0, col 0) of a 16 x 16 block; result lane l, element j = block[4 (l >> 4) + j][l & 15]
+  const int g = lane >> 4, p = lane & 15;
+  const bf16_t* addr = tile + (4 * g + (p >> 2)) * pitch + (p & 3) * 4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(addr));
+}
+
+template <int DH>
+__device__ __forceinline__ void stage_rows(const bf16_t* src, long ld, long rowbase, int L, int L16, int c0, bf16_t* R) {
+  constexpr int RP = AttnSmem<DH>::RP, CPR = DH / 8;
+  for (int c = threadIdx.x; c < L16 * CPR; c += blockDim.x) {
+    const int r = c / CPR, cc = (c % CPR) * 8;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (r < L) v = *reinterpret_cast<const u32x4_t*>(src + (rowbase + r) * ld + c0 + cc);
+    *reinterpret_cast<u32x4_t*>(&R[r * RP + cc]) = v;
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
+  constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
+  extern __shared__ __attribute__((aligned(16))) bf16_t sh_lds[];  // K | V, L16 rows each (sized by the launcher)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int n = blockIdx.y, h = blockIdx.x, L = a.Lk, L16 = nw * 16;
+  bf16_t* Ks = sh_lds;
+  bf16_t* Vs = sh_lds + L16 * RP;
+  const int nvalid = (int)a.lens[n];
+  const long base = (long)n * L;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int qrow = wave * 16 + lq;
+  const bool qok = qrow < L;
+  stage_rows<DH>(a.k, a.ldk, base, L, L16, h * DH, Ks);
+  stage_rows<DH>(a.v, a.ldv, base, L, L16, h * DH, Vs);
+  s16x4_t qf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    qf[ks] = s16x4_t{0, 0, 0, 0};
+    if (qok) qf[ks] = *reinterpret_cast<const s16x4_t*>(a.q + (base + qrow) * a.ldq + h * DH + ks * 16 + lg * 4);
+  }
+  __syncthreads();
+  f32x4_t s[SH_MAXW];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < SH_MAXW; ++kt) {
+    if (kt < nw) {
+      s[kt] = f32x4_t{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const s16x4_t kf = *reinterpret_cast<const s16x4_t*>(&Ks[(kt * 16 + lq) * RP + ks * 16 + lg * 4]);
+        s[kt] = mfma16(kf, qf[ks], s[kt]);  // s[i] = S^T[key kt*16 + lg*4 + i][query lq]
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kidx = kt * 16 + lg * 4 + i;
+        float v = s[kt][i] * a.scale;
+        if (kidx >= nvalid) v = kMaskFill;  // masked_fill(mask, -INF) (transformer_legacy.py:544)
+        if (kidx >= L) v = -INFINITY;       // beyond the padded length: does not exist
+        s[kt][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+  s16x4_t pf[SH_MAXW];
+#pragma unroll
+  for (int kt = 0; kt < SH_MAXW; ++kt) {
+    if (kt < nw) {
+      float p[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p[i] = __expf(s[kt][i] - mx);
+        sum += p[i];
+        if (a.drop.thr) {
+          const int kidx = kt * 16 + lg * 4 + i;
+          const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qrow) * L + kidx);
+          p[i] *= drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+        }
+      }
+      pf[kt] = pack4(p[0], p[1], p[2], p[3]);
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  f32x4_t oacc[NK];
+#pragma unroll
+  for (int dt = 0; dt < NK; ++dt) {
+    oacc[dt] = f32x4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int kt = 0; kt < SH_MAXW; ++kt)
+      if (kt < nw) oacc[dt] = mfma16(tr16(&Vs[kt * 16 * RP + dt * 16], RP, lane), pf[kt], oacc[dt]);  // A = V^T [dh][key]
+  }
+  if (qok) {
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) {
+      const u32x2_t pk = {pack2bf(oacc[dt][0] * inv, oacc[dt][1] * inv), pack2bf(oacc[dt][2] * inv, oacc[dt][3] * inv)};
+      *reinterpret_cast<u32x2_t*>(a.o + (base + qrow) * a.ldo + h * DH + dt * 16 + lg * 4) = pk;
+    }
+    if (lg == 0 && a.lse) a.lse[(base + qrow) * a.H + h] = mx + __logf(sum);
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
+  constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
+  extern __shared__ __attribute__((aligned(16))) bf16_t sh_lds[];  // K | V | Q | dO (L16 rows each) | lse, delta (fp32)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int n = blockIdx.y, h = blockIdx.x, L = a.Lk, L16 = nw * 16;
+  bf16_t* Ks = sh_lds;
+  bf16_t* Vs = Ks + L16 * RP;
+  bf16_t* Qs = Vs + L16 * RP;
+  bf16_t* dOs = Qs + L16 * RP;
+  float* lse_s = reinterpret_cast<float*>(dOs + L16 * RP);
+  float* delta_s = lse_s + L16;
+  const int nvalid = (int)a.lens[n];
+  const long base = (long)n * L;
+  const int l15 = lane & 15, lg = lane >> 4;
+  stage_rows<DH>(a.k, a.ldk, base, L, L16, h * DH, Ks);
+  stage_rows<DH>(a.v, a.ldv, base, L, L16, h * DH, Vs);
+  stage_rows<DH>(a.q, a.ldq, base, L, L16, h * DH, Qs);
+  stage_rows<DH>(a.dout, a.lddo, base, L, L16, h * DH, dOs);
+  // ---- phase A: this wave's 16 queries: delta, dQ ------------------------------------------------------------
+  const int qrow = wave * 16 + l15;
+  const bool qok = qrow < L;
+  s16x4_t qf[NK], dof[NK];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    qf[ks] = s16x4_t{0, 0, 0, 0}; dof[ks] = qf[ks];
+    if (qok) {
+      const long off = h * DH + ks * 16 + lg * 4;
+      qf[ks] = *reinterpret_cast<const s16x4_t*>(a.q + (base + qrow) * a.ldq + off);
+      dof[ks] = *reinterpret_cast<const s16x4_t*>(a.dout + (base + qrow) * a.lddo + off);
+      const s16x4_t of = *reinterpret_cast<const s16x4_t*>(a.o + (base + qrow) * a.ldo + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dl += bf2f((bf16_t)dof[ks][j]) * bf2f((bf16_t)of[j]);
+    }
+  }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  float lse = 0.f;
+  if (qok) lse = a.lse[(base + qrow) * a.H + h];
+  if (lg == 0) { lse_s[wave * 16 + l15] = lse; delta_s[wave * 16 + l15] = dl; }
+  __syncthreads();
+  {
+    s16x4_t dsf[SH_MAXW];
+#pragma unroll
+    for (int kt = 0; kt < SH_MAXW; ++kt) {
+      if (kt < nw) {
+        f32x4_t sv4 = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+          const s16x4_t kf = *reinterpret_cast<const s16x4_t*>(&Ks[(kt * 16 + l15) * RP + ks * 16 + lg * 4]);
+          const s16x4_t vf = *reinterpret_cast<const s16x4_t*>(&Vs[(kt * 16 + l15) * RP + ks * 16 + lg * 4]);
+          sv4 = mfma16(kf, qf[ks], sv4);
+          dp = mfma16(vf, dof[ks], dp);
+        }
+        float ds[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kidx = kt * 16 + lg * 4 + i;
+          float sv = sv4[i] * a.scale;
+          if (kidx >= nvalid) sv = kMaskFill;
+          const float p = (kidx < L && qok) ? __expf(sv - lse) : 0.f;
+          float dpe = dp[i];
+          if (a.drop.thr) {
+            const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qrow) * L + kidx);
+            dpe *= drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          }
+          ds[i] = (kidx < nvalid) ? p * (dpe - dl) * a.scale : 0.f;  // masked_fill blocks the gradient
+        }
+        dsf[kt] = pack4(ds[0], ds[1], ds[2], ds[3]);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) {
+      f32x4_t dq = {0, 0, 0, 0};
+#pragma unroll
+      for (int kt = 0; kt < SH_MAXW; ++kt)
+        if (kt < nw) dq = mfma16(tr16(&Ks[kt * 16 * RP + dt * 16], RP, lane), dsf[kt], dq);  // A = K^T [dh][key]
+      if (qok) {
+        const u32x2_t pk = {pack2bf(dq[0], dq[1]), pack2bf(dq[2], dq[3])};
+        *reinterpret_cast<u32x2_t*>(a.dq + (base + qrow) * a.lddq + h * DH + dt * 16 + lg * 4) = pk;
+      }
+    }
+  }
+  // ---- phase B: this wave's 16 keys: dK, dV (transposed products: a lane owns 4 channels of key l15) ---------------
+  const int krow = wave * 16 + l15;
+  const bool kin = krow < L, kvalid = krow < nvalid;
+  s16x4_t kf[NK], vf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    kf[ks] = *reinterpret_cast<const s16x4_t*>(&Ks[krow * RP + ks * 16 + lg * 4]);
+    vf[ks] = *reinterpret_cast<const s16x4_t*>(&Vs[krow * RP + ks * 16 + lg * 4]);
+  }
+  f32x4_t dkacc[NK], dvacc[NK];
+#pragma unroll
+  for (int dt = 0; dt < NK; ++dt) { dkacc[dt] = f32x4_t{0, 0, 0, 0}; dvacc[dt] = dkacc[dt]; }
+#pragma unroll
+  for (int qt = 0; qt < SH_MAXW; ++qt) {
+    if (qt < nw) {
+      f32x4_t sv4 = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const s16x4_t qfr = *reinterpret_cast<const s16x4_t*>(&Qs[(qt * 16 + l15) * RP + ks * 16 + lg * 4]);
+        const s16x4_t dofr = *reinterpret_cast<const s16x4_t*>(&dOs[(qt * 16 + l15) * RP + ks * 16 + lg * 4]);
+        sv4 = mfma16(qfr, kf[ks], sv4);  // sv4[i] = S[q = qt*16 + lg*4 + i][key = l15]
+        dp = mfma16(dofr, vf[ks], dp);
+      }
+      float p[4], ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qr = qt * 16 + lg * 4 + i;
+        const float pv = (kvalid && qr < L) ? __expf(sv4[i] * a.scale - lse_s[qr]) : 0.f;
+        float dsc = 1.f;
+        if (a.drop.thr) {
+          const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qr) * L + krow);
+          dsc = drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+        }
+        p[i] = pv * dsc;
+        ds[i] = pv * (dp[i] * dsc - delta_s[qr]) * a.scale;
+      }
+      const s16x4_t pf = pack4(p[0], p[1], p[2], p[3]), dsf = pack4(ds[0], ds[1], ds[2], ds[3]);  // B operands: [k = query][n = key]
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt) {
+        dvacc[dt] = mfma16(tr16(&dOs[qt * 16 * RP + dt * 16], RP, lane), pf, dvacc[dt]);   // dV^T[dh][key] = dO^T . P
+        dkacc[dt] = mfma16(tr16(&Qs[qt * 16 * RP + dt * 16], RP, lane), dsf, dkacc[dt]);   // dK^T[dh][key] = Q^T . dS
+      }
+    }
+  }
+  if (kin) {
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) {
+      const u32x2_t pk = {pack2bf(dkacc[dt][0], dkacc[dt][1]), pack2bf(dkacc[dt][2], dkacc[dt][3])};
+      const u32x2_t pv = {pack2bf(dvacc[dt][0], dvacc[dt][1]), pack2bf(dvacc[dt][2], dvacc[dt][3])};
+      *reinterpret_cast<u32x2_t*>(a.dk + (base + krow) * a.lddk + h * DH + dt * 16 + lg * 4) = pk;
+      *reinterpret_cast<u32x2_t*>(a.dv + (base + krow) * a.lddv + h * DH + dt * 16 + lg * 4) = pv;
+    }
+  }
+}
+
+static int g_attn_short = 1;
+void set_attn_short(int on) { g_attn_short = on; }
+static bool attn_short_ok(const AttnArgs& a) { return g_attn_short && a.Lq == a.Lk && a.Lk <= 16 * SH_MAXW && a.Lk >= 1; }
+
 template <int DH>
 static int attn_fwd_t(const AttnArgs& a, hipStream_t st) {
+  if (attn_short_ok(a)) {
+    const int nw = (a.Lk + 15) / 16;
+    hipLaunchKernelGGL(attn_short_fwd_kernel<DH>, dim3(a.H, a.Nseq), dim3(64 * nw), (size_t)2 * nw * 16 * AttnSmem<DH>::RP * sizeof(bf16_t), st, a);
+    COOT_CHECK_LAUNCH("attn_short_fwd");
+    return 0;
+  }
   dim3 grid((a.Lq + 63) / 64, a.H, a.Nseq);
   hipLaunchKernelGGL(attn_fwd_kernel<DH>, grid, dim3(256), 0, st, a);
   COOT_CHECK_LAUNCH("attn_fwd");
@@ -351,6 +616,13 @@ static int attn_fwd_t(const AttnArgs& a, hipStream_t st) {
 }
 template <int DH>
 static int attn_bwd_t(const AttnArgs& a, hipStream_t st) {
+  if (attn_short_ok(a)) {
+    const int nw = (a.Lk + 15) / 16;
+    hipLaunchKernelGGL(attn_short_bwd_kernel<DH>, dim3(a.H, a.Nseq), dim3(64 * nw),
+                       (size_t)4 * nw * 16 * AttnSmem<DH>::RP * sizeof(bf16_t) + (size_t)2 * nw * 16 * sizeof(float), st, a);
+    COOT_CHECK_LAUNCH("attn_short_bwd");
+    return 0;
+  }
   dim3 gq((a.Lq + 63) / 64, a.H, a.Nseq);
   hipLaunchKernelGGL(attn_bwd_q_kernel<DH>, gq, dim3(256), 0, st, a);
   COOT_CHECK_LAUNCH("attn_bwd_q");
