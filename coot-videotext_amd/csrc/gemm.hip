@@ -464,7 +464,7 @@ constexpr int TN_BC = 128;            // columns per operand tile
 constexpr int TN_PITCH = TN_BC + 16;  // mode 0: [t][col], 288-byte rows (8 consecutive rows -> 64 distinct banks)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split, int splits, float* ws) {
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split, int splits, float* ws, int direct) {
   // mode 0: As[t][col] (pitch TN_PITCH).  mode 1: At[col][t] (pitch PITCH).
   constexpr int ASZ = MODE == 0 ? TN_BT * TN_PITCH : TN_BC * PITCH;
   constexpr int OPER_ELEMS = 4 * ASZ;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split,
     if (st + 1 < nsteps) sstore(buf ^ 1);
     __syncthreads();
   }
-  if (ws == nullptr) {  // one-pass path: fp32 atomics straight into C
+  if (ws == nullptr && !direct) {  // one-pass path: fp32 atomics straight into C
     float* C = g.C + z * g.zC;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -600,8 +600,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split,
       *reinterpret_cast<f32x4_t*>(&Cs[r * CPITCH + c]) = acc[a][b];
     }
   __syncthreads();
-  float* wsp = ws + ((long)split * g.groups + z) * g.Mo * g.No;
   const int c4 = (tid & 31) * 4, rg = tid >> 5;  // 32 lanes x float4 = one 128-column row
+  if (direct) {  // a single split: this workgroup owns its output tile, C += alpha * tile without a second launch
+    float* C = g.C + z * g.zC;
+    if (n0 + c4 < g.No) {
+#pragma unroll 4
+      for (int i = 0; i < TN_BC / 8; ++i) {
+        const int rl = rg + 8 * i, row = m0 + rl;
+        if (row < g.Mo) {
+          f32x4_t* cp = reinterpret_cast<f32x4_t*>(C + (long)row * g.ldc + n0 + c4);
+          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(&Cs[rl * CPITCH + c4]);
+          f32x4_t o = *cp;
+          o[0] += t[0] * g.alpha; o[1] += t[1] * g.alpha; o[2] += t[2] * g.alpha; o[3] += t[3] * g.alpha;
+          *cp = o;
+        }
+      }
+    }
+    return;
+  }
+  float* wsp = ws + ((long)split * g.groups + z) * g.Mo * g.No;
   if (n0 + c4 < g.No) {
 #pragma unroll 4
     for (int i = 0; i < TN_BC / 8; ++i) {
@@ -662,10 +679,13 @@ int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
   if (g.ws && need <= g.ws_floats) ws = g.ws;
   else if (!g.ws && g_tn_ws && need <= g_tn_ws_floats) ws = g_tn_ws;
   dim3 grid((g.No + TN_BC - 1) / TN_BC, (g.Mo + TN_BC - 1) / TN_BC, g.groups * splits);
+  // one split (global networks): the tile owner adds into C itself — no workspace, no reduce launch (needs 16-byte rows)
+  const int direct = (splits == 1 && g.ldc % 4 == 0 && g.No % 4 == 0 && g.zC % 4 == 0) ? 1 : 0;
+  if (direct) ws = nullptr;
   if (g_tn_mode == 0)
-    hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, dim3(256), 0, stream, g, t_per_split, splits, ws);
+    hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, dim3(256), 0, stream, g, t_per_split, splits, ws, direct);
   else
-    hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, stream, g, t_per_split, splits, ws);
+    hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, stream, g, t_per_split, splits, ws, direct);
   COOT_CHECK_LAUNCH("gemm_tn");
   if (ws) {
     const long total4 = (long)g.Mo * g.No * g.groups / 4;

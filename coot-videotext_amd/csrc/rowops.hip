@@ -243,6 +243,8 @@ int launch_ln_bwd(const LnBwd& p_in, hipStream_t stream) {
   if (blocks > 1024) blocks = 1024;
   p.part_ws = partials_workspace((size_t)blocks * 3 * p.D);
   if (!p.part_ws && blocks > 256) { blocks = 256; p.part_ws = partials_workspace((size_t)blocks * 3 * p.D); }
+  // few rows (global networks): <= 128 atomics per address are cheaper than a second launch on the step's critical path
+  if (p.R <= 512) p.part_ws = nullptr;
   if (p.D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, stream, p);
   COOT_CHECK_LAUNCH("ln_bwd");
@@ -274,7 +276,7 @@ int launch_colsum_bf16(const bf16_t* x, long ldx, int R, int C, float* out, hipS
   if (R <= 0) return 0;
   int rpb = 64;
   dim3 grid((C / 2 + 255) / 256, (R + rpb - 1) / rpb);
-  float* part = partials_workspace((size_t)grid.y * C);
+  float* part = R <= 512 ? nullptr : partials_workspace((size_t)grid.y * C);  // few rows: atomics, no second launch
   hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, out, rpb, part);
   COOT_CHECK_LAUNCH("colsum_bf16");
   if (part) return launch_reduce_partials(part, (int)grid.y, C, C, out, stream);
