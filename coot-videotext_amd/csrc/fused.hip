@@ -8,6 +8,7 @@
 //   weight fragments: one 16-byte global load per lane from the P48 pack (1 KB contiguous per wave-load, L2 resident),
 //   register-prefetched 3 k-blocks ahead; no barrier inside a pass.
 #include "fused.h"
+#include "gemm.h"
 
 #include <type_traits>
 
@@ -412,6 +413,8 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
                p.h1 && p.a1 && p.r2 && p.z2, "post_attn_fwd: null pointer");
   COOT_REQUIRE(!p.do_pool || (p.pw1 && p.pw2 && p.pb1 && p.pb2 && p.hp && p.ap && p.s), "post_attn_fwd: pooling pointers");
   if (p.T <= 0) return 0;
+  // GEMM passes of the chain: out-proj, FF1, FF2 (+ pool FC1 768 wide, FC2 384 wide): 2 * T * 384 * 384 each
+  void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 384.0 * (p.do_pool ? 6.0 : 3.0), 0, st);
   const bool drop = p.d_postln.thr || p.d_ff1.thr || p.d_ff2.thr || p.d_pool1.thr || p.d_pool2.thr;
   if (drop) {
     COOT_REQUIRE(p.d_postln.thr && p.d_ff1.thr && p.d_ff2.thr && (!p.do_pool || (p.d_pool1.thr && p.d_pool2.thr)), "post_attn_fwd: dropout on some sites only");
@@ -419,6 +422,7 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   } else {
     hipLaunchKernelGGL((post_attn_fwd_kernel<8, false>), dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
   }
+  timing_end(ts, st);
   COOT_CHECK_LAUNCH("post_attn_fwd");
   return 0;
 }

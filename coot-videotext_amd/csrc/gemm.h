@@ -53,9 +53,12 @@ size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups);
 // default workspace used by launch_gemm_tn when GemmTN::ws is null (set by the orchestrator for one call)
 void set_tn_default_workspace(float* ws, size_t floats);
 
-// per-launch HIP-event timing of gemm_nt (bench roofline leg)
+// per-launch HIP-event timing of every MFMA GEMM kernel (bench roofline leg); events are recorded on the launch stream
+enum { TIMING_NT = 2, TIMING_NT_SMALL = 3, TIMING_TN = 4, TIMING_FUSED = 5 };
 void gemm_timing_enable(int on);
-int gemm_timing_collect(int only_big_k, double* ms, double* flops, int* launches);
+int gemm_timing_collect(int selector, double* ms, double* flops, int* launches);
+void* timing_begin(int kind, double flops, int big_k, hipStream_t stream);  // nullptr when timing is off
+void timing_end(void* slot, hipStream_t stream);
 
 // 0 = ds_read_b64_tr_b16 fragments (default), 1 = transposing LDS stores (fallback)
 void set_tn_mode(int mode);

@@ -374,33 +374,40 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmNT g) {
 }
 
 // ---- optional per-launch timing with HIP events (bench.py roofline leg) -------------------------------
-struct TimingSlot { hipEvent_t a, b; double flops; int big_k; };
+struct TimingSlot { hipEvent_t a, b; double flops; int kind; int big_k; };
 static int g_timing_on = 0;
 static int g_small_on = 1;
 void set_gemm_small(int on) { g_small_on = on; }
 static TimingSlot g_slots[8192];
 static int g_nslots = 0, g_slots_created = 0;
 void gemm_timing_enable(int on) { g_timing_on = on; g_nslots = 0; }
-int gemm_timing_collect(int only_big_k, double* ms, double* flops, int* launches) {
+// selector: 0 = every MFMA GEMM launch (all kinds), 1 = input-FC instances of gemm_nt (K >= 1024),
+//           2 = gemm_nt (LDS staged), 3 = gemm_nt_small, 4 = gemm_tn (+ its split reduction), 5 = fused token-tile chains
+int gemm_timing_collect(int selector, double* ms, double* flops, int* launches) {
   double tm = 0, fl = 0; int n = 0;
   for (int i = 0; i < g_nslots; ++i) {
-    if (only_big_k && !g_slots[i].big_k) continue;
-    if (hipEventSynchronize(g_slots[i].b) != hipSuccess) return -1;
+    const TimingSlot& sl = g_slots[i];
+    if (selector == 1 && !(sl.kind == TIMING_NT && sl.big_k)) continue;
+    if (selector >= 2 && sl.kind != selector) continue;
+    if (hipEventSynchronize(sl.b) != hipSuccess) return -1;
     float t = 0.f;
-    if (hipEventElapsedTime(&t, g_slots[i].a, g_slots[i].b) != hipSuccess) return -1;
-    tm += t; fl += g_slots[i].flops; ++n;
+    if (hipEventElapsedTime(&t, sl.a, sl.b) != hipSuccess) return -1;
+    tm += t; fl += sl.flops; ++n;
   }
   *ms = tm; *flops = fl; *launches = n;
   return 0;
 }
-static TimingSlot* timing_begin(const GemmNT& g, hipStream_t stream) {
+void* timing_begin(int kind, double flops, int big_k, hipStream_t stream) {
   if (!g_timing_on || g_nslots >= 8192) return nullptr;
   TimingSlot* s = &g_slots[g_nslots];
-  if (g_nslots >= g_slots_created) { hipEventCreate(&s->a); hipEventCreate(&s->b); g_slots_created = g_nslots + 1; }
+  if (g_nslots >= g_slots_created) { (void)hipEventCreate(&s->a); (void)hipEventCreate(&s->b); g_slots_created = g_nslots + 1; }
   ++g_nslots;
-  s->flops = 2.0 * g.M * g.N * g.K * g.groups; s->big_k = g.K >= 1024;
-  hipEventRecord(s->a, stream);
+  s->flops = flops; s->kind = kind; s->big_k = big_k;
+  (void)hipEventRecord(s->a, stream);
   return s;
+}
+void timing_end(void* slot, hipStream_t stream) {
+  if (slot) (void)hipEventRecord(static_cast<TimingSlot*>(slot)->b, stream);
 }
 
 int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
@@ -414,7 +421,7 @@ int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
                "gemm_nt: epilogue strides must be multiples of 8");
   if (g.M <= 0 || g.N <= 0) return 0;
   if (g.M <= 512 && g_small_on) {  // global networks / loss strips: direct-from-L2 fragments, no LDS
-    TimingSlot* ts = timing_begin(g, stream);
+    void* ts = timing_begin(TIMING_NT_SMALL, 2.0 * g.M * g.N * g.K * g.groups, 0, stream);
     g.epi.colsum_ws = nullptr;
     if ((long)((g.M + 15) / 16) * ((g.N + 31) / 32) >= 512) {
       dim3 grid((g.N + 4 * 32 - 1) / (4 * 32), (g.M + 15) / 16, g.groups);
@@ -423,7 +430,7 @@ int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
       dim3 grid((g.N + 4 * 16 - 1) / (4 * 16), (g.M + 15) / 16, g.groups);
       hipLaunchKernelGGL(gemm_nt_small_kernel<1>, grid, dim3(256), 0, stream, g);
     }
-    if (ts) hipEventRecord(ts->b, stream);
+    timing_end(ts, stream);
     COOT_CHECK_LAUNCH("gemm_nt_small");
     return 0;
   }
@@ -437,7 +444,7 @@ int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
     g.epi.colsum_ws = partials_workspace((size_t)row_blocks * ccols);
     g.epi.ld_colsum_ws = ccols;
   }
-  TimingSlot* ts = timing_begin(g, stream);
+  void* ts = timing_begin(TIMING_NT, 2.0 * g.M * g.N * g.K * g.groups, g.K >= 1024, stream);
   if (big) {
     dim3 grid(nb, row_blocks, g.groups);
     hipLaunchKernelGGL(gemm_nt_kernel<128>, grid, dim3(256), 0, stream, g);
@@ -445,7 +452,7 @@ int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
     dim3 grid(nb, row_blocks, g.groups);
     hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, stream, g);
   }
-  if (ts) hipEventRecord(ts->b, stream);
+  timing_end(ts, stream);
   COOT_CHECK_LAUNCH("gemm_nt");
   if (g.epi.colsum_ws) return launch_reduce_partials(g.epi.colsum_ws, row_blocks, ccols, ccols, g.epi.colsum, stream);
   return 0;
@@ -682,6 +689,7 @@ int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
   // one split (global networks): the tile owner adds into C itself — no workspace, no reduce launch (needs 16-byte rows)
   const int direct = (splits == 1 && g.ldc % 4 == 0 && g.No % 4 == 0 && g.zC % 4 == 0) ? 1 : 0;
   if (direct) ws = nullptr;
+  void* ts = timing_begin(TIMING_TN, 2.0 * g.T * g.Mo * g.No * g.groups, 0, stream);
   if (g_tn_mode == 0)
     hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, dim3(256), 0, stream, g, t_per_split, splits, ws, direct);
   else
@@ -694,6 +702,7 @@ int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g, splits, ws);
     COOT_CHECK_LAUNCH("gemm_tn_reduce");
   }
+  timing_end(ts, stream);
   return 0;
 }
 
