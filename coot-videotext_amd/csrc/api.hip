@@ -235,6 +235,15 @@ static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A,
       const int Hh = c.pool_heads, dhp = c.pool_hidden / Hh, dop = (int)D / Hh;
       mx(gemm_tn_workspace_floats((int)T, dhp, dop, Hh)); mx(gemm_tn_workspace_floats((int)T, (int)D, dhp, Hh));
     }
+    {  // batched weight-gradient launch (tn_batch_flush): every dW of the network in flight, <= 8 splits each
+      const size_t smax = T / 512 > 8 ? 8 : (T / 512 > 0 ? T / 512 : 1);
+      size_t sum = 0;
+      const size_t per_layer = 4 * D * D + 2 * D * F;
+      sum += per_layer * ((size_t)c.num_layers + (c.use_context ? (size_t)c.ctx_num_layers : 0));
+      if (c.use_input_fc) sum += D * (size_t)c.input_dim;
+      if (c.pooler == 0) sum += (size_t)c.pool_hidden * D + (size_t)c.pool_hidden * (D / c.pool_heads);
+      mx(smax * sum);
+    }
     S.tn_ws_floats = w; S.tn_ws = A.get<float>(w);
   }
   {
@@ -712,6 +721,11 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   COOT_REQUIRE(!AX.overflow, "net_bwd: scratch buffer too small (%zu < %zu)", scratch_bytes, AX.off);
   struct TnWs { TnWs(float* p, size_t n) { set_tn_default_workspace(p, n); } ~TnWs() { set_tn_default_workspace(nullptr, 0); } } tnws(X.tn_ws, X.tn_ws_floats);
   struct PartWs { PartWs(float* p, size_t n) { set_partials_workspace(p, n); } ~PartWs() { set_partials_workspace(nullptr, 0); } } partws(X.part_ws, X.part_floats);
+  // every weight gradient GEMM of the pass is recorded and launched as ONE batched kernel (gemm.h: tn_batch_*).  With a
+  // single encoder (and context) layer no operand buffer is re-used before the end of the pass; deeper networks flush
+  // after every layer, whose scratch buffers the next layer overwrites.
+  struct TnBatchScope { TnBatchScope() { tn_batch_begin(); } ~TnBatchScope() { tn_batch_end(); } } tnbatch;
+  const bool flush_per_layer = c.num_layers > 1 || (c.use_context && c.ctx_num_layers > 1);
   const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim;
   const long long* lens = sg.lens[0];
   const int out_dim = D * (c.use_context ? 2 : 1);
@@ -765,6 +779,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       RUN(layer_bwd(c, P, G, L.ctx[i], W.ctx[i], qin, N, zL, T, sg, b, w, last ? nullptr : X.c_dqin,
                     last ? dpooled + D : nullptr, out_dim, first ? nullptr : X.c_dqin, first ? dhidden : nullptr, dz, nullptr, nullptr,
                     c.ctx_dropout, train, seed, 16u * (8 + i), st));
+      if (flush_per_layer) RUN(tn_batch_flush(st));
     }
   }
 
@@ -777,12 +792,14 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     if (fc0) RUN(launch_fill_f32(X.cvec, D, 0.f, st));
     RUN(layer_bwd(c, P, G, L.layers[i], W.layers[i], zin, T, zin, T, sg, b, w, dz, nullptr, 0, dz_other, nullptr, nullptr,
                   fc0 ? S.h0 : nullptr, fc0 ? X.cvec : nullptr, c.dropout, train, seed, 16u * i, st));
+    if (flush_per_layer) RUN(tn_batch_flush(st));
     bf16_t* t = dz; dz = dz_other; dz_other = t;
   }
   // dz now holds: dh0 (input-FC nets: already multiplied by gelu'(h0)) or dz0 (grad wrt LN(x)+pe)
   if (c.use_input_fc) {
     RUN(launch_fill_f32(X.Mbuf, (long)D * Din, 0.f, st));
     { GemmTN t; t.A = dz; t.lda = D; t.B = S.xhat; t.ldb = Din; t.T = T; t.Mo = D; t.No = Din; t.C = X.Mbuf; t.ldc = Din; RUN(launch_gemm_tn(t, st)); }
+    RUN(tn_batch_flush(st));  // all weight gradients of the pass (the parameter-gradient kernel below reads Mbuf)
     RUN(launch_infc_param_grads(X.Mbuf, P + L.in_w, P + L.n_gain, P + L.n_bias, X.cvec, D, Din, G + L.in_w, G + L.n_gain, G + L.n_bias, st));
     RUN(launch_axpy_f32(G + L.in_b, X.cvec, D, 1.0f, st));  // db_in += colsum(dh0)
   } else {
@@ -790,6 +807,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     l.dx32 = dfeats; l.lddx32 = Din; l.dgain = G + L.n_gain; l.dbias = G + L.n_bias;
     if (!dfeats) { l.dx = dz_other; l.lddx = D; }
     RUN(launch_ln_bwd(l, st));
+    RUN(tn_batch_flush(st));
   }
   (void)pe; (void)hidden;
   return 0;

@@ -50,6 +50,12 @@ struct GemmTN {
 
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream);
 size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups);
+// Batching: between tn_batch_begin() and tn_batch_flush() every launch_gemm_tn() (without an explicit workspace) is only
+// recorded; flush launches all recorded problems as ONE kernel (+ one split reduction) on `stream`.  The operands must
+// stay untouched until the flush.  tn_batch_end() leaves the collecting mode.
+void tn_batch_begin();
+int tn_batch_flush(hipStream_t stream);
+void tn_batch_end();
 // default workspace used by launch_gemm_tn when GemmTN::ws is null (set by the orchestrator for one call)
 void set_tn_default_workspace(float* ws, size_t floats);
 

@@ -471,7 +471,7 @@ constexpr int TN_BC = 128;            // columns per operand tile
 constexpr int TN_PITCH = TN_BC + 16;  // mode 0: [t][col], 288-byte rows (8 consecutive rows -> 64 distinct banks)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split, int splits, float* ws, int direct) {
+__device__ __forceinline__ void gemm_tn_body(const GemmTN& g, int bx, int by, int bz, int t_per_split, int splits, float* ws, int direct) {
   // mode 0: As[t][col] (pitch TN_PITCH).  mode 1: At[col][t] (pitch PITCH).
   constexpr int ASZ = MODE == 0 ? TN_BT * TN_PITCH : TN_BC * PITCH;
   constexpr int OPER_ELEMS = 4 * ASZ;
@@ -483,8 +483,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split,
   float* Cs = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int z = blockIdx.z % g.groups, split = blockIdx.z / g.groups;
-  const int m0 = blockIdx.y * TN_BC, n0 = blockIdx.x * TN_BC;
+  const int z = bz % g.groups, split = bz / g.groups;
+  const int m0 = by * TN_BC, n0 = bx * TN_BC;
   const int t_begin = split * t_per_split;
   const int t_end = min(g.T, t_begin + t_per_split);
   const bf16_t* A = g.A + z * g.zA;
@@ -635,6 +635,47 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split,
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split, int splits, float* ws, int direct) {
+  gemm_tn_body<MODE>(g, blockIdx.x, blockIdx.y, blockIdx.z, t_per_split, splits, ws, direct);
+}
+
+// Several weight-gradient problems in ONE launch (every dW of a network's backward pass): with all of them in flight each
+// problem needs only a few splits over the token axis (4 instead of 32: an eighth of the fp32 partial-tile traffic, 8x
+// longer pipelined loops per workgroup), and the global networks' eight tiny problems cost one launch instead of sixteen.
+constexpr int TN_MAX_ITEMS = 10;
+struct TnItem { GemmTN g; int blk0, gx, gy, t_per_split, splits, direct; long ws_off; };
+struct TnBatch { int n; TnItem it[TN_MAX_ITEMS]; };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(TnBatch b, float* ws_base) {
+  int i = 0;
+  for (int t = 1; t < b.n; ++t) if ((int)blockIdx.x >= b.it[t].blk0) i = t;
+  const TnItem& it = b.it[i];
+  const int local = blockIdx.x - it.blk0;
+  const int bx = local % it.gx, by = (local / it.gx) % it.gy, bz = local / (it.gx * it.gy);
+  gemm_tn_body<MODE>(it.g, bx, by, bz, it.t_per_split, it.splits, it.direct ? nullptr : ws_base + it.ws_off, it.direct);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_batch_reduce_kernel(TnBatch b, const float* ws_base) {
+  const TnItem& it = b.it[blockIdx.y];
+  if (it.direct) return;
+  const GemmTN& g = it.g;
+  const float* ws = ws_base + it.ws_off;
+  const long per = (long)g.Mo * g.No;
+  const long total4 = per * g.groups / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    const int z = (int)(e / per);
+    const long r = e % per;
+    const int m = (int)(r / g.No), n = (int)(r % g.No);
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < it.splits; ++sp) s += *reinterpret_cast<const f32x4_t*>(ws + ((long)sp * g.groups + z) * per + r);
+    float* c = g.C + z * g.zC + (long)m * g.ldc + n;
+    c[0] += s[0] * g.alpha; c[1] += s[1] * g.alpha; c[2] += s[2] * g.alpha; c[3] += s[3] * g.alpha;
+  }
+}
+
 // C[z][m][n] += alpha * sum_s ws[s][z][m][n]
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTN g, int splits, const float* ws) {
   const long per = (long)g.Mo * g.No;
@@ -672,11 +713,75 @@ size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups) {
   return (size_t)tn_splits(T, Mo, No, groups) * groups * Mo * No;
 }
 
+static thread_local bool g_tn_collect = false;
+static thread_local int g_tn_nitems = 0;
+static thread_local GemmTN g_tn_items[TN_MAX_ITEMS];
+
+void tn_batch_begin() { g_tn_collect = true; g_tn_nitems = 0; }
+
+int tn_batch_flush(hipStream_t stream) {
+  const int n = g_tn_nitems;
+  g_tn_nitems = 0;
+  if (n == 0) return 0;
+  TnBatch b; b.n = n;
+  long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const GemmTN& g = g_tn_items[i];
+    tiles += (long)((g.No + TN_BC - 1) / TN_BC) * ((g.Mo + TN_BC - 1) / TN_BC) * g.groups;
+  }
+  int blk = 0; long ws_off = 0; bool any_ws = false;
+  for (int i = 0; i < n; ++i) {
+    TnItem& it = b.it[i];
+    it.g = g_tn_items[i];
+    const GemmTN& g = it.g;
+    it.gx = (g.No + TN_BC - 1) / TN_BC; it.gy = (g.Mo + TN_BC - 1) / TN_BC;
+    // about two workgroups per CU over the whole batch, every split >= 512 token rows, at most 8 splits
+    int splits = (int)((512 + tiles - 1) / tiles);
+    const int max_splits = g.T / 512 > 0 ? g.T / 512 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 8) splits = 8;
+    if (splits < 1) splits = 1;
+    int tps = (g.T + splits - 1) / splits;
+    tps = (tps + TN_BT - 1) / TN_BT * TN_BT;
+    splits = (g.T + tps - 1) / tps;
+    it.t_per_split = tps; it.splits = splits;
+    it.direct = (splits == 1 && g.ldc % 4 == 0 && g.No % 4 == 0 && g.zC % 4 == 0) ? 1 : 0;
+    it.blk0 = blk; blk += it.gx * it.gy * g.groups * splits;
+    it.ws_off = ws_off;
+    if (!it.direct) { ws_off += (long)splits * g.groups * g.Mo * g.No; any_ws = true; }
+  }
+  float* ws = g_tn_ws;
+  if (any_ws && (!ws || (size_t)ws_off > g_tn_ws_floats)) {  // no room for the batch: problem by problem
+    g_tn_collect = false;
+    for (int i = 0; i < n; ++i) { GemmTN g = g_tn_items[i]; int rc = launch_gemm_tn(g, stream); if (rc) { g_tn_collect = true; return rc; } }
+    g_tn_collect = true;
+    return 0;
+  }
+  double flops = 0;
+  for (int i = 0; i < n; ++i) flops += 2.0 * b.it[i].g.T * b.it[i].g.Mo * b.it[i].g.No * b.it[i].g.groups;
+  void* ts = timing_begin(TIMING_TN, flops, 0, stream);
+  if (g_tn_mode == 0) hipLaunchKernelGGL(gemm_tn_batch_kernel<0>, dim3(blk), dim3(256), 0, stream, b, ws);
+  else hipLaunchKernelGGL(gemm_tn_batch_kernel<1>, dim3(blk), dim3(256), 0, stream, b, ws);
+  COOT_CHECK_LAUNCH("gemm_tn_batch");
+  if (any_ws) {
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(256, n), dim3(256), 0, stream, b, (const float*)ws);
+    COOT_CHECK_LAUNCH("gemm_tn_batch_reduce");
+  }
+  timing_end(ts, stream);
+  return 0;
+}
+void tn_batch_end() { g_tn_collect = false; g_tn_nitems = 0; }
+
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
   COOT_REQUIRE(g.A && g.B && g.C, "gemm_tn: null operand");
   COOT_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.Mo % 8 == 0 && g.No % 8 == 0 && g.zA % 8 == 0 && g.zB % 8 == 0,
                "gemm_tn: lda/ldb/Mo/No must be multiples of 8 (Mo=%d No=%d lda=%ld ldb=%ld)", g.Mo, g.No, g.lda, g.ldb);
   if (g.T <= 0 || g.Mo <= 0 || g.No <= 0) return 0;
+  if (g_tn_collect && !g.ws) {  // inside tn_batch_begin() .. tn_batch_flush(): deferred, launched together
+    if (g_tn_nitems == TN_MAX_ITEMS) { int rc = tn_batch_flush(stream); if (rc) return rc; }
+    g_tn_items[g_tn_nitems++] = g;
+    return 0;
+  }
   int splits = tn_splits(g.T, g.Mo, g.No, g.groups);
   int t_per_split = (g.T + splits - 1) / splits;
   t_per_split = (t_per_split + TN_BT - 1) / TN_BT * TN_BT;
