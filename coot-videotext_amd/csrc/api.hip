@@ -443,8 +443,9 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
   a.dout = w.dctx; a.lddo = D; a.delta = w.delta; a.dq = w.dq; a.lddq = w.lddq; a.dk = w.dk; a.lddk = w.lddk; a.dv = w.dv; a.lddv = w.lddv;
   RUN(attention_all(a, sg, !self, true, st));
   if (self) {
-    RUN(launch_colsum_bf16(w.dq, 3 * D, rows_q, 3 * D, G + lp.bq, st));
-    { GemmTN t; t.A = w.dq; t.lda = 3 * D; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = 3 * D; t.No = D; t.C = G + lp.wqkv; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
+    // bq | bk | bv gradients = column sums of dqkv: taken by the weight-gradient GEMM that streams dqkv anyway
+    { GemmTN t; t.A = w.dq; t.lda = 3 * D; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = 3 * D; t.No = D; t.C = G + lp.wqkv; t.ldc = D;
+      t.a_colsum = G + lp.bq; RUN(launch_gemm_tn(t, st)); }
     GemmNT g; g.X = w.dq; g.ldx = 3 * D; g.W = lw.wqkv_kn; g.ldw = 3 * D; g.M = rows_q; g.N = D; g.K = 3 * D;
     g.epi.res = w.dr1; g.epi.ldres = D;
     if (gelu_aux) { g.epi.act = 2; g.epi.aux = gelu_aux; g.epi.ldaux = D; g.epi.colsum = gelu_colsum; }
@@ -452,10 +453,10 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
     g.epi.ldc = D;
     RUN(launch_gemm_nt(g, st));
   } else {
-    RUN(launch_colsum_bf16(w.dq, w.lddq, rows_q, D, G + lp.bq, st));
-    RUN(launch_colsum_bf16(w.dk, w.lddk, rows_kv, 2 * D, G + lp.bk, st));
-    { GemmTN t; t.A = w.dq; t.lda = w.lddq; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = D; t.No = D; t.C = G + lp.wqkv; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
-    { GemmTN t; t.A = w.dk; t.lda = w.lddk; t.B = xkv; t.ldb = D; t.T = rows_kv; t.Mo = 2 * D; t.No = D; t.C = G + lp.wqkv + (size_t)D * D; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
+    { GemmTN t; t.A = w.dq; t.lda = w.lddq; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = D; t.No = D; t.C = G + lp.wqkv; t.ldc = D;
+      t.a_colsum = G + lp.bq; RUN(launch_gemm_tn(t, st)); }
+    { GemmTN t; t.A = w.dk; t.lda = w.lddk; t.B = xkv; t.ldb = D; t.T = rows_kv; t.Mo = 2 * D; t.No = D; t.C = G + lp.wqkv + (size_t)D * D; t.ldc = D;
+      t.a_colsum = G + lp.bk; RUN(launch_gemm_tn(t, st)); }
     {  // dxq = dq . Wq + dr1
       GemmNT g; g.X = w.dq; g.ldx = w.lddq; g.W = lw.wqkv_kn; g.ldw = 3 * D; g.M = rows_q; g.N = D; g.K = D;
       g.epi.res = w.dr1; g.epi.ldres = D;

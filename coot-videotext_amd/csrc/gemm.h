@@ -46,6 +46,9 @@ struct GemmTN {
   float* C = nullptr; long ldc = 0;  // fp32 [Mo, No], accumulated with atomics
   int groups = 1; long zA = 0, zB = 0, zC = 0;
   float* ws = nullptr; size_t ws_floats = 0;  // optional split-reduction workspace (else the thread's default / atomics)
+  // optional: a_colsum[m] += sum_t A[t][m] (the bias gradient that goes with dW = dY^T X: the kernel streams dY anyway).
+  // groups must be 1; added with one fp32 atomic per column per split.
+  float* a_colsum = nullptr;
 };
 
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream);

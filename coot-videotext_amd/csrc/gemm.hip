@@ -524,10 +524,22 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& g, int bx, int by, in
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // column sums of the A operand (bias gradient), by the workgroups of the first column tile: a thread meets the same
+  // 8-column chunk (tid & 15) in every row group, out-of-range rows were loaded as zeros
+  const bool do_cs = g.a_colsum != nullptr && bx == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto cs_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      cs[0] += bflo(ar[i][0]); cs[1] += bfhi(ar[i][0]); cs[2] += bflo(ar[i][1]); cs[3] += bfhi(ar[i][1]);
+      cs[4] += bflo(ar[i][2]); cs[5] += bfhi(ar[i][2]); cs[6] += bflo(ar[i][3]); cs[7] += bfhi(ar[i][3]);
+    }
+  };
 
   const int nsteps = t_begin < t_end ? (t_end - t_begin + TN_BT - 1) / TN_BT : 0;
   if (nsteps > 0) {
     gload(t_begin);
+    if (do_cs) cs_acc();
     sstore(0);
   }
   __syncthreads();
@@ -579,7 +591,20 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& g, int bx, int by, in
         for (int b = 0; b < 4; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
     }
-    if (st + 1 < nsteps) sstore(buf ^ 1);
+    if (st + 1 < nsteps) { if (do_cs) cs_acc(); sstore(buf ^ 1); }
+    __syncthreads();
+  }
+  if (do_cs) {  // 16 row groups x 16 column chunks -> 128 column sums through LDS (the operand buffers are dead)
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(tid >> 4) * 128 + (tid & 15) * 8 + j] = cs[j];
+    __syncthreads();
+    if (tid < 128 && m0 + tid < g.Mo) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += red[r * 128 + tid];
+      atomicAdd(g.a_colsum + m0 + tid, v);
+    }
     __syncthreads();
   }
   if (ws == nullptr && !direct) {  // one-pass path: fp32 atomics straight into C
@@ -777,6 +802,7 @@ int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
   COOT_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.Mo % 8 == 0 && g.No % 8 == 0 && g.zA % 8 == 0 && g.zB % 8 == 0,
                "gemm_tn: lda/ldb/Mo/No must be multiples of 8 (Mo=%d No=%d lda=%ld ldb=%ld)", g.Mo, g.No, g.lda, g.ldb);
   if (g.T <= 0 || g.Mo <= 0 || g.No <= 0) return 0;
+  COOT_REQUIRE(!g.a_colsum || g.groups == 1, "gemm_tn: a_colsum needs groups == 1");
   if (g_tn_collect && !g.ws) {  // inside tn_batch_begin() .. tn_batch_flush(): deferred, launched together
     if (g_tn_nitems == TN_MAX_ITEMS) { int rc = tn_batch_flush(stream); if (rc) return rc; }
     g_tn_items[g_tn_nitems++] = g;
