@@ -59,6 +59,8 @@ size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups);
 void tn_batch_begin();
 int tn_batch_flush(hipStream_t stream);
 void tn_batch_end();
+// 1 (default): batched problems with Mo % 384 == 0 use the 384 x 128 output tiles; 0: always 128 x 128 (A/B switch)
+void set_tn_wide(int on);
 // default workspace used by launch_gemm_tn when GemmTN::ws is null (set by the orchestrator for one call)
 void set_tn_default_workspace(float* ws, size_t floats);
 

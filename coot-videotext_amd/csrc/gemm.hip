@@ -660,6 +660,154 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& g, int bx, int by, in
   }
 }
 
+// ---- wide variant: output tile 384 (m) x 128 (n), 512 threads -------------------------------------------------------
+// The 128 x 128 tiles above re-read both operand slabs once per output tile (64 FLOP per byte from L2/HBM): the batched
+// weight-gradient launch of one backward pass moved 1.7 GB at 5 TB/s.  With d_model = 384 every dY / X operand of the
+// encoder is 384 (or 3 x 384) columns wide: a 384 x 128 tile reads the whole A slab once per n-tile and each B column
+// block exactly once (98 FLOP per byte, a third less traffic).  8 waves = 4 (m, 96 rows) x 2 (n, 64 columns), 96
+// accumulator registers, partial tiles stored straight from registers (a lane owns 4 consecutive n of one m: 16-byte stores).
+constexpr int TNW_BM = 384, TNW_BN = 128;
+constexpr int TNW_PA = TNW_BM + 16;  // 800-byte rows (== 8 dwords mod 64, like TN_PITCH: tr reads conflict free)
+constexpr int TNW_PB = TNW_BN + 16;
+
+__device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int by, int bz, int t_per_split, float* ws, int direct) {
+  constexpr int ASZ = TN_BT * TNW_PA, BSZ = TN_BT * TNW_PB;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ASZ + 2 * BSZ];
+  __shared__ float cs_lds[TNW_BM];
+  bf16_t* As = smem;
+  bf16_t* Bs = smem + 2 * ASZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = bz % g.groups, split = bz / g.groups;
+  const int m0 = by * TNW_BM, n0 = bx * TNW_BN;
+  const int t_begin = split * t_per_split;
+  const int t_end = min(g.T, t_begin + t_per_split);
+  const bf16_t* A = g.A + z * g.zA;
+  const bf16_t* B = g.B + z * g.zB;
+  const bool do_cs = g.a_colsum != nullptr && bx == 0;
+  if (do_cs) for (int c = tid; c < TNW_BM; c += 512) cs_lds[c] = 0.f;
+
+  u32x4_t ar[6], br[2];
+  int arow[6], acol[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const int c = tid + 512 * i; arow[i] = c / 48; acol[i] = (c % 48) * 8; }
+  const int brow = tid >> 4, bcol = (tid & 15) * 8;
+  auto gload = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int t = t0 + arow[i];
+      ar[i] = load16_guard(A + (long)t * g.lda + m0 + acol[i], t < t_end && m0 + acol[i] < g.Mo);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = t0 + brow + 32 * i;
+      br[i] = load16_guard(B + (long)t * g.ldb + n0 + bcol, t < t_end && n0 + bcol < g.No);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4_t*>(&As[buf * ASZ + arow[i] * TNW_PA + acol[i]]) = ar[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(&Bs[buf * BSZ + (brow + 32 * i) * TNW_PB + bcol]) = br[i];
+  };
+  // bias gradient: column sums of the A slab; a thread meets the column chunks (tid % 48 + 32 i) % 48, i.e. 3 distinct ones
+  float cs[3][8];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[q][j] = 0.f;
+  auto cs_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float* c8 = cs[i % 3];
+      c8[0] += bflo(ar[i][0]); c8[1] += bfhi(ar[i][0]); c8[2] += bflo(ar[i][1]); c8[3] += bfhi(ar[i][1]);
+      c8[4] += bflo(ar[i][2]); c8[5] += bfhi(ar[i][2]); c8[6] += bflo(ar[i][3]); c8[7] += bfhi(ar[i][3]);
+    }
+  };
+
+  f32x4_t acc[6][4];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = t_begin < t_end ? (t_end - t_begin + TN_BT - 1) / TN_BT : 0;
+  if (nsteps > 0) {
+    gload(t_begin);
+    if (do_cs) cs_acc();
+    sstore(0);
+  }
+  __syncthreads();
+  const int grp = lane >> 4, p = lane & 15;
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) gload(t_begin + (st + 1) * TN_BT);
+    const bf16_t* ab = As + buf * ASZ;
+    const bf16_t* bb = Bs + buf * BSZ;
+#pragma unroll
+    for (int ks = 0; ks < TN_BT / 32; ++ks) {
+      // k-slot (grp*8 + j) <-> t = ks*32 + 4*grp + j, k-slot (grp*8 + 4 + j) <-> t = ks*32 + 16 + 4*grp + j (same map for both operands)
+      const int trow = ks * 32 + 4 * grp + (p >> 2);
+      const int tcol = (p & 3) * 4;
+      bf16x8_t bfr[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bf16_t* pb = &bb[trow * TNW_PB + wn * 64 + b * 16 + tcol];
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pb + 16 * TNW_PB));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfr[b] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const bf16_t* pa = &ab[trow * TNW_PA + wm * 96 + a * 16 + tcol];
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pa));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(pa + 16 * TNW_PA));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+        // lane reg j = C[row = m0 + wm*96 + a*16 + (lane&15)][col = n0 + wn*64 + b*16 + (lane>>4)*4 + j]
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af, acc[a][b], 0, 0, 0);
+      }
+    }
+    if (st + 1 < nsteps) { if (do_cs) cs_acc(); sstore(buf ^ 1); }
+    __syncthreads();
+  }
+  if (do_cs) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int cc = acol[q];  // chunk of iteration i = q (i and i + 3 share it)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&cs_lds[cc + j], cs[q][j]);
+    }
+    __syncthreads();
+    for (int c = tid; c < TNW_BM; c += 512)
+      if (m0 + c < g.Mo) atomicAdd(g.a_colsum + m0 + c, cs_lds[c]);
+  }
+  // partial tile straight from the accumulators: direct (single split) C += alpha * tile, else ws[split][z][Mo][No]
+  float* dst = direct ? g.C + z * g.zC : ws + ((long)split * g.groups + z) * g.Mo * g.No;
+  const long ldd = direct ? g.ldc : g.No;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int row = m0 + wm * 96 + a * 16 + (lane & 15);
+    if (row >= g.Mo) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = n0 + wn * 64 + b * 16 + (lane >> 4) * 4;
+      if (col >= g.No) continue;  // No % 4 == 0 (launcher): all four inside or all outside
+      f32x4_t* dp = reinterpret_cast<f32x4_t*>(dst + (long)row * ldd + col);
+      if (direct) {
+        f32x4_t o = *dp;
+        o[0] += acc[a][b][0] * g.alpha; o[1] += acc[a][b][1] * g.alpha; o[2] += acc[a][b][2] * g.alpha; o[3] += acc[a][b][3] * g.alpha;
+        *dp = o;
+      } else {
+        *dp = acc[a][b];
+      }
+    }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split, int splits, float* ws, int direct) {
   gemm_tn_body<MODE>(g, blockIdx.x, blockIdx.y, blockIdx.z, t_per_split, splits, ws, direct);
@@ -680,6 +828,15 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(TnBatch b, float* ws
   const int local = blockIdx.x - it.blk0;
   const int bx = local % it.gx, by = (local / it.gx) % it.gy, bz = local / (it.gx * it.gy);
   gemm_tn_body<MODE>(it.g, bx, by, bz, it.t_per_split, it.splits, it.direct ? nullptr : ws_base + it.ws_off, it.direct);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_wide_batch_kernel(TnBatch b, float* ws_base) {
+  int i = 0;
+  for (int t = 1; t < b.n; ++t) if ((int)blockIdx.x >= b.it[t].blk0) i = t;
+  const TnItem& it = b.it[i];
+  const int local = blockIdx.x - it.blk0;
+  const int bx = local % it.gx, by = (local / it.gx) % it.gy, bz = local / (it.gx * it.gy);
+  gemm_tn_wide_body(it.g, bx, by, bz, it.t_per_split, it.direct ? nullptr : ws_base + it.ws_off, it.direct);
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_batch_reduce_kernel(TnBatch b, const float* ws_base) {
@@ -744,24 +901,35 @@ static thread_local GemmTN g_tn_items[TN_MAX_ITEMS];
 
 void tn_batch_begin() { g_tn_collect = true; g_tn_nitems = 0; }
 
+static int g_tn_wide = 1;
+void set_tn_wide(int on) { g_tn_wide = on; }
+
 int tn_batch_flush(hipStream_t stream) {
   const int n = g_tn_nitems;
   g_tn_nitems = 0;
   if (n == 0) return 0;
-  TnBatch b; b.n = n;
-  long tiles = 0;
+  // two launches at most: problems whose m extent is a multiple of 384 take the wide 384 x 128 tiles, the rest 128 x 128
+  TnBatch bw, bn; bw.n = 0; bn.n = 0;
+  long tiles_w = 0, tiles_n = 0;
+  bool wide[TN_MAX_ITEMS];
   for (int i = 0; i < n; ++i) {
     const GemmTN& g = g_tn_items[i];
-    tiles += (long)((g.No + TN_BC - 1) / TN_BC) * ((g.Mo + TN_BC - 1) / TN_BC) * g.groups;
+    wide[i] = g_tn_wide && g_tn_mode == 0 && g.Mo % TNW_BM == 0 && g.No % 4 == 0 && g.ldc % 4 == 0 && g.zC % 4 == 0;
+    if (wide[i]) tiles_w += (long)((g.No + TNW_BN - 1) / TNW_BN) * (g.Mo / TNW_BM) * g.groups;
+    else tiles_n += (long)((g.No + TN_BC - 1) / TN_BC) * ((g.Mo + TN_BC - 1) / TN_BC) * g.groups;
   }
-  int blk = 0; long ws_off = 0; bool any_ws = false;
+  int blk_w = 0, blk_n = 0; long ws_off = 0; bool ws_w = false, ws_n = false;
   for (int i = 0; i < n; ++i) {
-    TnItem& it = b.it[i];
+    const bool w = wide[i];
+    TnBatch& b = w ? bw : bn;
+    TnItem& it = b.it[b.n++];
     it.g = g_tn_items[i];
     const GemmTN& g = it.g;
-    it.gx = (g.No + TN_BC - 1) / TN_BC; it.gy = (g.Mo + TN_BC - 1) / TN_BC;
-    // about two workgroups per CU over the whole batch, every split >= 512 token rows, at most 8 splits
-    int splits = (int)((512 + tiles - 1) / tiles);
+    it.gx = w ? (g.No + TNW_BN - 1) / TNW_BN : (g.No + TN_BC - 1) / TN_BC;
+    it.gy = w ? g.Mo / TNW_BM : (g.Mo + TN_BC - 1) / TN_BC;
+    // wide: one 512-thread workgroup per CU -> about 256 workgroups; narrow: two per CU.  Every split >= 512 token rows.
+    const long tiles = w ? tiles_w : tiles_n;
+    int splits = w ? (int)(256 / tiles) : (int)((512 + tiles - 1) / tiles);
     const int max_splits = g.T / 512 > 0 ? g.T / 512 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits > 8) splits = 8;
@@ -771,25 +939,36 @@ int tn_batch_flush(hipStream_t stream) {
     splits = (g.T + tps - 1) / tps;
     it.t_per_split = tps; it.splits = splits;
     it.direct = (splits == 1 && g.ldc % 4 == 0 && g.No % 4 == 0 && g.zC % 4 == 0) ? 1 : 0;
+    int& blk = w ? blk_w : blk_n;
     it.blk0 = blk; blk += it.gx * it.gy * g.groups * splits;
     it.ws_off = ws_off;
-    if (!it.direct) { ws_off += (long)splits * g.groups * g.Mo * g.No; any_ws = true; }
+    if (!it.direct) { ws_off += (long)splits * g.groups * g.Mo * g.No; (w ? ws_w : ws_n) = true; }
   }
   float* ws = g_tn_ws;
-  if (any_ws && (!ws || (size_t)ws_off > g_tn_ws_floats)) {  // no room for the batch: problem by problem
+  if ((ws_w || ws_n) && (!ws || (size_t)ws_off > g_tn_ws_floats)) {  // no room for the batch: problem by problem
     g_tn_collect = false;
     for (int i = 0; i < n; ++i) { GemmTN g = g_tn_items[i]; int rc = launch_gemm_tn(g, stream); if (rc) { g_tn_collect = true; return rc; } }
     g_tn_collect = true;
     return 0;
   }
   double flops = 0;
-  for (int i = 0; i < n; ++i) flops += 2.0 * b.it[i].g.T * b.it[i].g.Mo * b.it[i].g.No * b.it[i].g.groups;
+  for (int i = 0; i < n; ++i) flops += 2.0 * g_tn_items[i].T * g_tn_items[i].Mo * g_tn_items[i].No * g_tn_items[i].groups;
   void* ts = timing_begin(TIMING_TN, flops, 0, stream);
-  if (g_tn_mode == 0) hipLaunchKernelGGL(gemm_tn_batch_kernel<0>, dim3(blk), dim3(256), 0, stream, b, ws);
-  else hipLaunchKernelGGL(gemm_tn_batch_kernel<1>, dim3(blk), dim3(256), 0, stream, b, ws);
-  COOT_CHECK_LAUNCH("gemm_tn_batch");
-  if (any_ws) {
-    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(256, n), dim3(256), 0, stream, b, (const float*)ws);
+  if (bw.n) {
+    hipLaunchKernelGGL(gemm_tn_wide_batch_kernel, dim3(blk_w), dim3(512), 0, stream, bw, ws);
+    COOT_CHECK_LAUNCH("gemm_tn_wide_batch");
+  }
+  if (bn.n) {
+    if (g_tn_mode == 0) hipLaunchKernelGGL(gemm_tn_batch_kernel<0>, dim3(blk_n), dim3(256), 0, stream, bn, ws);
+    else hipLaunchKernelGGL(gemm_tn_batch_kernel<1>, dim3(blk_n), dim3(256), 0, stream, bn, ws);
+    COOT_CHECK_LAUNCH("gemm_tn_batch");
+  }
+  if (ws_w) {
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(256, bw.n), dim3(256), 0, stream, bw, (const float*)ws);
+    COOT_CHECK_LAUNCH("gemm_tn_batch_reduce");
+  }
+  if (ws_n) {
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(256, bn.n), dim3(256), 0, stream, bn, (const float*)ws);
     COOT_CHECK_LAUNCH("gemm_tn_batch_reduce");
   }
   timing_end(ts, stream);
