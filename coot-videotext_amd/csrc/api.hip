@@ -133,6 +133,7 @@ static void build_layout(const coot_net_config& c, NetLayout& L) {
 struct LayerW {
   bf16_t *wqkv_nk, *wqkv_kn, *wo_nk, *wo_kn, *w1_nk, *w1_kn, *w2_nk, *w2_kn;
   bf16_t *f_wo = nullptr, *f_w1 = nullptr, *f_w2 = nullptr;  // P48 packs of the fused chains (fused.h), d_model = 384 only
+  bf16_t *f_wo_kn = nullptr, *f_w1_kn = nullptr, *f_w2_kn = nullptr;  // the same for the dX orientation (backward chain)
 };
 struct WPack {
   bf16_t* in_w = nullptr;     // [D, Din]  = W * gain (LN affine folded)
@@ -140,6 +141,7 @@ struct WPack {
   std::vector<LayerW> layers, ctx;
   bf16_t *pw1_nk = nullptr, *pw1_kn = nullptr, *pw2_nk = nullptr, *pw2_kn = nullptr;
   bf16_t *f_pw1 = nullptr, *f_pw2 = nullptr;  // P48: [768 x 384] (head-major rows), 2 x [192 x 384]
+  bf16_t *f_pw1_kn = nullptr, *f_pw2_kn = nullptr;  // P48, dX orientation: 2 x [N = 384 (d), K = 384 (e)], 2 x [N = 384 (e), K = 192 (o)]
 };
 // the fused token-tile chains are specialised for the shipped model width
 static bool fused_layer_ok(const coot_net_config& c) { return c.hidden_dim == FZ_D && c.ff_dim == FZ_D; }
@@ -155,7 +157,10 @@ static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
     w.wo_nk = A.get<bf16_t>(D * D); w.wo_kn = A.get<bf16_t>(D * D);
     w.w1_nk = A.get<bf16_t>(F * D); w.w1_kn = A.get<bf16_t>(F * D);
     w.w2_nk = A.get<bf16_t>(F * D); w.w2_kn = A.get<bf16_t>(F * D);
-    if (fused_layer_ok(c)) { w.f_wo = A.get<bf16_t>(D * D); w.f_w1 = A.get<bf16_t>(F * D); w.f_w2 = A.get<bf16_t>(F * D); }
+    if (fused_layer_ok(c)) {
+      w.f_wo = A.get<bf16_t>(D * D); w.f_w1 = A.get<bf16_t>(F * D); w.f_w2 = A.get<bf16_t>(F * D);
+      w.f_wo_kn = A.get<bf16_t>(D * D); w.f_w1_kn = A.get<bf16_t>(F * D); w.f_w2_kn = A.get<bf16_t>(F * D);
+    }
     return w;
   };
   for (int i = 0; i < c.num_layers; ++i) W.layers.push_back(lay());
@@ -164,7 +169,10 @@ static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
     const size_t PH = c.pool_hidden;
     W.pw1_nk = A.get<bf16_t>(PH * D); W.pw1_kn = A.get<bf16_t>(PH * D);
     W.pw2_nk = A.get<bf16_t>(PH * (D / c.pool_heads)); W.pw2_kn = A.get<bf16_t>(PH * (D / c.pool_heads));
-    if (fused_pool_ok(c)) { W.f_pw1 = A.get<bf16_t>(PH * D); W.f_pw2 = A.get<bf16_t>(PH * (D / c.pool_heads)); }
+    if (fused_pool_ok(c)) {
+      W.f_pw1 = A.get<bf16_t>(PH * D); W.f_pw2 = A.get<bf16_t>(PH * (D / c.pool_heads));
+      W.f_pw1_kn = A.get<bf16_t>(PH * D); W.f_pw2_kn = A.get<bf16_t>(PH * (D / c.pool_heads));
+    }
   }
 }
 
@@ -219,7 +227,8 @@ struct Scratch {  // backward temporaries
   bf16_t *c_dq, *c_dkv, *c_d1, *c_d2, *c_dh1, *c_dz1, *c_dr1, *c_dctx, *c_dqin; float* c_delta;
 };
 static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A, Scratch& S) {
-  const size_t T = (size_t)Ttok, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
+  // whole 128-row tiles, like layout_saved (the fused backward chain writes whole tiles)
+  const size_t T = ((size_t)Ttok + 127) & ~(size_t)127, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
   S.dzA = A.get<bf16_t>(T * D); S.dzB = A.get<bf16_t>(T * D); S.dr2 = A.get<bf16_t>(T * D); S.dr2m = A.get<bf16_t>(T * D);
   S.dh1 = A.get<bf16_t>(T * F); S.dz1 = A.get<bf16_t>(T * D); S.dr1 = A.get<bf16_t>(T * D); S.dctx = A.get<bf16_t>(T * D);
   S.dqkv = A.get<bf16_t>(T * 3 * D); S.delta = A.get<float>(T * H);
@@ -248,7 +257,9 @@ static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A,
   }
   {
     size_t widest = 3 * D; if (F > widest) widest = F; if ((size_t)c.pool_hidden > widest) widest = c.pool_hidden;
-    S.part_floats = (T / 64 + 1024) * widest; S.part_ws = A.get<float>(S.part_floats);
+    S.part_floats = (T / 64 + 1024) * widest;
+    if (S.part_floats < (T / 128) * (size_t)FZ_BWD_NCS) S.part_floats = (T / 128) * (size_t)FZ_BWD_NCS;
+    S.part_ws = A.get<float>(S.part_floats);
   }
   if (c.use_context) {
     const size_t n = N;
@@ -323,6 +334,8 @@ static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipSt
 
 // GenPool score MLP fused behind the last encoder layer (fused path only)
 struct PoolFuse { const bf16_t *pw1, *pw2; const float *pb1, *pb2; bf16_t *hp, *ap, *s; DropCfg d1, d2; };
+struct PoolFuseBwd { const bf16_t *ds, *dzp, *hp, *pw2, *pw1; bf16_t* dhp; float* g_pb1; DropCfg d1; };
+static int g_use_fused_bwd = 1;  // coot_set_option("fused_bwd", 0/1)
 static int g_use_fused = 1;
 static int g_fz_debug = 0;
 static unsigned long long* g_fz_tstamps = nullptr;
@@ -402,37 +415,53 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
                      int rows_q, const bf16_t* xkv, int rows_kv, const Segs& sg,
                      const LayerBufs& b, const LayerBwdBufs& w, const bf16_t* dz2, const float* dz2_f32, long lddz2_f32,
                      bf16_t* dxq, float* dxq_f32, bf16_t* dxkv_accum, const bf16_t* gelu_aux, float* gelu_colsum, float pdrop,
-                     int train, uint64_t seed, unsigned site_base, hipStream_t st) {
+                     int train, uint64_t seed, unsigned site_base, hipStream_t st, const PoolFuseBwd* pool = nullptr, float* part_ws = nullptr) {
   const int D = c.hidden_dim, F = c.ff_dim, H = c.num_heads, dh = D / H;
   const bool self = (xq == xkv);
   const DropCfg d_ff2 = mkdrop(train, pdrop, seed, site_base + SITE_FF2);
-  {
+  const bool fused = g_use_fused && g_use_fused_bwd && lw.f_w2_kn && part_ws && rows_q >= g_fused_min_rows && (pool || dz2);
+  COOT_REQUIRE(!pool || fused, "layer_bwd: fused pooling backward requested on the unfused path");
+  if (fused) {  // pooling MLP dX + LN2 bwd + FF dX + LN1 bwd + out-proj dX as ONE launch over token tiles (+ one reduction)
+    PreAttnBwd f; f.T = rows_q; f.h1 = b.h1; f.r2 = b.r2; f.r1 = b.r1; f.w2 = lw.f_w2_kn; f.w1 = lw.f_w1_kn; f.wo = lw.f_wo_kn;
+    f.ln2g = P + lp.ln2g; f.ln1g = P + lp.ln1g; f.dr2 = w.dr2; f.dr2m = w.dr2m; f.dh1 = w.dh1; f.dr1 = w.dr1; f.dctx = w.dctx; f.part = part_ws;
+    f.g_ln2g = G + lp.ln2g; f.g_ln2b = G + lp.ln2b; f.g_b2 = G + lp.b2; f.g_b1 = G + lp.b1; f.g_ln1g = G + lp.ln1g; f.g_ln1b = G + lp.ln1b;
+    f.g_bo = G + lp.bo;
+    f.d_ff2 = d_ff2; f.d_ff1 = mkdrop(train, pdrop, seed, site_base + SITE_FF1); f.d_postln = mkdrop(train, pdrop, seed, site_base + SITE_POSTLN);
+    if (pool) {
+      f.do_pool = 1; f.ds = pool->ds; f.dzp = pool->dzp; f.hp = pool->hp; f.pw2 = pool->pw2; f.pw1 = pool->pw1; f.dhp = pool->dhp;
+      f.g_pb1 = pool->g_pb1; f.d_pool1 = pool->d1;
+    } else {
+      f.dz2 = dz2;
+    }
+    f.tstamps = g_fz_tstamps;
+    RUN(launch_pre_attn_bwd(f, st));
+  } else {
     LnBwd l; l.dy = dz2; l.lddy = D; l.dy32 = dz2_f32; l.lddy32 = lddz2_f32; l.x = b.r2; l.x_f32 = 0; l.ldx = D; l.gain = P + lp.ln2g;
     l.R = rows_q; l.D = D; l.dx = w.dr2; l.lddx = D; l.dgain = G + lp.ln2g; l.dbias = G + lp.ln2b; l.dxcolsum = G + lp.b2;
     if (d_ff2.thr) { l.dxm = w.dr2m; l.lddxm = D; l.dxm_drop = d_ff2; l.dxm_drop_ld = D; }
     RUN(launch_ln_bwd(l, st));
   }
   const bf16_t* df2 = d_ff2.thr ? w.dr2m : w.dr2;
-  {  // dh1 = (df2 . W2) * gelu'(h1) * drop1 ; db1 = colsum(dh1)
+  if (!fused) {  // dh1 = (df2 . W2) * gelu'(h1) * drop1 ; db1 = colsum(dh1)
     GemmNT g; g.X = df2; g.ldx = D; g.W = lw.w2_kn; g.ldw = D; g.M = rows_q; g.N = F; g.K = D;
     g.epi.act = 2; g.epi.aux = b.h1; g.epi.ldaux = F; g.epi.colsum = G + lp.b1; g.epi.out = w.dh1; g.epi.ldc = F;
     epi_drop(g.epi, mkdrop(train, pdrop, seed, site_base + SITE_FF1), F);
     RUN(launch_gemm_nt(g, st));
   }
   { GemmTN t; t.A = df2; t.lda = D; t.B = b.a1; t.ldb = F; t.T = rows_q; t.Mo = D; t.No = F; t.C = G + lp.w2; t.ldc = F; RUN(launch_gemm_tn(t, st)); }
-  {  // dz1 = dh1 . W1 + dr2
+  if (!fused) {  // dz1 = dh1 . W1 + dr2
     GemmNT g; g.X = w.dh1; g.ldx = F; g.W = lw.w1_kn; g.ldw = F; g.M = rows_q; g.N = D; g.K = F;
     g.epi.res = w.dr2; g.epi.ldres = D; g.epi.out = w.dz1; g.epi.ldc = D;
     RUN(launch_gemm_nt(g, st));
   }
   { GemmTN t; t.A = w.dh1; t.lda = F; t.B = b.z1; t.ldb = D; t.T = rows_q; t.Mo = F; t.No = D; t.C = G + lp.w1; t.ldc = D; RUN(launch_gemm_tn(t, st)); }
-  {
+  if (!fused) {
     LnBwd l; l.dy = w.dz1; l.lddy = D; l.x = b.r1; l.x_f32 = 0; l.ldx = D; l.gain = P + lp.ln1g; l.R = rows_q; l.D = D;
     l.dx = w.dr1; l.lddx = D; l.dgain = G + lp.ln1g; l.dbias = G + lp.ln1b; l.dxcolsum = G + lp.bo;
     l.drop = mkdrop(train, pdrop, seed, site_base + SITE_POSTLN);
     RUN(launch_ln_bwd(l, st));
   }
-  {
+  if (!fused) {
     GemmNT g; g.X = w.dr1; g.ldx = D; g.W = lw.wo_kn; g.ldw = D; g.M = rows_q; g.N = D; g.K = D; g.epi.out = w.dctx; g.epi.ldc = D;
     RUN(launch_gemm_nt(g, st));
   }
@@ -496,6 +525,7 @@ int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)d
 int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
+  if (!strcmp(name, "fused_bwd")) { g_use_fused_bwd = value; return 0; }
   if (!strcmp(name, "gemm_small")) { set_gemm_small(value); return 0; }
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
   if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
@@ -568,6 +598,10 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
       RUN(add48(lp.wo, D, D, D, lw.f_wo, 0));
       RUN(add48(lp.w1, D, F, D, lw.f_w1, 0));
       RUN(add48(lp.w2, F, D, F, lw.f_w2, 0));
+      // dX orientation: logical [n = input feature][k = output feature] = W^T
+      RUN(add48(lp.wo, D, D, D, lw.f_wo_kn, 1));
+      RUN(add48(lp.w1, D, F, D, lw.f_w1_kn, 1));
+      RUN(add48(lp.w2, F, D, F, lw.f_w2_kn, 1));
     }
     return 0;
   };
@@ -585,6 +619,9 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
       if (W.f_pw1) {  // logical [n = pool feature e][k = d] = W1[h]^T, [n = o][k = e] = W2[h]^T
         RUN(add48(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.f_pw1 + (size_t)h * dhp * D, 1));
         RUN(add48(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.f_pw2 + (size_t)h * dop * dhp, 1));
+        // dX orientation: dz[d] += sum_e dhp[e] W1[h][d][e];  dhp[e] = sum_o ds[o] W2[h][e][o]  (the sources are already [n][k])
+        RUN(add48(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.f_pw1_kn + (size_t)h * D * dhp, 0));
+        RUN(add48(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.f_pw2_kn + (size_t)h * dhp * dop, 0));
       }
     }
   }
@@ -735,6 +772,8 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   bf16_t* dz = X.dzA;     // grad wrt the last layer's output tokens
   bf16_t* dz_other = X.dzB;
 
+  // pooling MLP dX + the last encoder layer's LN / FF / out-proj dX in one fused launch (fused.hip: pre_attn_bwd_kernel)
+  const bool pool_bwd_fused = g_use_fused && g_use_fused_bwd && fused_pool_ok(c) && W.f_pw1_kn && !c.use_context && T >= g_fused_min_rows;
   if (c.pooler == 0) {
     const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
     long row = 0; int n0 = 0;
@@ -750,7 +789,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     }
     { GemmTN t; t.A = S.ap; t.lda = PH; t.B = X.ds; t.ldb = D; t.T = T; t.Mo = dhp; t.No = dop; t.C = G + L.pw2; t.ldc = dop;
       t.groups = H; t.zA = dhp; t.zB = dop; t.zC = (long)dhp * dop; RUN(launch_gemm_tn(t, st)); }
-    {  // dhp = (ds_h . W2[h]^T) * gelu'(hp) * drop1 ; db1p = colsum
+    if (!pool_bwd_fused) {  // dhp = (ds_h . W2[h]^T) * gelu'(hp) * drop1 ; db1p = colsum
       GemmNT g; g.X = X.ds; g.ldx = D; g.W = W.pw2_kn; g.ldw = dop; g.M = T; g.N = dhp; g.K = dop;
       g.groups = H; g.zX = dop; g.zW = (long)dhp * dop; g.zOut = dhp;
       g.epi.act = 2; g.epi.aux = S.hp; g.epi.ldaux = PH; g.epi.colsum = G + L.pb1; g.epi.out = X.dhp; g.epi.ldc = PH;
@@ -759,7 +798,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     }
     { GemmTN t; t.A = zL; t.lda = D; t.B = X.dhp; t.ldb = PH; t.T = T; t.Mo = D; t.No = dhp; t.C = G + L.pw1; t.ldc = dhp;
       t.groups = H; t.zA = 0; t.zB = dhp; t.zC = (long)D * dhp; RUN(launch_gemm_tn(t, st)); }
-    {  // dz = dhp . W1p + dz(pool direct)
+    if (!pool_bwd_fused) {  // dz = dhp . W1p + dz(pool direct)
       GemmNT g; g.X = X.dhp; g.ldx = PH; g.W = W.pw1_kn; g.ldw = PH; g.M = T; g.N = D; g.K = PH;
       g.epi.res = X.dzp; g.epi.ldres = D; g.epi.out = dz; g.epi.ldc = D;
       RUN(launch_gemm_nt(g, st));
@@ -792,8 +831,15 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     const bf16_t* zin = i == 0 ? S.z0 : S.layers[i - 1].z2;
     const bool fc0 = (i == 0 && c.use_input_fc);
     if (fc0) RUN(launch_fill_f32(X.cvec, D, 0.f, st));
+    PoolFuseBwd pfb;
+    const bool lastl = (i == c.num_layers - 1);
+    if (lastl && pool_bwd_fused) {
+      pfb.ds = X.ds; pfb.dzp = X.dzp; pfb.hp = S.hp; pfb.pw2 = W.f_pw2_kn; pfb.pw1 = W.f_pw1_kn; pfb.dhp = X.dhp; pfb.g_pb1 = G + L.pb1;
+      pfb.d1 = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL1);
+    }
     RUN(layer_bwd(c, P, G, L.layers[i], W.layers[i], zin, T, zin, T, sg, b, w, dz, nullptr, 0, dz_other, nullptr, nullptr,
-                  fc0 ? S.h0 : nullptr, fc0 ? X.cvec : nullptr, c.dropout, train, seed, 16u * i, st));
+                  fc0 ? S.h0 : nullptr, fc0 ? X.cvec : nullptr, c.dropout, train, seed, 16u * i, st,
+                  (lastl && pool_bwd_fused) ? &pfb : nullptr, X.part_ws));
     if (flush_per_layer) RUN(tn_batch_flush(st));
     bf16_t* t = dz; dz = dz_other; dz_other = t;
   }

@@ -40,4 +40,27 @@ struct PostAttnFwd {
 };
 int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st);
 
+// Backward of the same chain, from the GenPool score gradients (or the gradient wrt the layer output) down to the
+// gradient wrt the attention output: pooling MLP dX, LN2 backward, FF2 / FF1 dX (GELU'), LN1 backward, out-proj dX.
+// Every bias / LayerNorm parameter gradient (column sums over the tokens) leaves the kernel as one partial row per
+// tile; launch_pre_attn_bwd() reduces them into the gradient arena with one more launch.  The weight gradients stay
+// with the batched TN GEMM (gemm.h), which reads the dY tensors this kernel writes.
+struct PreAttnBwd {
+  int T = 0;
+  int do_pool = 0;
+  const bf16_t *ds = nullptr, *dzp = nullptr;  // [T, 384] pooling: score gradients (head h at columns 192 h), direct pooled-feature gradient
+  const bf16_t* dz2 = nullptr;                 // [T, 384] gradient wrt the layer output (do_pool == 0)
+  const bf16_t *hp = nullptr, *h1 = nullptr, *r2 = nullptr, *r1 = nullptr;  // saved: [T, 768], [T, 384] x 3
+  const bf16_t *pw2 = nullptr, *pw1 = nullptr, *w2 = nullptr, *w1 = nullptr, *wo = nullptr;  // P48 packs of the dX orientation
+  const float *ln2g = nullptr, *ln1g = nullptr;
+  bf16_t *dhp = nullptr, *dr2 = nullptr, *dr2m = nullptr, *dh1 = nullptr, *dr1 = nullptr, *dctx = nullptr;
+  float* part = nullptr;                       // [tiles, 3456] column-sum partials
+  float *g_pb1 = nullptr, *g_ln2g = nullptr, *g_ln2b = nullptr, *g_b2 = nullptr, *g_b1 = nullptr, *g_ln1g = nullptr, *g_ln1b = nullptr,
+        *g_bo = nullptr;                       // gradient arena destinations (+=)
+  DropCfg d_pool1, d_ff2, d_ff1, d_postln;
+  unsigned long long* tstamps = nullptr;  // profiling aid (block 0 phase stamps)
+};
+constexpr int FZ_BWD_NCS = 9 * FZ_D;  // floats per tile in PreAttnBwd::part
+int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st);
+
 }  // namespace coot

@@ -94,19 +94,19 @@ __device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f3
 }
 
 // global bf16 [., ld] rows [row0, row0 + 16 RF), columns [col0, col0 + 384) -> LDS tile (whole tiles are allocated)
-template <int RF>
+template <int RF, int CPR = 48>
 __device__ __forceinline__ void load_tile(bf16_t* As, const bf16_t* src, long ld, int col0, int row0) {
-  constexpr int CH = 16 * RF * 48, IT = (CH + NTHR - 1) / NTHR;
+  constexpr int CH = 16 * RF * CPR, IT = (CH + NTHR - 1) / NTHR;
   u32x4_t v[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int c = threadIdx.x + NTHR * i, rl = c / 48, ch = c - rl * 48;
+    const int c = threadIdx.x + NTHR * i, rl = c / CPR, ch = c - rl * CPR;
     v[i] = u32x4_t{0u, 0u, 0u, 0u};
     if (CH % NTHR == 0 || c < CH) v[i] = gld16(src, (unsigned)((row0 + rl) * (int)ld + col0 + ch * 8) * 2u);
   }
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int c = threadIdx.x + NTHR * i, rl = c / 48, ch = c - rl * 48;
+    const int c = threadIdx.x + NTHR * i, rl = c / CPR, ch = c - rl * CPR;
     if (CH % NTHR == 0 || c < CH) *reinterpret_cast<u32x4_t*>(&As[rl * APITCH + ch * 8]) = v[i];
   }
 }
@@ -195,7 +195,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
     for (int i = 0; i < IT; ++i) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[i][j] += bs[i][j];
-      fn(rbase + rl[i], col[i], v[i], par ? pv[1][i] : pv[0][i]);
+      fn(rbase + rl[i], col[i], v[i], par ? pv[1][i] : pv[0][i], i);
       // one chunk body at a time (8 independent elements give the VALU enough ILP): letting the scheduler interleave the
       // three bodies triples their temporaries while the accumulators of the later rounds are still live -> spills
       __builtin_amdgcn_sched_barrier(0);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   stamp();
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 0 * FZ_D,
       [&](int row, int col) { return PreRes{gld16(p.xres, (unsigned)(row * FZ_D + col) * 2u)}; },
-      [&](int row, int col, float (&v)[8], const PreRes& pr) {
+      [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
         float r[8];
         unpack8(pr.res, r);
 #pragma unroll
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
   stamp();
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 1 * FZ_D, [&](int, int) { return PreNone{}; },
-      [&](int row, int col, float (&v)[8], const PreNone&) {
+      [&](int row, int col, float (&v)[8], const PreNone&, int) {
         apply_drop<DROP>(p.d_ff1, (unsigned long long)row * FZ_D + col, v);
         gst16(p.h1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
 #pragma unroll
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 2 * FZ_D,
       [&](int row, int col) { return PreRes{gld16(p.z1, (unsigned)(row * FZ_D + col) * 2u)}; },
-      [&](int row, int col, float (&v)[8], const PreRes& pr) {
+      [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
         float r[8];
         unpack8(pr.res, r);
         apply_drop<DROP>(p.d_ff2, (unsigned long long)row * FZ_D + col, v);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       zero_acc<RF>(acc);
       gemm_pass<RF, 12>(As, p.pw1 + (h * 8 + wave) * GSZ, acc, lane);
       epilogue<RF, 8>(acc, Stg, As, row0, Bsm + h * FZ_D, [&](int, int) { return PreNone{}; },
-          [&](int row, int col, float (&v)[8], const PreNone&) {
+          [&](int row, int col, float (&v)[8], const PreNone&, int) {
             apply_drop<DROP>(p.d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
             gst16(p.hp, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u, pack8(v));
 #pragma unroll
@@ -397,13 +397,306 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       zero_acc<RF / 2>(acc2);
       gemm_pass<RF / 2, 12>(As + (wave >> 2) * (BT / 2) * APITCH, p.pw2 + (h * 4 + (wave & 3)) * GSZ, acc2, lane);
       epilogue<RF, 4>(acc2, Stg, As, row0, Bsm + 2 * FZ_D + h * (FZ_D / 2), [&](int, int) { return PreNone{}; },
-          [&](int row, int col, float (&v)[8], const PreNone&) {
+          [&](int row, int col, float (&v)[8], const PreNone&, int) {
             apply_drop<DROP>(p.d_pool2, (unsigned long long)row * FZ_D + h * (FZ_D / 2) + col, v);
             gst16(p.s, (unsigned)(row * FZ_D + h * (FZ_D / 2) + col) * 2u, pack8(v));
           }, false);
       stamp();
     }
   }
+}
+
+// ---- backward chain --------------------------------------------------------------------------------------------------
+
+// LayerNorm backward of every tile row, in place (dy -> dx), same thread mapping as ln_tile:
+//   xc = x - mean, s = std + eps, h = dy * gain;  dx = (h - mean(h)) / s - (sum h xc) / s^2 * xc / ((n - 1) std)
+// x = the saved LN input (global, bf16).  DROPY: dy is first multiplied by the dropout mask the forward applied to the LN
+// output.  MASKX: dxm = dx * mask(drop_x) is what stays in the tile and goes to out_dxm (dx itself goes to out_dx).
+// Column sums over the tile's valid rows (dgain = dy xc / s, dbias = dy, colsum of dxm or dx): lanes -> wave by two
+// xor-shuffles, waves -> workgroup through red[8][3 * 384] (plain LDS stores: LDS float atomics serialise per lane and
+// cost ~1.5k cycles per wave-instruction here), written to part_dst[3 * 384] (one partial row per tile).
+template <int RF, bool DROPY, bool MASKX>
+__device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, const bf16_t* xsaved, int row0, int T, bf16_t* out_dx,
+                                            bf16_t* out_dxm, const DropCfg& dy_drop, const DropCfg& dx_drop, float* red, float* part_dst) {
+  static_assert(RF == 8, "16 rows per wave, 4 per pass");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
+  u32x4_t xs[4][3];  // the saved LN input of this lane's 4 rows, kept packed (all loads in flight together)
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) xs[it][m] = gld16(xsaved, (unsigned)((row0 + wave * 16 + it * 4 + g) * FZ_D + m * 128 + j16 * 8) * 2u);
+  unsigned long long seed_y = 0, seed_x = 0;
+  if constexpr (DROPY) seed_y = eff_seed(dy_drop.seed, dy_drop.seed_ptr);
+  if constexpr (MASKX) seed_x = eff_seed(dx_drop.seed, dx_drop.seed_ptr);
+  // pass A: row statistics (4 scalars per row)
+  float mean[4], rsv[4], hmean[4], k2[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rl = wave * 16 + it * 4 + g, row = row0 + rl;
+    bf16_t* ar = As + rl * APITCH + j16 * 8;
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      float x[8];
+      unpack8(xs[it][m], x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[e];
+    }
+    const float mu = row16_sum(s) * (1.0f / 384.0f);
+    float q = 0.f, hs = 0.f, hx = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      float x[8], dy[8], gn[8];
+      unpack8(xs[it][m], x);
+      unpack8(*reinterpret_cast<const u32x4_t*>(ar + m * 128), dy);
+      load8f(gain_lds + m * 128 + j16 * 8, gn);
+      if constexpr (DROPY) {
+        float sc[8];
+        drop_scales<8>(seed_y, dy_drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dy_drop.thr, dy_drop.inv_keep, sc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dy[e] *= sc[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xc = x[e] - mu;
+        q += xc * xc;
+        const float h = dy[e] * gn[e];
+        hs += h; hx += h * xc;
+      }
+    }
+    q = row16_sum(q); hs = row16_sum(hs); hx = row16_sum(hx);
+    const float stdv = sqrtf(q * (1.0f / 383.0f));
+    const float rs = 1.0f / (stdv + kLnEps);
+    mean[it] = mu; rsv[it] = rs; hmean[it] = hs * (1.0f / 384.0f);
+    k2[it] = stdv > 0.f ? hx * rs * rs / (383.0f * stdv) : 0.f;
+  }
+  // pass B: one 8-column chunk at a time (24 column-sum accumulators live instead of 72)
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    float gn[8], csg[8], csb[8], csx[8];
+    load8f(gain_lds + m * 128 + j16 * 8, gn);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { csg[e] = 0.f; csb[e] = 0.f; csx[e] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = wave * 16 + it * 4 + g, row = row0 + rl;
+      bf16_t* ar = As + rl * APITCH + j16 * 8 + m * 128;
+      float x[8], dy[8], dx[8], dm[8];
+      unpack8(xs[it][m], x);
+      unpack8(*reinterpret_cast<const u32x4_t*>(ar), dy);
+      if constexpr (DROPY) {  // the same mask as in pass A (recomputed: cheaper than keeping 96 masked values live)
+        float sc[8];
+        drop_scales<8>(seed_y, dy_drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dy_drop.thr, dy_drop.inv_keep, sc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dy[e] *= sc[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        x[e] -= mean[it];
+        dx[e] = (dy[e] * gn[e] - hmean[it]) * rsv[it] - k2[it] * x[e];
+      }
+      if constexpr (MASKX) {
+        float sc[8];
+        drop_scales<8>(seed_x, dx_drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dx_drop.thr, dx_drop.inv_keep, sc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dm[e] = dx[e] * sc[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dm[e] = dx[e];
+      }
+      if (row < T) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csg[e] += dy[e] * x[e] * rsv[it]; csb[e] += dy[e]; csx[e] += dm[e]; }
+      }
+      const unsigned boff = (unsigned)(row * FZ_D + m * 128 + j16 * 8) * 2u;
+      gst16(out_dx, boff, pack8(dx));
+      const u32x4_t om = pack8(dm);
+      if constexpr (MASKX) gst16(out_dxm, boff, om);
+      *reinterpret_cast<u32x4_t*>(ar) = om;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {  // the 4 row groups of the wave (lanes j16 + 16 g)
+      csg[e] += __shfl_xor(csg[e], 16, 64); csg[e] += __shfl_xor(csg[e], 32, 64);
+      csb[e] += __shfl_xor(csb[e], 16, 64); csb[e] += __shfl_xor(csb[e], 32, 64);
+      csx[e] += __shfl_xor(csx[e], 16, 64); csx[e] += __shfl_xor(csx[e], 32, 64);
+    }
+    if (g == 0) {
+      float* rw = red + wave * (3 * FZ_D) + m * 128 + j16 * 8;
+      *reinterpret_cast<f32x4_t*>(rw) = f32x4_t{csg[0], csg[1], csg[2], csg[3]};
+      *reinterpret_cast<f32x4_t*>(rw + 4) = f32x4_t{csg[4], csg[5], csg[6], csg[7]};
+      *reinterpret_cast<f32x4_t*>(rw + FZ_D) = f32x4_t{csb[0], csb[1], csb[2], csb[3]};
+      *reinterpret_cast<f32x4_t*>(rw + FZ_D + 4) = f32x4_t{csb[4], csb[5], csb[6], csb[7]};
+      *reinterpret_cast<f32x4_t*>(rw + 2 * FZ_D) = f32x4_t{csx[0], csx[1], csx[2], csx[3]};
+      *reinterpret_cast<f32x4_t*>(rw + 2 * FZ_D + 4) = f32x4_t{csx[4], csx[5], csx[6], csx[7]};
+    }
+  }
+  __syncthreads();  // tile + per-wave column sums complete; the global stores (dx / dxm) are visible to the whole workgroup
+  for (int c = threadIdx.x; c < 3 * FZ_D; c += NTHR) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w * (3 * FZ_D) + c];
+    part_dst[c] = v;
+  }
+}
+
+// column sums a thread gathered over the epilogue rounds (its 3 fixed column chunks) -> one partial row of the tile.
+// For chunk index i the threads t = ch + 48 k (k < 11) share column chunk (ch + 32 i) % 48: they park their sums in
+// red[k][384] and 384 threads add the (up to) 11 rows.  `red` = the staging buffer (free between epilogues).
+__device__ __forceinline__ void colsum_flush(const float (&cs)[3][8], float* red, float* dst) {
+  const int tid = threadIdx.x, k = tid / 48;
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int col = ((tid + NTHR * i) % 48) * 8;
+    lds_barrier();
+    *reinterpret_cast<f32x4_t*>(&red[k * FZ_D + col]) = f32x4_t{cs[i][0], cs[i][1], cs[i][2], cs[i][3]};
+    *reinterpret_cast<f32x4_t*>(&red[k * FZ_D + col + 4]) = f32x4_t{cs[i][4], cs[i][5], cs[i][6], cs[i][7]};
+    lds_barrier();
+    if (tid < FZ_D) {
+      // chunk c8 = tid / 8 is held (for this i) by the threads with (t + 32 i) % 48 == c8, i.e. t % 48 == (c8 - 32 i) mod 48
+      const int ch = (tid / 8 + 48 * 2 - 32 * i) % 48;
+      const int nk = (NTHR - ch + 47) / 48;  // threads ch, ch + 48, ... < 512
+      for (int kk = 0; kk < nk; ++kk) tot += red[kk * FZ_D + tid];
+    }
+  }
+  if (tid < FZ_D) dst[tid] = tot;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
+  constexpr int RF = 8, BT = 128, RR = 32;
+  constexpr long GSZ192 = 6L * 3 * 512;  // one 48-column weight group at K = 192
+  // LDS: token tile | fp32 staging (also the LayerNorm column-sum buffer) | zero vector, ln2 gain, ln1 gain, column-sum buffer
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4 + 4 * FZ_D * 4];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);
+  float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
+  float* Bsm = reinterpret_cast<float*>(smem + BT * APITCH * 2 + RR * SPITCH * 4);
+  float* zero = Bsm, *g2 = Bsm + FZ_D, *g1 = Bsm + 2 * FZ_D, *cred = Bsm + 3 * FZ_D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * BT, T = p.T;
+  float* part = p.part + (long)blockIdx.x * FZ_BWD_NCS;
+  if (threadIdx.x < FZ_D / 4) {
+    reinterpret_cast<f32x4_t*>(zero)[threadIdx.x] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    reinterpret_cast<f32x4_t*>(g2)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(p.ln2g)[threadIdx.x];
+    reinterpret_cast<f32x4_t*>(g1)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(p.ln1g)[threadIdx.x];
+  }
+  f32x4_t acc[RF][3];
+  float cs[3][8];
+  int tsn = 0;
+  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  stamp();
+  auto cs_zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cs[i][j] = 0.f;
+  };
+
+  if (p.do_pool) {
+    // ---- GenPool score MLP backward: dhp_h = (ds_h . W2[h]^T) * GELU'(hp_h) * drop1;  dz = sum_h dhp_h . W1[h]^T + dzp ----
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      load_tile<RF, 24>(As, p.ds, FZ_D, h * (FZ_D / 2), row0);
+      __syncthreads();
+      zero_acc<RF>(acc);
+      gemm_pass<RF, 6>(As, p.pw2 + (h * 8 + wave) * GSZ192, acc, lane);
+      cs_zero();
+      epilogue<RF, 8>(acc, Stg, As, row0, zero,
+          [&](int row, int col) { return PreRes{gld16(p.hp, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u)}; },
+          [&](int row, int col, float (&v)[8], const PreRes& pr, int i) {
+            float a[8];
+            unpack8(pr.res, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+            apply_drop<DROP>(p.d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
+            if (row < T) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) cs[i][j] += v[j];
+            }
+            gst16(p.dhp, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u, pack8(v));
+          }, true);
+      colsum_flush(cs, Stg, part + h * FZ_D);  // pb1 gradient, head h
+      stamp();
+    }
+    // the tile holds dhp_1 now
+    zero_acc<RF>(acc);
+    gemm_pass<RF, 12>(As, p.pw1 + (8 + wave) * GSZ, acc, lane);
+    __syncthreads();  // every wave is done with dhp_1; dhp_0 (stored by this workgroup above) is visible
+    load_tile<RF>(As, p.dhp, 2 * FZ_D, 0, row0);
+    __syncthreads();
+    gemm_pass<RF, 12>(As, p.pw1 + wave * GSZ, acc, lane);
+    epilogue<RF, 8>(acc, Stg, As, row0, zero,
+        [&](int row, int col) { return PreRes{gld16(p.dzp, (unsigned)(row * FZ_D + col) * 2u)}; },
+        [&](int, int, float (&v)[8], const PreRes& pr, int) {
+          float r[8];
+          unpack8(pr.res, r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += r[j];
+        }, true);
+  } else {
+    load_tile<RF>(As, p.dz2, FZ_D, 0, row0);
+    __syncthreads();
+  }
+  stamp();
+  // ---- LN2 backward: dr2 (and dr2 * FF2 dropout mask = the gradient of the FF2 Linear output) ---------------------------
+  ln_bwd_tile<RF, false, DROP>(As, g2, p.r2, row0, T, p.dr2, p.dr2m, p.d_ff2, p.d_ff2, Stg, part + 2 * FZ_D);  // ln2 dgain | ln2 dbias | b2
+  stamp();
+  // ---- dh1 = (df2 . W2) * GELU'(h1) * drop(FF1) ---------------------------------------------------------------------------
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
+  cs_zero();
+  epilogue<RF, 8>(acc, Stg, As, row0, zero,
+      [&](int row, int col) { return PreRes{gld16(p.h1, (unsigned)(row * FZ_D + col) * 2u)}; },
+      [&](int row, int col, float (&v)[8], const PreRes& pr, int i) {
+        float a[8];
+        unpack8(pr.res, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+        apply_drop<DROP>(p.d_ff1, (unsigned long long)row * FZ_D + col, v);
+        if (row < T) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[i][j] += v[j];
+        }
+        gst16(p.dh1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+      }, true);
+  colsum_flush(cs, Stg, part + 5 * FZ_D);  // b1 gradient
+  stamp();
+  // ---- dz1 = dh1 . W1 + dr2 ----------------------------------------------------------------------------------------------------
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, zero,
+      [&](int row, int col) { return PreRes{gld16(p.dr2, (unsigned)(row * FZ_D + col) * 2u)}; },
+      [&](int, int, float (&v)[8], const PreRes& pr, int) {
+        float r[8];
+        unpack8(pr.res, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+      }, true);
+  stamp();
+  // ---- LN1 backward (through the post-LN dropout) -> dr1 -------------------------------------------------------------------
+  ln_bwd_tile<RF, DROP, false>(As, g1, p.r1, row0, T, p.dr1, nullptr, p.d_postln, p.d_postln, Stg, part + 6 * FZ_D);  // ln1 dgain | ln1 dbias | bo
+  stamp();
+  // ---- dctx = dr1 . Wo ------------------------------------------------------------------------------------------------------------
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, zero, [&](int, int) { return PreNone{}; },
+      [&](int row, int col, float (&v)[8], const PreNone&, int) { gst16(p.dctx, (unsigned)(row * FZ_D + col) * 2u, pack8(v)); }, false);
+  stamp();
+}
+
+// out[seg][c] += sum_tile part[tile][off + c]: the bias / LayerNorm gradients of pre_attn_bwd_kernel
+struct ScatterSeg { float* dst; int off, n; };
+struct ScatterArgs { ScatterSeg s[8]; int nseg, ntiles; const float* part; };
+__global__ __launch_bounds__(256) void colsum_scatter_kernel(ScatterArgs a) {
+  __shared__ float red[4][64];
+  const ScatterSeg& sg = a.s[blockIdx.y];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+  float v = 0.f;
+  if (c < sg.n && sg.dst)
+    for (int t = pg; t < a.ntiles; t += 4) v += a.part[(long)t * FZ_BWD_NCS + sg.off + c];
+  red[pg][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (pg == 0 && c < sg.n && sg.dst) sg.dst[c] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 }  // namespace
@@ -427,4 +720,32 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   return 0;
 }
 
+}  // namespace coot
+
+namespace coot {
+int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st) {
+  COOT_REQUIRE(p.h1 && p.r2 && p.r1 && p.w2 && p.w1 && p.wo && p.ln2g && p.ln1g && p.dr2 && p.dh1 && p.dr1 && p.dctx && p.part,
+               "pre_attn_bwd: null pointer");
+  COOT_REQUIRE(p.do_pool ? (p.ds && p.dzp && p.hp && p.pw2 && p.pw1 && p.dhp) : (p.dz2 != nullptr), "pre_attn_bwd: input gradient pointers");
+  if (p.T <= 0) return 0;
+  const int tiles = (p.T + 127) / 128;
+  const bool drop = p.d_ff2.thr || p.d_ff1.thr || p.d_postln.thr || p.d_pool1.thr;
+  void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 384.0 * (p.do_pool ? 6.0 : 3.0), 0, st);
+  if (drop) {
+    COOT_REQUIRE(p.d_ff2.thr && p.d_ff1.thr && p.d_postln.thr && (!p.do_pool || p.d_pool1.thr) && p.dr2m, "pre_attn_bwd: dropout on some sites only");
+    hipLaunchKernelGGL(pre_attn_bwd_kernel<true>, dim3(tiles), dim3(NTHR), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(pre_attn_bwd_kernel<false>, dim3(tiles), dim3(NTHR), 0, st, p);
+  }
+  timing_end(ts, st);
+  COOT_CHECK_LAUNCH("pre_attn_bwd");
+  ScatterArgs a; a.ntiles = tiles; a.part = p.part; a.nseg = 8;
+  a.s[0] = ScatterSeg{p.do_pool ? p.g_pb1 : nullptr, 0, 2 * FZ_D};
+  a.s[1] = ScatterSeg{p.g_ln2g, 2 * FZ_D, FZ_D}; a.s[2] = ScatterSeg{p.g_ln2b, 3 * FZ_D, FZ_D}; a.s[3] = ScatterSeg{p.g_b2, 4 * FZ_D, FZ_D};
+  a.s[4] = ScatterSeg{p.g_b1, 5 * FZ_D, FZ_D};
+  a.s[5] = ScatterSeg{p.g_ln1g, 6 * FZ_D, FZ_D}; a.s[6] = ScatterSeg{p.g_ln1b, 7 * FZ_D, FZ_D}; a.s[7] = ScatterSeg{p.g_bo, 8 * FZ_D, FZ_D};
+  hipLaunchKernelGGL(colsum_scatter_kernel, dim3(12, 8), dim3(256), 0, st, a);
+  COOT_CHECK_LAUNCH("colsum_scatter");
+  return 0;
+}
 }  // namespace coot
