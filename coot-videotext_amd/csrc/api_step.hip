@@ -178,6 +178,38 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   }
 }
 
+struct AdamSegs { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; const float* decay[4]; long n[4]; int blk0[5]; };
+__global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
+                                                    float inv_sqrt_bc2) {
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t) if ((int)blockIdx.x >= sg.blk0[t]) s = t;
+  float* p = sg.p[s]; const float* g = sg.g[s]; float* m = sg.m[s]; float* v = sg.v[s]; const float* decay = sg.decay[s];
+  const long n = sg.n[s];
+  const long i = ((long)(blockIdx.x - sg.blk0[s]) * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    f32x4_t pp = *reinterpret_cast<f32x4_t*>(p + i), gg = *reinterpret_cast<const f32x4_t*>(g + i);
+    f32x4_t mm = *reinterpret_cast<f32x4_t*>(m + i), vv = *reinterpret_cast<f32x4_t*>(v + i);
+    f32x4_t dd = decay ? *reinterpret_cast<const f32x4_t*>(decay + i) : f32x4_t{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = gg[j] + wd * dd[j] * pp[j];
+      mm[j] = b1 * mm[j] + (1.f - b1) * gj;
+      vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+      pp[j] -= lr * inv_bc1 * mm[j] / (sqrtf(vv[j]) * inv_sqrt_bc2 + eps);
+    }
+    *reinterpret_cast<f32x4_t*>(p + i) = pp; *reinterpret_cast<f32x4_t*>(m + i) = mm; *reinterpret_cast<f32x4_t*>(v + i) = vv;
+  } else {
+    for (long k = i; k < n; ++k) {
+      const float gj = g[k] + wd * (decay ? decay[k] : 1.f) * p[k];
+      m[k] = b1 * m[k] + (1.f - b1) * gj;
+      v[k] = b2 * v[k] + (1.f - b2) * gj * gj;
+      p[k] -= lr * inv_bc1 * m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -270,10 +302,21 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   RUN(coot_step_backward(cfg, b, x, d, W.local_v, W.local_t, W.resh_v, W.resh_t, W.d_local_v, W.d_local_t, W.d_glob_v, W.d_glob_t,
                          cfg->cc_weight != 0.f ? W.d_resh_v : nullptr, cfg->cc_weight != 0.f ? W.d_resh_t : nullptr, workspace,
                          workspace_bytes, train, seed, main_s, side_v, side_t));
-  if (do_optimizer)
-    for (int i = 0; i < 4; ++i)
-      RUN(coot_adam_step(b->params[i], b->grads[i], b->adam_m[i], b->adam_v[i], b->decay_mask[i], coot_net_param_numel(&cfg->net[i]),
-                         cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, step, main_s));
+  if (do_optimizer) {  // all four parameter arenas in ONE launch (four dependent 13 us launches ended the step)
+    AdamSegs sg;
+    int blk = 0;
+    for (int i = 0; i < 4; ++i) {
+      const long n = coot_net_param_numel(&cfg->net[i]);
+      sg.p[i] = b->params[i]; sg.g[i] = b->grads[i]; sg.m[i] = b->adam_m[i]; sg.v[i] = b->adam_v[i]; sg.decay[i] = b->decay_mask[i]; sg.n[i] = n;
+      sg.blk0[i] = blk;
+      blk += (int)((n / 4 + 255) / 256);
+    }
+    sg.blk0[4] = blk;
+    const double bc1 = 1.0 - pow((double)cfg->beta1, (double)step), bc2 = 1.0 - pow((double)cfg->beta2, (double)step);
+    hipLaunchKernelGGL(adam4_kernel, dim3(blk), dim3(256), 0, sm, sg, cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay,
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    COOT_CHECK_LAUNCH("adam4");
+  }
   return 0;
 }
 

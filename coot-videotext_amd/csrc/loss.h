@@ -1,22 +1,9 @@
-// Loss kernels: L2 normalisation, bidirectional max-margin ranking (ContrastiveLoss),
-// cycle-consistency (CycleConsistencyLoss).  coot/loss_fn.py, coot/trainer_retrieval.py:148-233.
+// Loss kernels: fused contrastive loss (L2 normalisation + bidirectional max-margin ranking + gradients, loss_fused.hip),
+// cycle-consistency (CycleConsistencyLoss, loss.hip).  coot/loss_fn.py, coot/trainer_retrieval.py:148-233.
 #pragma once
 #include "common.h"
 
 namespace coot {
-
-// a = v / max(||v||, 1e-12): writes bf16 a [N, lda], bf16 a^T [d, ldt] (zero padded columns), inv_norm [N]
-int launch_l2norm_fwd(const float* v, long ldv, int N, int d, bf16_t* a, long lda, bf16_t* aT, long ldt, float* inv_norm,
-                      hipStream_t st);
-// dv (+)= (da - a <a,da>) * inv_norm ;  a = v * inv_norm
-int launch_l2norm_bwd(const float* da, long ldda, const float* v, long ldv, const float* inv_norm, int N, int d, float* dv,
-                      long lddv, int accumulate, hipStream_t st);
-
-// From S [N, lds] (fp32 similarity):  loss += w/(N*N) * sum_{i!=j} relu(m+S_ij-S_ii) + relu(m+S_ij-S_jj)
-// G [N, ldg] / GT [N, ldg] bf16 = off-diagonal violation counts {0,1,2} (zero diagonal, zero padding),
-// gd[i] += -(w/(N*N)) * (#row violations of i in cost_s + #column violations of i in cost_im)
-int launch_hinge(const float* S, long lds, int N, float margin, float w, float* loss, bf16_t* G, bf16_t* GT, long ldg,
-                 float* gd, hipStream_t st);
 
 struct CycleArgs {
   const float* clip = nullptr;  // [B, Cc, D] zero padded

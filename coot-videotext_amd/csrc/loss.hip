@@ -1,112 +1,7 @@
-// Loss kernels for gfx950.  The N x N similarity GEMMs run on the MFMA GEMM (gemm.hip); this
-// file holds the wave-shuffle reductions around them and the per-video cycle-consistency kernel.
+// Cycle-consistency loss kernel for gfx950 (the contrastive loss lives in loss_fused.hip).
 #include "loss.h"
 
 namespace coot {
-
-// ---- F.normalize(p=2, dim=1, eps=1e-12) (coot/trainer_retrieval.py:161-166) -------------------
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* v, long ldv, int N, int d, bf16_t* a, long lda, bf16_t* aT,
-                                                         long ldt, float* inv_norm) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= N) return;
-  float s = 0.f;
-  for (int c = lane; c < d; c += 64) { float x = v[(long)row * ldv + c]; s += x * x; }
-  s = wave_sum(s);
-  const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
-  if (lane == 0) inv_norm[row] = inv;
-  for (int c = lane; c < d; c += 64) {
-    bf16_t h = f2bf(v[(long)row * ldv + c] * inv);
-    a[(long)row * lda + c] = h;
-    if (aT) aT[(long)c * ldt + row] = h;
-  }
-}
-int launch_l2norm_fwd(const float* v, long ldv, int N, int d, bf16_t* a, long lda, bf16_t* aT, long ldt, float* inv_norm, hipStream_t st) {
-  COOT_REQUIRE(v && a && inv_norm, "l2norm: null pointer");
-  if (N <= 0) return 0;
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, v, ldv, N, d, a, lda, aT, ldt, inv_norm);
-  COOT_CHECK_LAUNCH("l2norm_fwd");
-  return 0;
-}
-
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* da, long ldda, const float* v, long ldv, const float* inv_norm,
-                                                         int N, int d, float* dv, long lddv, int accumulate) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= N) return;
-  const float inv = inv_norm[row];
-  float dot = 0.f;
-  for (int c = lane; c < d; c += 64) dot += v[(long)row * ldv + c] * inv * da[(long)row * ldda + c];
-  dot = wave_sum(dot);
-  for (int c = lane; c < d; c += 64) {
-    const float a = v[(long)row * ldv + c] * inv;
-    const float g = (da[(long)row * ldda + c] - a * dot) * inv;
-    if (accumulate) dv[(long)row * lddv + c] += g; else dv[(long)row * lddv + c] = g;
-  }
-}
-int launch_l2norm_bwd(const float* da, long ldda, const float* v, long ldv, const float* inv_norm, int N, int d, float* dv, long lddv,
-                      int accumulate, hipStream_t st) {
-  COOT_REQUIRE(da && v && inv_norm && dv, "l2norm bwd: null pointer");
-  if (N <= 0) return 0;
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, da, ldda, v, ldv, inv_norm, N, d, dv, lddv, accumulate);
-  COOT_CHECK_LAUNCH("l2norm_bwd");
-  return 0;
-}
-
-// ---- ContrastiveLoss.forward (coot/loss_fn.py:63-100) + its gradient wrt S ---------------------
-// 64 x 64 tiles; thread (ty = tid/64 -> 16 rows each, tx = tid%64 -> column).
-__global__ __launch_bounds__(256) void hinge_kernel(const float* S, long lds, int N, float margin, float w, float* loss, bf16_t* G,
-                                                    bf16_t* GT, long ldg, float* gd) {
-  __shared__ float colcnt[64];
-  __shared__ float rowcnt[64];
-  __shared__ float lsum[4];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  if (threadIdx.x < 64) { colcnt[threadIdx.x] = 0.f; rowcnt[threadIdx.x] = 0.f; }
-  __syncthreads();
-  const int j = j0 + tx;
-  const float djj = j < N ? S[(long)j * lds + j] : 0.f;
-  float part = 0.f, ccnt = 0.f;
-  for (int r = 0; r < 16; ++r) {
-    const int il = ty * 16 + r, i = i0 + il;
-    float g = 0.f;
-    float rc = 0.f;
-    if (i < N && j < N && i != j) {
-      const float s = S[(long)i * lds + j];
-      const float dii = S[(long)i * lds + i];
-      const float cs = margin + s - dii;   // cost_s  (compare with the row's diagonal)
-      const float ci = margin + s - djj;   // cost_im (compare with the column's diagonal)
-      if (cs > 0.f) { part += cs; g += 1.f; rc = 1.f; }
-      if (ci > 0.f) { part += ci; g += 1.f; ccnt += 1.f; }
-    }
-    if (i < N && j < N) {
-      G[(long)i * ldg + j] = f2bf(g);
-      GT[(long)j * ldg + i] = f2bf(g);
-    }
-    rc = wave_sum(rc);  // the 64 lanes of a wave share row i
-    if (tx == 0 && rc != 0.f) atomicAdd(&rowcnt[il], rc);
-  }
-  atomicAdd(&colcnt[tx], ccnt);
-  part = wave_sum(part);
-  if (tx == 0) lsum[ty] = part;
-  __syncthreads();
-  const float sc = w / ((float)N * (float)N);
-  if (threadIdx.x == 0) atomicAdd(loss, (lsum[0] + lsum[1] + lsum[2] + lsum[3]) * sc);
-  if (threadIdx.x < 64) {
-    const int i = i0 + threadIdx.x, jj = j0 + threadIdx.x;
-    if (i < N && rowcnt[threadIdx.x] != 0.f) atomicAdd(gd + i, -sc * rowcnt[threadIdx.x]);
-    if (jj < N && colcnt[threadIdx.x] != 0.f) atomicAdd(gd + jj, -sc * colcnt[threadIdx.x]);
-  }
-}
-int launch_hinge(const float* S, long lds, int N, float margin, float w, float* loss, bf16_t* G, bf16_t* GT, long ldg, float* gd,
-                 hipStream_t st) {
-  COOT_REQUIRE(S && loss && G && GT && gd, "hinge: null pointer");
-  if (N <= 0) return 0;
-  dim3 grid((N + 63) / 64, (N + 63) / 64);
-  hipLaunchKernelGGL(hinge_kernel, grid, dim3(256), 0, st, S, lds, N, margin, w, loss, G, GT, ldg, gd);
-  COOT_CHECK_LAUNCH("hinge");
-  return 0;
-}
 
 // ---- CycleConsistencyLoss (coot/loss_fn.py:143-387), one workgroup per (video, direction) -------
 constexpr int CC_MAXC = 64;   // max clips / sentences per video
