@@ -18,8 +18,10 @@ __device__ __forceinline__ void store4_bf(bf16_t* p, f32x4_t v) {
 
 // LayerNormalization 'layernorm_coot' (nntrainer/models/normalizations.py:98-101):
 //   y = gain * (x - mean) / (std_unbiased + 1e-6) + bias
+// min 8 waves per SIMD: left alone hipcc keeps the 8-chunk row AND all unrolled epilogue temporaries live (239 VGPRs, 2 waves
+// per SIMD, 64 KB in flight per CU: the input LayerNorm ran at 2.4 TB/s); 64 VGPRs are enough and fill the CU
 template <int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
+__global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.R) return;
