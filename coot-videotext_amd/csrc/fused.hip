@@ -144,6 +144,12 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
     if constexpr (NCG == 8) { rl[i] = r_; col[i] = ch * 8; }
     else { rl[i] = r_ + (ch >= 24 ? 32 : 0); col[i] = (ch >= 24 ? ch - 24 : ch) * 8; }
   }
+  // the thread's three bias chunks (the chain's bias vectors live in LDS): read once per epilogue, not once per round
+  float bs[IT][8];
+  if (bias_lds) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) load8f(bias_lds + col[i], bs[i]);
+  }
   using P = decltype(pre(0, 0));
   P pv[2][IT];
 #pragma unroll
@@ -185,16 +191,15 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
       }
     }
     lds_barrier();
-    float v[IT][8], bs[IT][8];
+    float v[IT][8];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) load8f(&Stg[(rl[i] & 31) * SPITCH + col[i] + (rl[i] >= 32 ? 192 : 0)], v[i]);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      load8f(&Stg[(rl[i] & 31) * SPITCH + col[i] + (rl[i] >= 32 ? 192 : 0)], v[i]);
-      load8f(bias_lds + col[i], bs[i]);  // the chain's bias vectors live in LDS (loaded once per workgroup)
-    }
+      if (bias_lds) {
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] += bs[i][j];
+        for (int j = 0; j < 8; ++j) v[i][j] += bs[i][j];
+      }
       fn(rbase + rl[i], col[i], v[i], par ? pv[1][i] : pv[0][i], i);
       // one chunk body at a time (8 independent elements give the VALU enough ILP): letting the scheduler interleave the
       // three bodies triples their temporaries while the accumulators of the later rounds are still live -> spills
@@ -413,8 +418,8 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 // x = the saved LN input (global, bf16).  DROPY: dy is first multiplied by the dropout mask the forward applied to the LN
 // output.  MASKX: dxm = dx * mask(drop_x) is what stays in the tile and goes to out_dxm (dx itself goes to out_dx).
 // Column sums over the tile's valid rows (dgain = dy xc / s, dbias = dy, colsum of dxm or dx): lanes -> wave by two
-// xor-shuffles, waves -> workgroup through red[8][3 * 384] (plain LDS stores: LDS float atomics serialise per lane and
-// cost ~1.5k cycles per wave-instruction here), written to part_dst[3 * 384] (one partial row per tile).
+// plain LDS stores into red[32][3 * 128] per 128-column chunk (LDS float atomics serialise per lane and cost ~1.5k cycles
+// per wave-instruction here), summed by 384 threads into part_dst[3 * 384] (one partial row per tile).
 template <int RF, bool DROPY, bool MASKX>
 __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, const bf16_t* xsaved, int row0, int T, bf16_t* out_dx,
                                             bf16_t* out_dxm, const DropCfg& dy_drop, const DropCfg& dx_drop, float* red, float* part_dst) {
@@ -514,29 +519,28 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
       if constexpr (MASKX) gst16(out_dxm, boff, om);
       *reinterpret_cast<u32x4_t*>(ar) = om;
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {  // the 4 row groups of the wave (lanes j16 + 16 g)
-      csg[e] += __shfl_xor(csg[e], 16, 64); csg[e] += __shfl_xor(csg[e], 32, 64);
-      csb[e] += __shfl_xor(csb[e], 16, 64); csb[e] += __shfl_xor(csb[e], 32, 64);
-      csx[e] += __shfl_xor(csx[e], 16, 64); csx[e] += __shfl_xor(csx[e], 32, 64);
-    }
-    if (g == 0) {
-      float* rw = red + wave * (3 * FZ_D) + m * 128 + j16 * 8;
+    // 32 (wave, row group) partial rows of this 128-column chunk -> LDS -> 384 threads add them up (the register route,
+    // two xor-shuffles per value, is 144 ds_bpermute per wave and as slow as the LayerNorm itself)
+    {
+      float* rw = red + (wave * 4 + g) * (3 * 128) + j16 * 8;
       *reinterpret_cast<f32x4_t*>(rw) = f32x4_t{csg[0], csg[1], csg[2], csg[3]};
       *reinterpret_cast<f32x4_t*>(rw + 4) = f32x4_t{csg[4], csg[5], csg[6], csg[7]};
-      *reinterpret_cast<f32x4_t*>(rw + FZ_D) = f32x4_t{csb[0], csb[1], csb[2], csb[3]};
-      *reinterpret_cast<f32x4_t*>(rw + FZ_D + 4) = f32x4_t{csb[4], csb[5], csb[6], csb[7]};
-      *reinterpret_cast<f32x4_t*>(rw + 2 * FZ_D) = f32x4_t{csx[0], csx[1], csx[2], csx[3]};
-      *reinterpret_cast<f32x4_t*>(rw + 2 * FZ_D + 4) = f32x4_t{csx[4], csx[5], csx[6], csx[7]};
+      *reinterpret_cast<f32x4_t*>(rw + 128) = f32x4_t{csb[0], csb[1], csb[2], csb[3]};
+      *reinterpret_cast<f32x4_t*>(rw + 128 + 4) = f32x4_t{csb[4], csb[5], csb[6], csb[7]};
+      *reinterpret_cast<f32x4_t*>(rw + 256) = f32x4_t{csx[0], csx[1], csx[2], csx[3]};
+      *reinterpret_cast<f32x4_t*>(rw + 256 + 4) = f32x4_t{csx[4], csx[5], csx[6], csx[7]};
     }
+    lds_barrier();
+    if (threadIdx.x < 3 * 128) {
+      float v = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) v += red[r * (3 * 128) + threadIdx.x];
+      const int q = threadIdx.x / 128, c = threadIdx.x % 128;  // quantity (dgain, dbias, colsum dx), column within the chunk
+      part_dst[q * FZ_D + m * 128 + c] = v;
+    }
+    lds_barrier();
   }
-  __syncthreads();  // tile + per-wave column sums complete; the global stores (dx / dxm) are visible to the whole workgroup
-  for (int c = threadIdx.x; c < 3 * FZ_D; c += NTHR) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) v += red[w * (3 * FZ_D) + c];
-    part_dst[c] = v;
-  }
+  __syncthreads();  // tile complete; the global stores (dx / dxm) are visible to the whole workgroup
 }
 
 // column sums a thread gathered over the epilogue rounds (its 3 fixed column chunks) -> one partial row of the tile.
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
       zero_acc<RF>(acc);
       gemm_pass<RF, 6>(As, p.pw2 + (h * 8 + wave) * GSZ192, acc, lane);
       cs_zero();
-      epilogue<RF, 8>(acc, Stg, As, row0, zero,
+      epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
           [&](int row, int col) { return PreRes{gld16(p.hp, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u)}; },
           [&](int row, int col, float (&v)[8], const PreRes& pr, int i) {
             float a[8];
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
     load_tile<RF>(As, p.dhp, 2 * FZ_D, 0, row0);
     __syncthreads();
     gemm_pass<RF, 12>(As, p.pw1 + wave * GSZ, acc, lane);
-    epilogue<RF, 8>(acc, Stg, As, row0, zero,
+    epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
         [&](int row, int col) { return PreRes{gld16(p.dzp, (unsigned)(row * FZ_D + col) * 2u)}; },
         [&](int, int, float (&v)[8], const PreRes& pr, int) {
           float r[8];
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   zero_acc<RF>(acc);
   gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
   cs_zero();
-  epilogue<RF, 8>(acc, Stg, As, row0, zero,
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
       [&](int row, int col) { return PreRes{gld16(p.h1, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr, int i) {
         float a[8];
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   // ---- dz1 = dh1 . W1 + dr2 ----------------------------------------------------------------------------------------------------
   zero_acc<RF>(acc);
   gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
-  epilogue<RF, 8>(acc, Stg, As, row0, zero,
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
       [&](int row, int col) { return PreRes{gld16(p.dr2, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int, int, float (&v)[8], const PreRes& pr, int) {
         float r[8];
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   // ---- dctx = dr1 . Wo ------------------------------------------------------------------------------------------------------------
   zero_acc<RF>(acc);
   gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
-  epilogue<RF, 8>(acc, Stg, As, row0, zero, [&](int, int) { return PreNone{}; },
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&, int) { gst16(p.dctx, (unsigned)(row * FZ_D + col) * 2u, pack8(v)); }, false);
   stamp();
 }
