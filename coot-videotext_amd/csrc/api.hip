@@ -134,6 +134,7 @@ struct LayerW {
   bf16_t *wqkv_nk, *wqkv_kn, *wo_nk, *wo_kn, *w1_nk, *w1_kn, *w2_nk, *w2_kn;
   bf16_t *f_wo = nullptr, *f_w1 = nullptr, *f_w2 = nullptr;  // P48 packs of the fused chains (fused.h), d_model = 384 only
   bf16_t *f_wo_kn = nullptr, *f_w1_kn = nullptr, *f_w2_kn = nullptr;  // the same for the dX orientation (backward chain)
+  bf16_t *f_wqkv = nullptr, *f_wqkv_kn = nullptr;  // P48: [1152 x 384] forward, [384 x 1152] dX
 };
 struct WPack {
   bf16_t* in_w = nullptr;     // [D, Din]  = W * gain (LN affine folded)
@@ -160,6 +161,7 @@ static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
     if (fused_layer_ok(c)) {
       w.f_wo = A.get<bf16_t>(D * D); w.f_w1 = A.get<bf16_t>(F * D); w.f_w2 = A.get<bf16_t>(F * D);
       w.f_wo_kn = A.get<bf16_t>(D * D); w.f_w1_kn = A.get<bf16_t>(F * D); w.f_w2_kn = A.get<bf16_t>(F * D);
+      w.f_wqkv = A.get<bf16_t>(3 * D * D); w.f_wqkv_kn = A.get<bf16_t>(3 * D * D);
     }
     return w;
   };
@@ -347,7 +349,10 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
                      const PoolFuse* pool = nullptr) {
   const int D = c.hidden_dim, F = c.ff_dim, H = c.num_heads, dh = D / H;
   const bool self = (xq == xkv);
-  if (self) {
+  if (self && lw.f_wqkv && g_use_fused && rows_q >= g_fused_min_rows) {
+    QkvFwd f; f.T = rows_q; f.z = xq; f.wqkv = lw.f_wqkv; f.bias = P + lp.bq; f.qkv = b.q;
+    RUN(launch_qkv_fwd(f, st));
+  } else if (self) {
     GemmNT g; g.X = xq; g.ldx = D; g.W = lw.wqkv_nk; g.ldw = D; g.M = rows_q; g.N = 3 * D; g.K = D;
     g.epi.bias = P + lp.bq; g.epi.out = b.q; g.epi.ldc = 3 * D;
     RUN(launch_gemm_nt(g, st));
@@ -475,12 +480,17 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
     // bq | bk | bv gradients = column sums of dqkv: taken by the weight-gradient GEMM that streams dqkv anyway
     { GemmTN t; t.A = w.dq; t.lda = 3 * D; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = 3 * D; t.No = D; t.C = G + lp.wqkv; t.ldc = D;
       t.a_colsum = G + lp.bq; RUN(launch_gemm_tn(t, st)); }
-    GemmNT g; g.X = w.dq; g.ldx = 3 * D; g.W = lw.wqkv_kn; g.ldw = 3 * D; g.M = rows_q; g.N = D; g.K = 3 * D;
-    g.epi.res = w.dr1; g.epi.ldres = D;
-    if (gelu_aux) { g.epi.act = 2; g.epi.aux = gelu_aux; g.epi.ldaux = D; g.epi.colsum = gelu_colsum; }
-    if (dxq_f32) { g.epi.out = dxq_f32; g.epi.out_f32 = 1; } else g.epi.out = dxq;
-    g.epi.ldc = D;
-    RUN(launch_gemm_nt(g, st));
+    if (lw.f_wqkv_kn && g_use_fused && g_use_fused_bwd && rows_q >= g_fused_min_rows && !dxq_f32 && part_ws) {
+      QkvBwd f; f.T = rows_q; f.dqkv = w.dq; f.wqkv = lw.f_wqkv_kn; f.res = w.dr1; f.aux = gelu_aux; f.dz = dxq; f.colsum = gelu_colsum; f.part = part_ws;
+      RUN(launch_qkv_bwd(f, st));
+    } else {
+      GemmNT g; g.X = w.dq; g.ldx = 3 * D; g.W = lw.wqkv_kn; g.ldw = 3 * D; g.M = rows_q; g.N = D; g.K = 3 * D;
+      g.epi.res = w.dr1; g.epi.ldres = D;
+      if (gelu_aux) { g.epi.act = 2; g.epi.aux = gelu_aux; g.epi.ldaux = D; g.epi.colsum = gelu_colsum; }
+      if (dxq_f32) { g.epi.out = dxq_f32; g.epi.out_f32 = 1; } else g.epi.out = dxq;
+      g.epi.ldc = D;
+      RUN(launch_gemm_nt(g, st));
+    }
   } else {
     { GemmTN t; t.A = w.dq; t.lda = w.lddq; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = D; t.No = D; t.C = G + lp.wqkv; t.ldc = D;
       t.a_colsum = G + lp.bq; RUN(launch_gemm_tn(t, st)); }
@@ -602,6 +612,8 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
       RUN(add48(lp.wo, D, D, D, lw.f_wo_kn, 1));
       RUN(add48(lp.w1, D, F, D, lw.f_w1_kn, 1));
       RUN(add48(lp.w2, F, D, F, lw.f_w2_kn, 1));
+      RUN(add48(lp.wqkv, D, 3 * D, D, lw.f_wqkv, 0));
+      RUN(add48(lp.wqkv, D, 3 * D, D, lw.f_wqkv_kn, 1));
     }
     return 0;
   };

@@ -60,6 +60,24 @@ struct PreAttnBwd {
   DropCfg d_pool1, d_ff2, d_ff1, d_postln;
   unsigned long long* tstamps = nullptr;  // profiling aid (block 0 phase stamps)
 };
+// qkv = z . Wqkv^T + (bq | bk | bv): three full-width passes over one LDS-resident token tile (the LDS-staged GEMM re-reads
+// the token slab once per 128-column block: 9 times)
+struct QkvFwd { int T = 0; const bf16_t* z = nullptr; const bf16_t* wqkv = nullptr; const float* bias = nullptr; bf16_t* qkv = nullptr; };
+int launch_qkv_fwd(const QkvFwd& p, hipStream_t st);
+
+// dz = dqkv . Wqkv + dr1 [* GELU'(h0), column sums -> colsum (input-FC bias gradient)]: K = 1152 as three 384-wide token tiles
+struct QkvBwd {
+  int T = 0;
+  const bf16_t* dqkv = nullptr;  // [T, 1152]
+  const bf16_t* wqkv = nullptr;  // P48, logical [384][1152]
+  const bf16_t* res = nullptr;   // [T, 384] dr1
+  const bf16_t* aux = nullptr;   // [T, 384] h0 (pre-GELU of the input FC) or null
+  bf16_t* dz = nullptr;          // [T, 384]
+  float* colsum = nullptr;       // [384] += column sums of dz (only with aux)
+  float* part = nullptr;         // [tiles, 384] workspace (only with aux)
+};
+int launch_qkv_bwd(const QkvBwd& p, hipStream_t st);
+
 constexpr int FZ_BWD_NCS = 9 * FZ_D;  // floats per tile in PreAttnBwd::part
 int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st);
 

@@ -688,6 +688,92 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   stamp();
 }
 
+// ---- QKV projection (forward) and its dX (backward) on full-width token tiles ---------------------------------------
+__global__ __launch_bounds__(512) void qkv_fwd_kernel(QkvFwd p) {
+  constexpr int RF = 8, BT = 128, RR = 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4 + 3 * FZ_D * 4];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);
+  float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
+  float* Bsm = reinterpret_cast<float*>(smem + BT * APITCH * 2 + RR * SPITCH * 4);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * BT;
+  if (threadIdx.x < 3 * FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(p.bias)[threadIdx.x];
+  load_tile<RF>(As, p.z, FZ_D, 0, row0);
+  __syncthreads();
+  f32x4_t acc[RF][3];
+#pragma unroll 1
+  for (int q = 0; q < 3; ++q) {
+    zero_acc<RF>(acc);
+    gemm_pass<RF, 12>(As, p.wqkv + (q * 8 + wave) * GSZ, acc, lane);
+    epilogue<RF, 8>(acc, Stg, As, row0, Bsm + q * FZ_D, [&](int, int) { return PreNone{}; },
+        [&](int row, int col, float (&v)[8], const PreNone&, int) { gst16(p.qkv, (unsigned)(row * (3 * FZ_D) + q * FZ_D + col) * 2u, pack8(v)); },
+        false);
+  }
+}
+
+template <bool GELU>
+__global__ __launch_bounds__(512) void qkv_bwd_kernel(QkvBwd p) {
+  constexpr int RF = 8, BT = 128, RR = 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);
+  float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * BT, T = p.T;
+  f32x4_t acc[RF][3];
+  zero_acc<RF>(acc);
+  const bf16_t* wg = p.wqkv + (long)wave * (36L * 3 * 512);  // one 48-column group at K = 1152
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    if (c) __syncthreads();  // every wave is done with the previous 384-wide slab
+    load_tile<RF>(As, p.dqkv, 3 * FZ_D, c * FZ_D, row0);
+    __syncthreads();
+    gemm_pass<RF, 12>(As, wg + (long)c * 12 * 3 * 512, acc, lane);
+  }
+  float cs[3][8];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[i][j] = 0.f;
+  struct PreTwo { u32x4_t res, aux; };
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
+      [&](int row, int col) {
+        PreTwo pr;
+        pr.res = gld16(p.res, (unsigned)(row * FZ_D + col) * 2u);
+        if constexpr (GELU) pr.aux = gld16(p.aux, (unsigned)(row * FZ_D + col) * 2u);
+        return pr;
+      },
+      [&](int row, int col, float (&v)[8], const PreTwo& pr, int i) {
+        float r[8];
+        unpack8(pr.res, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+        if constexpr (GELU) {
+          float a[8];
+          unpack8(pr.aux, a);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+          if (row < T) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[i][j] += v[j];
+          }
+        }
+        gst16(p.dz, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+      }, false);
+  if constexpr (GELU) colsum_flush(cs, Stg, p.part + (long)blockIdx.x * FZ_D);
+}
+
+// out[c] += sum_tile part[tile][c]
+__global__ __launch_bounds__(256) void colsum_tiles_kernel(const float* part, int ntiles, int n, float* out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+  float v = 0.f;
+  if (c < n)
+    for (int t = pg; t < ntiles; t += 4) v += part[(long)t * n + c];
+  red[pg][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (pg == 0 && c < n) out[c] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // out[seg][c] += sum_tile part[tile][off + c]: the bias / LayerNorm gradients of pre_attn_bwd_kernel
 struct ScatterSeg { float* dst; int off, n; };
 struct ScatterArgs { ScatterSeg s[8]; int nseg, ntiles; const float* part; };
@@ -750,6 +836,34 @@ int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st) {
   a.s[5] = ScatterSeg{p.g_ln1g, 6 * FZ_D, FZ_D}; a.s[6] = ScatterSeg{p.g_ln1b, 7 * FZ_D, FZ_D}; a.s[7] = ScatterSeg{p.g_bo, 8 * FZ_D, FZ_D};
   hipLaunchKernelGGL(colsum_scatter_kernel, dim3(12, 8), dim3(256), 0, st, a);
   COOT_CHECK_LAUNCH("colsum_scatter");
+  return 0;
+}
+}  // namespace coot
+
+namespace coot {
+int launch_qkv_fwd(const QkvFwd& p, hipStream_t st) {
+  COOT_REQUIRE(p.z && p.wqkv && p.bias && p.qkv, "qkv_fwd: null pointer");
+  if (p.T <= 0) return 0;
+  void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 1152.0, 0, st);
+  hipLaunchKernelGGL(qkv_fwd_kernel, dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+  timing_end(ts, st);
+  COOT_CHECK_LAUNCH("qkv_fwd");
+  return 0;
+}
+int launch_qkv_bwd(const QkvBwd& p, hipStream_t st) {
+  COOT_REQUIRE(p.dqkv && p.wqkv && p.res && p.dz, "qkv_bwd: null pointer");
+  COOT_REQUIRE(!p.aux || (p.colsum && p.part), "qkv_bwd: GELU' needs the column-sum buffers");
+  if (p.T <= 0) return 0;
+  const int tiles = (p.T + 127) / 128;
+  void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 1152.0, 0, st);
+  if (p.aux) hipLaunchKernelGGL(qkv_bwd_kernel<true>, dim3(tiles), dim3(NTHR), 0, st, p);
+  else hipLaunchKernelGGL(qkv_bwd_kernel<false>, dim3(tiles), dim3(NTHR), 0, st, p);
+  timing_end(ts, st);
+  COOT_CHECK_LAUNCH("qkv_bwd");
+  if (p.aux) {
+    hipLaunchKernelGGL(colsum_tiles_kernel, dim3((FZ_D + 63) / 64), dim3(256), 0, st, (const float*)p.part, tiles, FZ_D, p.colsum);
+    COOT_CHECK_LAUNCH("colsum_tiles");
+  }
   return 0;
 }
 }  // namespace coot
