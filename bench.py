@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--workload", default="anet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="library A/B switch name=value (coot_set_option), repeatable")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--mode", default="native", choices=["native", "autograd", "graph"],
                     help="native: one C call per step (default); autograd: torch autograd Functions; graph: autograd step in a HIP graph")
@@ -110,6 +111,9 @@ def main():
     import coot_videotext_amd as cva
     from coot_videotext_amd import dist as cdist
     lib = cva.lib.load()
+    for kv in args.opt:
+        k, v = kv.split("=")
+        cva.lib.check(lib.coot_set_option(k.encode(), int(v)), "coot_set_option")
     dp = None
     if world > 1:
         import torch.distributed as dist

@@ -138,6 +138,7 @@ struct LayerW {
 };
 struct WPack {
   bf16_t* in_w = nullptr;     // [D, Din]  = W * gain (LN affine folded)
+  bf16_t* f_in_w = nullptr;   // the same in the P48 layout (fused input FC + QKV kernel)
   float* in_bias = nullptr;   // [D]       = b + W . norm_bias
   std::vector<LayerW> layers, ctx;
   bf16_t *pw1_nk = nullptr, *pw1_kn = nullptr, *pw2_nk = nullptr, *pw2_kn = nullptr;
@@ -151,7 +152,10 @@ static bool fused_pool_ok(const coot_net_config& c) {
 }
 static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
   const size_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
-  if (c.use_input_fc) { W.in_w = A.get<bf16_t>(D * Din); W.in_bias = A.get<float>(D); }
+  if (c.use_input_fc) {
+    W.in_w = A.get<bf16_t>(D * Din); W.in_bias = A.get<float>(D);
+    if (fused_layer_ok(c) && Din % 64 == 0) W.f_in_w = A.get<bf16_t>(D * Din);
+  }
   auto lay = [&]() {
     LayerW w;
     w.wqkv_nk = A.get<bf16_t>(3 * D * D); w.wqkv_kn = A.get<bf16_t>(3 * D * D);
@@ -338,6 +342,7 @@ static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipSt
 struct PoolFuse { const bf16_t *pw1, *pw2; const float *pb1, *pb2; bf16_t *hp, *ap, *s; DropCfg d1, d2; };
 struct PoolFuseBwd { const bf16_t *ds, *dzp, *hp, *pw2, *pw1; bf16_t* dhp; float* g_pb1; DropCfg d1; };
 static int g_use_fused_bwd = 1;  // coot_set_option("fused_bwd", 0/1)
+static int g_use_fused_infc = 0;  // coot_set_option("fused_infc", 0/1): input FC + QKV in one launch (measured neutral: off)
 static int g_use_fused = 1;
 static int g_fz_debug = 0;
 static unsigned long long* g_fz_tstamps = nullptr;
@@ -346,10 +351,12 @@ static int g_fused_min_rows = 1024;  // below this many tokens the per-op kernel
 static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp, const LayerW& lw, const bf16_t* xq, int rows_q,
                      const bf16_t* xkv, int rows_kv, const Segs& sg, const LayerBufs& b,
                      float* z2_f32, long ldz2_f32, float pdrop, int train, uint64_t seed, unsigned site_base, hipStream_t st,
-                     const PoolFuse* pool = nullptr) {
+                     const PoolFuse* pool = nullptr, bool qkv_done = false) {
   const int D = c.hidden_dim, F = c.ff_dim, H = c.num_heads, dh = D / H;
   const bool self = (xq == xkv);
-  if (self && lw.f_wqkv && g_use_fused && rows_q >= g_fused_min_rows) {
+  if (self && qkv_done) {
+    // q | k | v already written by the fused input-FC kernel
+  } else if (self && lw.f_wqkv && g_use_fused && rows_q >= g_fused_min_rows) {
     QkvFwd f; f.T = rows_q; f.z = xq; f.wqkv = lw.f_wqkv; f.bias = P + lp.bq; f.qkv = b.q;
     RUN(launch_qkv_fwd(f, st));
   } else if (self) {
@@ -536,6 +543,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
   if (!strcmp(name, "fused_bwd")) { g_use_fused_bwd = value; return 0; }
+  if (!strcmp(name, "fused_infc")) { g_use_fused_infc = value; return 0; }
   if (!strcmp(name, "gemm_small")) { set_gemm_small(value); return 0; }
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
   if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
@@ -593,6 +601,7 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
   };
   if (c.use_input_fc) {
     RUN(add(L.in_w, Din, D, Din, W.in_w, Din, 0, L.n_gain));  // W * gain: LN affine folded into the FC
+    if (W.f_in_w) { RUN(add(L.in_w, Din, D, Din, W.f_in_w, 0, 0, L.n_gain)); jobs.j[jobs.n - 1].p48 = 1; }
     RUN(launch_matvec_bias(P + L.in_w, Din, D, Din, P + L.n_bias, P + L.in_b, W.in_bias, st));
   }
   auto pack_layer = [&](const LayerP& lp, const LayerW& lw) -> int {
@@ -675,15 +684,23 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim, T0 = N * Lseq;
   const int out_dim = D * (c.use_context ? 2 : 1);
 
+  bool qkv_done = false;  // the fused input-FC kernel also produces layer 0's q | k | v
   if (c.use_input_fc) {
     LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T0; l.D = Din; l.y = S.xhat; l.ldy = Din;
     RUN(launch_ln_fwd(l, st));
     if (sg.n > 1) { l.x = feats2; l.R = T - T0; l.y = S.xhat + (size_t)T0 * Din; RUN(launch_ln_fwd(l, st)); }
-    GemmNT g; g.X = S.xhat; g.ldx = Din; g.W = W.in_w; g.ldw = Din; g.M = T; g.N = D; g.K = Din;
-    g.epi.bias = W.in_bias; g.epi.act = 1; g.epi.save_pre = S.h0; g.epi.ldpre = D; g.epi.pe = pe; g.epi.pe_L = Lseq;
-    g.epi.pe_T0 = T0; g.epi.pe_L2 = sg.n > 1 ? L2 : Lseq;
-    g.epi.out = S.z0; g.epi.ldc = D;
-    RUN(launch_gemm_nt(g, st));
+    if (W.f_in_w && W.layers[0].f_wqkv && g_use_fused && g_use_fused_infc && T >= g_fused_min_rows) {
+      InfcQkvFwd f; f.T = T; f.Din = Din; f.xhat = S.xhat; f.win = W.f_in_w; f.bin = W.in_bias; f.pe = pe; f.T0 = T0; f.L1 = Lseq;
+      f.L2 = sg.n > 1 ? L2 : Lseq; f.wqkv = W.layers[0].f_wqkv; f.bqkv = P + L.layers[0].bq; f.h0 = S.h0; f.z0 = S.z0; f.qkv = S.layers[0].qkv;
+      RUN(launch_infc_qkv_fwd(f, st));
+      qkv_done = true;
+    } else {
+      GemmNT g; g.X = S.xhat; g.ldx = Din; g.W = W.in_w; g.ldw = Din; g.M = T; g.N = D; g.K = Din;
+      g.epi.bias = W.in_bias; g.epi.act = 1; g.epi.save_pre = S.h0; g.epi.ldpre = D; g.epi.pe = pe; g.epi.pe_L = Lseq;
+      g.epi.pe_T0 = T0; g.epi.pe_L2 = sg.n > 1 ? L2 : Lseq;
+      g.epi.out = S.z0; g.epi.ldc = D;
+      RUN(launch_gemm_nt(g, st));
+    }
   } else {
     LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T0; l.D = Din; l.gain = P + L.n_gain; l.bias = P + L.n_bias;
     l.pe = pe; l.pe_L = Lseq; l.y = S.z0; l.ldy = D;
@@ -701,7 +718,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       pf.d1 = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL1); pf.d2 = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2);
     }
     RUN(layer_fwd(c, P, L.layers[i], W.layers[i], z, T, z, T, sg, b, last ? per_token : nullptr, D, c.dropout,
-                  train, seed, 16u * i, st, (last && pool_fused) ? &pf : nullptr));
+                  train, seed, 16u * i, st, (last && pool_fused) ? &pf : nullptr, i == 0 && qkv_done));
     z = S.layers[i].z2;
   }
   if (c.use_context) {

@@ -60,6 +60,20 @@ struct PreAttnBwd {
   DropCfg d_pool1, d_ff2, d_ff1, d_postln;
   unsigned long long* tstamps = nullptr;  // profiling aid (block 0 phase stamps)
 };
+// Input FC + GELU + positional encoding + QKV projection of a local network in one launch: the normalised input xhat
+// [T, Din] (bf16) streams through LDS in 64-column slabs, each read exactly once (the 128 x 128 tiles of the LDS-staged
+// GEMM read it three times), the 128 x 384 result tile never leaves the CU before the QKV passes.
+struct InfcQkvFwd {
+  int T = 0, Din = 0;
+  const bf16_t* xhat = nullptr;   // [T, Din]
+  const bf16_t* win = nullptr;    // P48 [384 x Din] (LayerNorm gain folded)
+  const float* bin = nullptr;     // [384] folded bias
+  const float* pe = nullptr; int T0 = 0, L1 = 1, L2 = 1;  // pe[pos][384]; pos = row < T0 ? row % L1 : (row - T0) % L2
+  const bf16_t* wqkv = nullptr; const float* bqkv = nullptr;
+  bf16_t *h0 = nullptr, *z0 = nullptr, *qkv = nullptr;
+};
+int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st);
+
 // qkv = z . Wqkv^T + (bq | bk | bv): three full-width passes over one LDS-resident token tile (the LDS-staged GEMM re-reads
 // the token slab once per 128-column block: 9 times)
 struct QkvFwd { int T = 0; const bf16_t* z = nullptr; const bf16_t* wqkv = nullptr; const float* bias = nullptr; bf16_t* qkv = nullptr; };

@@ -688,6 +688,99 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   stamp();
 }
 
+// ---- input FC (K = Din, streamed) + GELU + pe + QKV -----------------------------------------------------------------
+constexpr int XPITCH = 80;  // bf16 elements per row of a 64-column slab (160 B: conflict-free fragment reads)
+
+__global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
+  constexpr int RF = 8, BT = 128, RR = 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4 + 4 * FZ_D * 4];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);          // during the K loop: two [128][80] slabs of xhat
+  float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
+  float* Bsm = reinterpret_cast<float*>(smem + BT * APITCH * 2 + RR * SPITCH * 4);  // bin | bq | bk | bv
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * BT, Din = p.Din;
+  if (tid < FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[tid] = reinterpret_cast<const f32x4_t*>(p.bin)[tid];
+  else if (tid < 4 * FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[tid] = reinterpret_cast<const f32x4_t*>(p.bqkv)[tid - FZ_D / 4];
+  bf16_t* Xs = As;  // [2][BT * XPITCH]
+  // slab staging: 128 rows x 64 columns = 1024 16-byte chunks, two per thread (rows r and r + 64)
+  const int sr = tid >> 3, sc = (tid & 7) * 8;
+  const unsigned g0 = (unsigned)((row0 + sr) * Din + sc) * 2u, g1 = (unsigned)((row0 + sr + 64) * Din + sc) * 2u;
+  u32x4_t xr[2];
+  auto gload = [&](int k0) { xr[0] = gld16(p.xhat, g0 + (unsigned)k0 * 2u); xr[1] = gld16(p.xhat, g1 + (unsigned)k0 * 2u); };
+  auto sstore = [&](int buf) {
+    *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + sr * XPITCH + sc]) = xr[0];
+    *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + (sr + 64) * XPITCH + sc]) = xr[1];
+  };
+  f32x4_t acc[RF][3];
+  zero_acc<RF>(acc);
+  const int nkb = Din / 32, nslab = Din / 64;
+  const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(p.win + (long)wave * nkb * 3 * 512) + lane;
+  bf16x8_t w[4][3];  // ring over k-blocks: slab s uses k-blocks 2 s, 2 s + 1 -> ring slots (2 (s & 1) + kk)
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) w[kb][b] = wp[(kb * 3 + b) * 64];
+  gload(0);
+  sstore(0);
+  if (nslab > 1) gload(64);
+  __syncthreads();
+  const bf16_t* arow = Xs + (lane & 15) * XPITCH + (lane >> 4) * 8;
+  auto slab = [&](int s, auto parity) {
+    constexpr int PAR = decltype(parity)::value;
+    // weights of the NEXT slab into the other half of the ring (two k-blocks ahead of their use)
+    if (s + 1 < nslab) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[2 * (1 - PAR) + kk][b] = wp[(((s + 1) * 2 + kk) * 3 + b) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t* ab = arow + PAR * BT * XPITCH;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int a = 0; a < RF; ++a) {
+        const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(ab + a * 16 * XPITCH + kk * 32);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2 * PAR + kk][b], xf, acc[a][b], 0, 0, 0);
+      }
+    // next slab: registers -> the other LDS buffer (its previous readers finished before the last barrier), then the
+    // loads of the slab after it
+    if (s + 1 < nslab) sstore(1 - PAR);
+    if (s + 2 < nslab) gload((s + 2) * 64);
+    __syncthreads();
+  };
+#pragma unroll 1
+  for (int s = 0; s < nslab; s += 2) {
+    slab(s, std::integral_constant<int, 0>{});
+    if (s + 1 < nslab) slab(s + 1, std::integral_constant<int, 1>{});
+  }
+  // ---- epilogue: + folded bias, save h0, GELU, + pe -> z0 (tile + global) ------------------------------------------
+  struct PrePe { f32x4_t a, b; };
+  epilogue<RF, 8>(acc, Stg, As, row0, Bsm,
+      [&](int row, int col) {
+        const int pos = row < p.T0 ? row % p.L1 : (row - p.T0) % p.L2;
+        const float* pp = p.pe + (long)pos * FZ_D + col;
+        return PrePe{*reinterpret_cast<const f32x4_t*>(pp), *reinterpret_cast<const f32x4_t*>(pp + 4)};
+      },
+      [&](int row, int col, float (&v)[8], const PrePe& pr, int) {
+        gst16(p.h0, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        v[0] += pr.a[0]; v[1] += pr.a[1]; v[2] += pr.a[2]; v[3] += pr.a[3]; v[4] += pr.b[0]; v[5] += pr.b[1]; v[6] += pr.b[2]; v[7] += pr.b[3];
+        gst16(p.z0, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+      }, true);
+  // ---- QKV ------------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
+  for (int q = 0; q < 3; ++q) {
+    zero_acc<RF>(acc);
+    gemm_pass<RF, 12>(As, p.wqkv + (q * 8 + wave) * GSZ, acc, lane);
+    epilogue<RF, 8>(acc, Stg, As, row0, Bsm + (1 + q) * FZ_D, [&](int, int) { return PreNone{}; },
+        [&](int row, int col, float (&v)[8], const PreNone&, int) { gst16(p.qkv, (unsigned)(row * (3 * FZ_D) + q * FZ_D + col) * 2u, pack8(v)); },
+        false);
+  }
+}
+
 // ---- QKV projection (forward) and its dX (backward) on full-width token tiles ---------------------------------------
 __global__ __launch_bounds__(512) void qkv_fwd_kernel(QkvFwd p) {
   constexpr int RF = 8, BT = 128, RR = 32;
@@ -864,6 +957,19 @@ int launch_qkv_bwd(const QkvBwd& p, hipStream_t st) {
     hipLaunchKernelGGL(colsum_tiles_kernel, dim3((FZ_D + 63) / 64), dim3(256), 0, st, (const float*)p.part, tiles, FZ_D, p.colsum);
     COOT_CHECK_LAUNCH("colsum_tiles");
   }
+  return 0;
+}
+}  // namespace coot
+
+namespace coot {
+int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st) {
+  COOT_REQUIRE(p.xhat && p.win && p.bin && p.pe && p.wqkv && p.bqkv && p.h0 && p.z0 && p.qkv, "infc_qkv_fwd: null pointer");
+  COOT_REQUIRE(p.Din % 64 == 0 && p.Din >= 128 && p.L1 > 0 && p.L2 > 0, "infc_qkv_fwd: Din = %d must be a multiple of 64", p.Din);
+  if (p.T <= 0) return 0;
+  void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * (p.Din + 1152.0), 0, st);
+  hipLaunchKernelGGL(infc_qkv_fwd_kernel, dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+  timing_end(ts, st);
+  COOT_CHECK_LAUNCH("infc_qkv_fwd");
   return 0;
 }
 }  // namespace coot
