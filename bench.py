@@ -187,7 +187,8 @@ def main():
         names = {2: "gemm_nt_kernel (LDS-staged bf16 MFMA GEMM: Linear fwd + dX of the local networks)",
                  3: "gemm_nt_small_kernel (direct-from-L2 fragments, M <= 512: global networks)",
                  4: "gemm_tn_kernel + gemm_tn_reduce_kernel (weight gradients, split over tokens)",
-                 5: "post_attn_fwd_kernel (fused token-tile chain: out-proj, FF1, FF2, pooling MLP)"}
+                 5: "fused token-tile chain kernels (post_attn_fwd, pre_attn_bwd, qkv_fwd, qkv_bwd: LDS-resident 128 x 384 tile, "
+                    "384-wide GEMM passes with L2-streamed weights)"}
 
         def collect(sel):
             ms, fl, n = C.c_double(), C.c_double(), C.c_int()
