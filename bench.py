@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="library A/B switch name=value (coot_set_option), repeatable")
+    ap.add_argument("--step-stamps", action="store_true", help="print a HIP-event timeline of one training step to stderr")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--mode", default="native", choices=["native", "autograd", "graph"],
                     help="native: one C call per step (default); autograd: torch autograd Functions; graph: autograd step in a HIP graph")
@@ -172,6 +173,15 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(last)
+    if args.step_stamps and rank == 0 and not args.eval:
+        # HIP-event timeline of one more step, enqueued behind two others so the host is ahead as in the timed loop
+        lib.coot_set_option(b"step_stamps", 1)
+        for _ in range(3):
+            step()
+        buf = C.create_string_buffer(8192)
+        lib.coot_debug_step_stamps(buf, 8192)
+        lib.coot_set_option(b"step_stamps", 0)
+        sys.stderr.write("step timeline (HIP events, us since the step's first launch):\n" + buf.value.decode())
     ms_per_step = 1e3 * elapsed / args.steps
     value = clip_pairs * args.steps / elapsed
 

@@ -539,8 +539,10 @@ extern "C" {
 const char* coot_last_error(void) { return coot::g_err; }
 int coot_version(void) { return 1; }
 int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)dev_u64; return 0; }
+extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
 int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
+  if (!strcmp(name, "step_stamps")) { coot_step_stamps_enable(value); return 0; }
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
   if (!strcmp(name, "fused_bwd")) { g_use_fused_bwd = value; return 0; }
   if (!strcmp(name, "fused_infc")) { g_use_fused_infc = value; return 0; }

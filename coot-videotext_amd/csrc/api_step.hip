@@ -82,44 +82,68 @@ int check_cfg(const coot_step_config& c) {
   return 0;
 }
 
-// fork/join between the caller's main stream and the two side streams
-struct StreamJoin {
-  hipEvent_t ev[3]; bool made = false;
+// Cross-stream ordering.  A hop (event record + stream wait) costs ~30 us of latency on this stack (measured with the
+// step stamps below: 4 hops on the critical path of a 2.1 ms step), so the step is laid out to keep the heavier video
+// side on ONE stream from its first launch to its Adam update: the caller may pass side_v == main (hops between equal
+// streams vanish), the losses run on the video stream, and every hop left on the critical path waits for the text side,
+// which has slack.
+struct Hops {
+  static constexpr int N = 8;
+  hipEvent_t ev[N]; bool made = false;
   int init() {
     if (made) return 0;
-    for (int i = 0; i < 3; ++i) RUN(check_hip(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "hipEventCreate"));
+    for (int i = 0; i < N; ++i) RUN(check_hip(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "hipEventCreate"));
     made = true; return 0;
   }
-  int fork(hipStream_t main, hipStream_t a, hipStream_t b) {
-    RUN(init());
-    RUN(check_hip(hipEventRecord(ev[0], main), "eventRecord"));
-    RUN(check_hip(hipStreamWaitEvent(a, ev[0], 0), "streamWait"));
-    RUN(check_hip(hipStreamWaitEvent(b, ev[0], 0), "streamWait"));
-    return 0;
+  // everything enqueued on `to` after this call runs after everything enqueued on `from` before it
+  int hop(int slot, hipStream_t from, hipStream_t to) {
+    if (from == to) return 0;
+    RUN(record(slot, from));
+    return wait(slot, to);
   }
-  int join(hipStream_t main, hipStream_t a, hipStream_t b) {
-    RUN(check_hip(hipEventRecord(ev[1], a), "eventRecord"));
-    RUN(check_hip(hipEventRecord(ev[2], b), "eventRecord"));
-    RUN(check_hip(hipStreamWaitEvent(main, ev[1], 0), "streamWait"));
-    RUN(check_hip(hipStreamWaitEvent(main, ev[2], 0), "streamWait"));
-    return 0;
+  // the two halves, for a wait that is enqueued later than the record
+  int record(int slot, hipStream_t from) {
+    RUN(init());
+    return check_hip(hipEventRecord(ev[slot], from), "eventRecord");
+  }
+  int wait(int slot, hipStream_t to) { return check_hip(hipStreamWaitEvent(to, ev[slot], 0), "streamWait"); }
+};
+thread_local Hops g_hops;
+
+// Coarse timeline of one step measured with HIP events (coot_set_option("step_stamps", 1); coot_debug_step_stamps()):
+// a profiler's launch interception makes this path host-bound, so whether the two sides really overlap can only be
+// seen with events recorded by the step itself.
+struct StepStamps {
+  static constexpr int MAXN = 40;
+  hipEvent_t ev[MAXN]; const char* label[MAXN]; int n = 0, made = 0; bool on = false;
+  void begin() { n = 0; }
+  void mark(const char* what, hipStream_t st) {
+    if (!on || n >= MAXN) return;
+    if (made <= n) { if (hipEventCreate(&ev[n]) != hipSuccess) return; made = n + 1; }
+    if (hipEventRecord(ev[n], st) != hipSuccess) return;
+    label[n++] = what;
   }
 };
-thread_local StreamJoin g_join;
+StepStamps g_stamps;
 
 // one side (video or text): local(ctx segment + item segment) -> pack -> global
 int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, int gi, const float* ctx_feat, const int64_t* ctx_len,
                  int Lctx, const float* item_feat, const int64_t* item_len, int Litem, const int64_t* item_num, int Cmax,
                  const coot_step_dims& d, float* local_out, float* glob_out, float* resh, unsigned char* mask, long long* lens,
-                 void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, int train, uint64_t seed, hipStream_t st) {
+                 void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, int train, uint64_t seed, hipStream_t st, bool pack = true) {
   const int D = c.net[0].hidden_dim;
-  RUN(coot_net_pack_weights(&c.net[li], b.params[li], b.wpack[li], st));
-  RUN(coot_net_pack_weights(&c.net[gi], b.params[gi], b.wpack[gi], st));
+  if (pack) {
+    RUN(coot_net_pack_weights(&c.net[li], b.params[li], b.wpack[li], st));
+    RUN(coot_net_pack_weights(&c.net[gi], b.params[gi], b.wpack[gi], st));
+  }
+  g_stamps.mark(li == 0 ? "video: weights packed" : "text: weights packed", st);
   RUN(coot_net_fwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
                    nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, nullptr, st));
+  g_stamps.mark(li == 0 ? "video: local forward done" : "text: local forward done", st);
   RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
   RUN(coot_net_fwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0,
                    local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi, nullptr, st));
+  g_stamps.mark(li == 0 ? "video: global forward done" : "text: global forward done", st);
   return 0;
 }
 
@@ -131,13 +155,16 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
                   const float* d_resh, float* dhid, float* dfeat, void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, void* scratch,
                   size_t sz_scratch, int train, uint64_t seed, hipStream_t st) {
   const int D = c.net[0].hidden_dim;
+  g_stamps.mark(li == 0 ? "video: backward starts" : "text: backward starts", st);
   RUN(coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
                    b.grads[gi], dhid, dfeat, saved_g, sz_g, scratch, sz_scratch, train, seed + 11 * gi, nullptr, st));
+  g_stamps.mark(li == 0 ? "video: global backward done" : "text: global backward done", st);
   RUN(launch_axpy_f32(d_local, dhid, (long)d.B * D, 1.0f, st));                               // context grad += dhidden
   RUN(launch_pack_bwd(dfeat, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));  // item grads += unpack(global input grad)
   if (d_resh) RUN(launch_pack_bwd(d_resh, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));
   RUN(coot_net_bwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem, nullptr,
                    d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_scratch, train, seed + 11 * li, nullptr, st));
+  g_stamps.mark(li == 0 ? "video: local backward done" : "text: local backward done", st);
   return 0;
 }
 
@@ -210,6 +237,27 @@ __global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, float lr, float
   }
 }
 
+__global__ void loss_total_kernel(float* losses) { losses[0] = losses[1] + losses[2]; }
+
+// Adam update of `count` parameter arenas in ONE launch (four dependent 13 us launches used to end the step)
+int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int* nets, int count, int64_t step, hipStream_t st) {
+  AdamSegs sg;
+  int blk = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int i = nets[k < count ? k : count - 1];
+    const long n = k < count ? (long)coot_net_param_numel(&cfg.net[i]) : 0;
+    sg.p[k] = b.params[i]; sg.g[k] = b.grads[i]; sg.m[k] = b.adam_m[i]; sg.v[k] = b.adam_v[i]; sg.decay[k] = b.decay_mask[i]; sg.n[k] = n;
+    sg.blk0[k] = blk;
+    blk += (int)((n / 4 + 255) / 256);
+  }
+  sg.blk0[4] = blk;
+  const double bc1 = 1.0 - pow((double)cfg.beta1, (double)step), bc2 = 1.0 - pow((double)cfg.beta2, (double)step);
+  hipLaunchKernelGGL(adam4_kernel, dim3(blk), dim3(256), 0, st, sg, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay,
+                     (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+  COOT_CHECK_LAUNCH("adam4");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -239,12 +287,14 @@ int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, c
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
   COOT_REQUIRE(!A.overflow, "step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
-  RUN(g_join.fork(sm, sv, st));
+  RUN(g_hops.hop(0, sm, sv));
+  RUN(g_hops.hop(1, sm, st));
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                    local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv));
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
                    local_t, glob_t, resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st));
-  RUN(g_join.join(sm, sv, st));
+  RUN(g_hops.hop(2, sv, sm));
+  RUN(g_hops.hop(3, st, sm));
   return 0;
 }
 
@@ -257,14 +307,16 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* b, 
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
   COOT_REQUIRE(!A.overflow, "step: workspace too small");
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
-  RUN(g_join.fork(sm, sv, st));
+  RUN(g_hops.hop(0, sm, sv));
+  RUN(g_hops.hop(1, sm, st));
   RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d, local_v,
                     resh_v, d_local_v, d_glob_v, d_resh_v, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, W.scratch_v,
                     W.sz_sv, train, seed, sv));
   RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, local_t,
                     resh_t, d_local_t, d_glob_t, d_resh_t, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, W.scratch_t,
                     W.sz_st, train, seed + 1000, st));
-  RUN(g_join.join(sm, sv, st));
+  RUN(g_hops.hop(2, sv, sm));
+  RUN(g_hops.hop(3, st, sm));
   return 0;
 }
 
@@ -275,49 +327,86 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   COOT_REQUIRE(losses, "train_step: losses pointer");
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
   COOT_REQUIRE(!A.overflow, "train_step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
-  hipStream_t sm = (hipStream_t)main_s;
+  hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
+  COOT_REQUIRE(sv != st, "train_step: the two side streams must differ");
   const int D = cfg->net[0].hidden_dim;
-  // zero: parameter gradients (4 arenas), embedding gradients (one block), the three loss words
+  const bool optimize = (do_optimizer & COOT_STEP_OPTIMIZER) != 0, repack = optimize && (do_optimizer & COOT_STEP_REPACK) != 0;
+  const bool pack_first = (do_optimizer & COOT_STEP_PACKS_FRESH) == 0;
+  g_stamps.begin();
+  g_stamps.mark("step starts", sm);
+  RUN(g_hops.hop(0, sm, sv));
+  RUN(g_hops.hop(1, sm, st));
+  // text stream (it has slack): zero the parameter gradients (4 arenas), the embedding gradients (one block), the loss words.
+  // The video side first touches them after hop 2 below.
   for (int i = 0; i < 4; ++i)
-    RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), sm), "memset grads"));
-  RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, sm), "memset embedding grads"));
-  RUN(check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), sm), "memset losses"));
-  RUN(coot_step_forward(cfg, b, x, d, W.local_v, W.local_t, W.glob_v, W.glob_t, W.resh_v, W.resh_t, workspace, workspace_bytes, train, seed,
-                        main_s, side_v, side_t));
-  // losses on the main stream: contrastive -> losses[1], cycle-consistency -> losses[2]
-  RUN(coot_contrastive_fwd_bwd(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
-                               W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
-                               W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
-                               W.sz_loss, main_s));
-  if (cfg->cc_weight != 0.f) {
-    hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * d->B + 255) / 256), dim3(256), 0, sm, (const long long*)x->clip_num,
+    RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), st), "memset grads"));
+  RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, st), "memset embedding grads"));
+  RUN(check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), st), "memset losses"));
+  g_stamps.mark("text: gradients zeroed", st);
+  RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
+                   W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first));
+  RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
+                   W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st,
+                   pack_first));
+  RUN(g_hops.hop(2, st, sv));
+  g_stamps.mark("video: text forward joined", sv);
+  const bool cc = cfg->cc_weight != 0.f;
+  if (cc) {  // cycle-consistency -> losses[2] on the text stream, next to the contrastive loss on the video stream
+    RUN(g_hops.hop(6, sv, st));
+    hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * d->B + 255) / 256), dim3(256), 0, st, (const long long*)x->clip_num,
                        (const long long*)x->sent_num, d->B, (unsigned long long)seed, W.idx);
     COOT_CHECK_LAUNCH("sample_idx");
     RUN(coot_cyclecons_fwd_bwd(W.resh_v, W.resh_t, x->clip_num, x->sent_num, (const int64_t*)W.idx, (const int64_t*)(W.idx + d->B), d->B,
                                d->Cmax_clip, d->Cmax_sent, D, cfg->cc_weight, 1.0f / (float)d->B, losses + 2, nullptr, nullptr, W.d_resh_v,
-                               W.d_resh_t, main_s));
+                               W.d_resh_t, side_t));
+    RUN(g_hops.record(7, st));
+    g_stamps.mark("text: cycle-consistency done", st);
   }
-  RUN(launch_axpy_f32(losses, losses + 1, 1, 1.0f, sm));
-  RUN(launch_axpy_f32(losses, losses + 2, 1, 1.0f, sm));
-  RUN(coot_step_backward(cfg, b, x, d, W.local_v, W.local_t, W.resh_v, W.resh_t, W.d_local_v, W.d_local_t, W.d_glob_v, W.d_glob_t,
-                         cfg->cc_weight != 0.f ? W.d_resh_v : nullptr, cfg->cc_weight != 0.f ? W.d_resh_t : nullptr, workspace,
-                         workspace_bytes, train, seed, main_s, side_v, side_t));
-  if (do_optimizer) {  // all four parameter arenas in ONE launch (four dependent 13 us launches ended the step)
-    AdamSegs sg;
-    int blk = 0;
-    for (int i = 0; i < 4; ++i) {
-      const long n = coot_net_param_numel(&cfg->net[i]);
-      sg.p[i] = b->params[i]; sg.g[i] = b->grads[i]; sg.m[i] = b->adam_m[i]; sg.v[i] = b->adam_v[i]; sg.decay[i] = b->decay_mask[i]; sg.n[i] = n;
-      sg.blk0[i] = blk;
-      blk += (int)((n / 4 + 255) / 256);
-    }
-    sg.blk0[4] = blk;
-    const double bc1 = 1.0 - pow((double)cfg->beta1, (double)step), bc2 = 1.0 - pow((double)cfg->beta2, (double)step);
-    hipLaunchKernelGGL(adam4_kernel, dim3(blk), dim3(256), 0, sm, sg, cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay,
-                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
-    COOT_CHECK_LAUNCH("adam4");
-  }
+  // contrastive loss on the video stream -> losses[1]
+  RUN(coot_contrastive_fwd_bwd(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
+                               W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
+                               W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
+                               W.sz_loss, side_v));
+  g_stamps.mark("video: contrastive done", sv);
+  RUN(g_hops.hop(3, sv, st));  // text backward needs the contrastive gradients
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses);  // total = contrastive + cycle-consistency (not needed by the backward)
+  COOT_CHECK_LAUNCH("loss_total");
+  if (cc) RUN(g_hops.wait(7, sv));  // video backward needs d_resh_v (recorded on the text stream before it waited for the contrastive loss)
+  const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
+  RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d, W.local_v,
+                    W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv,
+                    W.scratch_v, W.sz_sv, train, seed, sv));
+  if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
+  if (repack) for (int i : vnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_v));
+  g_stamps.mark("video: updated", sv);
+  RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, W.local_t,
+                    W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt,
+                    W.scratch_t, W.sz_st, train, seed + 1000, st));
+  if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
+  if (repack) for (int i : tnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_t));
+  g_stamps.mark("text: updated", st);
+  RUN(g_hops.hop(4, sv, sm));
+  RUN(g_hops.hop(5, st, sm));
+  g_stamps.mark("step done", sm);
   return 0;
+}
+
+void coot_step_stamps_enable(int on) { g_stamps.on = on != 0; }
+
+// text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.
+int coot_debug_step_stamps(char* buf, int buf_bytes) {
+  if (!buf || buf_bytes <= 0) return 0;
+  buf[0] = 0;
+  if (g_stamps.n == 0) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  int off = 0;
+  for (int i = 0; i < g_stamps.n; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_stamps.ev[0], g_stamps.ev[i]) != hipSuccess) ms = -1.f;
+    off += snprintf(buf + off, off < buf_bytes ? buf_bytes - off : 0, "%9.1f us  %s\n", ms * 1e3f, g_stamps.label[i]);
+    if (off >= buf_bytes) break;
+  }
+  return g_stamps.n;
 }
 
 }  // extern "C"

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcoot_hip.so")
 
 EXPORTS = [
-    "coot_last_error", "coot_version", "coot_set_option", "coot_debug_timestamps", "coot_net_param_numel", "coot_net_param_count",
+    "coot_last_error", "coot_version", "coot_set_option", "coot_debug_timestamps", "coot_debug_step_stamps", "coot_net_param_numel", "coot_net_param_count",
     "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights",
     "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_pack_fwd",
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_cyclecons_fwd_bwd",
@@ -38,6 +38,9 @@ class ContrastiveConfig(C.Structure):
     _fields_ = [("margin", C.c_float), ("weight_high", C.c_float), ("weight_high_internal", C.c_float),
                 ("weight_low", C.c_float), ("weight_low_internal", C.c_float), ("weight_context", C.c_float),
                 ("weight_context_internal", C.c_float)]
+
+
+STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH = 1, 2, 4  # coot_train_step do_optimizer bits (include/coot_hip.h)
 
 
 class StepConfig(C.Structure):
@@ -81,6 +84,7 @@ def load():
     lib.coot_version.restype = i32
     lib.coot_set_option.argtypes = [C.c_char_p, i32]
     lib.coot_debug_timestamps.argtypes = [vp]
+    lib.coot_debug_step_stamps.argtypes = [C.c_char_p, i32]
     lib.coot_net_param_numel.restype = i64
     lib.coot_net_param_numel.argtypes = [cfgp]
     lib.coot_net_param_count.argtypes = [cfgp]

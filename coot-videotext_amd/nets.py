@@ -126,6 +126,16 @@ class TransformerHip(nn.Module):
         """Call after an optimizer step: the bf16 weight pack is rebuilt before the next forward."""
         self._dirty = True
 
+    def pack_is_fresh(self) -> bool:
+        """True when the bf16 weight pack matches the fp32 parameters (nothing touched them since the last packing)."""
+        return self._wpack is not None and not self._dirty and self._param_version() == getattr(self, "_packed_version", None)
+
+    def mark_packed(self) -> None:
+        """The library updated the parameters through the flat arena AND rebuilt the pack (coot_train_step with
+        COOT_STEP_REPACK): raw-pointer writes do not bump the tensors' version counters, so record the pack as current."""
+        self._dirty = False
+        self._packed_version = self._param_version()
+
     def bind_flat_grads(self) -> torch.Tensor:
         """Pre-assign every param.grad as a view of one flat fp32 gradient arena (zeroed), so the
         autograd accumulation lands in place and a fused optimizer / one all-reduce can use it."""

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Tuple
 
+import os
 import numpy as np
 import torch
 
@@ -222,7 +223,13 @@ class RetrievalTrainer:
                 st.decay.append(mask)
             st.bufs = _lib.StepBuffers()
             st.losses = torch.zeros(3, dtype=torch.float32, device=dev)
-            st.streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            # text side: a LOW priority stream — it has slack, the video side is the critical path of the step
+            prio = int(os.environ.get("COOT_TEXT_STREAM_PRIORITY", "1"))
+            try:
+                text_stream = torch.cuda.Stream(priority=prio)
+            except Exception:  # priority not supported by this runtime
+                text_stream = torch.cuda.Stream()
+            st.streams = (torch.cuda.Stream(), text_stream)
             st.step = 0
             st.dims_key = None
             self._native = st
@@ -272,11 +279,18 @@ class RetrievalTrainer:
             seed = (torch.initial_seed() * 1000003 + 7919 * (self.total_step + 1)) & 0xFFFFFFFFFFFFFFFF
         train = 1 if self.model_mgr.is_train else 0
         main = torch.cuda.current_stream()
-        _lib.check(lib.coot_train_step(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(st.dims), st.losses.data_ptr(),
-                                       st.ws.data_ptr(), st.ws.numel(), train, int(seed), max(st.step, 1), int(do_optimizer),
-                                       main.cuda_stream, st.streams[0].cuda_stream, st.streams[1].cuda_stream), "coot_train_step")
+        # the video side runs on the caller's stream itself (no cross-stream hop on the critical path), the text side on a side stream
+        flags = 0
         if do_optimizer:
-            self.model_mgr.mark_weights_dirty()
+            flags |= _lib.STEP_OPTIMIZER | _lib.STEP_REPACK
+        if all(n.pack_is_fresh() for n in st.nets):
+            flags |= _lib.STEP_PACKS_FRESH
+        _lib.check(lib.coot_train_step(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(st.dims), st.losses.data_ptr(),
+                                       st.ws.data_ptr(), st.ws.numel(), train, int(seed), max(st.step, 1), flags,
+                                       main.cuda_stream, main.cuda_stream, st.streams[1].cuda_stream), "coot_train_step")
+        if do_optimizer:  # the library rebuilt the bf16 packs right after its Adam update
+            for n in st.nets:
+                n.mark_packed()
         self.total_step += 1
         return st.losses[0], st.losses[1], st.losses[2]
 
@@ -323,7 +337,7 @@ class RetrievalTrainer:
             st.dp_key = key
         local_v, local_t, glob_v, glob_t, resh_v, resh_t = st.emb
         main = torch.cuda.current_stream()
-        sv, stt = st.streams
+        sv, stt = main, st.streams[1]  # video side on the caller's stream (no hop), text on a side stream
         for n in st.nets:
             n._grad_flat.zero_()
         for g in st.demb + st.dsets:

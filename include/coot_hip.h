@@ -46,6 +46,9 @@ int coot_version(void);
 int coot_set_option(const char* name, int value);
 /* profiling aid: device buffer (>= 64 x uint64) receiving s_memtime stamps of block 0 of the fused chain kernels (NULL = off) */
 int coot_debug_timestamps(void* dev_u64);
+/* coot_set_option("step_stamps", 1): coot_train_step records HIP events at its phase boundaries; this call synchronises
+ * the device and writes one line per boundary (microseconds since the start of the last step) into buf.  Profiling aid. */
+int coot_debug_step_stamps(char* buf, int buf_bytes);
 
 /* ---- parameter layout (flat fp32 arena per network; gradients use the same layout) -----------
  * Names and shapes are the reference state-dict names, e.g.
@@ -142,8 +145,14 @@ typedef struct coot_step_batch {                           /* RetrievalDataBatch
 } coot_step_batch;
 size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_dims* dims);
 /* One optimisation step in one call: grads zeroed, both sides encoded on side_v / side_t, contrastive +
- * cycle-consistency losses (cycle indices drawn on the device), backward, Adam (if do_optimizer; `step` is the 1-based
- * step count for the bias correction).  losses[3] = {total, contrastive, cycle-consistency} (device, overwritten). */
+ * cycle-consistency losses (cycle indices drawn on the device), backward, Adam (`step` is the 1-based step count for the
+ * bias correction).  losses[3] = {total, contrastive, cycle-consistency} (device, overwritten).
+ * do_optimizer: bit mask of COOT_STEP_*.  side_v may be the same stream as main_s (recommended: the heavier video side then
+ * runs without any cross-stream hop); side_t must differ from side_v.  On return main_s is ordered after both sides. */
+#define COOT_STEP_OPTIMIZER 1   /* Adam update of all four networks                                                          */
+#define COOT_STEP_REPACK 2      /* rebuild the bf16 weight packs right after the update (off the next step's critical path)  */
+#define COOT_STEP_PACKS_FRESH 4 /* wpack[] is current (previous step ran with REPACK and nothing else touched the parameters):
+                                   skip the packing at the start of the step                                                */
 int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
                     const coot_step_dims* dims, float* losses, void* workspace, size_t workspace_bytes, int train,
                     uint64_t seed, int64_t step, int do_optimizer, coot_stream_t main_stream, coot_stream_t side_v,
