@@ -346,6 +346,7 @@ static int g_use_fused_infc = 0;  // coot_set_option("fused_infc", 0/1): input F
 static int g_use_fused = 1;
 static int g_fz_debug = 0;
 static unsigned long long* g_fz_tstamps = nullptr;
+static int g_fused_fwd_small = 1;  // coot_set_option("fused_fwd_small", 0/1): forward chain on 32-token tiles below fused_min_rows
 static int g_fused_min_rows = 1024;  // below this many tokens the per-op kernels win (one or two tiles cannot fill the chip)  // coot_set_option("fused", 0/1): A/B switch between the fused chains and the per-op kernels
 
 static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp, const LayerW& lw, const bf16_t* xq, int rows_q,
@@ -375,7 +376,7 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
   a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
   a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
   RUN(attention_all(a, sg, !self, false, st));
-  if (lw.f_wo && g_use_fused && (rows_q >= g_fused_min_rows || pool)) {  // out-proj ... LN2 (and the GenPool score MLP) as ONE launch over token tiles
+  if (lw.f_wo && g_use_fused && (rows_q >= g_fused_min_rows || pool || g_fused_fwd_small)) {  // out-proj ... LN2 (and the GenPool score MLP) as ONE launch over token tiles
     PostAttnFwd f; f.T = rows_q; f.ctx = b.ctx; f.xres = xq; f.wo = lw.f_wo; f.w1 = lw.f_w1; f.w2 = lw.f_w2;
     f.bo = P + lp.bo; f.ln1g = P + lp.ln1g; f.ln1b = P + lp.ln1b; f.b1 = P + lp.b1; f.b2 = P + lp.b2; f.ln2g = P + lp.ln2g; f.ln2b = P + lp.ln2b;
     f.r1 = b.r1; f.z1 = b.z1; f.h1 = b.h1; f.a1 = b.a1; f.r2 = b.r2; f.z2 = b.z2; f.z2_f32 = z2_f32; f.ldz2_f32 = ldz2_f32;
@@ -551,6 +552,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
+  if (!strcmp(name, "fused_fwd_small")) { g_fused_fwd_small = value; return 0; }
   set_error("unknown option %s", name);
   return -2;
 }

@@ -906,8 +906,15 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   // GEMM passes of the chain: out-proj, FF1, FF2 (+ pool FC1 768 wide, FC2 384 wide): 2 * T * 384 * 384 each
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 384.0 * (p.do_pool ? 6.0 : 3.0), 0, st);
   const bool drop = p.d_postln.thr || p.d_ff1.thr || p.d_ff2.thr || p.d_pool1.thr || p.d_pool2.thr;
-  if (drop) {
+  if (drop)
     COOT_REQUIRE(p.d_postln.thr && p.d_ff1.thr && p.d_ff2.thr && (!p.do_pool || (p.d_pool1.thr && p.d_pool2.thr)), "post_attn_fwd: dropout on some sites only");
+  // Few tokens (the global networks: one row per clip): 32-token tiles.  The chain is then bound by every workgroup
+  // streaming the three weight matrices from L2, not by the MFMAs — but it is ONE launch instead of five dependent ones.
+  const bool small = !p.do_pool && p.T < 1024;
+  if (small) {
+    if (drop) hipLaunchKernelGGL((post_attn_fwd_kernel<2, true>), dim3((p.T + 31) / 32), dim3(NTHR), 0, st, p);
+    else hipLaunchKernelGGL((post_attn_fwd_kernel<2, false>), dim3((p.T + 31) / 32), dim3(NTHR), 0, st, p);
+  } else if (drop) {
     hipLaunchKernelGGL((post_attn_fwd_kernel<8, true>), dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
   } else {
     hipLaunchKernelGGL((post_attn_fwd_kernel<8, false>), dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
