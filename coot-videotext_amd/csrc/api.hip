@@ -550,6 +550,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_small")) { set_gemm_small(value); return 0; }
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
   if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
+  if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   if (!strcmp(name, "fused_fwd_small")) { g_fused_fwd_small = value; return 0; }

@@ -16,6 +16,7 @@ struct AttnArgs {
   const long long* lens = nullptr;          // [Nseq] valid keys
   int Nseq = 0, Lq = 0, Lk = 0, H = 0, dh = 0;
   float scale = 1.0f;
+  int xcd_order = 1;                        // short kernels: XCD-aware (sequence, head) order (set by the launcher)
   DropCfg drop;                             // dropout on the attention probabilities
   // backward only
   const bf16_t* dout = nullptr; long lddo = 0;

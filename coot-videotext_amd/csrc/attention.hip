@@ -7,6 +7,7 @@
 // The dK/dV kernel uses the mirrored orientation (lane owns one key).
 // K/V (resp. Q/dO) chunks of 64 rows are staged in LDS both row-major and transposed.
 #include "attention.h"
+#include "gemm.h"
 
 namespace coot {
 
@@ -361,6 +362,18 @@ __device__ __forceinline__ s16x4_t tr16(const bf16_t* tile, int pitch, int lane)
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(addr));
 }
 
+// Workgroup -> (sequence, head), XCD aware: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.
+// The heads of one sequence read interleaved 96-byte runs of the same q | k | v rows (and write interleaved runs of dq | dk
+// | dv), so they belong on ONE XCD, next to each other in time: id = 64 (n / 8) + 8 h + n % 8.  With (head, sequence) as
+// the grid, id % 8 = h: every 128-byte line was fetched (and partially written) by up to 8 different L2s.
+__device__ __forceinline__ bool short_wg(const AttnArgs& a, int& n, int& h) {
+  const int id = blockIdx.x, g = id / (8 * a.H), r = id - g * (8 * a.H);
+  if (a.xcd_order) { h = r >> 3; n = g * 8 + (r & 7); }
+  else { h = id % a.H; n = id / a.H; }
+  return n < a.Nseq;
+}
+static inline int short_grid(const AttnArgs& a) { return ((a.Nseq + 7) / 8) * 8 * a.H; }
+
 template <int DH>
 __device__ __forceinline__ void stage_rows(const bf16_t* src, long ld, long rowbase, int L, int L16, int c0, bf16_t* R) {
   constexpr int RP = AttnSmem<DH>::RP, CPR = DH / 8;
@@ -377,7 +390,9 @@ __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
   constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
   extern __shared__ __attribute__((aligned(16))) bf16_t sh_lds[];  // K | V, L16 rows each (sized by the launcher)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int n = blockIdx.y, h = blockIdx.x, L = a.Lk, L16 = nw * 16;
+  int n, h;
+  if (!short_wg(a, n, h)) return;
+  const int L = a.Lk, L16 = nw * 16;
   bf16_t* Ks = sh_lds;
   bf16_t* Vs = sh_lds + L16 * RP;
   const int nvalid = (int)a.lens[n];
@@ -463,7 +478,9 @@ __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
   constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
   extern __shared__ __attribute__((aligned(16))) bf16_t sh_lds[];  // K | V | Q | dO (L16 rows each) | lse, delta (fp32)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int n = blockIdx.y, h = blockIdx.x, L = a.Lk, L16 = nw * 16;
+  int n, h;
+  if (!short_wg(a, n, h)) return;
+  const int L = a.Lk, L16 = nw * 16;
   bf16_t* Ks = sh_lds;
   bf16_t* Vs = Ks + L16 * RP;
   bf16_t* Qs = Vs + L16 * RP;
@@ -602,10 +619,12 @@ void set_attn_short(int on) { g_attn_short = on; }
 static bool attn_short_ok(const AttnArgs& a) { return g_attn_short && a.Lq == a.Lk && a.Lk <= 16 * SH_MAXW && a.Lk >= 1; }
 
 template <int DH>
-static int attn_fwd_t(const AttnArgs& a, hipStream_t st) {
+static int attn_fwd_t(const AttnArgs& a_in, hipStream_t st) {
+  AttnArgs a = a_in;
+  a.xcd_order = get_xcd_order() & 4;
   if (attn_short_ok(a)) {
     const int nw = (a.Lk + 15) / 16;
-    hipLaunchKernelGGL(attn_short_fwd_kernel<DH>, dim3(a.H, a.Nseq), dim3(64 * nw), (size_t)2 * nw * 16 * AttnSmem<DH>::RP * sizeof(bf16_t), st, a);
+    hipLaunchKernelGGL(attn_short_fwd_kernel<DH>, dim3(short_grid(a)), dim3(64 * nw), (size_t)2 * nw * 16 * AttnSmem<DH>::RP * sizeof(bf16_t), st, a);
     COOT_CHECK_LAUNCH("attn_short_fwd");
     return 0;
   }
@@ -615,10 +634,12 @@ static int attn_fwd_t(const AttnArgs& a, hipStream_t st) {
   return 0;
 }
 template <int DH>
-static int attn_bwd_t(const AttnArgs& a, hipStream_t st) {
+static int attn_bwd_t(const AttnArgs& a_in, hipStream_t st) {
+  AttnArgs a = a_in;
+  a.xcd_order = get_xcd_order() & 4;
   if (attn_short_ok(a)) {
     const int nw = (a.Lk + 15) / 16;
-    hipLaunchKernelGGL(attn_short_bwd_kernel<DH>, dim3(a.H, a.Nseq), dim3(64 * nw),
+    hipLaunchKernelGGL(attn_short_bwd_kernel<DH>, dim3(short_grid(a)), dim3(64 * nw),
                        (size_t)4 * nw * 16 * AttnSmem<DH>::RP * sizeof(bf16_t) + (size_t)2 * nw * 16 * sizeof(float), st, a);
     COOT_CHECK_LAUNCH("attn_short_bwd");
     return 0;

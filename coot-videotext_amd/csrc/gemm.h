@@ -33,6 +33,7 @@ struct GemmNT {
   const int* M_dev = nullptr;  // optional device-side row count (<= M): tiles beyond it exit
   // grouped launch: blockIdx.z = g adds these element offsets
   int groups = 1; long zX = 0, zW = 0, zOut = 0;  // zOut applies to out/aux/save_pre/res/bias/colsum columns
+  int xcd_order = 1;  // set by the launcher (coot_set_option("xcd_order", 0/1))
   GemmEpi epi;
 };
 
@@ -61,6 +62,8 @@ int tn_batch_flush(hipStream_t stream);
 void tn_batch_end();
 // 1 (default): batched problems with Mo % 384 == 0 use the 384 x 128 output tiles; 0: always 128 x 128 (A/B switch)
 void set_tn_wide(int on);
+void set_xcd_order(int bits);  // XCD-aware workgroup -> tile order: 1 = gemm_nt, 4 = short attention (A/B switch)
+int get_xcd_order();
 // default workspace used by launch_gemm_tn when GemmTN::ws is null (set by the orchestrator for one call)
 void set_tn_default_workspace(float* ws, size_t floats);
 

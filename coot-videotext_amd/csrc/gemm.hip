@@ -113,7 +113,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (linear id % 8), each with a private L2.  The column
+  // blocks of one token slab share that slab, so they are given ids of the SAME residue, 8 apart (same L2, consecutive
+  // in time): id = 8 nb G + 8 bx + (by % 8), by = 8 G + id % 8.  With id = bx + nb by every slab was pulled into nb L2s.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_order) {
+    const int nb = gridDim.x, id = blockIdx.x + nb * blockIdx.y, grp = id / (8 * nb), r = id - grp * (8 * nb);
+    bx = r >> 3;
+    by = grp * 8 + (r & 7);
+  }
+  const int row0 = by * BM, col0 = bx * BN;
   const int M = g.M_dev ? min(g.M, *g.M_dev) : g.M;
   if (row0 >= M) return;
   const int z = blockIdx.z;
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
       }
       __syncthreads();
       if (tid < 128 && col0 + tid < N)
-        e.colsum_ws[(long)blockIdx.y * e.ld_colsum_ws + zo + col0 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+        e.colsum_ws[(long)(row0 / BM) * e.ld_colsum_ws + zo + col0 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
     } else if (lane < 16 && cok) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) atomicAdd(e.colsum + zo + col + j, csum[j]);
@@ -410,6 +419,7 @@ void timing_end(void* slot, hipStream_t stream) {
   if (slot) (void)hipEventRecord(static_cast<TimingSlot*>(slot)->b, stream);
 }
 
+static int g_xcd_order = 5;  // coot_set_option("xcd_order", bits): 1 = gemm_nt tile order, 4 = short attention (sequence, head) order
 int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
   GemmNT g = g_in;
   COOT_REQUIRE(g.X && g.W && g.epi.out, "gemm_nt: null operand");
@@ -420,6 +430,7 @@ int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
   COOT_REQUIRE(g.epi.ldres % 8 == 0 && g.epi.ldaux % 8 == 0 && g.epi.ldpre % 8 == 0 && g.epi.ldres32 % 4 == 0 && g.epi.lddiag % 8 == 0,
                "gemm_nt: epilogue strides must be multiples of 8");
   if (g.M <= 0 || g.N <= 0) return 0;
+  g.xcd_order = g_xcd_order & 1;
   if (g.M <= 512 && g_small_on) {  // global networks / loss strips: direct-from-L2 fragments, no LDS
     void* ts = timing_begin(TIMING_NT_SMALL, 2.0 * g.M * g.N * g.K * g.groups, 0, stream);
     g.epi.colsum_ws = nullptr;
@@ -445,13 +456,9 @@ int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
     g.epi.ld_colsum_ws = ccols;
   }
   void* ts = timing_begin(TIMING_NT, 2.0 * g.M * g.N * g.K * g.groups, g.K >= 1024, stream);
-  if (big) {
-    dim3 grid(nb, row_blocks, g.groups);
-    hipLaunchKernelGGL(gemm_nt_kernel<128>, grid, dim3(256), 0, stream, g);
-  } else {
-    dim3 grid(nb, row_blocks, g.groups);
-    hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, stream, g);
-  }
+  const dim3 grid(nb, (row_blocks + 7) / 8 * 8, g.groups);  // whole groups of 8 token slabs (XCD-aware tile order)
+  if (big) hipLaunchKernelGGL(gemm_nt_kernel<128>, grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, stream, g);
   timing_end(ts, stream);
   COOT_CHECK_LAUNCH("gemm_nt");
   if (g.epi.colsum_ws) return launch_reduce_partials(g.epi.colsum_ws, row_blocks, ccols, ccols, g.epi.colsum, stream);
@@ -835,6 +842,8 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_batch_kernel(TnBatch b, floa
   for (int t = 1; t < b.n; ++t) if ((int)blockIdx.x >= b.it[t].blk0) i = t;
   const TnItem& it = b.it[i];
   const int local = blockIdx.x - it.blk0;
+  // (an XCD-aware order — the gx column blocks of one dY slab on one XCD — was measured 6 % SLOWER on the whole step: the
+  // blocks of a slab then start together on one L2 and queue on the same channels; id = bx + gx * (...) spreads them)
   const int bx = local % it.gx, by = (local / it.gx) % it.gy, bz = local / (it.gx * it.gy);
   gemm_tn_wide_body(it.g, bx, by, bz, it.t_per_split, it.direct ? nullptr : ws_base + it.ws_off, it.direct);
 }
@@ -903,6 +912,8 @@ void tn_batch_begin() { g_tn_collect = true; g_tn_nitems = 0; }
 
 static int g_tn_wide = 1;
 void set_tn_wide(int on) { g_tn_wide = on; }
+void set_xcd_order(int on) { g_xcd_order = on; }
+int get_xcd_order() { return g_xcd_order; }
 
 int tn_batch_flush(hipStream_t stream) {
   const int n = g_tn_nitems;
