@@ -483,6 +483,8 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
   a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
   a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
   a.dout = w.dctx; a.lddo = D; a.delta = w.delta; a.dq = w.dq; a.lddq = w.lddq; a.dk = w.dk; a.lddk = w.lddk; a.dv = w.dv; a.lddv = w.lddv;
+  // the weight gradients recorded so far (pooling MLP, FF2, FF1, out-proj) next to the attention backward, if the step gave an aux stream
+  if (fused && self) RUN(tn_batch_flush_aux(st));
   RUN(attention_all(a, sg, !self, true, st));
   if (self) {
     // bq | bk | bv gradients = column sums of dqkv: taken by the weight-gradient GEMM that streams dqkv anyway
@@ -541,6 +543,7 @@ const char* coot_last_error(void) { return coot::g_err; }
 int coot_version(void) { return 1; }
 int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)dev_u64; return 0; }
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
+extern "C" void coot_step_tn_aux(int sides);
 int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
   if (!strcmp(name, "step_stamps")) { coot_step_stamps_enable(value); return 0; }
@@ -551,6 +554,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
   if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
+  if (!strcmp(name, "tn_aux")) { coot_step_tn_aux(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   if (!strcmp(name, "fused_fwd_small")) { g_fused_fwd_small = value; return 0; }
@@ -891,6 +895,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     RUN(launch_ln_bwd(l, st));
     RUN(tn_batch_flush(st));
   }
+  RUN(tn_batch_join(st));
   (void)pe; (void)hidden;
   return 0;
 }

@@ -60,6 +60,10 @@ size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups);
 void tn_batch_begin();
 int tn_batch_flush(hipStream_t stream);
 void tn_batch_end();
+// optional second stream for early flushes (thread-local, set by the step; nullptr = off)
+void set_tn_aux_stream(hipStream_t aux);
+int tn_batch_flush_aux(hipStream_t st);  // flush what is recorded so far on the aux stream, ordered after `st`
+int tn_batch_join(hipStream_t st);       // `st` waits for the aux flushes of the current scope
 // 1 (default): batched problems with Mo % 384 == 0 use the 384 x 128 output tiles; 0: always 128 x 128 (A/B switch)
 void set_tn_wide(int on);
 void set_xcd_order(int bits);  // XCD-aware workgroup -> tile order: 1 = gemm_nt, 4 = short attention (A/B switch)

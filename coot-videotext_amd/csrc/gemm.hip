@@ -908,7 +908,14 @@ static thread_local bool g_tn_collect = false;
 static thread_local int g_tn_nitems = 0;
 static thread_local GemmTN g_tn_items[TN_MAX_ITEMS];
 
-void tn_batch_begin() { g_tn_collect = true; g_tn_nitems = 0; }
+static thread_local long g_tn_ws_used = 0;  // floats of the default workspace taken by the flushes of the current scope
+static thread_local hipStream_t g_tn_aux = nullptr;
+static thread_local bool g_tn_aux_pending = false;
+static thread_local hipEvent_t g_tn_ev[2];
+static thread_local bool g_tn_ev_made = false;
+
+void tn_batch_begin() { g_tn_collect = true; g_tn_nitems = 0; g_tn_ws_used = 0; g_tn_aux_pending = false; }
+void set_tn_aux_stream(hipStream_t aux) { g_tn_aux = aux; }
 
 static int g_tn_wide = 1;
 void set_tn_wide(int on) { g_tn_wide = on; }
@@ -929,7 +936,8 @@ int tn_batch_flush(hipStream_t stream) {
     if (wide[i]) tiles_w += (long)((g.No + TNW_BN - 1) / TNW_BN) * (g.Mo / TNW_BM) * g.groups;
     else tiles_n += (long)((g.No + TN_BC - 1) / TN_BC) * ((g.Mo + TN_BC - 1) / TN_BC) * g.groups;
   }
-  int blk_w = 0, blk_n = 0; long ws_off = 0; bool ws_w = false, ws_n = false;
+  // every flush of a scope takes its own part of the workspace: an earlier flush may still be running on the aux stream
+  int blk_w = 0, blk_n = 0; long ws_off = g_tn_ws_used; bool ws_w = false, ws_n = false;
   for (int i = 0; i < n; ++i) {
     const bool w = wide[i];
     TnBatch& b = w ? bw : bn;
@@ -962,6 +970,7 @@ int tn_batch_flush(hipStream_t stream) {
     g_tn_collect = true;
     return 0;
   }
+  g_tn_ws_used = ws_off;
   double flops = 0;
   for (int i = 0; i < n; ++i) flops += 2.0 * g_tn_items[i].T * g_tn_items[i].Mo * g_tn_items[i].No * g_tn_items[i].groups;
   void* ts = timing_begin(TIMING_TN, flops, 0, stream);
@@ -986,6 +995,29 @@ int tn_batch_flush(hipStream_t stream) {
   return 0;
 }
 void tn_batch_end() { g_tn_collect = false; g_tn_nitems = 0; }
+
+#define RUN(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+// The weight gradients recorded so far, launched on the aux stream (ordered after everything enqueued on `st`): they run
+// NEXT TO the rest of the backward chain of `st` (attention backward, QKV dX: memory / latency bound kernels that leave
+// the matrix cores idle) instead of after it.  tn_batch_join() orders `st` after them.
+int tn_batch_flush_aux(hipStream_t st) {
+  if (!g_tn_aux || !g_tn_collect || g_tn_nitems == 0 || g_tn_aux == st) return 0;
+  if (!g_tn_ev_made) {
+    for (int i = 0; i < 2; ++i) RUN(check_hip(hipEventCreateWithFlags(&g_tn_ev[i], hipEventDisableTiming), "hipEventCreate"));
+    g_tn_ev_made = true;
+  }
+  RUN(check_hip(hipEventRecord(g_tn_ev[0], st), "eventRecord"));
+  RUN(check_hip(hipStreamWaitEvent(g_tn_aux, g_tn_ev[0], 0), "streamWait"));
+  RUN(tn_batch_flush(g_tn_aux));
+  RUN(check_hip(hipEventRecord(g_tn_ev[1], g_tn_aux), "eventRecord"));
+  g_tn_aux_pending = true;
+  return 0;
+}
+int tn_batch_join(hipStream_t st) {
+  if (!g_tn_aux_pending) return 0;
+  g_tn_aux_pending = false;
+  return check_hip(hipStreamWaitEvent(st, g_tn_ev[1], 0), "streamWait");
+}
 
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
   COOT_REQUIRE(g.A && g.B && g.C, "gemm_tn: null operand");

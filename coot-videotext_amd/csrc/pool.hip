@@ -1,6 +1,5 @@
 // GenPool softmax-over-sequence pooling, avg_special pooling, clip packing (gfx950).
-// All HBM-bound and tiny next to the GEMMs: one workgroup per sequence, a thread owns two
-// adjacent channels (4-byte bf16x2 loads, fully coalesced rows), the L loop runs in registers.
+// All HBM-bound and tiny next to the GEMMs: 16-byte loads, fully coalesced rows, the L loop runs in registers.
 #include "pool.h"
 
 namespace coot {
@@ -8,69 +7,86 @@ namespace coot {
 // GenPool.forward tail (nntrainer/models/poolers.py:188-206): padded rows -> -INF, softmax over the sequence axis per
 // channel, pooled = sum_l z * w.
 //
-// One workgroup per sequence.  A thread owns 8 adjacent channels (16-byte loads) of every RG-th row: thread t ->
-// channel chunk t % NCH, row group t / NCH (NCH = D / 8 chunks, RG = 256 / NCH row groups).  Each thread runs an online
-// softmax over its rows (all of its loads are independent: they are in flight together), the RG partial states are merged
-// through LDS.  The first version walked the L rows twice with one dependent 4-byte load per step: 48 us per launch
-// at 0.8 TB/s; this one is a single pass of 16-byte loads.
+// The channels are independent, so a workgroup takes one sequence x 128 channels (grid = sequences x D / 128; the whole
+// row if D is not a multiple of 128): thread t -> 8-channel chunk t % CPB (16-byte loads), row group t / CPB (RG = 256 /
+// CPB = 16 row groups).  A thread walks its rows four at a time — the eight loads of a batch are in flight together —
+// with an online softmax; the RG partial states are merged through LDS.  History: two passes of dependent 4-byte loads,
+// one workgroup per sequence: 48 us per launch (0.8 TB/s); one pass of 16-byte loads, 4 row groups: 17 us (one 4-wave
+// workgroup per CU walking 20 rows one load pair at a time); this version fills the chip.
 constexpr int POOL_MAXCH = 64;  // D <= 512
-struct PoolState { float m[8], z[8], a[8]; };
+constexpr int POOL_RB = 4;      // rows per load batch
 
 __device__ __forceinline__ void pool_unpack(u32x4_t u, float* v) {
   v[0] = bflo(u[0]); v[1] = bfhi(u[0]); v[2] = bflo(u[1]); v[3] = bfhi(u[1]);
   v[4] = bflo(u[2]); v[5] = bfhi(u[2]); v[6] = bflo(u[3]); v[7] = bfhi(u[3]);
 }
+// chunks per workgroup / row groups for D channels
+__host__ __device__ inline int pool_cpb(int D) { return (D % 128 == 0) ? 16 : D / 8; }
 
 __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
-  __shared__ float red[3][4][POOL_MAXCH * 8 + 8];
-  const int n = blockIdx.x, nch = p.D / 8, rgs = min(4, 256 / nch);
-  const int ch = threadIdx.x % nch, rg = threadIdx.x / nch, c = ch * 8;
+  __shared__ float red[3][256 * 8 + 8];
+  const int n = blockIdx.x, cpb = pool_cpb(p.D), rgs = 256 / cpb;
+  const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, c = (blockIdx.y * cpb + cl) * 8;
   const int len = (int)p.lens[n];
   const long r0 = (long)n * p.L;
   float m[8], z[8], a[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; z[j] = 0.f; a[j] = 0.f; }
   if (rg < rgs) {
-    for (int l = rg; l < len; l += rgs) {
-      float s[8], f[8];
-      pool_unpack(*reinterpret_cast<const u32x4_t*>(p.s + (r0 + l) * p.lds + c), s);
-      pool_unpack(*reinterpret_cast<const u32x4_t*>(p.z + (r0 + l) * p.ldz + c), f);
-      float sc[8];
+    for (int l0 = rg; l0 < len; l0 += rgs * POOL_RB) {
+      u32x4_t su[POOL_RB], fu[POOL_RB];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sc[j] = 1.f;
-      if (p.drop_w.thr) drop_scales<8>(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, (unsigned long long)(r0 + l) * p.D + c, p.drop_w.thr, p.drop_w.inv_keep, sc);
+      for (int b = 0; b < POOL_RB; ++b) {
+        const int l = l0 + b * rgs;
+        su[b] = u32x4_t{0u, 0u, 0u, 0u}; fu[b] = su[b];
+        if (l < len) {
+          su[b] = *reinterpret_cast<const u32x4_t*>(p.s + (r0 + l) * p.lds + c);
+          fu[b] = *reinterpret_cast<const u32x4_t*>(p.z + (r0 + l) * p.ldz + c);
+        }
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float mn = fmaxf(m[j], s[j]);
-        const float r = __expf(m[j] - mn), e = __expf(s[j] - mn);  // first row: exp(-inf) = 0
-        z[j] = z[j] * r + e;
-        a[j] = a[j] * r + e * sc[j] * f[j];
-        m[j] = mn;
+      for (int b = 0; b < POOL_RB; ++b) {
+        const int l = l0 + b * rgs;
+        if (l < len) {
+          float s[8], f[8], sc[8];
+          pool_unpack(su[b], s);
+          pool_unpack(fu[b], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sc[j] = 1.f;
+          if (p.drop_w.thr) drop_scales<8>(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, (unsigned long long)(r0 + l) * p.D + c, p.drop_w.thr, p.drop_w.inv_keep, sc);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float mn = fmaxf(m[j], s[j]);
+            const float r = __expf(m[j] - mn), e = __expf(s[j] - mn);  // first row: exp(-inf) = 0
+            z[j] = z[j] * r + e;
+            a[j] = a[j] * r + e * sc[j] * f[j];
+            m[j] = mn;
+          }
+        }
       }
     }
+    float* w = &red[0][(rg * cpb + cl) * 8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[0][rg][c + j] = m[j]; red[1][rg][c + j] = z[j]; red[2][rg][c + j] = a[j]; }
+    for (int j = 0; j < 8; ++j) { w[j] = m[j]; w[(256 * 8 + 8) + j] = z[j]; w[2 * (256 * 8 + 8) + j] = a[j]; }
   }
   __syncthreads();
-  if (rg == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float mm = m[j];
-      for (int g = 1; g < rgs; ++g) mm = fmaxf(mm, red[0][g][c + j]);
-      // rows >= len hold -INF (= -32752) after masked_fill (poolers.py:190)
-      if (len < p.L) mm = fmaxf(mm, kMaskFill);
-      float zz = 0.f, aa = 0.f;
-      for (int g = 0; g < rgs; ++g) {
-        const float mg = red[0][g][c + j];
-        const float r = mg == -INFINITY ? 0.f : __expf(mg - mm);
-        zz += red[1][g][c + j] * r; aa += red[2][g][c + j] * r;
-      }
-      if (len < p.L) zz += (float)(p.L - len) * __expf(kMaskFill - mm);  // 0 in fp32 unless every row is masked
-      const float pooled = aa / zz;
-      p.pooled[(long)n * p.ldp + c + j] = pooled;
-      if (p.pooled_copy) p.pooled_copy[(long)n * p.D + c + j] = pooled;
-      if (p.smax) { p.smax[(long)n * p.D + c + j] = mm; p.ssum[(long)n * p.D + c + j] = zz; }
+  for (int cc = threadIdx.x; cc < cpb * 8; cc += 256) {  // one thread per channel of the block merges the row groups
+    float mm = -INFINITY;
+    for (int g = 0; g < rgs; ++g) mm = fmaxf(mm, red[0][g * cpb * 8 + cc]);
+    // rows >= len hold -INF (= -32752) after masked_fill (poolers.py:190)
+    if (len < p.L) mm = fmaxf(mm, kMaskFill);
+    float zz = 0.f, aa = 0.f;
+    for (int g = 0; g < rgs; ++g) {
+      const float mg = red[0][g * cpb * 8 + cc];
+      const float r = mg == -INFINITY ? 0.f : __expf(mg - mm);
+      zz += red[1][g * cpb * 8 + cc] * r; aa += red[2][g * cpb * 8 + cc] * r;
     }
+    if (len < p.L) zz += (float)(p.L - len) * __expf(kMaskFill - mm);  // 0 in fp32 unless every row is masked
+    const float pooled = aa / zz;
+    const int ch = blockIdx.y * cpb * 8 + cc;
+    p.pooled[(long)n * p.ldp + ch] = pooled;
+    if (p.pooled_copy) p.pooled_copy[(long)n * p.D + ch] = pooled;
+    if (p.smax) { p.smax[(long)n * p.D + ch] = mm; p.ssum[(long)n * p.D + ch] = zz; }
   }
 }
 
@@ -78,9 +94,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
 // Purely elementwise given the saved softmax statistics, plus the column sum of ds (bias gradient of the second pooling
 // FC): same thread mapping as the forward, 16-byte loads and stores, the RG partial column sums merged through LDS.
 __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs p) {
-  __shared__ float red[4][POOL_MAXCH * 8 + 8];
-  const int n = blockIdx.x, nch = p.D / 8, rgs = min(4, 256 / nch);
-  const int ch = threadIdx.x % nch, rg = threadIdx.x / nch, c = ch * 8;
+  __shared__ float red[256 * 8 + 8];
+  const int n = blockIdx.x, cpb = pool_cpb(p.D), rgs = 256 / cpb;
+  const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, c = (blockIdx.y * cpb + cl) * 8;
   const int len = (int)p.lens[n];
   const long r0 = (long)n * p.L;
   float cs[8];
@@ -95,41 +111,56 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs p) {
       g[j] = p.dpooled[(long)n * p.lddp + c + j];
       gp[j] = g[j] * p.pooled[(long)n * p.ldp + c + j];
     }
-    for (int l = rg; l < p.L; l += rgs) {
-      float ds[8], dz[8];
+    for (int l0 = rg; l0 < p.L; l0 += rgs * POOL_RB) {
+      u32x4_t su[POOL_RB], fu[POOL_RB];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ds[j] = 0.f; dz[j] = 0.f; }
-      if (l < len) {
-        float s[8], f[8], d3[8], d2[8];
-        pool_unpack(*reinterpret_cast<const u32x4_t*>(p.s + (r0 + l) * p.lds + c), s);
-        pool_unpack(*reinterpret_cast<const u32x4_t*>(p.z + (r0 + l) * p.ldz + c), f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { d3[j] = 1.f; d2[j] = 1.f; }
-        if (p.drop_w.thr) drop_scales<8>(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, (unsigned long long)(r0 + l) * p.D + c, p.drop_w.thr, p.drop_w.inv_keep, d3);
-        if (p.drop_s.thr) drop_scales<8>(eff_seed(p.drop_s.seed, p.drop_s.seed_ptr), p.drop_s.site, (unsigned long long)(p.drop_s_row0 + r0 + l) * p.drop_s_ld + c, p.drop_s.thr, p.drop_s.inv_keep, d2);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float w = __expf(s[j] - m[j]) * iz[j];
-          ds[j] = w * (g[j] * f[j] * d3[j] - gp[j]) * d2[j];
-          dz[j] = g[j] * w * d3[j];
-          cs[j] += ds[j];
+      for (int b = 0; b < POOL_RB; ++b) {
+        const int l = l0 + b * rgs;
+        su[b] = u32x4_t{0u, 0u, 0u, 0u}; fu[b] = su[b];
+        if (l < len) {
+          su[b] = *reinterpret_cast<const u32x4_t*>(p.s + (r0 + l) * p.lds + c);
+          fu[b] = *reinterpret_cast<const u32x4_t*>(p.z + (r0 + l) * p.ldz + c);
         }
       }
-      *reinterpret_cast<u32x4_t*>(p.ds + (r0 + l) * p.ldds + c) = u32x4_t{pack2bf(ds[0], ds[1]), pack2bf(ds[2], ds[3]), pack2bf(ds[4], ds[5]), pack2bf(ds[6], ds[7])};
-      *reinterpret_cast<u32x4_t*>(p.dz + (r0 + l) * p.lddz + c) = u32x4_t{pack2bf(dz[0], dz[1]), pack2bf(dz[2], dz[3]), pack2bf(dz[4], dz[5]), pack2bf(dz[6], dz[7])};
-    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[rg][c + j] = cs[j];
+      for (int b = 0; b < POOL_RB; ++b) {
+        const int l = l0 + b * rgs;
+        if (l < p.L) {
+          float ds[8], dz[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ds[j] = 0.f; dz[j] = 0.f; }
+          if (l < len) {
+            float s[8], f[8], d3[8], d2[8];
+            pool_unpack(su[b], s);
+            pool_unpack(fu[b], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { d3[j] = 1.f; d2[j] = 1.f; }
+            if (p.drop_w.thr) drop_scales<8>(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, (unsigned long long)(r0 + l) * p.D + c, p.drop_w.thr, p.drop_w.inv_keep, d3);
+            if (p.drop_s.thr) drop_scales<8>(eff_seed(p.drop_s.seed, p.drop_s.seed_ptr), p.drop_s.site, (unsigned long long)(p.drop_s_row0 + r0 + l) * p.drop_s_ld + c, p.drop_s.thr, p.drop_s.inv_keep, d2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float w = __expf(s[j] - m[j]) * iz[j];
+              ds[j] = w * (g[j] * f[j] * d3[j] - gp[j]) * d2[j];
+              dz[j] = g[j] * w * d3[j];
+              cs[j] += ds[j];
+            }
+          }
+          *reinterpret_cast<u32x4_t*>(p.ds + (r0 + l) * p.ldds + c) = u32x4_t{pack2bf(ds[0], ds[1]), pack2bf(ds[2], ds[3]), pack2bf(ds[4], ds[5]), pack2bf(ds[6], ds[7])};
+          *reinterpret_cast<u32x4_t*>(p.dz + (r0 + l) * p.lddz + c) = u32x4_t{pack2bf(dz[0], dz[1]), pack2bf(dz[2], dz[3]), pack2bf(dz[4], dz[5]), pack2bf(dz[6], dz[7])};
+        }
+      }
+    }
+    float* w = &red[(rg * cpb + cl) * 8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = cs[j];
   }
   __syncthreads();
-  if (rg == 0 && (p.part_ws || p.ds_colsum)) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = cs[j];
-      for (int g2 = 1; g2 < rgs; ++g2) v += red[g2][c + j];
-      if (p.part_ws) p.part_ws[(long)n * p.D + c + j] = v;
-      else atomicAdd(p.ds_colsum + c + j, v);
-    }
+  for (int cc = threadIdx.x; cc < cpb * 8 && (p.part_ws || p.ds_colsum); cc += 256) {
+    const int ch = blockIdx.y * cpb * 8 + cc;
+    float v = 0.f;
+    for (int g2 = 0; g2 < rgs; ++g2) v += red[g2 * cpb * 8 + cc];
+    if (p.part_ws) p.part_ws[(long)n * p.D + ch] = v;
+    else atomicAdd(p.ds_colsum + ch, v);
   }
 }
 
@@ -142,7 +173,7 @@ static int pool_check(const PoolArgs& p) {
 int launch_pool_fwd(const PoolArgs& p, hipStream_t st) {
   if (int rc = pool_check(p)) return rc;
   if (p.N <= 0) return 0;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(p.N), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(p.N, p.D / 8 / pool_cpb(p.D)), dim3(256), 0, st, p);
   COOT_CHECK_LAUNCH("pool_fwd");
   return 0;
 }
@@ -152,7 +183,7 @@ int launch_pool_bwd(const PoolArgs& p_in, hipStream_t st) {
   COOT_REQUIRE(p.dpooled && p.ds && p.dz && p.smax && p.ssum, "pool bwd: null pointer");
   if (p.N <= 0) return 0;
   p.part_ws = p.ds_colsum ? partials_workspace((size_t)p.N * p.D) : nullptr;
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(p.N), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(p.N, p.D / 8 / pool_cpb(p.D)), dim3(256), 0, st, p);
   COOT_CHECK_LAUNCH("pool_bwd");
   if (p.part_ws) return launch_reduce_partials(p.part_ws, p.N, p.D, p.D, p.ds_colsum, st);
   return 0;
