@@ -150,10 +150,14 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
 #pragma unroll
     for (int i = 0; i < IT; ++i) load8f(bias_lds + col[i], bs[i]);
   }
+  // ONE register set for the chunks' prefetched global loads, refilled at the END of a round for the next one (they fly
+  // during the two barriers and the staging traffic).  The first version kept two sets selected by the round's parity:
+  // hipcc merged every load into both sets with v_cndmask right behind it, i.e. s_waitcnt vmcnt(0) after each of the
+  // three loads of a round — no prefetch at all, and each wait also drained the previous round's stores.
   using P = decltype(pre(0, 0));
-  P pv[2][IT];
+  P pv[IT];
 #pragma unroll
-  for (int i = 0; i < IT; ++i) pv[0][i] = pre(row0 + rl[i], col[i]);
+  for (int i = 0; i < IT; ++i) pv[i] = pre(row0 + rl[i], col[i]);
   float* sw = &Stg[(lane & 15) * SPITCH + cg * 48 + (lane >> 4) * 4];
 #pragma unroll 1
   for (int r = 0; r < ROUNDS; ++r) {
@@ -182,14 +186,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
           for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + (a & 1) * 16 * SPITCH + (a >> 1) * 192 + b * 16) = acc[a][b];
       }
     }
-    const int par = r & 1, rbase = row0 + r * RPR;
-    if (r + 1 < ROUNDS) {
-#pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const P nx = pre(rbase + RPR + rl[i], col[i]);
-        if (par) pv[0][i] = nx; else pv[1][i] = nx;
-      }
-    }
+    const int rbase = row0 + r * RPR;
     lds_barrier();
     float v[IT][8];
 #pragma unroll
@@ -200,7 +197,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[i][j] += bs[i][j];
       }
-      fn(rbase + rl[i], col[i], v[i], par ? pv[1][i] : pv[0][i], i);
+      fn(rbase + rl[i], col[i], v[i], pv[i], i);
       // one chunk body at a time (8 independent elements give the VALU enough ILP): letting the scheduler interleave the
       // three bodies triples their temporaries while the accumulators of the later rounds are still live -> spills
       __builtin_amdgcn_sched_barrier(0);
@@ -208,6 +205,10 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
     if (to_lds) {
 #pragma unroll
       for (int i = 0; i < IT; ++i) *reinterpret_cast<u32x4_t*>(&As[(r * RPR + rl[i]) * APITCH + col[i]]) = pack8(v[i]);
+    }
+    if (r + 1 < ROUNDS) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) pv[i] = pre(rbase + RPR + rl[i], col[i]);
     }
   }
   lds_barrier();
@@ -286,6 +287,11 @@ __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const flo
 struct PreNone {};
 struct PreRes { u32x4_t res; };
 
+// Dropout configuration with the device base seed folded in ONCE per kernel.  Reading *seed_ptr where the mask is drawn
+// put a global load + s_waitcnt vmcnt(0) into every chunk body of the epilogues (the compiler cannot hoist it across the
+// chunk's global stores), and vmcnt(0) also waits for all of the previous chunk's stores.
+__device__ __forceinline__ DropCfg resolve_drop(DropCfg d, unsigned long long base) { d.seed += base; d.seed_ptr = nullptr; return d; }
+
 template <bool DROP>
 __device__ __forceinline__ void apply_drop(const DropCfg& d, unsigned long long idx0, float (&v)[8]) {
   if constexpr (DROP) {
@@ -316,6 +322,10 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   }
   int tsn = 0;
   auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  unsigned long long sbase = 0;
+  if constexpr (DROP) { if (p.d_ff1.seed_ptr) sbase = *p.d_ff1.seed_ptr; }
+  const DropCfg d_postln = resolve_drop(p.d_postln, sbase), d_ff1 = resolve_drop(p.d_ff1, sbase), d_ff2 = resolve_drop(p.d_ff2, sbase),
+                d_pool1 = resolve_drop(p.d_pool1, sbase), d_pool2 = resolve_drop(p.d_pool2, sbase);
   stamp();
 
   // ---- attention output projection + residual -> r1 ------------------------------------------------------------
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       }, true);
   stamp();
   // ---- LN1 (+ dropout) -> z1 ---------------------------------------------------------------------------------------
-  ln_tile<RF, DROP, false>(As, Bsm + 3 * FZ_D, Bsm + 4 * FZ_D, row0, T, p.z1, nullptr, 0, p.d_postln);
+  ln_tile<RF, DROP, false>(As, Bsm + 3 * FZ_D, Bsm + 4 * FZ_D, row0, T, p.z1, nullptr, 0, d_postln);
   __syncthreads();
   stamp();
   // ---- FF1: Linear -> Dropout -> GELU ------------------------------------------------------------------------------
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   stamp();
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 1 * FZ_D, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&, int) {
-        apply_drop<DROP>(p.d_ff1, (unsigned long long)row * FZ_D + col, v);
+        apply_drop<DROP>(d_ff1, (unsigned long long)row * FZ_D + col, v);
         gst16(p.h1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
         float r[8];
         unpack8(pr.res, r);
-        apply_drop<DROP>(p.d_ff2, (unsigned long long)row * FZ_D + col, v);
+        apply_drop<DROP>(d_ff2, (unsigned long long)row * FZ_D + col, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
         gst16(p.r2, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       gemm_pass<RF, 12>(As, p.pw1 + (h * 8 + wave) * GSZ, acc, lane);
       epilogue<RF, 8>(acc, Stg, As, row0, Bsm + h * FZ_D, [&](int, int) { return PreNone{}; },
           [&](int row, int col, float (&v)[8], const PreNone&, int) {
-            apply_drop<DROP>(p.d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
+            apply_drop<DROP>(d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
             gst16(p.hp, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u, pack8(v));
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       gemm_pass<RF / 2, 12>(As + (wave >> 2) * (BT / 2) * APITCH, p.pw2 + (h * 4 + (wave & 3)) * GSZ, acc2, lane);
       epilogue<RF, 4>(acc2, Stg, As, row0, Bsm + 2 * FZ_D + h * (FZ_D / 2), [&](int, int) { return PreNone{}; },
           [&](int row, int col, float (&v)[8], const PreNone&, int) {
-            apply_drop<DROP>(p.d_pool2, (unsigned long long)row * FZ_D + h * (FZ_D / 2) + col, v);
+            apply_drop<DROP>(d_pool2, (unsigned long long)row * FZ_D + h * (FZ_D / 2) + col, v);
             gst16(p.s, (unsigned)(row * FZ_D + h * (FZ_D / 2) + col) * 2u, pack8(v));
           }, false);
       stamp();
@@ -588,6 +598,10 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   float cs[3][8];
   int tsn = 0;
   auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  unsigned long long sbase = 0;
+  if constexpr (DROP) { if (p.d_ff1.seed_ptr) sbase = *p.d_ff1.seed_ptr; }
+  const DropCfg d_postln = resolve_drop(p.d_postln, sbase), d_ff1 = resolve_drop(p.d_ff1, sbase), d_ff2 = resolve_drop(p.d_ff2, sbase),
+                d_pool1 = resolve_drop(p.d_pool1, sbase);
   stamp();
   auto cs_zero = [&]() {
 #pragma unroll
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
             unpack8(pr.res, a);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
-            apply_drop<DROP>(p.d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
+            apply_drop<DROP>(d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
             if (row < T) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) cs[i][j] += v[j];
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   }
   stamp();
   // ---- LN2 backward: dr2 (and dr2 * FF2 dropout mask = the gradient of the FF2 Linear output) ---------------------------
-  ln_bwd_tile<RF, false, DROP>(As, g2, p.r2, row0, T, p.dr2, p.dr2m, p.d_ff2, p.d_ff2, Stg, part + 2 * FZ_D);  // ln2 dgain | ln2 dbias | b2
+  ln_bwd_tile<RF, false, DROP>(As, g2, p.r2, row0, T, p.dr2, p.dr2m, d_ff2, d_ff2, Stg, part + 2 * FZ_D);  // ln2 dgain | ln2 dbias | b2
   stamp();
   // ---- dh1 = (df2 . W2) * GELU'(h1) * drop(FF1) ---------------------------------------------------------------------------
   zero_acc<RF>(acc);
@@ -656,7 +670,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
         unpack8(pr.res, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
-        apply_drop<DROP>(p.d_ff1, (unsigned long long)row * FZ_D + col, v);
+        apply_drop<DROP>(d_ff1, (unsigned long long)row * FZ_D + col, v);
         if (row < T) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) cs[i][j] += v[j];
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
       }, true);
   stamp();
   // ---- LN1 backward (through the post-LN dropout) -> dr1 -------------------------------------------------------------------
-  ln_bwd_tile<RF, DROP, false>(As, g1, p.r1, row0, T, p.dr1, nullptr, p.d_postln, p.d_postln, Stg, part + 6 * FZ_D);  // ln1 dgain | ln1 dbias | bo
+  ln_bwd_tile<RF, DROP, false>(As, g1, p.r1, row0, T, p.dr1, nullptr, d_postln, d_postln, Stg, part + 6 * FZ_D);  // ln1 dgain | ln1 dbias | bo
   stamp();
   // ---- dctx = dr1 . Wo ------------------------------------------------------------------------------------------------------------
   zero_acc<RF>(acc);
