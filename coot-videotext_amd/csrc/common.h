@@ -86,13 +86,24 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long salt, 
 }
 // Dropout masks.  The first version drew one rng_u32 (3 x mix32 = 6 integer multiplies) per element: ~100 SIMD cycles
 // per 64 elements, which made the mask generation of one encoder layer cost more than its MFMAs (profiles/README.md).
-// Now: key = f(seed, site) once per call site; ONE mix32 per PAIR of consecutive elements (2 q, 2 q + 1), 16 bits each,
+// Now: key = f(seed, site) once per call site; ONE hash (drop_hash below) per PAIR of consecutive elements (2 q, 2 q + 1), 16 bits each,
 // compared with the 16-bit threshold thr >> 16 (mkdrop() quantises p to 1/65536 and derives 1/(1-p) from the quantised
 // value, so E[mask * inv_keep] = 1 exactly).  Element index < 2^33.
 __device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned site) {
   return mix32((unsigned)seed ^ mix32((unsigned)(seed >> 32) + site * 0x9E3779B9u));
 }
-__device__ __forceinline__ unsigned drop_pair(unsigned key, unsigned long long idx) { return mix32((unsigned)(idx >> 1) ^ key); }
+// The per-pair mixer.  mix32's two v_mul_lo_u32 run at a quarter of the VALU rate on CDNA (16 cycles per wave each): 15
+// issue slots per pair, and the mask generation was ~20 % of the fused chains in training mode.  This one uses the
+// full-rate 24 x 24 -> 32 bit multiply-add (v_mad_u32_u24): 9 slots.  Rate / correlation statistics over 4M consecutive
+// pairs (neighbours, next row, the two halves, keys one bit apart) are as good as mix32's (tools: see DESIGN.md).
+__device__ __forceinline__ unsigned drop_hash(unsigned t) {
+  t = __umul24(t, 0xD2B54Bu) + (t >> 16);
+  t ^= t >> 13;
+  t = __umul24(t, 0x95A53Du) + (t >> 11);
+  t ^= t >> 16;
+  return t;
+}
+__device__ __forceinline__ unsigned drop_pair(unsigned key, unsigned long long idx) { return drop_hash((unsigned)(idx >> 1) ^ key); }
 // keep-scale of one element: 0 if dropped else 1/(1-p)
 __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned site, unsigned long long idx,
                                             unsigned thr, float inv_keep) {
@@ -102,16 +113,20 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned si
 }
 // keep-scales of N consecutive elements starting at an EVEN index (N even): N / 2 hashes
 template <int N>
-__device__ __forceinline__ void drop_scales(unsigned long long seed, unsigned site, unsigned long long idx0, unsigned thr,
-                                            float inv_keep, float* sc) {
-  const unsigned key = drop_key(seed, site), t16 = thr >> 16;
+__device__ __forceinline__ void drop_scales_key(unsigned key, unsigned long long idx0, unsigned thr, float inv_keep, float* sc) {
+  const unsigned t16 = thr >> 16;
   const unsigned q0 = (unsigned)(idx0 >> 1);
 #pragma unroll
   for (int j = 0; j < N / 2; ++j) {
-    const unsigned h = mix32((q0 + j) ^ key);
+    const unsigned h = drop_hash((q0 + j) ^ key);
     sc[2 * j] = (h & 0xFFFFu) >= t16 ? inv_keep : 0.0f;
     sc[2 * j + 1] = (h >> 16) >= t16 ? inv_keep : 0.0f;
   }
+}
+template <int N>
+__device__ __forceinline__ void drop_scales(unsigned long long seed, unsigned site, unsigned long long idx0, unsigned thr,
+                                            float inv_keep, float* sc) {
+  drop_scales_key<N>(drop_key(seed, site), idx0, thr, inv_keep, sc);
 }
 
 }  // namespace coot

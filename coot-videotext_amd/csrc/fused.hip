@@ -129,7 +129,14 @@ __device__ __forceinline__ void load_bias(const float* bias, float (&bs)[IT][8])
 // the kernel was 190 KB of straight-line code, three times the instruction cache two CUs share.
 template <int RF, int NCG, typename PreF, typename Fn>
 __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float* Stg, bf16_t* As, int row0, const float* bias_lds,
-                                         PreF pre, Fn fn, bool to_lds) {
+                                         PreF pre, Fn fn, bool to_lds, unsigned long long* prof = nullptr) {
+#ifdef FZ_PROFILE_EPI  // sub-phase cycle counters of one epilogue (thread 0 of block 0), tools/fused_stamps.py --epi
+  unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, pacc[6] = {0, 0, 0, 0, 0, 0};
+  const bool profiling = prof && blockIdx.x == 0 && threadIdx.x == 0;
+#define FZ_PT(k) do { if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pt[k] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define FZ_PT(k) do { } while (0)
+#endif
   // NCG = 8: 384 output columns, wave = column group, all rows; a round = 32 rows x 384 columns.
   // NCG = 4: 192 output columns, wave = 4 * row half + column group; a round = 64 rows x 192 columns, staged as two
   //          32-row groups side by side (staging columns 0..191 and 192..383), so the tile pass is the same 3 chunks/thread.
@@ -161,7 +168,9 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
   float* sw = &Stg[(lane & 15) * SPITCH + cg * 48 + (lane >> 4) * 4];
 #pragma unroll 1
   for (int r = 0; r < ROUNDS; ++r) {
+    FZ_PT(0);
     lds_barrier();  // staging free again; (r == 0) every wave is done reading the tile in the GEMM
+    FZ_PT(1);
     if constexpr (NCG == 8) {
       auto put = [&](auto rc) {
         constexpr int R = decltype(rc)::value;
@@ -170,6 +179,9 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
           for (int a2 = 0; a2 < FR; ++a2)
 #pragma unroll
             for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + a2 * 16 * SPITCH + b * 16) = acc[R * FR + a2][b];
+          // keep the stores inside their case: hipcc otherwise turns the switch into a register select (48 v_mov_b64 per
+          // round to funnel the round's accumulators into one set of store operands) followed by one copy of the stores
+          asm volatile("" ::: "memory");
         }
       };
       switch (r) {
@@ -187,10 +199,13 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
       }
     }
     const int rbase = row0 + r * RPR;
+    FZ_PT(2);
     lds_barrier();
+    FZ_PT(3);
     float v[IT][8];
 #pragma unroll
     for (int i = 0; i < IT; ++i) load8f(&Stg[(rl[i] & 31) * SPITCH + col[i] + (rl[i] >= 32 ? 192 : 0)], v[i]);
+    FZ_PT(4);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       if (bias_lds) {
@@ -202,6 +217,7 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
       // three bodies triples their temporaries while the accumulators of the later rounds are still live -> spills
       __builtin_amdgcn_sched_barrier(0);
     }
+    FZ_PT(5);
     if (to_lds) {
 #pragma unroll
       for (int i = 0; i < IT; ++i) *reinterpret_cast<u32x4_t*>(&As[(r * RPR + rl[i]) * APITCH + col[i]]) = pack8(v[i]);
@@ -210,8 +226,22 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
 #pragma unroll
       for (int i = 0; i < IT; ++i) pv[i] = pre(rbase + RPR + rl[i], col[i]);
     }
+    FZ_PT(6);
+#ifdef FZ_PROFILE_EPI
+    if (prof) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pacc[k] += pt[k + 1] - pt[k];
+    }
+#endif
   }
   lds_barrier();
+#ifdef FZ_PROFILE_EPI
+  if (profiling) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) prof[k] = pacc[k];
+  }
+#endif
+#undef FZ_PT
 }
 
 // sum over the 16 lanes of a DPP row (full-rate VALU, no LDS crossbar): every lane of the row receives the total
@@ -226,19 +256,36 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Dropout site with the device base seed folded in and the site key derived ONCE per kernel.  Reading *seed_ptr where the
+// mask is drawn put a global load + s_waitcnt vmcnt(0) into every chunk body of the epilogues (the compiler cannot hoist
+// it across the chunk's global stores; vmcnt(0) also waits for all of the previous chunk's stores), and deriving the key
+// there cost ~55 scalar instructions per chunk.
+struct DropK { unsigned key = 0, thr = 0; float inv_keep = 1.f; };
+__device__ __forceinline__ DropK resolve_drop(const DropCfg& d, unsigned long long base) {
+  DropK k; k.key = drop_key(d.seed + base, d.site); k.thr = d.thr; k.inv_keep = d.inv_keep; return k;
+}
+
+template <bool DROP>
+__device__ __forceinline__ void apply_drop(const DropK& d, unsigned long long idx0, float (&v)[8]) {
+  if constexpr (DROP) {
+    float sc[8];
+    drop_scales_key<8>(d.key, idx0, d.thr, d.inv_keep, sc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= sc[j];
+  }
+}
+
 // COOT LayerNorm (nntrainer/models/normalizations.py:98-101) of every tile row, in place.  Wave w owns rows
 // [2 RF w, 2 RF w + 2 RF); 16 lanes share a row (4 rows per wave in flight): lane j holds the three 8-element chunks at
 // columns 8 j, 128 + 8 j, 256 + 8 j (16-byte LDS / global accesses), reductions are 4 DPP steps.
 template <int RF, bool DROP, bool OUT32>
 __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const float* bias, int row0, int T, bf16_t* out, float* out32,
-                                        long ld32, const DropCfg& drop) {
+                                        long ld32, const DropK& drop) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
   constexpr int RW = 2 * RF, ITR = (RW + 3) / 4;
   float gn[3][8], bi[3][8];
 #pragma unroll
   for (int m = 0; m < 3; ++m) { load8f(gain + m * 128 + j16 * 8, gn[m]); load8f(bias + m * 128 + j16 * 8, bi[m]); }
-  unsigned long long seed = 0;
-  if constexpr (DROP) seed = eff_seed(drop.seed, drop.seed_ptr);
 #pragma unroll
   for (int it = 0; it < ITR; ++it) {
     const int rw = (RW >= 4) ? it * 4 + g : (g < RW ? g : 0);  // RF = 1: two rows per wave, lanes 32..63 repeat row 0
@@ -266,7 +313,7 @@ __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const flo
       for (int e = 0; e < 8; ++e) y[e] = x[m][e] * rs * gn[m][e] + bi[m][e];
       if constexpr (DROP) {
         float sc[8];
-        drop_scales<8>(seed, drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, drop.thr, drop.inv_keep, sc);
+        drop_scales_key<8>(drop.key, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, drop.thr, drop.inv_keep, sc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] *= sc[e];
       }
@@ -286,21 +333,6 @@ __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const flo
 
 struct PreNone {};
 struct PreRes { u32x4_t res; };
-
-// Dropout configuration with the device base seed folded in ONCE per kernel.  Reading *seed_ptr where the mask is drawn
-// put a global load + s_waitcnt vmcnt(0) into every chunk body of the epilogues (the compiler cannot hoist it across the
-// chunk's global stores), and vmcnt(0) also waits for all of the previous chunk's stores.
-__device__ __forceinline__ DropCfg resolve_drop(DropCfg d, unsigned long long base) { d.seed += base; d.seed_ptr = nullptr; return d; }
-
-template <bool DROP>
-__device__ __forceinline__ void apply_drop(const DropCfg& d, unsigned long long idx0, float (&v)[8]) {
-  if constexpr (DROP) {
-    float sc[8];
-    drop_scales<8>(eff_seed(d.seed, d.seed_ptr), d.site, idx0, d.thr, d.inv_keep, sc);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= sc[j];
-  }
-}
 
 template <int RF, bool DROP>
 __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
@@ -324,7 +356,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
   unsigned long long sbase = 0;
   if constexpr (DROP) { if (p.d_ff1.seed_ptr) sbase = *p.d_ff1.seed_ptr; }
-  const DropCfg d_postln = resolve_drop(p.d_postln, sbase), d_ff1 = resolve_drop(p.d_ff1, sbase), d_ff2 = resolve_drop(p.d_ff2, sbase),
+  const DropK d_postln = resolve_drop(p.d_postln, sbase), d_ff1 = resolve_drop(p.d_ff1, sbase), d_ff2 = resolve_drop(p.d_ff2, sbase),
                 d_pool1 = resolve_drop(p.d_pool1, sbase), d_pool2 = resolve_drop(p.d_pool2, sbase);
   stamp();
 
@@ -360,7 +392,11 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
         gst16(p.a1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
-      }, true);
+      }, true
+#ifdef FZ_PROFILE_EPI
+      , p.tstamps ? p.tstamps + 32 : nullptr
+#endif
+      );
   stamp();
   // ---- FF2: Linear -> Dropout, + residual z1 -> r2 -----------------------------------------------------------------
   zero_acc<RF>(acc);
@@ -378,7 +414,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   stamp();
   // ---- LN2 -> z2 ------------------------------------------------------------------------------------------------------
   {
-    DropCfg none;
+    const DropK none;
     if (p.z2_f32) ln_tile<RF, false, true>(As, Bsm + 5 * FZ_D, Bsm + 6 * FZ_D, row0, T, p.z2, p.z2_f32, p.ldz2_f32, none);
     else ln_tile<RF, false, false>(As, Bsm + 5 * FZ_D, Bsm + 6 * FZ_D, row0, T, p.z2, nullptr, 0, none);
   }
@@ -432,7 +468,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 // per wave-instruction here), summed by 384 threads into part_dst[3 * 384] (one partial row per tile).
 template <int RF, bool DROPY, bool MASKX>
 __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, const bf16_t* xsaved, int row0, int T, bf16_t* out_dx,
-                                            bf16_t* out_dxm, const DropCfg& dy_drop, const DropCfg& dx_drop, float* red, float* part_dst) {
+                                            bf16_t* out_dxm, const DropK& dy_drop, const DropK& dx_drop, float* red, float* part_dst) {
   static_assert(RF == 8, "16 rows per wave, 4 per pass");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
   u32x4_t xs[4][3];  // the saved LN input of this lane's 4 rows, kept packed (all loads in flight together)
@@ -440,9 +476,6 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
   for (int it = 0; it < 4; ++it)
 #pragma unroll
     for (int m = 0; m < 3; ++m) xs[it][m] = gld16(xsaved, (unsigned)((row0 + wave * 16 + it * 4 + g) * FZ_D + m * 128 + j16 * 8) * 2u);
-  unsigned long long seed_y = 0, seed_x = 0;
-  if constexpr (DROPY) seed_y = eff_seed(dy_drop.seed, dy_drop.seed_ptr);
-  if constexpr (MASKX) seed_x = eff_seed(dx_drop.seed, dx_drop.seed_ptr);
   // pass A: row statistics (4 scalars per row)
   float mean[4], rsv[4], hmean[4], k2[4];
 #pragma unroll
@@ -467,7 +500,7 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
       load8f(gain_lds + m * 128 + j16 * 8, gn);
       if constexpr (DROPY) {
         float sc[8];
-        drop_scales<8>(seed_y, dy_drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dy_drop.thr, dy_drop.inv_keep, sc);
+        drop_scales_key<8>(dy_drop.key, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dy_drop.thr, dy_drop.inv_keep, sc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dy[e] *= sc[e];
       }
@@ -501,7 +534,7 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
       unpack8(*reinterpret_cast<const u32x4_t*>(ar), dy);
       if constexpr (DROPY) {  // the same mask as in pass A (recomputed: cheaper than keeping 96 masked values live)
         float sc[8];
-        drop_scales<8>(seed_y, dy_drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dy_drop.thr, dy_drop.inv_keep, sc);
+        drop_scales_key<8>(dy_drop.key, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dy_drop.thr, dy_drop.inv_keep, sc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dy[e] *= sc[e];
       }
@@ -512,7 +545,7 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
       }
       if constexpr (MASKX) {
         float sc[8];
-        drop_scales<8>(seed_x, dx_drop.site, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dx_drop.thr, dx_drop.inv_keep, sc);
+        drop_scales_key<8>(dx_drop.key, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dx_drop.thr, dx_drop.inv_keep, sc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dm[e] = dx[e] * sc[e];
       } else {
@@ -600,7 +633,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
   unsigned long long sbase = 0;
   if constexpr (DROP) { if (p.d_ff1.seed_ptr) sbase = *p.d_ff1.seed_ptr; }
-  const DropCfg d_postln = resolve_drop(p.d_postln, sbase), d_ff1 = resolve_drop(p.d_ff1, sbase), d_ff2 = resolve_drop(p.d_ff2, sbase),
+  const DropK d_postln = resolve_drop(p.d_postln, sbase), d_ff1 = resolve_drop(p.d_ff1, sbase), d_ff2 = resolve_drop(p.d_ff2, sbase),
                 d_pool1 = resolve_drop(p.d_pool1, sbase);
   stamp();
   auto cs_zero = [&]() {
