@@ -70,26 +70,27 @@ __device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f3
 #pragma unroll
       for (int b = 0; b < 3; ++b) w[s][b] = wp[(s * 3 + b) * 64];
     }
-  bf16x8_t xf[2][RF];
+  // token fragments: ONE register set, refreshed row fragment by row fragment — xf[a] of the next k-block is read right
+  // after the three MFMAs that consume the current xf[a] (its next use is 21 MFMAs away, several LDS latencies).  A
+  // second full set (double buffering) costs 4 RF registers the epilogues then spill.
+  bf16x8_t xf[RF];
 #pragma unroll
-  for (int a = 0; a < RF; ++a) xf[0][a] = *reinterpret_cast<const bf16x8_t*>(arow + a * 16 * APITCH);
+  for (int a = 0; a < RF; ++a) xf[a] = *reinterpret_cast<const bf16x8_t*>(arow + a * 16 * APITCH);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     if (kb + PD < KB) {
 #pragma unroll
       for (int b = 0; b < 3; ++b) w[(kb + PD) % NB][b] = wp[((kb + PD) * 3 + b) * 64];
     }
-    if (kb + 1 < KB) {
-#pragma unroll
-      for (int a = 0; a < RF; ++a) xf[(kb + 1) & 1][a] = *reinterpret_cast<const bf16x8_t*>(arow + a * 16 * APITCH + (kb + 1) * 32);
-    }
     // pin the prefetches where they are written: without this hipcc sinks the weight loads next to their first use
     // (vmcnt(0) in front of every k-block: one full L2 round trip per 24 MFMAs)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int a = 0; a < RF; ++a)
+    for (int a = 0; a < RF; ++a) {
 #pragma unroll
-      for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kb % NB][b], xf[kb & 1][a], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kb % NB][b], xf[a], acc[a][b], 0, 0, 0);
+      if (kb + 1 < KB) xf[a] = *reinterpret_cast<const bf16x8_t*>(arow + a * 16 * APITCH + (kb + 1) * 32);
+    }
   }
 }
 
@@ -97,6 +98,9 @@ __device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f3
 template <int RF, int CPR = 48>
 __device__ __forceinline__ void load_tile(bf16_t* As, const bf16_t* src, long ld, int col0, int row0) {
   constexpr int CH = 16 * RF * CPR, IT = (CH + NTHR - 1) / NTHR;
+  // launder the (uniform) tile origin: otherwise hipcc shares the 12 per-thread offsets of this call with every later
+  // phase that addresses the same rows (z2 reload, residual loads) and keeps them alive — in scratch — across the kernel
+  asm volatile("" : "+s"(row0));
   u32x4_t v[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void cl_half_kernel(ClHalfArgs A) {
   for (int cb = wave; cb * 16 < Np; cb += 4) {
     const bf16_t* yrow = H.Y + (long)(cb * 16 + l15) * d + l4 * 8;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 12
     for (int kb = 0; kb < kbs; ++kb) {
       const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xrow + kb * 32);
       const bf16x8_t yf = *reinterpret_cast<const bf16x8_t*>(yrow + kb * 32);
@@ -185,17 +185,37 @@ __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
   const float inv = S.inv[row];
   float gdc[3];
   for (int t = 0; t < S.nc; ++t) gdc[t] = -S.c[t].dcoef * (S.c[t].c1p[row] + S.c[t].c1q[row]);
-  auto grad_at = [&](int c) {
-    float g = 0.f;
-    for (int t = 0; t < S.nc; ++t) g += S.c[t].coef * S.c[t].dX[(long)row * d + c] + gdc[t] * bf2f(S.c[t].other[(long)row * d + c]);
-    return g;
-  };
+  // a lane owns the 4-element chunks lane, lane + 64, ... of the row (d % 32 == 0, d <= 1024): the gradient is formed ONCE,
+  // kept in registers across the dot-product reduction (the first version recomputed it element by element in a second
+  // pass: two serial chains of dependent 4-byte loads, 30 us for a few hundred rows)
+  constexpr int MAXC = 4;
+  f32x4_t g[MAXC], a[MAXC];
   float dot = 0.f;
-  for (int c = lane; c < d; c += 64) dot += S.v[(long)row * d + c] * inv * grad_at(c);
+  const int nch = d / 4;
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int ch = lane + 64 * q;
+    g[q] = f32x4_t{0.f, 0.f, 0.f, 0.f}; a[q] = g[q];
+    if (ch < nch) {
+      const long o = (long)row * d + ch * 4;
+      for (int t = 0; t < S.nc; ++t) {
+        const f32x4_t dx = *reinterpret_cast<const f32x4_t*>(S.c[t].dX + o);
+        const u32x2_t ob = *reinterpret_cast<const u32x2_t*>(S.c[t].other + o);
+        const f32x4_t of = {bflo(ob[0]), bfhi(ob[0]), bflo(ob[1]), bfhi(ob[1])};
+        g[q] += S.c[t].coef * dx + gdc[t] * of;
+      }
+      a[q] = *reinterpret_cast<const f32x4_t*>(S.v + o) * inv;
+      dot += a[q][0] * g[q][0] + a[q][1] * g[q][1] + a[q][2] * g[q][2] + a[q][3] * g[q][3];
+    }
+  }
   dot = wave_sum(dot);
-  for (int c = lane; c < d; c += 64) {
-    const float a = S.v[(long)row * d + c] * inv;
-    S.dv[(long)row * d + c] += (grad_at(c) - a * dot) * inv;
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int ch = lane + 64 * q;
+    if (ch < nch) {
+      float* o = S.dv + (long)row * d + ch * 4;
+      *reinterpret_cast<f32x4_t*>(o) = *reinterpret_cast<const f32x4_t*>(o) + (g[q] - a[q] * dot) * inv;
+    }
   }
 }
 
@@ -242,6 +262,7 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
   {
     const bool hi_on = w_pair[0] != 0.f || w_self[0] != 0.f, lo_on = w_pair[1] != 0.f || w_self[1] != 0.f || w_pair[2] != 0.f || w_self[2] != 0.f;
     COOT_REQUIRE((!hi_on || d_high % 32 == 0) && (!lo_on || d_low % 32 == 0), "contrastive: embedding dims must be multiples of 32 (%d, %d)", d_high, d_low);
+    COOT_REQUIRE(d_high <= 1024 && d_low <= 1024, "contrastive: embedding dims up to 1024 (%d, %d)", d_high, d_low);
   }
   FBump B(scratch, scratch_bytes); FusedLayout L; layout_fused(n_high, n_low, d_high, d_low, B, L);
   COOT_REQUIRE(!B.overflow, "contrastive: scratch too small (%zu < %zu)", scratch_bytes, B.off);

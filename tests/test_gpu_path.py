@@ -365,6 +365,43 @@ def test_native_step_matches_autograd_path(env):
             assert float(diff.max()) <= 2.05e-3, (name, float(diff.max()))
 
 
+def test_native_step_repack_is_equivalent_to_packing_at_start(env):
+    """coot_train_step with COOT_STEP_REPACK | COOT_STEP_PACKS_FRESH (the bf16 weight packs are rebuilt right after the
+    Adam update and trusted at the start of the next call) against packing at the start of every step: same kernels on
+    the same packs; the eval path afterwards sees current packs."""
+    torch, cva = env
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batch = cva.synthetic.make_batch(7, 6, [1, 2, 3, 4, 2, 1], 12, 10, 9, 6, dims[0], dims[1], ragged=True)
+    res = []
+    for force_pack in (False, True):
+        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.05, cc_weight=0.01)
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg_x, mgr)
+        losses = []
+        for it in range(4):
+            if force_pack:
+                mgr.mark_weights_dirty()  # -> no COOT_STEP_PACKS_FRESH: the step packs at its start
+            losses.append(float(tr.train_step_native(batch, seed=1000 + it)[0]))
+        if not force_pack:
+            assert all(n.pack_is_fresh() for n in mgr.model_dict.values())
+        mgr.set_all_models_eval()
+        with torch.no_grad():
+            v = mgr.encode_visual(batch)
+        torch.cuda.synchronize()
+        res.append((losses, [n._flat.clone() for n in mgr.model_dict.values()], v.vid_emb.clone()))
+    (la, pa, va), (lb, pb, vb) = res
+    # not bit-exact run to run: a few parameter gradients are accumulated with fp32 atomics (summation order), and Adam
+    # turns last-bit noise on near-zero gradients into +-lr steps — so: same losses to fp32 round-off, the bulk of the
+    # parameters identical, the embeddings of the updated networks indistinguishable
+    assert np.allclose(la, lb, rtol=1e-5, atol=1e-6), (la, lb)
+    for a, b in zip(pa, pb):
+        d = (a - b).abs()
+        assert float((d > 1e-6).float().mean()) < 2e-3 and float(d.max()) <= 8.1e-3, (float((d > 1e-6).float().mean()), float(d.max()))
+    assert float(torch.nn.functional.cosine_similarity(va.flatten(), vb.flatten(), dim=0)) > 1 - 1e-5
+
+
 def test_fused_adam_matches_torch_adam(env):
     """coot_adam_step on identical gradients vs torch.optim.Adam (coupled weight decay with a per-element decay mask =
     the reference's bias decay_mult 0, nntrainer/optimization.py:45-74, model_manager_base.py:152-154)."""

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""HBM traffic per launch of the MFMA kernel families from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs,
+tools/rocpd_pmc.py csv summaries) -> profiles/<tag>_traffic.json, which bench.py quotes as roofline.traffic.
+
+Corrections (MI355X_MICROARCH.md, HBM section; calibrated here on ln_fwd_kernel<8>, a pure 16-byte streaming kernel with
+known byte counts: FETCH_SIZE reported 82,241 KiB for 163,840 KiB read, WRITE_SIZE 81,920 KiB for 81,920 KiB written):
+  bytes read  = 2 * FETCH_SIZE [KiB] * 1024      (gfx950 tallies 128-byte read requests at 64 bytes)
+  bytes written = WRITE_SIZE [KiB] * 1024
+Usage: python tools/pmc_traffic.py fetch.csv write.csv out.json"""
+import csv
+import json
+import sys
+
+FAMILIES = {
+    "fused": ("post_attn_fwd_kernel", "pre_attn_bwd_kernel", "qkv_fwd_kernel", "qkv_bwd_kernel", "infc_qkv_fwd_kernel"),
+    "gemm_nt": ("gemm_nt_kernel",),
+    "gemm_nt_small": ("gemm_nt_small_kernel",),
+    "gemm_tn": ("gemm_tn_wide_batch_kernel", "gemm_tn_batch_kernel", "gemm_tn_batch_reduce_kernel", "gemm_tn_kernel", "gemm_tn_reduce_kernel"),
+}
+
+
+def read(path):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        out[r["kernel"]] = (int(r["dispatches"]), float(r["total"]))
+    return out
+
+
+def main(fetch_csv, write_csv, out_json):
+    f, w = read(fetch_csv), read(write_csv)
+    res = {"source": {"fetch": fetch_csv, "write": write_csv},
+           "correction": "read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950, calibrated on ln_fwd_kernel<8>); write bytes = WRITE_SIZE KiB x 1024",
+           "families": {}, "kernels": {}}
+    for k in sorted(set(f) | set(w)):
+        n = f.get(k, w.get(k))[0]
+        rb = 2.0 * f.get(k, (0, 0.0))[1] * 1024.0
+        wb = w.get(k, (0, 0.0))[1] * 1024.0
+        res["kernels"][k] = {"dispatches": n, "read_bytes_per_launch": round(rb / n), "write_bytes_per_launch": round(wb / n)}
+    for fam, pats in FAMILIES.items():
+        n = 0; rb = 0.0; wb = 0.0
+        for k in set(f) | set(w):
+            if any(p in k for p in pats):
+                if "gemm_nt_kernel" in pats and "gemm_nt_small" in k:
+                    continue
+                # launches of the family = launches that carry a timing record (the reduce kernels ride on their GEMM's record)
+                if "reduce" not in k:
+                    n += f.get(k, w.get(k))[0]
+                rb += 2.0 * f.get(k, (0, 0.0))[1] * 1024.0
+                wb += w.get(k, (0, 0.0))[1] * 1024.0
+        if n:
+            res["families"][fam] = {"launches": n, "read_bytes_per_launch": round(rb / n), "write_bytes_per_launch": round(wb / n),
+                                    "hbm_bytes_per_launch": round((rb + wb) / n)}
+    json.dump(res, open(out_json, "w"), indent=1)
+    print(json.dumps(res["families"], indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
