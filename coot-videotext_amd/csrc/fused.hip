@@ -285,6 +285,7 @@ __device__ __forceinline__ void apply_drop(const DropK& d, unsigned long long id
 template <int RF, bool DROP, bool OUT32>
 __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const float* bias, int row0, int T, bf16_t* out, float* out32,
                                         long ld32, const DropK& drop) {
+  asm volatile("" : "+s"(row0));  // see ln_bwd_tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
   constexpr int RW = 2 * RF, ITR = (RW + 3) / 4;
   float gn[3][8], bi[3][8];
@@ -474,6 +475,7 @@ template <int RF, bool DROPY, bool MASKX>
 __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, const bf16_t* xsaved, int row0, int T, bf16_t* out_dx,
                                             bf16_t* out_dxm, const DropK& dy_drop, const DropK& dx_drop, float* red, float* part_dst) {
   static_assert(RF == 8, "16 rows per wave, 4 per pass");
+  asm volatile("" : "+s"(row0));  // keep this call's per-thread offsets out of the other LayerNorm's live range (they were spilled across the chain)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
   u32x4_t xs[4][3];  // the saved LN input of this lane's 4 rows, kept packed (all loads in flight together)
 #pragma unroll
