@@ -59,6 +59,7 @@ __device__ __forceinline__ void stage_chunk(const bf16_t* src, long ld, long row
 // ---------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP, NK = DH / 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[KC * RP];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[DH * TP];
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         if (a.drop.thr) {
           const int kidx = kc + kt * 16 + lg * 4 + i;
           unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qrow) * Lk + kidx);
-          p[i] *= drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          p[i] *= drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
         }
       }
       pf[kt] = pack4(p[0], p[1], p[2], p[3]);
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
+  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP, NK = DH / 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[KC * RP];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[KC * RP];
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
         float dpe = dp[i];
         if (a.drop.thr) {
           unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qrow) * Lk + kidx);
-          dpe *= drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          dpe *= drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
         }
         ds[i] = (kidx < nvalid) ? p * (dpe - dl) * a.scale : 0.f;  // masked_fill blocks the gradient
       }
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
+  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP, NK = DH / 16;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[KC * RP];
   __shared__ __attribute__((aligned(16))) bf16_t dOs[KC * RP];
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
         float dsc = 1.f;
         if (a.drop.thr) {
           unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qr) * Lk + krow);
-          dsc = drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          dsc = drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
         }
         p[i] = pv * dsc;
         ds[i] = pv * (dp[i] * dsc - delta_s[ql]) * a.scale;
@@ -387,6 +390,7 @@ __device__ __forceinline__ void stage_rows(const bf16_t* src, long ld, long rowb
 
 template <int DH>
 __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
+  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
   extern __shared__ __attribute__((aligned(16))) bf16_t sh_lds[];  // K | V, L16 rows each (sized by the launcher)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
         if (a.drop.thr) {
           const int kidx = kt * 16 + lg * 4 + i;
           const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qrow) * L + kidx);
-          p[i] *= drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          p[i] *= drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
         }
       }
       pf[kt] = pack4(p[0], p[1], p[2], p[3]);
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
 
 template <int DH>
 __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
+  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
   extern __shared__ __attribute__((aligned(16))) bf16_t sh_lds[];  // K | V | Q | dO (L16 rows each) | lse, delta (fp32)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
           float dpe = dp[i];
           if (a.drop.thr) {
             const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qrow) * L + kidx);
-            dpe *= drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+            dpe *= drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
           }
           ds[i] = (kidx < nvalid) ? p * (dpe - dl) * a.scale : 0.f;  // masked_fill blocks the gradient
         }
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
         float dsc = 1.f;
         if (a.drop.thr) {
           const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qr) * L + krow);
-          dsc = drop_scale(eff_seed(a.drop.seed, a.drop.seed_ptr), a.drop.site, idx, a.drop.thr, a.drop.inv_keep);
+          dsc = drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
         }
         p[i] = pv * dsc;
         ds[i] = pv * (dp[i] * dsc - delta_s[qr]) * a.scale;

@@ -111,6 +111,16 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned si
   const unsigned u = (idx & 1ull) ? (h >> 16) : (h & 0xFFFFu);
   return u >= (thr >> 16) ? inv_keep : 0.0f;
 }
+// the same with the site key derived once per kernel (drop_site_key): the mask sites of a kernel share (seed, site), and
+// reading *seed_ptr where the mask is drawn costs a global load + s_waitcnt vmcnt(0) per element group
+__device__ __forceinline__ unsigned drop_site_key(unsigned long long salt, const unsigned long long* base, unsigned site) {
+  return drop_key(eff_seed(salt, base), site);
+}
+__device__ __forceinline__ float drop_scale_key(unsigned key, unsigned long long idx, unsigned thr, float inv_keep) {
+  const unsigned h = drop_pair(key, idx);
+  const unsigned u = (idx & 1ull) ? (h >> 16) : (h & 0xFFFFu);
+  return u >= (thr >> 16) ? inv_keep : 0.0f;
+}
 // keep-scales of N consecutive elements starting at an EVEN index (N even): N / 2 hashes
 template <int N>
 __device__ __forceinline__ void drop_scales_key(unsigned key, unsigned long long idx0, unsigned thr, float inv_keep, float* sc) {

@@ -35,14 +35,14 @@ __device__ __forceinline__ u32x4_t pack8(const float* v) {
 }
 
 // Fused epilogue on 8 consecutive features [col, col+8) of token `row`; v = raw accumulators.
-__device__ __forceinline__ void epilogue8(const GemmEpi& e, float* v, int row, int col, long zo, int N, const float* bias8) {
+__device__ __forceinline__ void epilogue8(const GemmEpi& e, float* v, int row, int col, long zo, int N, const float* bias8, unsigned dkey) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + bias8[j];
   float dsc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) dsc[j] = 1.f;
   if (e.drop_thr) {
-    drop_scales<8>(eff_seed(e.drop_seed, e.drop_seed_ptr), e.drop_site, (unsigned long long)row * e.drop_ld + zo + col, e.drop_thr, e.drop_inv_keep, dsc);
+    drop_scales_key<8>(dkey, (unsigned long long)row * e.drop_ld + zo + col, e.drop_thr, e.drop_inv_keep, dsc);
     if (e.act != 2) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= dsc[j];
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const unsigned dkey = g.epi.drop_thr ? drop_site_key(g.epi.drop_seed, g.epi.drop_seed_ptr, g.epi.drop_site) : 0u;
   // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (linear id % 8), each with a private L2.  The column
   // blocks of one token slab share that slab, so they are given ids of the SAME residue, 8 apart (same L2, consecutive
   // in time): id = 8 nb G + 8 bx + (by % 8), by = 8 G + id % 8.  With id = bx + nb by every slab was pulled into nb L2s.
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
     const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(&Cs[rl * CPITCH + cch * 8]);
     const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(&Cs[rl * CPITCH + cch * 8 + 4]);
     v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
-    epilogue8(e, v, row, col, zo, N, bias8);
+    epilogue8(e, v, row, col, zo, N, bias8, dkey);
 #pragma unroll
     for (int j = 0; j < 8; ++j) csum[j] += v[j];
   }
@@ -264,12 +265,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
 // MFMA fragments straight from global memory (the operands are L2 resident), up to 6 k-steps of loads in flight at
 // once, no LDS, no barriers: ~2 memory round trips per launch.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void epilogue4(const GemmEpi& e, float* v, int row, int col, long zo, int N, const float* bias4) {
+__device__ __forceinline__ void epilogue4(const GemmEpi& e, float* v, int row, int col, long zo, int N, const float* bias4, unsigned dkey) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = v[j] * e.alpha + bias4[j];
   float dsc[4] = {1.f, 1.f, 1.f, 1.f};
   if (e.drop_thr) {
-    drop_scales<4>(eff_seed(e.drop_seed, e.drop_seed_ptr), e.drop_site, (unsigned long long)row * e.drop_ld + zo + col, e.drop_thr, e.drop_inv_keep, dsc);
+    drop_scales_key<4>(dkey, (unsigned long long)row * e.drop_ld + zo + col, e.drop_thr, e.drop_inv_keep, dsc);
     if (e.act != 2) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] *= dsc[j];
@@ -324,6 +325,7 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, float* v, int row, i
 
 template <int NF>
 __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmNT g) {
+  const unsigned dkey = g.epi.drop_thr ? drop_site_key(g.epi.drop_seed, g.epi.drop_seed_ptr, g.epi.drop_site) : 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int z = blockIdx.z;
   const int M = g.M_dev ? min(g.M, *g.M_dev) : g.M, N = g.N, K = g.K;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmNT g) {
     float v[4] = {acc[f][0], acc[f][1], acc[f][2], acc[f][3]};
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (ok && e.bias) { const f32x4_t b = *reinterpret_cast<const f32x4_t*>(e.bias + zo + col); b4[0] = b[0]; b4[1] = b[1]; b4[2] = b[2]; b4[3] = b[3]; }
-    if (ok) epilogue4(e, v, row, col, zo, N, b4);
+    if (ok) epilogue4(e, v, row, col, zo, N, b4, dkey);
     if (e.colsum) {  // 16 tokens of this wave share a feature: reduce over l15, one atomic per feature (<= M/16 adds per address)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -25,6 +25,7 @@ __host__ __device__ inline int pool_cpb(int D) { return (D % 128 == 0) ? 16 : D 
 
 __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
   __shared__ float red[3][256 * 8 + 8];
+  const unsigned kw = p.drop_w.thr ? drop_site_key(p.drop_w.seed, p.drop_w.seed_ptr, p.drop_w.site) : 0u;
   const int n = blockIdx.x, cpb = pool_cpb(p.D), rgs = 256 / cpb;
   const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, c = (blockIdx.y * cpb + cl) * 8;
   const int len = (int)p.lens[n];
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
           pool_unpack(fu[b], f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) sc[j] = 1.f;
-          if (p.drop_w.thr) drop_scales<8>(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, (unsigned long long)(r0 + l) * p.D + c, p.drop_w.thr, p.drop_w.inv_keep, sc);
+          if (p.drop_w.thr) drop_scales_key<8>(kw, (unsigned long long)(r0 + l) * p.D + c, p.drop_w.thr, p.drop_w.inv_keep, sc);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float mn = fmaxf(m[j], s[j]);
@@ -95,6 +96,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
 // FC): same thread mapping as the forward, 16-byte loads and stores, the RG partial column sums merged through LDS.
 __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs p) {
   __shared__ float red[256 * 8 + 8];
+  const unsigned kw = p.drop_w.thr ? drop_site_key(p.drop_w.seed, p.drop_w.seed_ptr, p.drop_w.site) : 0u;
+  const unsigned ks = p.drop_s.thr ? drop_site_key(p.drop_s.seed, p.drop_s.seed_ptr, p.drop_s.site) : 0u;
   const int n = blockIdx.x, cpb = pool_cpb(p.D), rgs = 256 / cpb;
   const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, c = (blockIdx.y * cpb + cl) * 8;
   const int len = (int)p.lens[n];
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs p) {
             pool_unpack(fu[b], f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { d3[j] = 1.f; d2[j] = 1.f; }
-            if (p.drop_w.thr) drop_scales<8>(eff_seed(p.drop_w.seed, p.drop_w.seed_ptr), p.drop_w.site, (unsigned long long)(r0 + l) * p.D + c, p.drop_w.thr, p.drop_w.inv_keep, d3);
-            if (p.drop_s.thr) drop_scales<8>(eff_seed(p.drop_s.seed, p.drop_s.seed_ptr), p.drop_s.site, (unsigned long long)(p.drop_s_row0 + r0 + l) * p.drop_s_ld + c, p.drop_s.thr, p.drop_s.inv_keep, d2);
+            if (p.drop_w.thr) drop_scales_key<8>(kw, (unsigned long long)(r0 + l) * p.D + c, p.drop_w.thr, p.drop_w.inv_keep, d3);
+            if (p.drop_s.thr) drop_scales_key<8>(ks, (unsigned long long)(p.drop_s_row0 + r0 + l) * p.drop_s_ld + c, p.drop_s.thr, p.drop_s.inv_keep, d2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float w = __expf(s[j] - m[j]) * iz[j];

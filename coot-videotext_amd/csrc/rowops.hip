@@ -22,6 +22,7 @@ __device__ __forceinline__ void store4_bf(bf16_t* p, f32x4_t v) {
 // per SIMD, 64 KB in flight per CU: the input LayerNorm ran at 2.4 TB/s); 64 VGPRs are enough and fill the CU
 template <int NV>
 __global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
+  const unsigned dkey = p.drop.thr ? drop_site_key(p.drop.seed, p.drop.seed_ptr, p.drop.site) : 0u;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.R) return;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
     }
     if (p.drop.thr) {
       float sc[4];
-      drop_scales<4>(eff_seed(p.drop.seed, p.drop.seed_ptr), p.drop.site, (unsigned long long)row * D + col, p.drop.thr, p.drop.inv_keep, sc);
+      drop_scales_key<4>(dkey, (unsigned long long)row * D + col, p.drop.thr, p.drop.inv_keep, sc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) y[j] *= sc[j];
     }
@@ -139,6 +140,8 @@ int launch_reduce_partials(const float* ws, int nparts, long ld, int C, float* o
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
   __shared__ float red[3][4][NV * 256];
+  const unsigned dkey = p.drop.thr ? drop_site_key(p.drop.seed, p.drop.seed_ptr, p.drop.site) : 0u;
+  const unsigned dkey_m = (p.dxm && p.dxm_drop.thr) ? drop_site_key(p.dxm_drop.seed, p.dxm_drop.seed_ptr, p.dxm_drop.site) : 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = p.D, nch = D >> 2;
   f32x4_t ag[NV], ab[NV], ac[NV];
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         if (p.dy_add) { f32x4_t t = load4(p.dy_add, 0, (long)row * p.lddy_add + col); dy[i] += t; }
         if (p.drop.thr) {
           float sc[4];
-          drop_scales<4>(eff_seed(p.drop.seed, p.drop.seed_ptr), p.drop.site, (unsigned long long)row * D + col, p.drop.thr, p.drop.inv_keep, sc);
+          drop_scales_key<4>(dkey, (unsigned long long)row * D + col, p.drop.thr, p.drop.inv_keep, sc);
 #pragma unroll
           for (int j = 0; j < 4; ++j) dy[i][j] *= sc[j];
         }
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
       f32x4_t dx, dm;
       float msc[4] = {1.f, 1.f, 1.f, 1.f};
       if (p.dxm && p.dxm_drop.thr)
-        drop_scales<4>(eff_seed(p.dxm_drop.seed, p.dxm_drop.seed_ptr), p.dxm_drop.site, (unsigned long long)row * p.dxm_drop_ld + col, p.dxm_drop.thr,
+        drop_scales_key<4>(dkey_m, (unsigned long long)row * p.dxm_drop_ld + col, p.dxm_drop.thr,
                        p.dxm_drop.inv_keep, msc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
