@@ -209,11 +209,33 @@ def main():
                     "algorithmic_gflop_per_step": round(fl.value / nst / 1e9, 2)}
 
         by = {names[k]: collect(k) for k in (2, 3, 4, 5)}
+        # algorithmic HBM bytes of the fused chains: bf16 tensors each read / written exactly once per token:
+        # forward chain 1536 read + 8448 written, backward chain 5376 + 5376, QKV 768 + 2304, QKV dX 3840 + 768
+        tok = w["B"] * w["Lv"] + w["B"] * w["C"] * w["Lc"] + w["B"] * w["Lp"] + w["B"] * w["C"] * w["Ls"]
+        fused = names[5]
+        if by[fused]["launches_per_step"]:
+            by[fused]["algorithmic_bytes_per_launch"] = int(tok * (9984 + 10752 + 3072 + 4608) / by[fused]["launches_per_step"])
         allk, infc = collect(0), collect(1)
         lib.coot_timing_enable(0)
         dom = max(by, key=lambda k: by[k]["ms_per_step"])  # the kernel the step spends most MFMA time in
+        # HBM bytes per launch of that family from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
+        # WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py)
+        traffic, traffic_src = None, None
+        fam_key = {2: "gemm_nt", 3: "gemm_nt_small", 4: "gemm_tn", 5: "fused"}[[k for k in names if names[k] == dom][0]]
+        import glob
+        cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
+        if cands:
+            try:
+                tj = json.load(open(cands[-1]))
+                traffic = tj["families"][fam_key]["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(cands[-1], os.path.dirname(os.path.abspath(__file__)))
+            except (KeyError, ValueError, OSError):
+                traffic = None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": by[dom]["achieved"], "peak": 2500.0, "unit": "TFLOP/s",
-                    "frac": by[dom]["frac"], "traffic": None, "launches_per_step": by[dom]["launches_per_step"],
+                    "frac": by[dom]["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, "
+                    "family average)", "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": by[dom].get("algorithmic_bytes_per_launch"),
+                    "launches_per_step": by[dom]["launches_per_step"],
                     "avg_launch_us": by[dom]["avg_launch_us"], "ms_per_step": by[dom]["ms_per_step"],
                     "note": "algorithmic 2*M*N*K per launch / HIP-event duration on the launch stream, measured while both "
                             "sides (two streams) run concurrently; 'by_kernel' lists every MFMA kernel family the same way",
