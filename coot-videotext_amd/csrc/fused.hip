@@ -62,7 +62,9 @@ template <int RF, int KB>
 __device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f32x4_t (&acc)[RF][3], int lane) {
   const bf16_t* arow = As + (lane & 15) * APITCH + (lane >> 4) * 8;
   const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(wg) + lane;
-  constexpr int PD = 2, NB = PD + 1;  // prefetch distance (k-blocks) and register ring size
+  // prefetch distance (k-blocks) and register ring size.  Small tiles (the global networks: RF <= 2) do almost no MFMA
+  // work per k-block, the pass is the latency of streaming 295 KB of weights: keep 6 k-blocks (18 KB per wave) in flight
+  constexpr int PD = RF <= 2 ? 6 : 2, NB = PD + 1;
   bf16x8_t w[NB][3];
 #pragma unroll
   for (int s = 0; s < PD; ++s)

@@ -323,49 +323,70 @@ int launch_cast_weight(const float* src, long lds, int R, int C, bf16_t* dst, lo
   return 0;
 }
 
-// one workgroup per 32 x 32 tile of one job: blockIdx.x -> (job, tile) through the jobs' tile prefix (a (max tiles, jobs)
-// grid launched 21k workgroups for the 2.6M-parameter local network, most of which returned at once: 16 us per launch)
-struct PackTiles { int tile0[57]; };
+// One thread per 8 consecutive bf16 of the DESTINATION (one 16-byte store): blockIdx.x -> (job, group) through the jobs'
+// workgroup prefix.  The logical matrix is [n][k] = dst row, dst column (source [r][c] with (n, k) = (r, c), or (c, r) when
+// transposed); k is the contiguous destination index in both layouts (row-major with ldd, or P48: fused.h p48_offset).
+// History: a (max tiles, jobs) grid of 32 x 32 LDS-transposed tiles with 2-byte scattered stores: 21k workgroups for the
+// 2.6M-parameter local network, 16 us per launch, four launches per step, two of them on the critical path.
+struct PackTiles { int blk0[57]; };
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const float* P, char* wpack, PackJobs jobs, PackTiles pt) {
-  __shared__ float tile[32][33];
   int ji = 0;
-  for (int t = 1; t < jobs.n; ++t) if ((int)blockIdx.x >= pt.tile0[t]) ji = t;
+  for (int t = 1; t < jobs.n; ++t) if ((int)blockIdx.x >= pt.blk0[t]) ji = t;
   const PackJob& jb = jobs.j[ji];
-  const int tiles_x = (jb.C + 31) / 32;
-  const int local = blockIdx.x - pt.tile0[ji];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c0 = (local % tiles_x) * 32, r0 = (local / tiles_x) * 32;
-  const float* src = P + jb.src_off;
-  const float* colscale = jb.colscale_off >= 0 ? P + jb.colscale_off : nullptr;
-  bf16_t* dst = reinterpret_cast<bf16_t*>(wpack + jb.dst_byte_off);
-  for (int i = ty; i < 32; i += 8) {
-    int r = r0 + i, c = c0 + tx;
-    float v = 0.f;
-    if (r < jb.R && c < jb.C) { v = src[(long)r * jb.lds + c]; if (colscale) v *= colscale[c]; }
-    tile[i][tx] = v;
-  }
-  __syncthreads();
-  if (!jb.transpose) {
-    for (int i = ty; i < 32; i += 8) {
-      int r = r0 + i, c = c0 + tx;
-      if (r < jb.R && c < jb.C) dst[jb.p48 ? p48_offset(r, c, jb.C) : (long)r * jb.ldd + c] = f2bf(tile[i][tx]);
-    }
+  const int Nn = jb.transpose ? jb.C : jb.R, Kk = jb.transpose ? jb.R : jb.C;  // logical [n][k]
+  const int k8n = Kk >> 3;
+  const long g = (long)(blockIdx.x - pt.blk0[ji]) * 256 + threadIdx.x;
+  if (g >= (long)Nn * k8n) return;
+  int n, k;
+  long doff;
+  if (jb.p48) {  // invert p48_offset for the group's first element: offset = 8 g
+    const int l64 = (int)(g & 63), q = l64 >> 4, r = l64 & 15;
+    long t = g >> 6;
+    const int b = (int)(t % 3); t /= 3;
+    const int kbn = Kk >> 5, kb = (int)(t % kbn), grp = (int)(t / kbn);
+    n = grp * 48 + b * 16 + r; k = kb * 32 + q * 8;
+    doff = g * 8;
   } else {
-    for (int i = ty; i < 32; i += 8) {
-      int c = c0 + i, r = r0 + tx;
-      if (r < jb.R && c < jb.C) dst[jb.p48 ? p48_offset(c, r, jb.R) : (long)c * jb.ldd + r] = f2bf(tile[tx][i]);
+    n = (int)(g / k8n); k = (int)(g - (long)n * k8n) * 8;
+    doff = (long)n * jb.ldd + k;
+  }
+  const float* src = P + jb.src_off;
+  float v[8];
+  if (!jb.transpose) {  // source row n, columns k .. k + 8 (contiguous)
+    const float* sp = src + (long)n * jb.lds + k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = sp[e];
+    if (jb.colscale_off >= 0) {
+      const float* cs = P + jb.colscale_off + k;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= cs[e];
+    }
+  } else {  // source rows k .. k + 8, column n
+    const float* sp = src + (long)k * jb.lds + n;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = sp[(long)e * jb.lds];
+    if (jb.colscale_off >= 0) {
+      const float sc = P[jb.colscale_off + n];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= sc;
     }
   }
+  bf16_t* dst = reinterpret_cast<bf16_t*>(wpack + jb.dst_byte_off);
+  *reinterpret_cast<u32x4_t*>(dst + doff) = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
 }
 int launch_pack_jobs(const float* P, void* wpack, const PackJobs& jobs, hipStream_t stream) {
   if (jobs.n <= 0) return 0;
   PackTiles pt;
   int total = 0;
   for (int i = 0; i < jobs.n; ++i) {
-    pt.tile0[i] = total;
-    total += ((jobs.j[i].C + 31) / 32) * ((jobs.j[i].R + 31) / 32);
+    const PackJob& j = jobs.j[i];
+    const int Nn = j.transpose ? j.C : j.R, Kk = j.transpose ? j.R : j.C;
+    COOT_REQUIRE(Kk % 8 == 0 && (j.p48 ? (Nn % 48 == 0 && Kk % 32 == 0) : (j.ldd % 8 == 0)) && j.dst_byte_off % 16 == 0,
+                 "pack: job %d: [%d x %d] not packable in 16-byte groups", i, Nn, Kk);
+    pt.blk0[i] = total;
+    total += (int)(((long)Nn * (Kk / 8) + 255) / 256);
   }
-  pt.tile0[jobs.n] = total;
+  pt.blk0[jobs.n] = total;
   hipLaunchKernelGGL(pack_jobs_kernel, dim3(total), dim3(256), 0, stream, P, (char*)wpack, jobs, pt);
   COOT_CHECK_LAUNCH("pack_jobs");
   return 0;
