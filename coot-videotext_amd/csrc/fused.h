@@ -71,6 +71,7 @@ struct InfcQkvFwd {
   const float* pe = nullptr; int T0 = 0, L1 = 1, L2 = 1;  // pe[pos][384]; pos = row < T0 ? row % L1 : (row - T0) % L2
   const bf16_t* wqkv = nullptr; const float* bqkv = nullptr;
   bf16_t *h0 = nullptr, *z0 = nullptr, *qkv = nullptr;
+  unsigned long long* tstamps = nullptr;  // profiling aid: block 0 phase stamps at slots 48.. (tools/fused_stamps.py)
 };
 int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st);
 

@@ -63,7 +63,8 @@ __device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f3
   const bf16_t* arow = As + (lane & 15) * APITCH + (lane >> 4) * 8;
   const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(wg) + lane;
   // prefetch distance (k-blocks) and register ring size.  Small tiles (the global networks: RF <= 2) do almost no MFMA
-  // work per k-block, the pass is the latency of streaming 295 KB of weights: keep 6 k-blocks (18 KB per wave) in flight
+  // work per k-block, the pass is the latency of streaming 295 KB of weights: keep 6 k-blocks (18 KB per wave) in flight.
+  // Full tiles: a pass is at the MFMA time of 2 waves/SIMD; PD = 3 / 4 measured no faster and cost 60 / 140 B/lane of spills.
   constexpr int PD = RF <= 2 ? 6 : 2, NB = PD + 1;
   bf16x8_t w[NB][3];
 #pragma unroll
@@ -754,41 +755,49 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
   float* Bsm = reinterpret_cast<float*>(smem + BT * APITCH * 2 + RR * SPITCH * 4);  // bin | bq | bk | bv
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * BT, Din = p.Din;
+  int tsn = 48;
+  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  stamp();
   if (tid < FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[tid] = reinterpret_cast<const f32x4_t*>(p.bin)[tid];
   else if (tid < 4 * FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[tid] = reinterpret_cast<const f32x4_t*>(p.bqkv)[tid - FZ_D / 4];
   bf16_t* Xs = As;  // [2][BT * XPITCH]
   // slab staging: 128 rows x 64 columns = 1024 16-byte chunks, two per thread (rows r and r + 64)
   const int sr = tid >> 3, sc = (tid & 7) * 8;
   const unsigned g0 = (unsigned)((row0 + sr) * Din + sc) * 2u, g1 = (unsigned)((row0 + sr + 64) * Din + sc) * 2u;
-  u32x4_t xr[2];
-  auto gload = [&](int k0) { xr[0] = gld16(p.xhat, g0 + (unsigned)k0 * 2u); xr[1] = gld16(p.xhat, g1 + (unsigned)k0 * 2u); };
-  auto sstore = [&](int buf) {
-    *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + sr * XPITCH + sc]) = xr[0];
-    *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + (sr + 64) * XPITCH + sc]) = xr[1];
+  // Software pipeline of the K loop (one 64-column slab = two k-blocks = 48 MFMAs per wave, ~0.6 us per slab and CU):
+  //   xhat: two register sets, each holding the slab TWO ahead (HBM latency > one slab); stored to the free LDS buffer at
+  //         the end of the slab before its use;
+  //   weights: a ring of three slabs (6 k-blocks), filled two slabs ahead of their use (L2 latency ~ one slab);
+  //   one LDS-only barrier per slab (a __syncthreads() would also drain the prefetches: one memory round trip per slab).
+  u32x4_t xr[2][2];
+  auto gload = [&](int set, int k0) { xr[set][0] = gld16(p.xhat, g0 + (unsigned)k0 * 2u); xr[set][1] = gld16(p.xhat, g1 + (unsigned)k0 * 2u); };
+  auto sstore = [&](int set, int buf) {
+    *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + sr * XPITCH + sc]) = xr[set][0];
+    *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + (sr + 64) * XPITCH + sc]) = xr[set][1];
   };
   f32x4_t acc[RF][3];
   zero_acc<RF>(acc);
   const int nkb = Din / 32, nslab = Din / 64;
   const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(p.win + (long)wave * nkb * 3 * 512) + lane;
-  bf16x8_t w[4][3];  // ring over k-blocks: slab s uses k-blocks 2 s, 2 s + 1 -> ring slots (2 (s & 1) + kk)
+  bf16x8_t w[6][3];  // ring over k-blocks: slab s uses slots 2 (s % 3) + kk
+  auto wload = [&](int s, auto slot3) {
+    constexpr int S3 = decltype(slot3)::value;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) w[kb][b] = wp[(kb * 3 + b) * 64];
-  gload(0);
-  sstore(0);
-  if (nslab > 1) gload(64);
+      for (int b = 0; b < 3; ++b) w[2 * S3 + kk][b] = wp[((s * 2 + kk) * 3 + b) * 64];
+  };
+  wload(0, std::integral_constant<int, 0>{});
+  if (nslab > 1) wload(1, std::integral_constant<int, 1>{});
+  gload(0, 0);
+  sstore(0, 0);
+  if (nslab > 1) gload(1, 64);
+  if (nslab > 2) gload(0, 128);
   __syncthreads();
   const bf16_t* arow = Xs + (lane & 15) * XPITCH + (lane >> 4) * 8;
-  auto slab = [&](int s, auto parity) {
-    constexpr int PAR = decltype(parity)::value;
-    // weights of the NEXT slab into the other half of the ring (two k-blocks ahead of their use)
-    if (s + 1 < nslab) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) w[2 * (1 - PAR) + kk][b] = wp[(((s + 1) * 2 + kk) * 3 + b) * 64];
-    }
+  auto slab = [&](int s, auto j6) {
+    constexpr int J = decltype(j6)::value, PAR = J & 1, S3 = J % 3;
+    if (s + 2 < nslab) wload(s + 2, std::integral_constant<int, (S3 + 2) % 3>{});
     __builtin_amdgcn_sched_barrier(0);
     const bf16_t* ab = arow + PAR * BT * XPITCH;
 #pragma unroll
@@ -797,19 +806,24 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
       for (int a = 0; a < RF; ++a) {
         const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(ab + a * 16 * XPITCH + kk * 32);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2 * PAR + kk][b], xf, acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2 * S3 + kk][b], xf, acc[a][b], 0, 0, 0);
       }
-    // next slab: registers -> the other LDS buffer (its previous readers finished before the last barrier), then the
-    // loads of the slab after it
-    if (s + 1 < nslab) sstore(1 - PAR);
-    if (s + 2 < nslab) gload((s + 2) * 64);
-    __syncthreads();
+    // slab s + 1 (register set 1 - PAR) -> the other LDS buffer (its readers finished before the last barrier), then that
+    // set takes the loads of slab s + 3
+    if (s + 1 < nslab) sstore(1 - PAR, 1 - PAR);
+    if (s + 3 < nslab) gload(1 - PAR, (s + 3) * 64);
+    lds_barrier();
   };
 #pragma unroll 1
-  for (int s = 0; s < nslab; s += 2) {
+  for (int s = 0; s < nslab; s += 6) {
     slab(s, std::integral_constant<int, 0>{});
     if (s + 1 < nslab) slab(s + 1, std::integral_constant<int, 1>{});
+    if (s + 2 < nslab) slab(s + 2, std::integral_constant<int, 2>{});
+    if (s + 3 < nslab) slab(s + 3, std::integral_constant<int, 3>{});
+    if (s + 4 < nslab) slab(s + 4, std::integral_constant<int, 4>{});
+    if (s + 5 < nslab) slab(s + 5, std::integral_constant<int, 5>{});
   }
+  stamp();
   // ---- epilogue: + folded bias, save h0, GELU, + pe -> z0 (tile + global) ------------------------------------------
   struct PrePe { f32x4_t a, b; };
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm,
@@ -825,6 +839,7 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
         v[0] += pr.a[0]; v[1] += pr.a[1]; v[2] += pr.a[2]; v[3] += pr.a[3]; v[4] += pr.b[0]; v[5] += pr.b[1]; v[6] += pr.b[2]; v[7] += pr.b[3];
         gst16(p.z0, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
       }, true);
+  stamp();
   // ---- QKV ------------------------------------------------------------------------------------------------------------------
 #pragma unroll 1
   for (int q = 0; q < 3; ++q) {
@@ -833,6 +848,7 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
     epilogue<RF, 8>(acc, Stg, As, row0, Bsm + (1 + q) * FZ_D, [&](int, int) { return PreNone{}; },
         [&](int row, int col, float (&v)[8], const PreNone&, int) { gst16(p.qkv, (unsigned)(row * (3 * FZ_D) + q * FZ_D + col) * 2u, pack8(v)); },
         false);
+    stamp();
   }
 }
 

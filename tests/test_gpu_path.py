@@ -508,7 +508,7 @@ def test_fused_chain_matches_per_op_kernels(env, name, cfg, N, L, with_ctx, trai
     x, lens, hid, R = _inputs(cfg, N, L, 32, with_ctx)
     res = []
     cva.lib.check(lib.coot_set_option(b"fused_min_rows", 1))  # default 1024: small calls stay on the per-op kernels
-    cva.lib.check(lib.coot_set_option(b"fused_infc", 1))      # also the optional fused input-FC + QKV kernel (default off: perf neutral)
+    cva.lib.check(lib.coot_set_option(b"fused_infc", 1))      # the fused input-FC + QKV kernel (default on)
     for fused in (0, 1):
         cva.lib.check(lib.coot_set_option(b"fused", fused))
         net = H.make_hip_net(cfg, P, dropout=0.1 if train else 0.0)
@@ -523,7 +523,6 @@ def test_fused_chain_matches_per_op_kernels(env, name, cfg, N, L, with_ctx, trai
                     {n: p.grad.detach().cpu().numpy() for n, p in net.named_parameters() if p.requires_grad}))
     cva.lib.check(lib.coot_set_option(b"fused", 1))
     cva.lib.check(lib.coot_set_option(b"fused_min_rows", 1024))
-    cva.lib.check(lib.coot_set_option(b"fused_infc", 0))
     (p0, t0, g0), (p1, t1, g1) = res
     ep, et = H.rel_err(p1, p0), H.rel_err(t1, t0)
     print(f"[{name}] fused vs per-op: pooled rel err {ep:.2e}, tokens {et:.2e}")

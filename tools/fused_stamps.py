@@ -31,4 +31,9 @@ for train in (False, True):
             t = ts.cpu().numpy()[:len(names)]
             d = (t[1:] - t[:-1])
             print(f"train={train} N={N} dbg={dbg}: total {(t[-1]-t[0])} ticks; " + ", ".join(f"{n} {int(v)}" for n, v in zip(names[1:], d)))
+            ti = ts.cpu().numpy()[48:54]
+            if ti[0] and dbg == 0:
+                di = ti[1:] - ti[:-1]
+                print(f"    input FC + QKV kernel: total {int(ti[-1] - ti[0])}; K loop {int(di[0])}, epilogue (h0, GELU, pe, z0) {int(di[1])}, "
+                      f"q {int(di[2])}, k {int(di[3])}, v {int(di[4])}")
 cva.lib.check(lib.coot_set_option(b"fz_debug", 0))
