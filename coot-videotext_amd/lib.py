@@ -21,7 +21,7 @@ EXPORTS = [
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
-    "coot_adam_step",
+    "coot_adam_step", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
 ]
 
 
@@ -105,6 +105,9 @@ def load():
     lib.coot_contrastive_scratch_bytes.argtypes = [i32, i32, i32, i32]
     lib.coot_contrastive_fwd_bwd.argtypes = [C.POINTER(ContrastiveConfig), i32, i32, i32, i32] + [vp] * 6 + [vp] + [vp] * 6 + [vp, sz, vp]
     lib.coot_cyclecons_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp]
+    lib.coot_retrieval_workspace_bytes.argtypes = [i32, i32]
+    lib.coot_retrieval_workspace_bytes.restype = C.c_size_t
+    lib.coot_retrieval_ranks.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.coot_gemm_nt.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp, i64, i32, vp]
     lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, sz, vp]
     lib.coot_gemm_tn_workspace_bytes.restype = sz

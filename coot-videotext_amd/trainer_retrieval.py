@@ -21,7 +21,7 @@ from . import loss_fn
 from .config import RetrievalConfig, RetrievalNetworksConst
 from .model_retrieval import (RetrievalDataBatchTuple, RetrievalModelManager, RetrievalTextEmbTuple,
                               RetrievalVisualEmbTuple)
-from .retrieval import compute_retrieval
+from .retrieval import compute_retrieval, compute_retrieval_device  # noqa: F401
 
 
 def make_optimizer(cfg_opt, params, capturable: bool = False) -> torch.optim.Optimizer:
@@ -405,13 +405,14 @@ class RetrievalTrainer:
             losses.append(contr + cc)
             coll["vid_emb"].append(visual_data.vid_emb); coll["par_emb"].append(text_data.par_emb)
             coll["clip_emb"].append(visual_data.clip_emb); coll["sent_emb"].append(text_data.sent_emb)
-        data = {k: torch.cat(v, 0) for k, v in coll.items()}
-        # manual L2 normalisation without eps (:397-402)
-        data = {k: (v / (v * v).sum(-1).sqrt().unsqueeze(-1)).float().cpu().numpy() for k, v in data.items()}
-        v2p, p2v, vp_sum = compute_retrieval(data["vid_emb"], data["par_emb"])
+        data = {k: torch.cat(v, 0).float() for k, v in coll.items()}
+        # The reference moves every batch to the host, normalises there (manual L2 without eps, :397-402) and ranks with one
+        # numpy argsort per row (nntrainer/retrieval.py:68-98).  Here the embeddings never leave the GPU: normalisation,
+        # similarities, ranks and the metric dictionaries are libcoot_hip.so kernels (coot_retrieval_ranks).
+        v2p, p2v, vp_sum = compute_retrieval_device(data["vid_emb"], data["par_emb"], normalize=True)
         out = {"v2p": v2p, "p2v": p2v, "val_score_at_1": vp_sum}
         if val_clips:
-            c2s, s2c, cs_sum = compute_retrieval(data["clip_emb"], data["sent_emb"])
+            c2s, s2c, cs_sum = compute_retrieval_device(data["clip_emb"], data["sent_emb"], normalize=True)
             out.update({"c2s": c2s, "s2c": s2c, "val_clip_sent_score_at_1": cs_sum})
         out["loss"] = float(torch.stack(losses).mean())
         return out

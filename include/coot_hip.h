@@ -123,6 +123,20 @@ int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* 
                            int Cc, int Cs, int D, float weight, float inv_batch, float* loss, float* rows_clip,
                            float* rows_sent, float* dclip, float* dsent, coot_stream_t stream);
 
+/* ---- retrieval ranking on the device -----------------------------------------------------------
+ * validate_epoch's metric tail (coot/trainer_retrieval.py:397-402, :425-436) + nntrainer/retrieval.py:31-98 for one pair
+ * of embedding sets emb1, emb2 [N, d] fp32 (e.g. vid_emb / par_emb of the whole validation set), both directions:
+ *   normalize != 0: rows are first divided by sqrt(sum x^2) (the reference's manual normalisation, no eps);
+ *   ranks_12[i] = position of i in argsort(d[i])[::-1], d = emb1 . emb2^T (fp32 FMA chains in k order);  ranks_21: the same
+ *   for d^T.  Exact ties are ordered as the reversal of a stable ascending sort (j > i ahead of i);
+ *   metrics (optional, 14 floats): {r1, r5, r10, r50, medr, meanr, sum} for 1 -> 2, then for 2 -> 1 (VALKEYS order,
+ *   R@K as fractions, medr = floor(median) + 1, meanr = mean + 1);
+ *   sim_out (optional, [N, N]): the similarity matrix the ranks were counted on (testing aid).
+ * The similarity matrix is never materialised otherwise.  workspace: coot_retrieval_workspace_bytes(N, d). */
+size_t coot_retrieval_workspace_bytes(int N, int d);
+int coot_retrieval_ranks(const float* emb1, const float* emb2, int N, int d, int normalize, int32_t* ranks_12, int32_t* ranks_21,
+                         float* metrics, float* sim_out, void* workspace, size_t workspace_bytes, coot_stream_t stream);
+
 /* ---- the whole training step as native code (coot/trainer_retrieval.py:253-291) -------------------------------
  * Networks are indexed 0 = net_video_local, 1 = net_video_global, 2 = net_text_local, 3 = net_text_global
  * (coot/configs_retrieval.py:182-189).  All buffers are caller-owned device memory. */
