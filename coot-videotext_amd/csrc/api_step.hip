@@ -196,63 +196,83 @@ __global__ void sample_idx_kernel(const long long* lens_a, const long long* lens
   idx[i] = v < len ? v : len - 1;
 }
 
-// torch.optim.Adam (coupled L2 weight decay, nntrainer/optimization.py:45-74); bias corrections precomputed on the host
-__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, const float* decay, long n, float lr,
-                                                   float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
-    if (i + 3 < n) {
-      f32x4_t pp = *reinterpret_cast<f32x4_t*>(p + i), gg = *reinterpret_cast<const f32x4_t*>(g + i);
-      f32x4_t mm = *reinterpret_cast<f32x4_t*>(m + i), vv = *reinterpret_cast<f32x4_t*>(v + i);
-      f32x4_t dd = decay ? *reinterpret_cast<const f32x4_t*>(decay + i) : f32x4_t{1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float gj = gg[j] + wd * dd[j] * pp[j];
-        mm[j] = b1 * mm[j] + (1.f - b1) * gj;
-        vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
-        pp[j] -= lr * inv_bc1 * mm[j] / (sqrtf(vv[j]) * inv_sqrt_bc2 + eps);
-      }
-      *reinterpret_cast<f32x4_t*>(p + i) = pp; *reinterpret_cast<f32x4_t*>(m + i) = mm; *reinterpret_cast<f32x4_t*>(v + i) = vv;
-    } else {
-      for (long k = i; k < n; ++k) {
-        const float gj = g[k] + wd * (decay ? decay[k] : 1.f) * p[k];
-        m[k] = b1 * m[k] + (1.f - b1) * gj;
-        v[k] = b2 * v[k] + (1.f - b2) * gj * gj;
-        p[k] -= lr * inv_bc1 * m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps);
-      }
+// The optimizers of nntrainer/optimization.py:45-181, one elementwise rule each, scalars precomputed on the host:
+//   mode 0  torch.optim.Adam (coupled L2 weight decay):  g' = g + wd d p;  m, v <- g';  p -= lr a m / (sqrt(v) b + eps)
+//           a = 1 / (1 - beta1^t), b = 1 / sqrt(1 - beta2^t)
+//   RAdam (the in-file class, :79-181; decoupled decay p -= wd d lr p, moments from the raw gradient):
+//   mode 1  rectified (N_sma >= 5):  p -= a lr m / (sqrt(v) + eps),  a = step_size
+//   mode 2  degenerated to SGD:      p -= a lr m
+//   mode 3  N_sma < 5 without degenerated_to_sgd: only the moments move
+// d = the per-element decay multiplier (decay_mult, model_manager_base.py:152-154), or 1.
+struct OptK { int mode; float lr, b1, b2, eps, wd, a, b; };
+
+__device__ __forceinline__ void opt_update(const OptK& k, float& p, float g, float& m, float& v, float d) {
+  if (k.mode == 0) {
+    const float gj = g + k.wd * d * p;
+    m = k.b1 * m + (1.f - k.b1) * gj;
+    v = k.b2 * v + (1.f - k.b2) * gj * gj;
+    p -= k.lr * k.a * m / (sqrtf(v) * k.b + k.eps);
+  } else {
+    v = k.b2 * v + (1.f - k.b2) * g * g;
+    m = k.b1 * m + (1.f - k.b1) * g;
+    if (k.mode == 1) {
+      p -= k.wd * d * k.lr * p;
+      p -= k.a * k.lr * m / (sqrtf(v) + k.eps);
+    } else if (k.mode == 2) {
+      p -= k.wd * d * k.lr * p;
+      p -= k.a * k.lr * m;
     }
   }
 }
 
-struct AdamSegs { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; const float* decay[4]; long n[4]; int blk0[5]; };
-__global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
-                                                    float inv_sqrt_bc2) {
-  int s = 0;
-#pragma unroll
-  for (int t = 1; t < 4; ++t) if ((int)blockIdx.x >= sg.blk0[t]) s = t;
-  float* p = sg.p[s]; const float* g = sg.g[s]; float* m = sg.m[s]; float* v = sg.v[s]; const float* decay = sg.decay[s];
-  const long n = sg.n[s];
-  const long i = ((long)(blockIdx.x - sg.blk0[s]) * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
+__device__ __forceinline__ void opt_update_range(const OptK& k, float* p, const float* g, float* m, float* v, const float* decay, long i, long n) {
   if (i + 3 < n) {
     f32x4_t pp = *reinterpret_cast<f32x4_t*>(p + i), gg = *reinterpret_cast<const f32x4_t*>(g + i);
     f32x4_t mm = *reinterpret_cast<f32x4_t*>(m + i), vv = *reinterpret_cast<f32x4_t*>(v + i);
     f32x4_t dd = decay ? *reinterpret_cast<const f32x4_t*>(decay + i) : f32x4_t{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gj = gg[j] + wd * dd[j] * pp[j];
-      mm[j] = b1 * mm[j] + (1.f - b1) * gj;
-      vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
-      pp[j] -= lr * inv_bc1 * mm[j] / (sqrtf(vv[j]) * inv_sqrt_bc2 + eps);
-    }
-    *reinterpret_cast<f32x4_t*>(p + i) = pp; *reinterpret_cast<f32x4_t*>(m + i) = mm; *reinterpret_cast<f32x4_t*>(v + i) = vv;
+    for (int j = 0; j < 4; ++j) { float pj = pp[j], mj = mm[j], vj = vv[j]; opt_update(k, pj, gg[j], mj, vj, dd[j]); pp[j] = pj; mm[j] = mj; vv[j] = vj; }
+    if (k.mode != 3) *reinterpret_cast<f32x4_t*>(p + i) = pp;
+    *reinterpret_cast<f32x4_t*>(m + i) = mm; *reinterpret_cast<f32x4_t*>(v + i) = vv;
   } else {
-    for (long k = i; k < n; ++k) {
-      const float gj = g[k] + wd * (decay ? decay[k] : 1.f) * p[k];
-      m[k] = b1 * m[k] + (1.f - b1) * gj;
-      v[k] = b2 * v[k] + (1.f - b2) * gj * gj;
-      p[k] -= lr * inv_bc1 * m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps);
+    for (long e = i; e < n; ++e) opt_update(k, p[e], g[e], m[e], v[e], decay ? decay[e] : 1.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, const float* decay, long n, OptK k) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) opt_update_range(k, p, g, m, v, decay, i, n);
+}
+
+struct AdamSegs { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; const float* decay[4]; long n[4]; int blk0[5]; };
+__global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, OptK k) {
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t) if ((int)blockIdx.x >= sg.blk0[t]) s = t;
+  const long n = sg.n[s];
+  const long i = ((long)(blockIdx.x - sg.blk0[s]) * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  opt_update_range(k, sg.p[s], sg.g[s], sg.m[s], sg.v[s], sg.decay[s], i, n);
+}
+
+// host side of the rules above; optimizer: 0 = Adam, 1 = RAdam
+OptK opt_scalars(int optimizer, int radam_degentosgd, float lr, float beta1, float beta2, float eps, float wd, int64_t step) {
+  OptK k; k.lr = lr; k.b1 = beta1; k.b2 = beta2; k.eps = eps; k.wd = wd; k.a = 0.f; k.b = 0.f;
+  const double b1t = pow((double)beta1, (double)step), b2t = pow((double)beta2, (double)step);
+  if (optimizer == 0) {
+    k.mode = 0; k.a = (float)(1.0 / (1.0 - b1t)); k.b = (float)(1.0 / sqrt(1.0 - b2t));
+  } else {  // nntrainer/optimization.py:144-164
+    const double nmax = 2.0 / (1.0 - (double)beta2) - 1.0;
+    const double nsma = nmax - 2.0 * (double)step * b2t / (1.0 - b2t);
+    if (nsma >= 5.0) {
+      k.mode = 1;
+      k.a = (float)(sqrt((1.0 - b2t) * (nsma - 4.0) / (nmax - 4.0) * (nsma - 2.0) / nsma * nmax / (nmax - 2.0)) / (1.0 - b1t));
+    } else if (radam_degentosgd) {
+      k.mode = 2; k.a = (float)(1.0 / (1.0 - b1t));
+    } else {
+      k.mode = 3;
     }
   }
+  return k;
 }
 
 __global__ void loss_total_kernel(float* losses) { losses[0] = losses[1] + losses[2]; }
@@ -269,9 +289,8 @@ int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int
     blk += (int)((n / 4 + 255) / 256);
   }
   sg.blk0[4] = blk;
-  const double bc1 = 1.0 - pow((double)cfg.beta1, (double)step), bc2 = 1.0 - pow((double)cfg.beta2, (double)step);
-  hipLaunchKernelGGL(adam4_kernel, dim3(blk), dim3(256), 0, st, sg, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay,
-                     (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+  const OptK k = opt_scalars(cfg.optimizer, cfg.radam_degentosgd, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, step);
+  hipLaunchKernelGGL(adam4_kernel, dim3(blk), dim3(256), 0, st, sg, k);
   COOT_CHECK_LAUNCH("adam4");
   return 0;
 }
@@ -280,18 +299,27 @@ int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int
 
 extern "C" {
 
-int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream) {
-  COOT_REQUIRE(params && grads && m && v && step >= 1, "adam: bad arguments");
+static int optimizer_step(int optimizer, int degen, float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream) {
+  COOT_REQUIRE(params && grads && m && v && step >= 1, "optimizer step: bad arguments");
   if (n <= 0) return 0;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   int blocks = (int)((n / 4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, decay_mask, (long)n, lr, beta1, beta2,
-                     eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
-  COOT_CHECK_LAUNCH("adam");
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, decay_mask, (long)n,
+                     opt_scalars(optimizer, degen, lr, beta1, beta2, eps, weight_decay, step));
+  COOT_CHECK_LAUNCH("optimizer step");
   return 0;
+}
+
+int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream) {
+  return optimizer_step(0, 0, params, grads, m, v, decay_mask, n, lr, beta1, beta2, eps, weight_decay, step, stream);
+}
+
+int coot_radam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, int degenerated_to_sgd, coot_stream_t stream) {
+  return optimizer_step(1, degenerated_to_sgd, params, grads, m, v, decay_mask, n, lr, beta1, beta2, eps, weight_decay, step, stream);
 }
 
 size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_dims* dims) {

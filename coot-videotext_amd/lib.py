@@ -21,7 +21,7 @@ EXPORTS = [
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
-    "coot_adam_step", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
+    "coot_adam_step", "coot_radam_step", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
 ]
 
 
@@ -46,7 +46,8 @@ STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH = 1, 2, 4  # coot_train_step do_op
 class StepConfig(C.Structure):
     """coot_step_config."""
     _fields_ = [("net", NetConfig * 4), ("contr", ContrastiveConfig), ("cc_weight", C.c_float), ("lr", C.c_float),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("optimizer", C.c_int), ("radam_degentosgd", C.c_int)]
 
 
 class StepDims(C.Structure):
@@ -124,6 +125,7 @@ def load():
     lib.coot_step_forward.argtypes = [scp, sbp, sxp, sdp] + [vp] * 6 + [vp, sz, i32, u64, vp, vp, vp]
     lib.coot_step_backward.argtypes = [scp, sbp, sxp, sdp] + [vp] * 10 + [vp, sz, i32, u64, vp, vp, vp]
     lib.coot_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp]
+    lib.coot_radam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, i32, vp]
     _lib = lib
     return lib
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Tuple
 
+import math
 import os
 import numpy as np
 import torch
@@ -24,21 +25,84 @@ from .model_retrieval import (RetrievalDataBatchTuple, RetrievalModelManager, Re
 from .retrieval import compute_retrieval, compute_retrieval_device  # noqa: F401
 
 
+class RAdam(torch.optim.Optimizer):
+    """Rectified Adam as the reference's in-file class behaves (nntrainer/optimization.py:79-181; Liu et al. 2019): moments
+    from the raw gradient, decoupled weight decay ``p -= wd * lr * p``, the variance-rectified adaptive step once the SMA length
+    N_sma >= 5, before that a momentum-SGD step (``degenerated_to_sgd``) or no parameter update at all.  Written on the
+    torch._foreach primitives; the native step uses the same rule in the library (coot_radam_step / coot_train_step)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, degenerated_to_sgd=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.degenerated_to_sgd = degenerated_to_sgd
+
+    @staticmethod
+    def scalars(step: int, beta1: float, beta2: float, degenerated_to_sgd: bool):
+        beta2_t = beta2 ** step
+        n_max = 2.0 / (1.0 - beta2) - 1.0
+        n_sma = n_max - 2.0 * step * beta2_t / (1.0 - beta2_t)
+        if n_sma >= 5:
+            rect = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2))
+            return "rect", rect / (1 - beta1 ** step)
+        if degenerated_to_sgd:
+            return "sgd", 1.0 / (1 - beta1 ** step)
+        return "none", -1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            beta1, beta2 = group["betas"]
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+            steps = {self.state[p]["step"] for p in ps}
+            assert len(steps) == 1, "parameters of one group step together"
+            t = steps.pop() + 1
+            gs = [p.grad for p in ps]
+            ms = [self.state[p]["exp_avg"] for p in ps]
+            vs = [self.state[p]["exp_avg_sq"] for p in ps]
+            torch._foreach_mul_(vs, beta2); torch._foreach_addcmul_(vs, gs, gs, value=1 - beta2)
+            torch._foreach_mul_(ms, beta1); torch._foreach_add_(ms, gs, alpha=1 - beta1)
+            for p in ps:
+                self.state[p]["step"] = t
+            mode, step_size = self.scalars(t, beta1, beta2, self.degenerated_to_sgd)
+            if mode == "none":
+                continue
+            if group["weight_decay"] != 0:
+                torch._foreach_mul_(ps, 1.0 - group["weight_decay"] * group["lr"])
+            if mode == "rect":
+                den = torch._foreach_sqrt(vs)
+                torch._foreach_add_(den, group["eps"])
+                torch._foreach_addcdiv_(ps, ms, den, value=-step_size * group["lr"])
+            else:
+                torch._foreach_add_(ps, ms, alpha=-step_size * group["lr"])
+        return loss
+
+
 def make_optimizer(cfg_opt, params, capturable: bool = False) -> torch.optim.Optimizer:
-    """nntrainer/optimization.py:45-74 for name == 'adam': Adam(lr, betas=(momentum, adam_beta2), eps,
-    weight_decay * decay_mult per parameter).  Parameters are grouped by decay_mult (same update rule,
+    """nntrainer/optimization.py:45-74: Adam(lr, betas=(momentum, adam_beta2), eps, amsgrad) or RAdam(..., degenerated_to_sgd =
+    radam_degentosgd), weight_decay * decay_mult per parameter.  Parameters are grouped by decay_mult (same update rule,
     fewer groups)."""
     name = getattr(cfg_opt, "name", "adam")
-    if name != "adam":
-        raise NotImplementedError(f"optimizer {name}: only adam is wired up (RAdam is SURVEY 8f row 3, next)")
     lr, wd = float(cfg_opt.lr), float(cfg_opt.weight_decay)
     groups: Dict[float, list] = {}
     for p in params:
         groups.setdefault(p["decay_mult"] * wd, []).append(p["params"])
     param_groups = [{"params": ps, "weight_decay": w, "lr": lr} for w, ps in groups.items()]
-    return torch.optim.Adam(param_groups, lr=lr, betas=(float(cfg_opt.momentum), float(cfg_opt.adam_beta2)),
-                            eps=float(cfg_opt.adam_eps), amsgrad=bool(getattr(cfg_opt, "adam_amsgrad", False)),
-                            foreach=True, capturable=capturable)
+    betas = (float(cfg_opt.momentum), float(cfg_opt.adam_beta2))
+    if name == "adam":
+        return torch.optim.Adam(param_groups, lr=lr, betas=betas, eps=float(cfg_opt.adam_eps),
+                                amsgrad=bool(getattr(cfg_opt, "adam_amsgrad", False)), foreach=True, capturable=capturable)
+    if name == "radam":
+        return RAdam(param_groups, lr=lr, betas=betas, eps=float(cfg_opt.adam_eps),
+                     degenerated_to_sgd=bool(getattr(cfg_opt, "radam_degentosgd", False)))
+    raise NotImplementedError(f"Unknown optimizer {name}")  # as nntrainer/optimization.py:62
 
 
 class RetrievalTrainer:
@@ -211,6 +275,11 @@ class RetrievalTrainer:
             o = self.cfg.optimizer
             st.cfg.lr, st.cfg.beta1, st.cfg.beta2 = float(o.lr), float(o.momentum), float(o.adam_beta2)
             st.cfg.eps, st.cfg.weight_decay = float(o.adam_eps), float(o.weight_decay)
+            oname = getattr(o, "name", "adam")
+            if oname not in ("adam", "radam"):
+                raise NotImplementedError(f"Unknown optimizer {oname}")
+            st.cfg.optimizer = 1 if oname == "radam" else 0
+            st.cfg.radam_degentosgd = int(bool(getattr(o, "radam_degentosgd", False)))
             wd_bias = bool(getattr(o, "weight_decay_for_bias", False))
             st.m = [torch.zeros_like(n._flat) for n in nets]
             st.v = [torch.zeros_like(n._flat) for n in nets]
@@ -384,9 +453,12 @@ class RetrievalTrainer:
         st.losses[0:1].copy_(st.losses[1:2] + st.losses[2:3])
         if do_optimizer:
             for i, n in enumerate(st.nets):
-                _lib.check(lib.coot_adam_step(st.bufs.params[i], st.bufs.grads[i], st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i],
-                                              n.numel, st.cfg.lr, st.cfg.beta1, st.cfg.beta2, st.cfg.eps, st.cfg.weight_decay, max(st.step, 1), sp),
-                           "coot_adam_step")
+                args = (st.bufs.params[i], st.bufs.grads[i], st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i], n.numel, st.cfg.lr,
+                        st.cfg.beta1, st.cfg.beta2, st.cfg.eps, st.cfg.weight_decay, max(st.step, 1))
+                if st.cfg.optimizer == 1:
+                    _lib.check(lib.coot_radam_step(*args, st.cfg.radam_degentosgd, sp), "coot_radam_step")
+                else:
+                    _lib.check(lib.coot_adam_step(*args, sp), "coot_adam_step")
             self.model_mgr.mark_weights_dirty()
         self.total_step += 1
         return st.losses[0], st.losses[1], st.losses[2]

@@ -144,7 +144,9 @@ typedef struct coot_step_config {
   coot_net_config net[4];
   coot_contrastive_config contr;
   float cc_weight;                               /* train.loss_cycle_cons                                    */
-  float lr, beta1, beta2, eps, weight_decay;     /* Adam as built by nntrainer/optimization.py:45-74          */
+  float lr, beta1, beta2, eps, weight_decay;     /* optimizer as built by nntrainer/optimization.py:45-74     */
+  int optimizer;                                 /* 0 = torch.optim.Adam, 1 = the in-file RAdam (:79-181)     */
+  int radam_degentosgd;                          /* RAdam degenerated_to_sgd (optimizer.radam_degentosgd)     */
 } coot_step_config;
 typedef struct coot_step_dims { int B, Nc, Lv, Lc, Lp, Ls, Cmax_clip, Cmax_sent; } coot_step_dims;
 typedef struct coot_step_buffers {
@@ -186,6 +188,11 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* buf
                        coot_stream_t side_t);
 int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream);
+/* RAdam of nntrainer/optimization.py:79-181 on one flat arena: decoupled decay weight_decay * decay_mask,
+ * rectified update when N_sma >= 5, otherwise SGD-with-momentum (degenerated_to_sgd) or no parameter update. */
+int coot_radam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int64_t step, int degenerated_to_sgd,
+                    coot_stream_t stream);
 
 /* ---- kernel-level entry points (unit tests / microbenchmarks) ---------------------------------- */
 /* C[M,N] (bf16 or fp32) = act(X[M,K] . W[N,K]^T + bias) (+ residual)   (bf16 operands as uint16) */

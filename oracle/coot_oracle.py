@@ -635,6 +635,38 @@ def cycle_consistency_bwd(clip, clip_valid, sent, sent_valid, idx_clip, idx_sent
 
 
 # ---------------------------------------------------------------------------------------------
+# optimizers (nntrainer/optimization.py): Adam as torch.optim.Adam (coupled L2), RAdam as the in-file class (:79-181)
+# ---------------------------------------------------------------------------------------------
+def radam_scalars(step: int, beta1: float, beta2: float, degenerated_to_sgd: bool):
+    """nntrainer/optimization.py:144-164: (mode, step_size).  mode 'rect': adaptive update with the variance rectification
+    term; 'sgd': momentum-only update (only with degenerated_to_sgd); 'none': the parameters are left alone (moments still move)."""
+    beta2_t = beta2 ** step
+    n_sma_max = 2.0 / (1.0 - beta2) - 1.0
+    n_sma = n_sma_max - 2.0 * step * beta2_t / (1.0 - beta2_t)
+    if n_sma >= 5:
+        return "rect", math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma * n_sma_max / (n_sma_max - 2)) / (
+            1 - beta1 ** step)
+    if degenerated_to_sgd:
+        return "sgd", 1.0 / (1 - beta1 ** step)
+    return "none", -1.0
+
+
+def radam_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float, eps: float, weight_decay, degenerated_to_sgd: bool):
+    """One RAdam step, in place on float64 arrays (nntrainer/optimization.py:112-181).  weight_decay may be an array
+    (weight_decay * decay_mult per element, :66-72).  Decoupled decay: p -= wd * lr * p before the update."""
+    v *= beta2; v += (1 - beta2) * g * g
+    m *= beta1; m += (1 - beta1) * g
+    mode, step_size = radam_scalars(step, beta1, beta2, degenerated_to_sgd)
+    if mode == "rect":
+        p -= weight_decay * lr * p
+        p -= step_size * lr * m / (np.sqrt(v) + eps)
+    elif mode == "sgd":
+        p -= weight_decay * lr * p
+        p -= step_size * lr * m
+    return p
+
+
+# ---------------------------------------------------------------------------------------------
 # retrieval metrics
 # ---------------------------------------------------------------------------------------------
 def compute_retrieval_cosine(dot_product: np.ndarray) -> Tuple[Dict[str, float], np.ndarray]:

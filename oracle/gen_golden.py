@@ -255,6 +255,30 @@ def gen_retrieval_metrics():
     print("wrote retrieval_metrics")
 
 
+def gen_radam():
+    """The reference's in-file RAdam (nntrainer/optimization.py:79-181) for 9 steps from a seeded state, with and without
+    degenerated_to_sgd, two parameter groups (weight_decay, and decay_mult = 0): parameters after every step."""
+    from nntrainer import optimization
+    rs = np.random.RandomState(11)
+    n = 257
+    p0 = (rs.randn(n) * 0.05).astype(np.float32)
+    grads = [(rs.randn(n) * (0.1 ** (s % 3))).astype(np.float32) for s in range(9)]
+    out = {"p0": p0, "grads": np.stack(grads), "lr": 3.6e-4, "beta1": 0.56, "beta2": 0.98, "eps": 1.5e-9, "wd": 2e-3}
+    for degen in (False, True):
+        pa = th.nn.Parameter(th.from_numpy(p0[:200].copy()))
+        pb = th.nn.Parameter(th.from_numpy(p0[200:].copy()))
+        opt = optimization.RAdam([dict(params=[pa], weight_decay=2e-3), dict(params=[pb], weight_decay=0.0)], lr=3.6e-4,
+                                 betas=(0.56, 0.98), eps=1.5e-9, degenerated_to_sgd=degen)
+        traj = []
+        for g in grads:
+            pa.grad = th.from_numpy(g[:200].copy()); pb.grad = th.from_numpy(g[200:].copy())
+            opt.step()
+            traj.append(np.concatenate([pa.detach().numpy(), pb.detach().numpy()]))
+        out[f"traj_degen{int(degen)}"] = np.stack(traj)
+    np.savez_compressed(os.path.join(OUT, "radam.npz"), **out)
+    print("wrote radam")
+
+
 def gen_mask_semantics():
     """Numeric version of tests_nntrainer/test_transformers.py:22-79: perturbing masked inputs
     must not change un-masked outputs of the encoder; we store outputs before/after."""
@@ -296,6 +320,7 @@ def main():
     gen_full("full_anet", (2048, 1536, 384, 8, 384, 768), B=6, counts=[3, 1, 4, 2, 2, 5], Ls=(20, 16, 18, 9),
              seed=31, full_grads=False)
     gen_retrieval_metrics()
+    gen_radam()
     gen_mask_semantics()
 
 

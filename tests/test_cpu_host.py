@@ -132,3 +132,32 @@ def test_unsupported_options_raise(cva):
     bad = cva.TransformerConfig(H.ocfg_to_dict(O.NetConfig(input_dim=64, hidden_dim=60, num_heads=4, ff_dim=64)), 64)
     with pytest.raises(RuntimeError, match="d_head"):
         cva.lib.param_table(bad.to_c())
+
+
+def test_radam_optimizer_matches_reference_trajectory(cva):
+    """The package's torch RAdam (autograd path of the yc2 configs: optimizer.name = radam) against the trajectory the
+    reference's in-file class produced (tests/golden/radam.npz, oracle/gen_golden.py) — two parameter groups, both
+    degenerated_to_sgd settings, all three phases of the rule."""
+    import torch
+    from coot_videotext_amd.trainer_retrieval import RAdam, make_optimizer
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "radam.npz"))
+    lr, b1, b2, eps, wd = (float(g[k]) for k in ("lr", "beta1", "beta2", "eps", "wd"))
+    for degen in (0, 1):
+        pa = torch.nn.Parameter(torch.from_numpy(g["p0"][:200].copy()))
+        pb = torch.nn.Parameter(torch.from_numpy(g["p0"][200:].copy()))
+        opt = RAdam([dict(params=[pa], weight_decay=wd), dict(params=[pb], weight_decay=0.0)], lr=lr, betas=(b1, b2), eps=eps,
+                    degenerated_to_sgd=bool(degen))
+        for s_ in range(len(g["grads"])):
+            pa.grad = torch.from_numpy(g["grads"][s_][:200].copy()); pb.grad = torch.from_numpy(g["grads"][s_][200:].copy())
+            opt.step()
+            got = np.concatenate([pa.detach().numpy(), pb.detach().numpy()])
+            ref = g[f"traj_degen{degen}"][s_]
+            assert np.abs(got - ref).max() <= 2e-7 + 2e-6 * np.abs(ref).max(), (degen, s_, np.abs(got - ref).max())
+    # make_optimizer dispatch (nntrainer/optimization.py:45-74)
+    sec = type("S", (), dict(name="radam", lr=1e-3, weight_decay=1e-2, momentum=0.56, adam_beta2=0.98, adam_eps=1e-8, radam_degentosgd=False))
+    p = torch.nn.Parameter(torch.zeros(3))
+    o = make_optimizer(sec, [dict(params=p, decay_mult=1.0)])
+    assert isinstance(o, RAdam) and o.degenerated_to_sgd is False and o.param_groups[0]["weight_decay"] == 1e-2
+    sec.name = "sgd"
+    with pytest.raises(NotImplementedError):
+        make_optimizer(sec, [dict(params=p, decay_mult=1.0)])

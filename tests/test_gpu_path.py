@@ -430,6 +430,65 @@ def test_fused_adam_matches_torch_adam(env):
     assert float((pa - ref).abs().max()) < 2e-6
 
 
+def test_fused_radam_matches_reference_trajectory(env, golden_dir):
+    """coot_radam_step on the gradient sequence of tests/golden/radam.npz (written by the reference's in-file RAdam,
+    nntrainer/optimization.py:79-181): decay mask = the two parameter groups, degenerated_to_sgd off and on."""
+    torch, cva = env
+    lib = cva.lib.load()
+    g = np.load(os.path.join(golden_dir, "radam.npz"))
+    lr, b1, b2, eps, wd = (float(g[k]) for k in ("lr", "beta1", "beta2", "eps", "wd"))
+    n = len(g["p0"])
+    mask = torch.from_numpy((np.arange(n) < 200).astype(np.float32)).cuda()
+    for degen in (0, 1):
+        p = torch.from_numpy(g["p0"].copy()).cuda()
+        m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        for s_ in range(len(g["grads"])):
+            gr = torch.from_numpy(g["grads"][s_].copy()).cuda()
+            cva.lib.check(lib.coot_radam_step(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), mask.data_ptr(), n, lr, b1, b2, eps, wd,
+                                              s_ + 1, degen, torch.cuda.current_stream().cuda_stream), "radam")
+            torch.cuda.synchronize()
+            ref = g[f"traj_degen{degen}"][s_]
+            assert np.abs(p.cpu().numpy() - ref).max() <= 2e-7 + 2e-6 * np.abs(ref).max(), (degen, s_)
+
+
+def test_native_step_with_radam_matches_autograd_path(env):
+    """yc2-style optimizer section (radam, degenerated_to_sgd false): the native step (RAdam inside coot_train_step) against the
+    autograd path with the package's torch RAdam, 7 steps so that the no-update phase and the rectified phase are both crossed
+    (beta2 = 0.98: N_sma reaches 5 at step 6).  Same comparison rules as the Adam test."""
+    torch, cva = env
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batch = cva.synthetic.make_batch(7, 6, [1, 2, 3, 4, 2, 1], 12, 10, 9, 6, dims[0], dims[1], ragged=True)
+    trainers = []
+    for _ in range(2):
+        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+        cfg_x.optimizer.name = "radam"; cfg_x.optimizer.radam_degentosgd = False
+        cfg_x.optimizer.momentum = 0.56; cfg_x.optimizer.adam_beta2 = 0.98
+        mgr.set_all_models_train()
+        trainers.append((cva.RetrievalTrainer(cfg_x, mgr), mgr))
+    (ta, ma), (tb, mb) = trainers
+    from coot_videotext_amd.trainer_retrieval import RAdam
+    assert isinstance(tb.optimizer, RAdam)
+    p_init = [n._flat.clone() for n in ma.model_dict.values()]
+    for it in range(7):
+        la = ta.train_step_native(batch)
+        lb = tb.train_step(batch)
+        torch.cuda.synchronize()
+        assert abs(float(la[0]) - float(lb[0])) < 2e-3 * max(1.0, abs(float(lb[0]))), (it, float(la[0]), float(lb[0]))
+        if it == 3:  # still in the no-update phase: parameters untouched in both
+            for na, p0 in zip(ma.model_dict.values(), p_init):
+                assert torch.equal(na._flat, p0)
+    moved = 0.0
+    for na, nb, p0 in zip(ma.model_dict.values(), mb.model_dict.values(), p_init):
+        d = (na._flat - nb._flat).abs()
+        moved = max(moved, float((na._flat - p0).abs().max()))
+        gmax = float(nb._grad_flat.abs().max())
+        sig = nb._grad_flat.abs() > 1e-2 * gmax
+        assert float(d[sig].max()) < 3e-4 and float(d.max()) <= 4.1e-3
+    assert moved > 1e-4  # the rectified phase did update the parameters
+
+
 def test_native_step_trains_with_dropout_and_cycle_loss(env):
     torch, cva = env
     dims = (64, 48, 64, 4, 64, 128)

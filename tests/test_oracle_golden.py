@@ -173,6 +173,23 @@ def test_retrieval_metrics(golden_dir):
         _close([res[k] for k in ("r1", "r5", "r10", "r50", "medr", "meanr")], g[f"res{i}"], 1e-9, 1e-12)
 
 
+def test_radam_oracle_matches_reference(golden_dir):
+    """oracle radam_step against the trajectory of the reference's in-file RAdam (nntrainer/optimization.py:79-181),
+    degenerated_to_sgd off (the paper configs) and on; both phases (N_sma < 5: no update / SGD, N_sma >= 5: rectified)."""
+    g = _load(golden_dir, "radam")
+    lr, b1, b2, eps, wd = (float(g[k]) for k in ("lr", "beta1", "beta2", "eps", "wd"))
+    n = len(g["p0"])
+    wdv = np.where(np.arange(n) < 200, wd, 0.0)
+    modes = set()
+    for degen in (0, 1):
+        p = g["p0"].astype(np.float64); m = np.zeros(n); v = np.zeros(n)
+        for s in range(len(g["grads"])):
+            O.radam_step(p, g["grads"][s].astype(np.float64), m, v, s + 1, lr, b1, b2, eps, wdv, bool(degen))
+            modes.add(O.radam_scalars(s + 1, b1, b2, bool(degen))[0])
+            _close(p, g[f"traj_degen{degen}"][s], 2e-6, 2e-8, what=f"radam degen={degen} step {s + 1}")
+    assert modes == {"rect", "sgd", "none"}
+
+
 def test_mask_semantics(golden_dir):
     """tests_nntrainer/test_transformers.py:22-79 in numeric form."""
     g = _load(golden_dir, "mask_semantics")
