@@ -250,7 +250,9 @@ def main():
             "value": round(value, 1), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"ActivityNet-shaped paper config (anet_coot): {w['B']} videos x {w['C']} clips per GPU, "
+            "config": {"workload": f"{dict(anet='ActivityNet', yc2_100m='YouCook2 (100M features)', yc2_2d3d='YouCook2 (2D+3D features)')[args.workload]}"
+                                   f"-shaped paper config ({dict(anet='anet_coot', yc2_100m='yc2_100m_coot', yc2_2d3d='yc2_2d3d_coot')[args.workload]}): "
+                                   f"{w['B']} videos x {w['C']} clips per GPU, "
                                    f"Lc=Lv={w['Lc']}, Ls={w['Ls']}, Lp={w['Lp']}, Dv={w['Dv']}, Dt={w['Dt']}, d_model=384",
                        "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
                        "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",
