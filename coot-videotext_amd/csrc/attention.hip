@@ -11,6 +11,16 @@
 
 namespace coot {
 
+// Dropout mask of attention probability (sequence n, head h, query q, key k): 32-bit index arithmetic (it is only a hash
+// input, wrap-around is harmless): the pair (k / 2) of row r = (n H + h) Lq + q shares one hash, k & 1 picks the half.
+// The 64-bit element index of the first version cost ~8 VALU instructions per probability (v_mad_u64_u32, 64-bit shifts
+// and compares) in kernels that are VALU bound.  All attention kernels (forward and the backward passes) use this map.
+__device__ __forceinline__ float attn_drop(unsigned key, unsigned row, int k, unsigned lk_half, unsigned thr, float inv_keep) {
+  const unsigned h = drop_hash((row * lk_half + ((unsigned)k >> 1)) ^ key);
+  const unsigned u = (k & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return u >= (thr >> 16) ? inv_keep : 0.0f;
+}
+
 constexpr int KC = 64;  // rows per staged chunk
 
 template <int DH>
@@ -124,8 +134,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         csum += p[i];
         if (a.drop.thr) {
           const int kidx = kc + kt * 16 + lg * 4 + i;
-          unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qrow) * Lk + kidx);
-          p[i] *= drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
+          p[i] *= attn_drop(dkey, (unsigned)((n * a.H + h) * Lq + qrow), kidx, (unsigned)(Lk + 1) >> 1, a.drop.thr, a.drop.inv_keep);
         }
       }
       pf[kt] = pack4(p[0], p[1], p[2], p[3]);
@@ -226,8 +235,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
         float p = (kidx < Lk && qok) ? __expf(sv - lse) : 0.f;
         float dpe = dp[i];
         if (a.drop.thr) {
-          unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qrow) * Lk + kidx);
-          dpe *= drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
+          dpe *= attn_drop(dkey, (unsigned)((n * a.H + h) * Lq + qrow), kidx, (unsigned)(Lk + 1) >> 1, a.drop.thr, a.drop.inv_keep);
         }
         ds[i] = (kidx < nvalid) ? p * (dpe - dl) * a.scale : 0.f;  // masked_fill blocks the gradient
       }
@@ -315,8 +323,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
         float pv = (kvalid && qr < Lq) ? __expf(sv - lse_s[ql]) : 0.f;
         float dsc = 1.f;
         if (a.drop.thr) {
-          unsigned long long idx = (((unsigned long long)(n * a.H + h) * Lq + qr) * Lk + krow);
-          dsc = drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
+          dsc = attn_drop(dkey, (unsigned)((n * a.H + h) * Lq + qr), krow, (unsigned)(Lk + 1) >> 1, a.drop.thr, a.drop.inv_keep);
         }
         p[i] = pv * dsc;
         ds[i] = pv * (dp[i] * dsc - delta_s[ql]) * a.scale;
@@ -449,8 +456,7 @@ __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
         sum += p[i];
         if (a.drop.thr) {
           const int kidx = kt * 16 + lg * 4 + i;
-          const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qrow) * L + kidx);
-          p[i] *= drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
+          p[i] *= attn_drop(dkey, (unsigned)((n * a.H + h) * L + qrow), kidx, (unsigned)(L + 1) >> 1, a.drop.thr, a.drop.inv_keep);
         }
       }
       pf[kt] = pack4(p[0], p[1], p[2], p[3]);
@@ -544,8 +550,7 @@ __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
           const float p = (kidx < L && qok) ? __expf(sv - lse) : 0.f;
           float dpe = dp[i];
           if (a.drop.thr) {
-            const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qrow) * L + kidx);
-            dpe *= drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
+            dpe *= attn_drop(dkey, (unsigned)((n * a.H + h) * L + qrow), kidx, (unsigned)(L + 1) >> 1, a.drop.thr, a.drop.inv_keep);
           }
           ds[i] = (kidx < nvalid) ? p * (dpe - dl) * a.scale : 0.f;  // masked_fill blocks the gradient
         }
@@ -594,8 +599,7 @@ __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
         const float pv = (kvalid && qr < L) ? __expf(sv4[i] * a.scale - lse_s[qr]) : 0.f;
         float dsc = 1.f;
         if (a.drop.thr) {
-          const unsigned long long idx = (((unsigned long long)(n * a.H + h) * L + qr) * L + krow);
-          dsc = drop_scale_key(dkey, idx, a.drop.thr, a.drop.inv_keep);
+          dsc = attn_drop(dkey, (unsigned)((n * a.H + h) * L + qr), krow, (unsigned)(L + 1) >> 1, a.drop.thr, a.drop.inv_keep);
         }
         p[i] = pv * dsc;
         ds[i] = pv * (dp[i] * dsc - delta_s[qr]) * a.scale;

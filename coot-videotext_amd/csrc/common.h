@@ -47,8 +47,9 @@ __device__ __forceinline__ GeluParts gelu_parts(float x) {
 }
 __device__ __forceinline__ float gelu_f(float x) {
   const GeluParts g = gelu_parts(x);
-  const float xh = x * g.h;
-  return x >= 0.0f ? x - xh : xh;
+  // x Phi(x) = max(x, 0) - |x| Phi(-|x|): one max and one fma (|x| and the sign are source modifiers) instead of
+  // mul + sub + compare + select
+  return fmaf(-fabsf(x), g.h, fmaxf(x, 0.0f));
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   const GeluParts g = gelu_parts(x);

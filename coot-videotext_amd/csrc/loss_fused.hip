@@ -85,14 +85,21 @@ __global__ __launch_bounds__(256) void cl_half_kernel(ClHalfArgs A) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) { const int i = i0 + l4 * 4 + r; di[r] = i < N ? H.diag[i] : 0.f; }
   float lsum = 0.f, c1r[4] = {0.f, 0.f, 0.f, 0.f};
+  // the strip's own rows (MFMA A operand) are the same for every column block: read once (d <= 1024: up to 32 fragments)
+  constexpr int CL_MAXKB = 32;
+  bf16x8_t xfr[CL_MAXKB];
+#pragma unroll
+  for (int kb = 0; kb < CL_MAXKB; ++kb)
+    if (kb < kbs) xfr[kb] = *reinterpret_cast<const bf16x8_t*>(xrow + kb * 32);
   for (int cb = wave; cb * 16 < Np; cb += 4) {
     const bf16_t* yrow = H.Y + (long)(cb * 16 + l15) * d + l4 * 8;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 12
-    for (int kb = 0; kb < kbs; ++kb) {
-      const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xrow + kb * 32);
-      const bf16x8_t yf = *reinterpret_cast<const bf16x8_t*>(yrow + kb * 32);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc, 0, 0, 0);
+#pragma unroll
+    for (int kb = 0; kb < CL_MAXKB; ++kb) {
+      if (kb < kbs) {
+        const bf16x8_t yf = *reinterpret_cast<const bf16x8_t*>(yrow + kb * 32);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfr[kb], yf, acc, 0, 0, 0);
+      }
     }
     // acc[r] = S[i0 + l4*4 + r][cb*16 + l15]
     const int j = cb * 16 + l15;
