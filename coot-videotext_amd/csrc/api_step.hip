@@ -382,18 +382,21 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   g_stamps.mark("step starts", sm);
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
-  // text stream (it has slack): zero the parameter gradients (4 arenas), the embedding gradients (one block), the loss words.
-  // The video side first touches them after hop 2 below.
-  for (int i = 0; i < 4; ++i)
-    RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), st), "memset grads"));
-  RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, st), "memset embedding grads"));
-  RUN(check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), st), "memset losses"));
-  g_stamps.mark("text: gradients zeroed", st);
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                    W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first));
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
                    W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st,
                    pack_first));
+  // Zero the parameter gradients (4 arenas), the embedding gradients (one block) and the loss words at the END of the text
+  // forward: the text side shares the chip with the three times larger video side and, started at the same time, finishes its
+  // forward ~75 us earlier (HIP-event timeline), so the six fills are free there.  (At the head of the text stream they delayed
+  // its start by 70 us; behind the video forward they sat on the critical path.)  Everything that accumulates into these
+  // buffers is ordered after hop 2: the losses on the video stream, the text side through hop 6 / hop 3.
+  for (int i = 0; i < 4; ++i)
+    RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), st), "memset grads"));
+  RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, st), "memset embedding grads"));
+  RUN(check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), st), "memset losses"));
+  g_stamps.mark("text: gradients zeroed", st);
   RUN(g_hops.hop(2, st, sv));
   g_stamps.mark("video: text forward joined", sv);
   const bool cc = cfg->cc_weight != 0.f;
