@@ -594,7 +594,7 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
   Arena A(wpack, (size_t)-1); WPack W; layout_wpack(c, A, W);
   const int D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
   PackJobs jobs;
-  auto flush = [&]() -> int { int rc = launch_pack_jobs(P, wpack, jobs, st); jobs.n = 0; return rc; };
+  auto flush = [&]() -> int { int rc = launch_pack_jobs(P, wpack, jobs, st); jobs.n = 0; jobs.mv = PackMatvec(); return rc; };
   auto add = [&](int64_t src_off, long lds, int R, int Cc, bf16_t* dst, long ldd, int transpose, int64_t colscale_off) -> int {
     if (jobs.n == 56) RUN(flush());
     PackJob& j = jobs.j[jobs.n++];
@@ -611,7 +611,8 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
   if (c.use_input_fc) {
     RUN(add(L.in_w, Din, D, Din, W.in_w, Din, 0, L.n_gain));  // W * gain: LN affine folded into the FC
     if (W.f_in_w) { RUN(add(L.in_w, Din, D, Din, W.f_in_w, 0, 0, L.n_gain)); jobs.j[jobs.n - 1].p48 = 1; }
-    RUN(launch_matvec_bias(P + L.in_w, Din, D, Din, P + L.n_bias, P + L.in_b, W.in_bias, st));
+    // folded bias b' = b + W . norm_bias: rides on the (last) pack launch of this call
+    jobs.mv.W = P + L.in_w; jobs.mv.ldw = Din; jobs.mv.N = D; jobs.mv.K = Din; jobs.mv.v = P + L.n_bias; jobs.mv.b = P + L.in_b; jobs.mv.out = W.in_bias;
   }
   auto pack_layer = [&](const LayerP& lp, const LayerW& lw) -> int {
     RUN(add(lp.wqkv, D, 3 * D, D, lw.wqkv_nk, D, 0, -1));

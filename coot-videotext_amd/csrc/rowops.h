@@ -49,7 +49,9 @@ int launch_cast_weight(const float* src, long lds, int R, int C, bf16_t* dst, lo
 // p48 != 0: the destination is the fragment-major "P48" layout of the fused kernels (fused.h: p48_offset) of the logical
 // matrix [n][k] = dst row, dst column (after the optional transpose); ldd is ignored.
 struct PackJob { long src_off; long dst_byte_off; int R, C; long lds, ldd; int transpose; int p48; long colscale_off; };
-struct PackJobs { int n = 0; PackJob j[56]; };
+// optional rider of a pack launch: out[n] = b[n] + sum_k W[n,k] v[k] (the folded input-FC bias), one wave per row in extra workgroups
+struct PackMatvec { const float* W = nullptr; long ldw = 0; int N = 0, K = 0; const float* v = nullptr; const float* b = nullptr; float* out = nullptr; };
+struct PackJobs { int n = 0; PackJob j[56]; PackMatvec mv; };
 int launch_pack_jobs(const float* P, void* wpack, const PackJobs& jobs, hipStream_t stream);
 
 // out[n] = b[n] + sum_k W[n,k] * v[k]   (tiny mat-vec; used for the folded input-FC bias)

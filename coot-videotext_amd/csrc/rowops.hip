@@ -323,6 +323,21 @@ int launch_cast_weight(const float* src, long lds, int R, int C, bf16_t* dst, lo
   return 0;
 }
 
+__device__ __forceinline__ void matvec_rows(int blk, const float* W, long ldw, int N, int K, const float* v, const float* b, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blk * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains: the loads of a batch are in flight together
+  int k = lane;
+  for (; k + 192 < K; k += 256) {
+    s0 += W[(long)n * ldw + k] * v[k]; s1 += W[(long)n * ldw + k + 64] * v[k + 64];
+    s2 += W[(long)n * ldw + k + 128] * v[k + 128]; s3 += W[(long)n * ldw + k + 192] * v[k + 192];
+  }
+  for (; k < K; k += 64) s0 += W[(long)n * ldw + k] * v[k];
+  float s = wave_sum((s0 + s1) + (s2 + s3));
+  if (lane == 0) out[n] = s + (b ? b[n] : 0.f);
+}
+
 // One thread per 8 consecutive bf16 of the DESTINATION (one 16-byte store): blockIdx.x -> (job, group) through the jobs'
 // workgroup prefix.  The logical matrix is [n][k] = dst row, dst column (source [r][c] with (n, k) = (r, c), or (c, r) when
 // transposed); k is the contiguous destination index in both layouts (row-major with ldd, or P48: fused.h p48_offset).
@@ -330,6 +345,10 @@ int launch_cast_weight(const float* src, long lds, int R, int C, bf16_t* dst, lo
 // 2.6M-parameter local network, 16 us per launch, four launches per step, two of them on the critical path.
 struct PackTiles { int blk0[57]; };
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const float* P, char* wpack, PackJobs jobs, PackTiles pt) {
+  if ((int)blockIdx.x >= pt.blk0[jobs.n]) {  // rider: the folded input-FC bias (was its own 12 us launch in front of the pack)
+    matvec_rows((int)blockIdx.x - pt.blk0[jobs.n], jobs.mv.W, jobs.mv.ldw, jobs.mv.N, jobs.mv.K, jobs.mv.v, jobs.mv.b, jobs.mv.out);
+    return;
+  }
   int ji = 0;
   for (int t = 1; t < jobs.n; ++t) if ((int)blockIdx.x >= pt.blk0[t]) ji = t;
   const PackJob& jb = jobs.j[ji];
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const float* P, char* wp
   *reinterpret_cast<u32x4_t*>(dst + doff) = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
 }
 int launch_pack_jobs(const float* P, void* wpack, const PackJobs& jobs, hipStream_t stream) {
-  if (jobs.n <= 0) return 0;
+  if (jobs.n <= 0 && !jobs.mv.W) return 0;
   PackTiles pt;
   int total = 0;
   for (int i = 0; i < jobs.n; ++i) {
@@ -387,24 +406,14 @@ int launch_pack_jobs(const float* P, void* wpack, const PackJobs& jobs, hipStrea
     total += (int)(((long)Nn * (Kk / 8) + 255) / 256);
   }
   pt.blk0[jobs.n] = total;
+  if (jobs.mv.W) total += (jobs.mv.N + 3) / 4;
   hipLaunchKernelGGL(pack_jobs_kernel, dim3(total), dim3(256), 0, stream, P, (char*)wpack, jobs, pt);
   COOT_CHECK_LAUNCH("pack_jobs");
   return 0;
 }
 
 __global__ __launch_bounds__(256) void matvec_bias_kernel(const float* W, long ldw, int N, int K, const float* v, const float* b, float* out) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains: the loads of a batch are in flight together
-  int k = lane;
-  for (; k + 192 < K; k += 256) {
-    s0 += W[(long)n * ldw + k] * v[k]; s1 += W[(long)n * ldw + k + 64] * v[k + 64];
-    s2 += W[(long)n * ldw + k + 128] * v[k + 128]; s3 += W[(long)n * ldw + k + 192] * v[k + 192];
-  }
-  for (; k < K; k += 64) s0 += W[(long)n * ldw + k] * v[k];
-  float s = wave_sum((s0 + s1) + (s2 + s3));
-  if (lane == 0) out[n] = s + (b ? b[n] : 0.f);
+  matvec_rows(blockIdx.x, W, ldw, N, K, v, b, out);
 }
 
 int launch_matvec_bias(const float* W, long ldw, int N, int K, const float* v, const float* b, float* out, hipStream_t stream) {
