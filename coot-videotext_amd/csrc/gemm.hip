@@ -682,7 +682,6 @@ constexpr int TNW_PB = TNW_BN + 16;
 __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int by, int bz, int t_per_split, float* ws, int direct) {
   constexpr int ASZ = TN_BT * TNW_PA, BSZ = TN_BT * TNW_PB;
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ASZ + 2 * BSZ];
-  __shared__ float cs_lds[TNW_BM];
   bf16_t* As = smem;
   bf16_t* Bs = smem + 2 * ASZ;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -694,7 +693,6 @@ __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int b
   const bf16_t* A = g.A + z * g.zA;
   const bf16_t* B = g.B + z * g.zB;
   const bool do_cs = g.a_colsum != nullptr && bx == 0;
-  if (do_cs) for (int c = tid; c < TNW_BM; c += 512) cs_lds[c] = 0.f;
 
   u32x4_t ar[6], br[2];
   int arow[6], acol[6];
@@ -784,15 +782,27 @@ __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int b
     __syncthreads();
   }
   if (do_cs) {
+    // Per-thread partial column sums -> LDS rows -> 384 threads add them up.  (The first version used LDS float atomics:
+    // 24 ds_add_f32 wave-instructions that serialise per lane, ~1.5k cycles each — the workgroups carrying a bias gradient
+    // ran 40 us longer than the others and set the duration of the whole launch; the global networks' weight-gradient
+    // launch, a few k-steps per workgroup, took 43 us because of them.)
+    // For iteration q the threads t = ch + 48 k (k <= 10) hold column chunk (ch + 32 q) % 48: rows k of red[11][384].
+    float* red = reinterpret_cast<float*>(smem);  // the operand buffers are free: every wave passed the last barrier of the k loop
+    float tot = 0.f;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const int cc = acol[q];  // chunk of iteration i = q (i and i + 3 share it)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(&cs_lds[cc + j], cs[q][j]);
+      __syncthreads();
+      float* rw = red + (tid / 48) * TNW_BM + acol[q];
+      *reinterpret_cast<f32x4_t*>(rw) = f32x4_t{cs[q][0], cs[q][1], cs[q][2], cs[q][3]};
+      *reinterpret_cast<f32x4_t*>(rw + 4) = f32x4_t{cs[q][4], cs[q][5], cs[q][6], cs[q][7]};
+      __syncthreads();
+      if (tid < TNW_BM) {
+        const int ch = (tid / 8 + 96 - 32 * q) % 48;   // threads with t % 48 == ch hold this column in iteration q
+        const int nk = (512 - ch + 47) / 48;
+        for (int kk = 0; kk < nk; ++kk) tot += red[kk * TNW_BM + tid];
+      }
     }
-    __syncthreads();
-    for (int c = tid; c < TNW_BM; c += 512)
-      if (m0 + c < g.Mo) atomicAdd(g.a_colsum + m0 + c, cs_lds[c]);
+    if (tid < TNW_BM && m0 + tid < g.Mo) atomicAdd(g.a_colsum + m0 + tid, tot);
   }
   // partial tile straight from the accumulators: direct (single split) C += alpha * tile, else ws[split][z][Mo][No]
   float* dst = direct ? g.C + z * g.zC : ws + ((long)split * g.groups + z) * g.Mo * g.No;
