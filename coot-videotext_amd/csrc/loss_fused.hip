@@ -36,17 +36,40 @@ __global__ __launch_bounds__(256) void cl_norm_kernel(ClNormArgs A) {
     }
     return;
   }
+  // the two rows in registers (d % 32 == 0, d <= 1024: up to four 4-element chunks per lane): one pass of 16-byte loads
+  constexpr int MAXC = 4;
+  f32x4_t xa[MAXC], xb[MAXC];
+  const int nch = d / 4;
   float sa = 0.f, sb = 0.f;
-  for (int c = lane; c < d; c += 64) { const float x = P.va[(long)row * d + c], y = P.vb[(long)row * d + c]; sa += x * x; sb += y * y; }
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int ch = lane + 64 * q;
+    xa[q] = f32x4_t{0.f, 0.f, 0.f, 0.f}; xb[q] = xa[q];
+    if (ch < nch) {
+      xa[q] = *reinterpret_cast<const f32x4_t*>(P.va + (long)row * d + ch * 4);
+      xb[q] = *reinterpret_cast<const f32x4_t*>(P.vb + (long)row * d + ch * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sa += xa[q][j] * xa[q][j]; sb += xb[q][j] * xb[q][j]; }
+  }
   sa = wave_sum(sa); sb = wave_sum(sb);
   const float ia = 1.0f / fmaxf(sqrtf(sa), 1e-12f), ib = 1.0f / fmaxf(sqrtf(sb), 1e-12f);
   float dab = 0.f, daa = 0.f, dbb = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    const bf16_t ha = f2bf(P.va[(long)row * d + c] * ia), hb = f2bf(P.vb[(long)row * d + c] * ib);
-    P.a[(long)row * d + c] = ha; P.b[(long)row * d + c] = hb;
-    P.aT[(long)c * P.Np + row] = ha; P.bT[(long)c * P.Np + row] = hb;
-    const float fa = bf2f(ha), fb = bf2f(hb);
-    dab += fa * fb; daa += fa * fa; dbb += fb * fb;
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int ch = lane + 64 * q;
+    if (ch < nch) {
+      bf16_t ha[4], hb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ha[j] = f2bf(xa[q][j] * ia); hb[j] = f2bf(xb[q][j] * ib);
+        const float fa = bf2f(ha[j]), fb = bf2f(hb[j]);
+        dab += fa * fb; daa += fa * fa; dbb += fb * fb;
+        P.aT[(long)(ch * 4 + j) * P.Np + row] = ha[j]; P.bT[(long)(ch * 4 + j) * P.Np + row] = hb[j];
+      }
+      *reinterpret_cast<u32x2_t*>(P.a + (long)row * d + ch * 4) = u32x2_t{(unsigned)ha[0] | ((unsigned)ha[1] << 16), (unsigned)ha[2] | ((unsigned)ha[3] << 16)};
+      *reinterpret_cast<u32x2_t*>(P.b + (long)row * d + ch * 4) = u32x2_t{(unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16)};
+    }
   }
   dab = wave_sum(dab); daa = wave_sum(daa); dbb = wave_sum(dbb);
   if (lane == 0) { P.inva[row] = ia; P.invb[row] = ib; P.dab[row] = dab; P.daa[row] = daa; P.dbb[row] = dbb; }
@@ -138,6 +161,7 @@ __global__ __launch_bounds__(256) void cl_half_kernel(ClHalfArgs A) {
     f32x4_t acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8  // 8 k-blocks of Y^T loads in flight (not unrolled, every k-block was its own L2 round trip)
     for (int kb = 0; kb * 32 < Np32; ++kb) {
       const int kk = kb * 32 + l4 * 8;
       const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(&Gs[l15 * gp + kk]);
