@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Timeline of the LAST training step in a rocprofv3 rocpd (.db) kernel trace: one line per kernel dispatch with its
 queue (= HIP stream), start offset and duration, plus per-queue busy time and the idle gaps on the busiest queue.
-A step is delimited by the single-launch Adam kernel (adam4_kernel).
+A step is delimited by cl_norm_kernel (the first launch of the contrastive loss: exactly one per step): the window shown
+runs from one loss section to the next, i.e. backward of step n followed by forward of step n + 1.
 Usage: python tools/rocpd_timeline.py x_results.db [out.txt]"""
 import re
 import sqlite3
@@ -21,13 +22,13 @@ def main(db, out=None):
     gcols = [c for c in ("grid_size_x", "workgroup_size_x") if c in cols]
     sel = f"s.{namecol}, d.start, d.end, " + (f"d.{qcol}" if qcol else "0") + "".join(f", d.{c}" for c in gcols)
     rows = list(cur.execute(f"select {sel} from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
-    ad = [i for i, r in enumerate(rows) if "adam4" in r[0]]
+    ad = [i for i, r in enumerate(rows) if "cl_norm_kernel" in r[0]]
     if len(ad) < 3:
         raise SystemExit("need at least 3 steps in the trace")
     lo, hi = ad[-2] + 1, ad[-1] + 1
     step = rows[lo:hi]
     t0 = rows[ad[-2]][2]
-    lines = [f"# step: {len(step)} dispatches, {(step[-1][2] - t0) / 1e3:.1f} us from the end of the previous Adam to the end of this one"]
+    lines = [f"# step: {len(step)} dispatches, {(step[-1][2] - t0) / 1e3:.1f} us from one contrastive-loss launch to the next"]
     busy = {}
     for r in step:
         name = re.sub(r"\(.*", "", r[0]).replace("coot::", "").replace("(anonymous namespace)::", "")
