@@ -197,7 +197,7 @@ def main():
         names = {2: "gemm_nt_kernel (LDS-staged bf16 MFMA GEMM: Linear fwd + dX of the local networks)",
                  3: "gemm_nt_small_kernel (direct-from-L2 fragments, M <= 512: global networks)",
                  4: "gemm_tn_kernel + gemm_tn_reduce_kernel (weight gradients, split over tokens)",
-                 5: "fused token-tile chain kernels (post_attn_fwd, pre_attn_bwd, qkv_fwd, qkv_bwd: LDS-resident 128 x 384 tile, "
+                 5: "fused token-tile chain kernels (infc_qkv_fwd, post_attn_fwd, pre_attn_bwd, qkv_bwd: LDS-resident 128 x 384 tile, "
                     "384-wide GEMM passes with L2-streamed weights)"}
 
         def collect(sel):
@@ -210,11 +210,14 @@ def main():
 
         by = {names[k]: collect(k) for k in (2, 3, 4, 5)}
         # algorithmic HBM bytes of the fused chains: bf16 tensors each read / written exactly once per token:
-        # forward chain 1536 read + 8448 written, backward chain 5376 + 5376, QKV 768 + 2304, QKV dX 3840 + 768
-        tok = w["B"] * w["Lv"] + w["B"] * w["C"] * w["Lc"] + w["B"] * w["Lp"] + w["B"] * w["C"] * w["Ls"]
+        # input FC + QKV (reads xhat [Din], writes h0, z0, qkv), forward chain 1536 read + 8448 written, backward chain 5376 + 5376,
+        # QKV dX 3840 + 768
+        tok_v = w["B"] * w["Lv"] + w["B"] * w["C"] * w["Lc"]
+        tok_t = w["B"] * w["Lp"] + w["B"] * w["C"] * w["Ls"]
         fused = names[5]
         if by[fused]["launches_per_step"]:
-            by[fused]["algorithmic_bytes_per_launch"] = int(tok * (9984 + 10752 + 3072 + 4608) / by[fused]["launches_per_step"])
+            alg = tok_v * (2 * w["Dv"] + 1536 + 2304) + tok_t * (2 * w["Dt"] + 1536 + 2304) + (tok_v + tok_t) * (9984 + 10752 + 4608)
+            by[fused]["algorithmic_bytes_per_launch"] = int(alg / by[fused]["launches_per_step"])
         allk, infc = collect(0), collect(1)
         lib.coot_timing_enable(0)
         dom = max(by, key=lambda k: by[k]["ms_per_step"])  # the kernel the step spends most MFMA time in
