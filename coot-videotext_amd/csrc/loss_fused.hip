@@ -88,40 +88,50 @@ struct ClHalfArgs { ClHalf h[CL_MAX_HALF]; int nh; int nblk; float margin; };
 
 constexpr int CL_GP = 8;  // G strip pitch padding (elements)
 
-__global__ __launch_bounds__(256) void cl_half_kernel(ClHalfArgs A) {
+constexpr int CL_NW = 8;  // waves per strip workgroup: the strip is a chain of L2 round trips, more waves = fewer trips each
+__global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
   extern __shared__ __attribute__((aligned(16))) bf16_t Gs[];  // [16][Np32 + CL_GP]
-  __shared__ float c1s[16];
-  __shared__ float lred[4];
+  __shared__ int c1s[16];  // violation counts: integer LDS atomics (ds_add_u32), not float ones
+  __shared__ float lred[CL_NW];
   int hi = 0;
   for (int t = 1; t < A.nh; ++t) if ((int)blockIdx.x >= A.h[t].blk0) hi = t;
   const ClHalf& H = A.h[hi];
   const int rb = blockIdx.x - H.blk0, i0 = rb * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = H.N, Np = H.Np, d = H.d, Np32 = (Np + 31) & ~31, gp = Np32 + CL_GP;
-  if (tid < 16) c1s[tid] = 0.f;
+  if (tid < 16) c1s[tid] = 0;
   __syncthreads();
-  // ---- S strip: wave w takes column blocks w, w+4, ...; X (A operand, m = row i), Y (B operand, n = column j) ----
+  // ---- S strip: wave w takes column blocks w, w + CL_NW, ...; X (A operand, m = row i), Y (B operand, n = column j) ----
   const int kbs = d / 32;
   const int l15 = lane & 15, l4 = lane >> 4;
   const bf16_t* xrow = H.X + (long)(i0 + l15) * d + l4 * 8;
   float di[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { const int i = i0 + l4 * 4 + r; di[r] = i < N ? H.diag[i] : 0.f; }
-  float lsum = 0.f, c1r[4] = {0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+  int c1r[4] = {0, 0, 0, 0};
   // the strip's own rows (MFMA A operand) are the same for every column block: read once (d <= 1024: up to 32 fragments)
   constexpr int CL_MAXKB = 32;
   bf16x8_t xfr[CL_MAXKB];
 #pragma unroll
-  for (int kb = 0; kb < CL_MAXKB; ++kb)
-    if (kb < kbs) xfr[kb] = *reinterpret_cast<const bf16x8_t*>(xrow + kb * 32);
-  for (int cb = wave; cb * 16 < Np; cb += 4) {
+  for (int kb = 0; kb < CL_MAXKB; ++kb) xfr[kb] = *reinterpret_cast<const bf16x8_t*>(xrow + min(kb, kbs - 1) * 32);
+  for (int cb = wave; cb * 16 < Np; cb += CL_NW) {
     const bf16_t* yrow = H.Y + (long)(cb * 16 + l15) * d + l4 * 8;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    // eight k-blocks of Y per round trip: the loads of a group first, then its MFMAs.  (One predicated load + MFMA per
+    // k-block compiled to load, s_waitcnt vmcnt(0), mfma — 12 to 24 serial L2 round trips per column block, 33 us per launch.)
 #pragma unroll
-    for (int kb = 0; kb < CL_MAXKB; ++kb) {
-      if (kb < kbs) {
-        const bf16x8_t yf = *reinterpret_cast<const bf16x8_t*>(yrow + kb * 32);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfr[kb], yf, acc, 0, 0, 0);
+    for (int k0 = 0; k0 < CL_MAXKB; k0 += 8) {
+      if (k0 < kbs) {
+        bf16x8_t yf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kb = min(k0 + j, kbs - 1);  // clamp instead of branching: every load of the group issues unconditionally
+          yf[j] = *reinterpret_cast<const bf16x8_t*>(yrow + kb * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k0 + j < kbs) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfr[k0 + j], yf[j], acc, 0, 0, 0);
       }
     }
     // acc[r] = S[i0 + l4*4 + r][cb*16 + l15]
@@ -134,50 +144,64 @@ __global__ __launch_bounds__(256) void cl_half_kernel(ClHalfArgs A) {
       if (i < N && j < N && i != j) {
         const float cs = A.margin + acc[r] - di[r];
         const float ci = A.margin + acc[r] - dj;
-        if (cs > 0.f) { lsum += cs; g += 1.f; c1r[r] += 1.f; }
+        if (cs > 0.f) { lsum += cs; g += 1.f; c1r[r] += 1; }
         if (ci > 0.f) { lsum += ci; g += 1.f; }
       }
       Gs[(l4 * 4 + r) * gp + j] = f2bf(g);
     }
   }
   // zero the K padding of the strip (columns Np .. Np32)
-  for (int c = Np + tid; c < Np32; c += 256)
+  for (int c = Np + tid; c < Np32; c += 64 * CL_NW)
 #pragma unroll
     for (int r = 0; r < 16; ++r) Gs[r * gp + c] = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float v = c1r[r];
+    int v = c1r[r];
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-    if (l15 == 0 && v != 0.f) atomicAdd(&c1s[l4 * 4 + r], v);  // exact small integers: order independent
+    if (l15 == 0 && v != 0) atomicAdd(&c1s[l4 * 4 + r], v);
   }
   lsum = wave_sum(lsum);
   if (lane == 0) lred[wave] = lsum;
   __syncthreads();
-  if (tid < 16 && i0 + tid < N) H.c1[i0 + tid] = c1s[tid];
-  if (tid == 0 && H.primary) H.loss_part[rb] = lred[0] + lred[1] + lred[2] + lred[3];
+  if (tid < 16 && i0 + tid < N) H.c1[i0 + tid] = (float)c1s[tid];
+  if (tid == 0 && H.primary) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < CL_NW; ++w) t += lred[w];
+    H.loss_part[rb] = t;
+  }
   // ---- dX strip [16, d] = G strip [16, Np] . Y [Np, d]: A operand = G (LDS), B operand = Y^T rows (k contiguous) ----
   const int nf = d / 16;
-  for (int f0 = wave; f0 < nf; f0 += 4 * 3) {
+  for (int f0 = wave; f0 < nf; f0 += CL_NW * 3) {
     f32x4_t acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8  // 8 k-blocks of Y^T loads in flight (not unrolled, every k-block was its own L2 round trip)
-    for (int kb = 0; kb * 32 < Np32; ++kb) {
-      const int kk = kb * 32 + l4 * 8;
-      const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(&Gs[l15 * gp + kk]);
+    // four k-blocks x three feature fragments of Y^T per round trip (loads first, clamped addresses instead of branches:
+    // the padded columns of G are zero, so what a clamped load brings in does not matter)
+    const int nkb = Np32 / 32;
+    for (int k0 = 0; k0 < nkb; k0 += 4) {
+      bf16x8_t yf[4][3], gf[4];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int f = f0 + 4 * q;
-        if (f < nf) {
-          bf16x8_t yf = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (kk < Np) yf = *reinterpret_cast<const bf16x8_t*>(H.YT + (long)(f * 16 + l15) * Np + kk);
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, yf, acc[q], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const int kk = min(k0 + j, nkb - 1) * 32 + l4 * 8;
+        gf[j] = *reinterpret_cast<const bf16x8_t*>(&Gs[l15 * gp + kk]);
+        const int kc = min(kk, Np - 8);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int f = min(f0 + CL_NW * q, nf - 1);
+          yf[j][q] = *reinterpret_cast<const bf16x8_t*>(H.YT + (long)(f * 16 + l15) * Np + kc);
         }
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k0 + j < nkb) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[j], yf[j][q], acc[q], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const int f = f0 + 4 * q;
+      const int f = f0 + CL_NW * q;
       if (f < nf) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -340,7 +364,7 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
   if (nblk > 0) {
     const size_t smem = (size_t)16 * (((maxNp + 31) & ~31) + CL_GP) * sizeof(bf16_t);
     COOT_REQUIRE(smem <= 150 * 1024, "contrastive: batch of %d rows exceeds the LDS strip (max ~4600)", maxNp);
-    hipLaunchKernelGGL(cl_half_kernel, dim3(nblk), dim3(256), smem, st, ha);
+    hipLaunchKernelGGL(cl_half_kernel, dim3(nblk), dim3(64 * CL_NW), smem, st, ha);
     COOT_CHECK_LAUNCH("cl_half");
   }
   // finish: per set contributions
