@@ -320,6 +320,11 @@ static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipSt
     a.lens = sg.lens[0]; a.Nseq = sg.N[0]; a.Lq = 1; a.Lk = sg.L[0];
     return bwd ? launch_attn_bwd(a, st) : launch_attn_fwd(a, st);
   }
+  if (sg.n == 2 && attn_short_path(sg.L[0]) && attn_short_path(sg.L[1])) {  // both segments in ONE launch of the short kernels
+    a.lens = sg.lens[0]; a.Nseq = sg.N[0]; a.Lq = sg.L[0]; a.Lk = sg.L[0];
+    a.Nseq2 = sg.N[1]; a.L2 = sg.L[1]; a.lens2 = sg.lens[1]; a.seed2_delta = 0x9E3779B97F4A7C15ull;
+    return bwd ? launch_attn_bwd(a, st) : launch_attn_fwd(a, st);
+  }
   long row = 0;
   const AttnArgs base = a;
   for (int s = 0; s < sg.n; ++s) {
@@ -759,14 +764,15 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       RUN(launch_gemm_nt(g, st));
     }
     long row = 0; int n0 = 0;
+    PoolArgs ps[2];
     for (int sidx = 0; sidx < sg.n; ++sidx) {
-      PoolArgs p; p.s = S.s + row * D; p.lds = D; p.z = z + row * D; p.ldz = D; p.lens = sg.lens[sidx]; p.N = sg.N[sidx]; p.L = sg.L[sidx];
+      PoolArgs& p = ps[sidx]; p.s = S.s + row * D; p.lds = D; p.z = z + row * D; p.ldz = D; p.lens = sg.lens[sidx]; p.N = sg.N[sidx]; p.L = sg.L[sidx];
       p.D = D; p.pooled = pooled + (size_t)n0 * out_dim; p.ldp = out_dim;
       p.pooled_copy = S.pooled + (size_t)n0 * D; p.smax = S.smax + (size_t)n0 * D; p.ssum = S.ssum + (size_t)n0 * D;
       p.drop_w = mkdrop(train, c.pool_dropout, seed + 977u * sidx, 16u * 15 + SITE_POOL3);
-      RUN(launch_pool_fwd(p, st));
       row += (long)sg.N[sidx] * sg.L[sidx]; n0 += sg.N[sidx];
     }
+    RUN(launch_pool_fwd2(ps, sg.n, st));  // both segments (e.g. videos and clips) in one launch
   } else {
     COOT_REQUIRE(sg.n == 1, "avg_special networks take a single segment");
     RUN(launch_avgpool_fwd(z, D, sg.lens[0], N, Lseq, D, pooled, out_dim, st));
@@ -817,16 +823,17 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   if (c.pooler == 0) {
     const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
     long row = 0; int n0 = 0;
+    PoolArgs ps[2];
     for (int sidx = 0; sidx < sg.n; ++sidx) {
-      PoolArgs p; p.s = S.s + row * D; p.lds = D; p.z = zL + row * D; p.ldz = D; p.lens = sg.lens[sidx]; p.N = sg.N[sidx]; p.L = sg.L[sidx];
+      PoolArgs& p = ps[sidx]; p.s = S.s + row * D; p.lds = D; p.z = zL + row * D; p.ldz = D; p.lens = sg.lens[sidx]; p.N = sg.N[sidx]; p.L = sg.L[sidx];
       p.D = D; p.pooled = S.pooled + (size_t)n0 * D; p.ldp = D; p.smax = S.smax + (size_t)n0 * D; p.ssum = S.ssum + (size_t)n0 * D;
       p.drop_w = mkdrop(train, c.pool_dropout, seed + 977u * sidx, 16u * 15 + SITE_POOL3);
       p.drop_s = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2); p.drop_s_ld = D; p.drop_s_row0 = row;
       p.dpooled = dpooled + (size_t)n0 * out_dim; p.lddp = out_dim; p.ds = X.ds + row * D; p.ldds = D; p.dz = X.dzp + row * D; p.lddz = D;
       p.ds_colsum = G + L.pb2;
-      RUN(launch_pool_bwd(p, st));
       row += (long)sg.N[sidx] * sg.L[sidx]; n0 += sg.N[sidx];
     }
+    RUN(launch_pool_bwd2(ps, sg.n, st));  // one launch + one bias-gradient reduction for both segments
     { GemmTN t; t.A = S.ap; t.lda = PH; t.B = X.ds; t.ldb = D; t.T = T; t.Mo = dhp; t.No = dop; t.C = G + L.pw2; t.ldc = dop;
       t.groups = H; t.zA = dhp; t.zB = dop; t.zC = (long)dhp * dop; RUN(launch_gemm_tn(t, st)); }
     if (!pool_bwd_fused) {  // dhp = (ds_h . W2[h]^T) * gelu'(hp) * drop1 ; db1p = colsum

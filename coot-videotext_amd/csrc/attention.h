@@ -17,6 +17,10 @@ struct AttnArgs {
   int Nseq = 0, Lq = 0, Lk = 0, H = 0, dh = 0;
   float scale = 1.0f;
   int xcd_order = 1;                        // short kernels: XCD-aware (sequence, head) order (set by the launcher)
+  // short self-attention kernels only: an optional SECOND segment of sequences behind the first one in the same token
+  // matrices (rows Nseq * Lk ..): Nseq2 sequences of length L2 (e.g. 64 videos x 80 frames, then 256 clips x 80 frames) —
+  // one launch for both (launch_attn_fwd/bwd fall back to one launch per segment when a segment is too long)
+  int Nseq2 = 0, L2 = 0; const long long* lens2 = nullptr; unsigned long long seed2_delta = 0;
   DropCfg drop;                             // dropout on the attention probabilities
   // backward only
   const bf16_t* dout = nullptr; long lddo = 0;
@@ -30,5 +34,6 @@ int launch_attn_fwd(const AttnArgs& a, hipStream_t stream);
 int launch_attn_bwd(const AttnArgs& a, hipStream_t stream);
 // 1 (default): self-attention with L <= 128 uses the one-workgroup-per-(sequence, head) kernels; 0: chunked kernels (A/B switch)
 void set_attn_short(int on);
+bool attn_short_path(int L);  // true if self-attention over sequences of length L takes the short kernels
 
 }  // namespace coot

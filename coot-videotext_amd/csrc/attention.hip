@@ -380,9 +380,22 @@ __device__ __forceinline__ bool short_wg(const AttnArgs& a, int& n, int& h) {
   const int id = blockIdx.x, g = id / (8 * a.H), r = id - g * (8 * a.H);
   if (a.xcd_order) { h = r >> 3; n = g * 8 + (r & 7); }
   else { h = id % a.H; n = id / a.H; }
-  return n < a.Nseq;
+  return n < a.Nseq + a.Nseq2;
 }
-static inline int short_grid(const AttnArgs& a) { return ((a.Nseq + 7) / 8) * 8 * a.H; }
+static inline int short_grid(const AttnArgs& a) { return ((a.Nseq + a.Nseq2 + 7) / 8) * 8 * a.H; }
+// sequence n of the launch -> its segment: length, valid keys, first token row, dropout key
+struct ShortSeq { int n, L, nvalid; long base; unsigned dkey; };
+__device__ __forceinline__ ShortSeq short_seq(const AttnArgs& a, int n) {
+  ShortSeq s;
+  if (n >= a.Nseq) {
+    s.n = n - a.Nseq; s.L = a.L2; s.nvalid = (int)a.lens2[s.n]; s.base = (long)a.Nseq * a.Lk + (long)s.n * a.L2;
+    s.dkey = a.drop.thr ? drop_site_key(a.drop.seed + a.seed2_delta, a.drop.seed_ptr, a.drop.site) : 0u;
+  } else {
+    s.n = n; s.L = a.Lk; s.nvalid = (int)a.lens[n]; s.base = (long)n * a.Lk;
+    s.dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;
+  }
+  return s;
+}
 
 template <int DH>
 __device__ __forceinline__ void stage_rows(const bf16_t* src, long ld, long rowbase, int L, int L16, int c0, bf16_t* R) {
@@ -397,17 +410,19 @@ __device__ __forceinline__ void stage_rows(const bf16_t* src, long ld, long rowb
 
 template <int DH>
 __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
-  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
   extern __shared__ __attribute__((aligned(16))) bf16_t sh_lds[];  // K | V, L16 rows each (sized by the launcher)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   int n, h;
   if (!short_wg(a, n, h)) return;
-  const int L = a.Lk, L16 = nw * 16;
+  const ShortSeq sq = short_seq(a, n);
+  n = sq.n;
+  const unsigned dkey = sq.dkey;
+  const int L = sq.L, L16 = nw * 16;
   bf16_t* Ks = sh_lds;
   bf16_t* Vs = sh_lds + L16 * RP;
-  const int nvalid = (int)a.lens[n];
-  const long base = (long)n * L;
+  const int nvalid = sq.nvalid;
+  const long base = sq.base;
   const int lq = lane & 15, lg = lane >> 4;
   const int qrow = wave * 16 + lq;
   const bool qok = qrow < L;
@@ -485,21 +500,23 @@ __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
 
 template <int DH>
 __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
-  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
   extern __shared__ __attribute__((aligned(16))) bf16_t sh_lds[];  // K | V | Q | dO (L16 rows each) | lse, delta (fp32)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   int n, h;
   if (!short_wg(a, n, h)) return;
-  const int L = a.Lk, L16 = nw * 16;
+  const ShortSeq sq = short_seq(a, n);
+  n = sq.n;
+  const unsigned dkey = sq.dkey;
+  const int L = sq.L, L16 = nw * 16;
   bf16_t* Ks = sh_lds;
   bf16_t* Vs = Ks + L16 * RP;
   bf16_t* Qs = Vs + L16 * RP;
   bf16_t* dOs = Qs + L16 * RP;
   float* lse_s = reinterpret_cast<float*>(dOs + L16 * RP);
   float* delta_s = lse_s + L16;
-  const int nvalid = (int)a.lens[n];
-  const long base = (long)n * L;
+  const int nvalid = sq.nvalid;
+  const long base = sq.base;
   const int l15 = lane & 15, lg = lane >> 4;
   stage_rows<DH>(a.k, a.ldk, base, L, L16, h * DH, Ks);
   stage_rows<DH>(a.v, a.ldv, base, L, L16, h * DH, Vs);
@@ -625,14 +642,17 @@ __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
 
 static int g_attn_short = 1;
 void set_attn_short(int on) { g_attn_short = on; }
-static bool attn_short_ok(const AttnArgs& a) { return g_attn_short && a.Lq == a.Lk && a.Lk <= 16 * SH_MAXW && a.Lk >= 1; }
+static bool attn_short_ok(const AttnArgs& a) {
+  return g_attn_short && a.Lq == a.Lk && a.Lk <= 16 * SH_MAXW && a.Lk >= 1 && (a.Nseq2 == 0 || (a.L2 >= 1 && a.L2 <= 16 * SH_MAXW));
+}
+bool attn_short_path(int L) { return g_attn_short && L >= 1 && L <= 16 * SH_MAXW; }
 
 template <int DH>
 static int attn_fwd_t(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.xcd_order = get_xcd_order() & 4;
   if (attn_short_ok(a)) {
-    const int nw = (a.Lk + 15) / 16;
+    const int nw = ((a.Nseq2 > 0 && a.L2 > a.Lk ? a.L2 : a.Lk) + 15) / 16;
     hipLaunchKernelGGL(attn_short_fwd_kernel<DH>, dim3(short_grid(a)), dim3(64 * nw), (size_t)2 * nw * 16 * AttnSmem<DH>::RP * sizeof(bf16_t), st, a);
     COOT_CHECK_LAUNCH("attn_short_fwd");
     return 0;
@@ -647,7 +667,7 @@ static int attn_bwd_t(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.xcd_order = get_xcd_order() & 4;
   if (attn_short_ok(a)) {
-    const int nw = (a.Lk + 15) / 16;
+    const int nw = ((a.Nseq2 > 0 && a.L2 > a.Lk ? a.L2 : a.Lk) + 15) / 16;
     hipLaunchKernelGGL(attn_short_bwd_kernel<DH>, dim3(short_grid(a)), dim3(64 * nw),
                        (size_t)4 * nw * 16 * AttnSmem<DH>::RP * sizeof(bf16_t) + (size_t)2 * nw * 16 * sizeof(float), st, a);
     COOT_CHECK_LAUNCH("attn_short_bwd");

@@ -26,6 +26,10 @@ struct PoolArgs {
 };
 int launch_pool_fwd(const PoolArgs& p, hipStream_t stream);
 int launch_pool_bwd(const PoolArgs& p, hipStream_t stream);
+// the same for up to two segments of sequences (e.g. 64 videos and 256 clips through the same network) in ONE launch:
+// grid = all sequences; the backward's bias-gradient partials of both segments take one reduction (same D, same ds_colsum)
+int launch_pool_fwd2(const PoolArgs* segs, int nseg, hipStream_t stream);
+int launch_pool_bwd2(const PoolArgs* segs, int nseg, hipStream_t stream);
 
 // TemporalAvgPool (poolers.py:232-241): sum over ALL L rows / len
 int launch_avgpool_fwd(const bf16_t* z, long ldz, const long long* lens, int N, int L, int D, float* out, long ldo, hipStream_t st);

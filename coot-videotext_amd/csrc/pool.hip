@@ -23,10 +23,14 @@ __device__ __forceinline__ void pool_unpack(u32x4_t u, float* v) {
 // chunks per workgroup / row groups for D channels
 __host__ __device__ inline int pool_cpb(int D) { return (D % 128 == 0) ? 16 : D / 8; }
 
-__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
+struct PoolArgs2 { PoolArgs seg[2]; int n0; };  // sequences [0, n0) = segment 0, the rest segment 1
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs2 pp) {
   __shared__ float red[3][256 * 8 + 8];
+  const bool second = (int)blockIdx.x >= pp.n0;
+  const PoolArgs& p = pp.seg[second ? 1 : 0];
   const unsigned kw = p.drop_w.thr ? drop_site_key(p.drop_w.seed, p.drop_w.seed_ptr, p.drop_w.site) : 0u;
-  const int n = blockIdx.x, cpb = pool_cpb(p.D), rgs = 256 / cpb;
+  const int n = (int)blockIdx.x - (second ? pp.n0 : 0), cpb = pool_cpb(p.D), rgs = 256 / cpb;
   const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, c = (blockIdx.y * cpb + cl) * 8;
   const int len = (int)p.lens[n];
   const long r0 = (long)n * p.L;
@@ -94,11 +98,13 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
 // dw = dpooled*z; ds = w*(dw - sum_l w*dw) = w*(dw*drop3 - dpooled*pooled); dz = dpooled*w*drop3.
 // Purely elementwise given the saved softmax statistics, plus the column sum of ds (bias gradient of the second pooling
 // FC): same thread mapping as the forward, 16-byte loads and stores, the RG partial column sums merged through LDS.
-__global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs p) {
+__global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs2 pp) {
   __shared__ float red[256 * 8 + 8];
+  const bool second = (int)blockIdx.x >= pp.n0;
+  const PoolArgs& p = pp.seg[second ? 1 : 0];
   const unsigned kw = p.drop_w.thr ? drop_site_key(p.drop_w.seed, p.drop_w.seed_ptr, p.drop_w.site) : 0u;
   const unsigned ks = p.drop_s.thr ? drop_site_key(p.drop_s.seed, p.drop_s.seed_ptr, p.drop_s.site) : 0u;
-  const int n = blockIdx.x, cpb = pool_cpb(p.D), rgs = 256 / cpb;
+  const int n = (int)blockIdx.x - (second ? pp.n0 : 0), cpb = pool_cpb(p.D), rgs = 256 / cpb;
   const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, c = (blockIdx.y * cpb + cl) * 8;
   const int len = (int)p.lens[n];
   const long r0 = (long)n * p.L;
@@ -173,24 +179,42 @@ static int pool_check(const PoolArgs& p) {
                "pool: D = %d unsupported (multiple of 8, 64..512)", p.D);
   return 0;
 }
-int launch_pool_fwd(const PoolArgs& p, hipStream_t st) {
-  if (int rc = pool_check(p)) return rc;
-  if (p.N <= 0) return 0;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(p.N, p.D / 8 / pool_cpb(p.D)), dim3(256), 0, st, p);
+int launch_pool_fwd2(const PoolArgs* segs, int nseg, hipStream_t st) {
+  COOT_REQUIRE(nseg >= 1 && nseg <= 2, "pool: one or two segments");
+  PoolArgs2 pp; int total = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (int rc = pool_check(segs[i])) return rc;
+    COOT_REQUIRE(segs[i].D == segs[0].D, "pool: the segments share the channel count");
+    pp.seg[i] = segs[i]; total += segs[i].N > 0 ? segs[i].N : 0;
+  }
+  pp.n0 = segs[0].N > 0 ? segs[0].N : 0;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(total, segs[0].D / 8 / pool_cpb(segs[0].D)), dim3(256), 0, st, pp);
   COOT_CHECK_LAUNCH("pool_fwd");
   return 0;
 }
-int launch_pool_bwd(const PoolArgs& p_in, hipStream_t st) {
-  PoolArgs p = p_in;
-  if (int rc = pool_check(p)) return rc;
-  COOT_REQUIRE(p.dpooled && p.ds && p.dz && p.smax && p.ssum, "pool bwd: null pointer");
-  if (p.N <= 0) return 0;
-  p.part_ws = p.ds_colsum ? partials_workspace((size_t)p.N * p.D) : nullptr;
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(p.N, p.D / 8 / pool_cpb(p.D)), dim3(256), 0, st, p);
+int launch_pool_fwd(const PoolArgs& p, hipStream_t st) { return launch_pool_fwd2(&p, 1, st); }
+
+int launch_pool_bwd2(const PoolArgs* segs, int nseg, hipStream_t st) {
+  COOT_REQUIRE(nseg >= 1 && nseg <= 2, "pool: one or two segments");
+  PoolArgs2 pp; int total = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (int rc = pool_check(segs[i])) return rc;
+    COOT_REQUIRE(segs[i].dpooled && segs[i].ds && segs[i].dz && segs[i].smax && segs[i].ssum, "pool bwd: null pointer");
+    COOT_REQUIRE(segs[i].D == segs[0].D && segs[i].ds_colsum == segs[0].ds_colsum, "pool bwd: the segments share D and the bias gradient");
+    pp.seg[i] = segs[i]; total += segs[i].N > 0 ? segs[i].N : 0;
+  }
+  pp.n0 = segs[0].N > 0 ? segs[0].N : 0;
+  if (total <= 0) return 0;
+  const int D = segs[0].D;
+  float* part = segs[0].ds_colsum ? partials_workspace((size_t)total * D) : nullptr;
+  for (int i = 0; i < nseg; ++i) pp.seg[i].part_ws = part ? part + (i == 1 ? (size_t)pp.n0 * D : 0) : nullptr;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(total, D / 8 / pool_cpb(D)), dim3(256), 0, st, pp);
   COOT_CHECK_LAUNCH("pool_bwd");
-  if (p.part_ws) return launch_reduce_partials(p.part_ws, p.N, p.D, p.D, p.ds_colsum, st);
+  if (part) return launch_reduce_partials(part, total, D, D, segs[0].ds_colsum, st);
   return 0;
 }
+int launch_pool_bwd(const PoolArgs& p, hipStream_t st) { return launch_pool_bwd2(&p, 1, st); }
 
 // ---- avg_special ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* z, long ldz, const long long* lens, int L, int D, float* out, long ldo) {
