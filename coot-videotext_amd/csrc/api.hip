@@ -702,8 +702,8 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   bool qkv_done = false;  // the fused input-FC kernel also produces layer 0's q | k | v
   if (c.use_input_fc) {
     LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T0; l.D = Din; l.y = S.xhat; l.ldy = Din;
+    if (sg.n > 1) { l.x2 = feats2; l.R0 = T0; l.R = T; }  // both segments in one launch
     RUN(launch_ln_fwd(l, st));
-    if (sg.n > 1) { l.x = feats2; l.R = T - T0; l.y = S.xhat + (size_t)T0 * Din; RUN(launch_ln_fwd(l, st)); }
     if (W.f_in_w && W.layers[0].f_wqkv && g_use_fused && g_use_fused_infc && T >= g_fused_min_rows) {
       InfcQkvFwd f; f.T = T; f.Din = Din; f.xhat = S.xhat; f.win = W.f_in_w; f.bin = W.in_bias; f.pe = pe; f.T0 = T0; f.L1 = Lseq;
       f.L2 = sg.n > 1 ? L2 : Lseq; f.wqkv = W.layers[0].f_wqkv; f.bqkv = P + L.layers[0].bq; f.h0 = S.h0; f.z0 = S.z0; f.qkv = S.layers[0].qkv;

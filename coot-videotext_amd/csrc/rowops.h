@@ -11,6 +11,7 @@ struct DropCfg {
 
 struct LnFwd {
   const void* x = nullptr; int x_f32 = 1; long ldx = 0;  // [R, D]
+  const void* x2 = nullptr; int R0 = 0;                  // optional second source: rows [R0, R) are rows 0.. of x2 (two segments, one launch)
   int R = 0, D = 0;
   const float* gain = nullptr; const float* bias = nullptr;  // null gain => xhat only (affine folded elsewhere)
   const float* pe = nullptr; int pe_L = 1;                   // + pe[(row % pe_L) * D + col] after the affine

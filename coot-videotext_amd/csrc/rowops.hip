@@ -27,13 +27,16 @@ __global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.R) return;
   const int D = p.D, nch = D >> 2;
+  const bool second = p.x2 && row >= p.R0;
+  const void* xsrc = second ? p.x2 : p.x;
+  const long xrow = second ? row - p.R0 : row;
   f32x4_t v[NV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int c = lane + 64 * i;
     v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (c < nch) v[i] = load4(p.x, p.x_f32, (long)row * p.ldx + c * 4);
+    if (c < nch) v[i] = load4(xsrc, p.x_f32, xrow * p.ldx + c * 4);
     s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
   }
   const float mean = wave_sum(s) / (float)D;
