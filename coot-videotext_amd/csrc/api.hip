@@ -429,6 +429,10 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
 // Outputs: dxq (bf16 [rows_q, D], or fp32 dxq_f32), and for cross-attention dxkv_accum (bf16 [rows_kv, D], in-place +=).
 struct LayerBwdBufs { bf16_t *dr2, *dr2m, *dh1, *dz1, *dr1, *dctx, *dq; long lddq; bf16_t* dk; long lddk; bf16_t* dv; long lddv; float* delta; };
 
+static bool qkv_bwd_is_fused(const LayerW& lw, int rows_q, bool dxq_is_f32, const float* part_ws) {
+  return lw.f_wqkv_kn && g_use_fused && g_use_fused_bwd && rows_q >= g_fused_min_rows && !dxq_is_f32 && part_ws;
+}
+
 static int layer_bwd(const coot_net_config& c, const float* P, float* G, const LayerP& lp, const LayerW& lw, const bf16_t* xq,
                      int rows_q, const bf16_t* xkv, int rows_kv, const Segs& sg,
                      const LayerBufs& b, const LayerBwdBufs& w, const bf16_t* dz2, const float* dz2_f32, long lddz2_f32,
@@ -495,8 +499,9 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
     // bq | bk | bv gradients = column sums of dqkv: taken by the weight-gradient GEMM that streams dqkv anyway
     { GemmTN t; t.A = w.dq; t.lda = 3 * D; t.B = xq; t.ldb = D; t.T = rows_q; t.Mo = 3 * D; t.No = D; t.C = G + lp.wqkv; t.ldc = D;
       t.a_colsum = G + lp.bq; RUN(launch_gemm_tn(t, st)); }
-    if (lw.f_wqkv_kn && g_use_fused && g_use_fused_bwd && rows_q >= g_fused_min_rows && !dxq_f32 && part_ws) {
+    if (qkv_bwd_is_fused(lw, rows_q, dxq_f32 != nullptr, part_ws)) {
       QkvBwd f; f.T = rows_q; f.dqkv = w.dq; f.wqkv = lw.f_wqkv_kn; f.res = w.dr1; f.aux = gelu_aux; f.dz = dxq; f.colsum = gelu_colsum; f.part = part_ws;
+      f.colsum_overwrite = 1;  // the column sums are written, not accumulated: the caller skips the zero fill on this path
       RUN(launch_qkv_bwd(f, st));
     } else {
       GemmNT g; g.X = w.dq; g.ldx = 3 * D; g.W = lw.wqkv_kn; g.ldw = 3 * D; g.M = rows_q; g.N = D; g.K = 3 * D;
@@ -877,7 +882,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     w.dq = X.dqkv; w.lddq = 3 * D; w.dk = X.dqkv + D; w.lddk = 3 * D; w.dv = X.dqkv + 2 * D; w.lddv = 3 * D; w.delta = X.delta;
     const bf16_t* zin = i == 0 ? S.z0 : S.layers[i - 1].z2;
     const bool fc0 = (i == 0 && c.use_input_fc);
-    if (fc0) RUN(launch_fill_f32(X.cvec, D, 0.f, st));
+    if (fc0 && !qkv_bwd_is_fused(W.layers[i], T, false, X.part_ws)) RUN(launch_fill_f32(X.cvec, D, 0.f, st));  // the fused QKV dX writes it
     PoolFuseBwd pfb;
     const bool lastl = (i == c.num_layers - 1);
     if (lastl && pool_bwd_fused) {
@@ -892,11 +897,12 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   }
   // dz now holds: dh0 (input-FC nets: already multiplied by gelu'(h0)) or dz0 (grad wrt LN(x)+pe)
   if (c.use_input_fc) {
-    RUN(launch_fill_f32(X.Mbuf, (long)D * Din, 0.f, st));
-    { GemmTN t; t.A = dz; t.lda = D; t.B = S.xhat; t.ldb = Din; t.T = T; t.Mo = D; t.No = Din; t.C = X.Mbuf; t.ldc = Din; RUN(launch_gemm_tn(t, st)); }
+    { GemmTN t; t.A = dz; t.lda = D; t.B = S.xhat; t.ldb = Din; t.T = T; t.Mo = D; t.No = Din; t.C = X.Mbuf; t.ldc = Din;
+      t.overwrite = 1;  // M = dh0^T . xhat: written, not accumulated (was a zero-fill launch in front of the batch)
+      RUN(launch_gemm_tn(t, st)); }
     RUN(tn_batch_flush(st));  // all weight gradients of the pass (the parameter-gradient kernel below reads Mbuf)
-    RUN(launch_infc_param_grads(X.Mbuf, P + L.in_w, P + L.n_gain, P + L.n_bias, X.cvec, D, Din, G + L.in_w, G + L.n_gain, G + L.n_bias, st));
-    RUN(launch_axpy_f32(G + L.in_b, X.cvec, D, 1.0f, st));  // db_in += colsum(dh0)
+    RUN(launch_infc_param_grads(X.Mbuf, P + L.in_w, P + L.n_gain, P + L.n_bias, X.cvec, D, Din, G + L.in_w, G + L.n_gain, G + L.n_bias,
+                                G + L.in_b /* db_in += colsum(dh0) */, st));
   } else {
     LnBwd l; l.dy = dz; l.lddy = D; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.gain = P + L.n_gain; l.R = T; l.D = D;
     l.dx32 = dfeats; l.lddx32 = Din; l.dgain = G + L.n_gain; l.dbias = G + L.n_bias;

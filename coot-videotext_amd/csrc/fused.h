@@ -88,7 +88,8 @@ struct QkvBwd {
   const bf16_t* res = nullptr;   // [T, 384] dr1
   const bf16_t* aux = nullptr;   // [T, 384] h0 (pre-GELU of the input FC) or null
   bf16_t* dz = nullptr;          // [T, 384]
-  float* colsum = nullptr;       // [384] += column sums of dz (only with aux)
+  float* colsum = nullptr;       // [384] column sums of dz (only with aux): += , or = when colsum_overwrite
+  int colsum_overwrite = 0;
   float* part = nullptr;         // [tiles, 384] workspace (only with aux)
 };
 int launch_qkv_bwd(const QkvBwd& p, hipStream_t st);

@@ -950,10 +950,10 @@ __device__ __forceinline__ float colsum_groups(const float* src, long ld, int nt
   return r;
 }
 
-__global__ __launch_bounds__(256) void colsum_tiles_kernel(const float* part, int ntiles, int n, float* out) {
+__global__ __launch_bounds__(256) void colsum_tiles_kernel(const float* part, int ntiles, int n, float* out, int overwrite) {
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const float r = colsum_groups(part + c, n, ntiles, c < n);
-  if ((threadIdx.x >> 4) == 0 && c < n) out[c] += r;
+  if ((threadIdx.x >> 4) == 0 && c < n) out[c] = overwrite ? r : out[c] + r;
 }
 
 // out[seg][c] += sum_tile part[tile][off + c]: the bias / LayerNorm gradients of pre_attn_bwd_kernel
@@ -1046,7 +1046,7 @@ int launch_qkv_bwd(const QkvBwd& p, hipStream_t st) {
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("qkv_bwd");
   if (p.aux) {
-    hipLaunchKernelGGL(colsum_tiles_kernel, dim3((FZ_D + 15) / 16), dim3(256), 0, st, (const float*)p.part, tiles, FZ_D, p.colsum);
+    hipLaunchKernelGGL(colsum_tiles_kernel, dim3((FZ_D + 15) / 16), dim3(256), 0, st, (const float*)p.part, tiles, FZ_D, p.colsum, p.colsum_overwrite);
     COOT_CHECK_LAUNCH("colsum_tiles");
   }
   return 0;

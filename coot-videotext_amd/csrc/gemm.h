@@ -50,6 +50,7 @@ struct GemmTN {
   // optional: a_colsum[m] += sum_t A[t][m] (the bias gradient that goes with dW = dY^T X: the kernel streams dY anyway).
   // groups must be 1; added with one fp32 atomic per column per split.
   float* a_colsum = nullptr;
+  int overwrite = 0;  // C = alpha * (...) instead of += (saves the caller a zero fill; groups == 1)
 };
 
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream);

@@ -651,7 +651,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& g, int bx, int by, in
         if (row < g.Mo) {
           f32x4_t* cp = reinterpret_cast<f32x4_t*>(C + (long)row * g.ldc + n0 + c4);
           const f32x4_t t = *reinterpret_cast<const f32x4_t*>(&Cs[rl * CPITCH + c4]);
-          f32x4_t o = *cp;
+          f32x4_t o = g.overwrite ? f32x4_t{0.f, 0.f, 0.f, 0.f} : *cp;
           o[0] += t[0] * g.alpha; o[1] += t[1] * g.alpha; o[2] += t[2] * g.alpha; o[3] += t[3] * g.alpha;
           *cp = o;
         }
@@ -817,7 +817,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int b
       if (col >= g.No) continue;  // No % 4 == 0 (launcher): all four inside or all outside
       f32x4_t* dp = reinterpret_cast<f32x4_t*>(dst + (long)row * ldd + col);
       if (direct) {
-        f32x4_t o = *dp;
+        f32x4_t o = g.overwrite ? f32x4_t{0.f, 0.f, 0.f, 0.f} : *dp;
         o[0] += acc[a][b][0] * g.alpha; o[1] += acc[a][b][1] * g.alpha; o[2] += acc[a][b][2] * g.alpha; o[3] += acc[a][b][3] * g.alpha;
         *dp = o;
       } else {
@@ -875,7 +875,8 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_reduce_kernel(TnBatch b, co
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
     for (int sp = 0; sp < it.splits; ++sp) s += *reinterpret_cast<const f32x4_t*>(ws + ((long)sp * g.groups + z) * per + r);
     float* c = g.C + z * g.zC + (long)m * g.ldc + n;
-    c[0] += s[0] * g.alpha; c[1] += s[1] * g.alpha; c[2] += s[2] * g.alpha; c[3] += s[3] * g.alpha;
+    if (g.overwrite) { c[0] = s[0] * g.alpha; c[1] = s[1] * g.alpha; c[2] = s[2] * g.alpha; c[3] = s[3] * g.alpha; }
+    else { c[0] += s[0] * g.alpha; c[1] += s[1] * g.alpha; c[2] += s[2] * g.alpha; c[3] += s[3] * g.alpha; }
   }
 }
 
@@ -891,7 +892,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTN g, int split
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
     for (int sp = 0; sp < splits; ++sp) s += *reinterpret_cast<const f32x4_t*>(ws + ((long)sp * g.groups + z) * per + r);
     float* c = g.C + z * g.zC + (long)m * g.ldc + n;
-    c[0] += s[0] * g.alpha; c[1] += s[1] * g.alpha; c[2] += s[2] * g.alpha; c[3] += s[3] * g.alpha;
+    if (g.overwrite) { c[0] = s[0] * g.alpha; c[1] = s[1] * g.alpha; c[2] = s[2] * g.alpha; c[3] = s[3] * g.alpha; }
+    else { c[0] += s[0] * g.alpha; c[1] += s[1] * g.alpha; c[2] += s[2] * g.alpha; c[3] += s[3] * g.alpha; }
   }
 }
 
@@ -1041,6 +1043,13 @@ int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
     if (g_tn_nitems == TN_MAX_ITEMS) { int rc = tn_batch_flush(stream); if (rc) return rc; }
     g_tn_items[g_tn_nitems++] = g;
     return 0;
+  }
+  if (g.overwrite) {  // the single-problem path may use the atomic mode: zero C here and accumulate
+    COOT_REQUIRE(g.groups == 1 && g.ldc == g.No, "gemm_tn: overwrite needs a dense single-group C");
+    int rc = launch_fill_f32(g.C, (long)g.Mo * g.No, 0.f, stream);
+    if (rc) return rc;
+    GemmTN g2 = g; g2.overwrite = 0;
+    return launch_gemm_tn(g2, stream);
   }
   int splits = tn_splits(g.T, g.Mo, g.No, g.groups);
   int t_per_split = (g.T + splits - 1) / splits;

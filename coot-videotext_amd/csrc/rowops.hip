@@ -430,7 +430,9 @@ int launch_matvec_bias(const float* W, long ldw, int N, int K, const float* v, c
 // serial loop was a 20 us chain of load latencies); dg0/db0 partials via atomics
 constexpr int IPG_ROWS = 8;
 __global__ __launch_bounds__(256) void infc_param_grads_kernel(const float* M, const float* W, const float* g0, const float* b0,
-                                                               const float* c, int N, int K, float* dW, float* dg0, float* db0) {
+                                                               const float* c, int N, int K, float* dW, float* dg0, float* db0, float* db_in) {
+  if (db_in && blockIdx.x == 0 && blockIdx.y == 0)  // db_in += colsum(dh0) (was its own axpy launch)
+    for (int n = threadIdx.x; n < N; n += 256) db_in[n] += c[n];
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= K) return;
   const int n0 = blockIdx.y * IPG_ROWS;
@@ -457,9 +459,9 @@ __global__ __launch_bounds__(256) void infc_param_grads_kernel(const float* M, c
 }
 
 int launch_infc_param_grads(const float* M, const float* W, const float* g0, const float* b0, const float* c,
-                            int N, int K, float* dW, float* dg0, float* db0, hipStream_t stream) {
+                            int N, int K, float* dW, float* dg0, float* db0, float* db_in, hipStream_t stream) {
   hipLaunchKernelGGL(infc_param_grads_kernel, dim3((K + 255) / 256, (N + IPG_ROWS - 1) / IPG_ROWS), dim3(256), 0, stream, M, W, g0, b0, c, N, K,
-                     dW, dg0, db0);
+                     dW, dg0, db0, db_in);
   COOT_CHECK_LAUNCH("infc_param_grads");
   return 0;
 }
