@@ -229,7 +229,7 @@ static void layout_saved(const coot_net_config& c, int N_in, long Ttok, Arena& A
 
 struct Scratch {  // backward temporaries
   bf16_t *dzA, *dzB, *dr2, *dr2m, *dh1, *dz1, *dr1, *dctx, *dqkv, *ds, *dhp, *dzp;
-  float *delta, *Mbuf, *cvec, *tn_ws; size_t tn_ws_floats; float* part_ws; size_t part_floats;
+  float *delta, *Mbuf, *cvec, *tn_ws; size_t tn_ws_floats; float* part_ws; size_t part_floats, part_low;
   bf16_t *c_dq, *c_dkv, *c_d1, *c_d2, *c_dh1, *c_dz1, *c_dr1, *c_dctx, *c_dqin; float* c_delta;
 };
 static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A, Scratch& S) {
@@ -265,6 +265,8 @@ static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A,
     size_t widest = 3 * D; if (F > widest) widest = F; if ((size_t)c.pool_hidden > widest) widest = c.pool_hidden;
     S.part_floats = (T / 64 + 1024) * widest;
     if (S.part_floats < (T / 128) * (size_t)FZ_BWD_NCS) S.part_floats = (T / 128) * (size_t)FZ_BWD_NCS;
+    S.part_low = S.part_floats;  // immediate users; behind it: the regions of the deferred reductions of one layer (rowops.h):
+    S.part_floats += (T / 128 + 1) * ((size_t)FZ_BWD_NCS + D) + (size_t)N * D + 1024;  // fused backward chain, QKV dX, pooling
     S.part_ws = A.get<float>(S.part_floats);
   }
   if (c.use_context) {
@@ -810,11 +812,13 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, Ntot, sg.T(), AX, X);
   COOT_REQUIRE(!AX.overflow, "net_bwd: scratch buffer too small (%zu < %zu)", scratch_bytes, AX.off);
   struct TnWs { TnWs(float* p, size_t n) { set_tn_default_workspace(p, n); } ~TnWs() { set_tn_default_workspace(nullptr, 0); } } tnws(X.tn_ws, X.tn_ws_floats);
-  struct PartWs { PartWs(float* p, size_t n) { set_partials_workspace(p, n); } ~PartWs() { set_partials_workspace(nullptr, 0); } } partws(X.part_ws, X.part_floats);
+  struct PartWs { PartWs(float* p, size_t n, size_t lo) { set_partials_workspace(p, n, lo); } ~PartWs() { set_partials_workspace(nullptr, 0); } } partws(X.part_ws, X.part_floats, X.part_low);
   // every weight gradient GEMM of the pass is recorded and launched as ONE batched kernel (gemm.h: tn_batch_*).  With a
   // single encoder (and context) layer no operand buffer is re-used before the end of the pass; deeper networks flush
   // after every layer, whose scratch buffers the next layer overwrites.
   struct TnBatchScope { TnBatchScope() { tn_batch_begin(); } ~TnBatchScope() { tn_batch_end(); } } tnbatch;
+  // the column-sum reductions of the fused kernels (bias / LayerNorm gradients) are recorded and run as one launch at the end
+  struct DeferScope { DeferScope() { colsum_defer_begin(); } ~DeferScope() { colsum_defer_end(); } } deferscope;
   const bool flush_per_layer = c.num_layers > 1 || (c.use_context && c.ctx_num_layers > 1);
   const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim;
   const long long* lens = sg.lens[0];
@@ -872,7 +876,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       RUN(layer_bwd(c, P, G, L.ctx[i], W.ctx[i], qin, N, zL, T, sg, b, w, last ? nullptr : X.c_dqin,
                     last ? dpooled + D : nullptr, out_dim, first ? nullptr : X.c_dqin, first ? dhidden : nullptr, dz, nullptr, nullptr,
                     c.ctx_dropout, train, seed, 16u * (8 + i), st));
-      if (flush_per_layer) RUN(tn_batch_flush(st));
+      if (flush_per_layer) { RUN(tn_batch_flush(st)); RUN(colsum_defer_flush(st)); }
     }
   }
 
@@ -892,7 +896,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     RUN(layer_bwd(c, P, G, L.layers[i], W.layers[i], zin, T, zin, T, sg, b, w, dz, nullptr, 0, dz_other, nullptr, nullptr,
                   fc0 ? S.h0 : nullptr, fc0 ? X.cvec : nullptr, c.dropout, train, seed, 16u * i, st,
                   (lastl && pool_bwd_fused) ? &pfb : nullptr, X.part_ws));
-    if (flush_per_layer) RUN(tn_batch_flush(st));
+    if (flush_per_layer) { RUN(tn_batch_flush(st)); RUN(colsum_defer_flush(st)); }
     bf16_t* t = dz; dz = dz_other; dz_other = t;
   }
   // dz now holds: dh0 (input-FC nets: already multiplied by gelu'(h0)) or dz0 (grad wrt LN(x)+pe)
@@ -901,6 +905,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       t.overwrite = 1;  // M = dh0^T . xhat: written, not accumulated (was a zero-fill launch in front of the batch)
       RUN(launch_gemm_tn(t, st)); }
     RUN(tn_batch_flush(st));  // all weight gradients of the pass (the parameter-gradient kernel below reads Mbuf)
+    RUN(colsum_defer_flush(st));  // ... and every deferred column sum (it reads cvec)
     RUN(launch_infc_param_grads(X.Mbuf, P + L.in_w, P + L.n_gain, P + L.n_bias, X.cvec, D, Din, G + L.in_w, G + L.n_gain, G + L.n_bias,
                                 G + L.in_b /* db_in += colsum(dh0) */, st));
   } else {
@@ -909,6 +914,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     if (!dfeats) { l.dx = dz_other; l.lddx = D; }
     RUN(launch_ln_bwd(l, st));
     RUN(tn_batch_flush(st));
+    RUN(colsum_defer_flush(st));
   }
   RUN(tn_batch_join(st));
   (void)pe; (void)hidden;

@@ -998,12 +998,16 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
 }  // namespace coot
 
 namespace coot {
-int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st) {
+int launch_pre_attn_bwd(const PreAttnBwd& p_in, hipStream_t st) {
+  PreAttnBwd p = p_in;
   COOT_REQUIRE(p.h1 && p.r2 && p.r1 && p.w2 && p.w1 && p.wo && p.ln2g && p.ln1g && p.dr2 && p.dh1 && p.dr1 && p.dctx && p.part,
                "pre_attn_bwd: null pointer");
   COOT_REQUIRE(p.do_pool ? (p.ds && p.dzp && p.hp && p.pw2 && p.pw1 && p.dhp) : (p.dz2 != nullptr), "pre_attn_bwd: input gradient pointers");
   if (p.T <= 0) return 0;
   const int tiles = (p.T + 127) / 128;
+  // the per-tile partial rows: kept until the pass's single reduction launch if the caller opened a deferred scope (rowops.h)
+  float* top = colsum_defer_room() >= 8 ? partials_workspace_top((size_t)tiles * FZ_BWD_NCS) : nullptr;
+  if (top) p.part = top;
   const bool drop = p.d_ff2.thr || p.d_ff1.thr || p.d_postln.thr || p.d_pool1.thr;
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 384.0 * (p.do_pool ? 6.0 : 3.0), 0, st);
   if (drop) {
@@ -1019,6 +1023,11 @@ int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st) {
   a.s[1] = ScatterSeg{p.g_ln2g, 2 * FZ_D, FZ_D}; a.s[2] = ScatterSeg{p.g_ln2b, 3 * FZ_D, FZ_D}; a.s[3] = ScatterSeg{p.g_b2, 4 * FZ_D, FZ_D};
   a.s[4] = ScatterSeg{p.g_b1, 5 * FZ_D, FZ_D};
   a.s[5] = ScatterSeg{p.g_ln1g, 6 * FZ_D, FZ_D}; a.s[6] = ScatterSeg{p.g_ln1b, 7 * FZ_D, FZ_D}; a.s[7] = ScatterSeg{p.g_bo, 8 * FZ_D, FZ_D};
+  if (top) {  // room for all eight was checked above
+    for (int i = 0; i < 8; ++i)
+      if (a.s[i].dst) colsum_defer_add(a.s[i].dst, p.part + a.s[i].off, FZ_BWD_NCS, tiles, a.s[i].n, 0);
+    return 0;
+  }
   hipLaunchKernelGGL(colsum_scatter_kernel, dim3(48, 8), dim3(256), 0, st, a);
   COOT_CHECK_LAUNCH("colsum_scatter");
   return 0;
@@ -1035,17 +1044,24 @@ int launch_qkv_fwd(const QkvFwd& p, hipStream_t st) {
   COOT_CHECK_LAUNCH("qkv_fwd");
   return 0;
 }
-int launch_qkv_bwd(const QkvBwd& p, hipStream_t st) {
+int launch_qkv_bwd(const QkvBwd& p_in, hipStream_t st) {
+  QkvBwd p = p_in;
   COOT_REQUIRE(p.dqkv && p.wqkv && p.res && p.dz, "qkv_bwd: null pointer");
   COOT_REQUIRE(!p.aux || (p.colsum && p.part), "qkv_bwd: GELU' needs the column-sum buffers");
   if (p.T <= 0) return 0;
   const int tiles = (p.T + 127) / 128;
+  bool deferred = false;
+  if (p.aux) {  // per-tile column sums -> the pass's single deferred reduction, if a scope is open (rowops.h)
+    float* top = partials_workspace_top((size_t)tiles * FZ_D);
+    if (top && colsum_defer_add(p.colsum, top, FZ_D, tiles, FZ_D, p.colsum_overwrite)) { p.part = top; deferred = true; }
+  }
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 1152.0, 0, st);
   if (p.aux) hipLaunchKernelGGL(qkv_bwd_kernel<true>, dim3(tiles), dim3(NTHR), 0, st, p);
   else hipLaunchKernelGGL(qkv_bwd_kernel<false>, dim3(tiles), dim3(NTHR), 0, st, p);
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("qkv_bwd");
   if (p.aux) {
+    if (deferred) return 0;
     hipLaunchKernelGGL(colsum_tiles_kernel, dim3((FZ_D + 15) / 16), dim3(256), 0, st, (const float*)p.part, tiles, FZ_D, p.colsum, p.colsum_overwrite);
     COOT_CHECK_LAUNCH("colsum_tiles");
   }

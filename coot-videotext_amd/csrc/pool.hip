@@ -207,11 +207,17 @@ int launch_pool_bwd2(const PoolArgs* segs, int nseg, hipStream_t st) {
   pp.n0 = segs[0].N > 0 ? segs[0].N : 0;
   if (total <= 0) return 0;
   const int D = segs[0].D;
-  float* part = segs[0].ds_colsum ? partials_workspace((size_t)total * D) : nullptr;
+  // bias-gradient partials: deferred to the pass's single reduction launch if the caller opened a scope (rowops.h)
+  float* part = nullptr; bool deferred = false;
+  if (segs[0].ds_colsum) {
+    part = partials_workspace_top((size_t)total * D);
+    deferred = part && colsum_defer_add(segs[0].ds_colsum, part, D, total, D, 0);
+    if (!deferred) part = partials_workspace((size_t)total * D);
+  }
   for (int i = 0; i < nseg; ++i) pp.seg[i].part_ws = part ? part + (i == 1 ? (size_t)pp.n0 * D : 0) : nullptr;
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(total, D / 8 / pool_cpb(D)), dim3(256), 0, st, pp);
   COOT_CHECK_LAUNCH("pool_bwd");
-  if (part) return launch_reduce_partials(part, total, D, D, segs[0].ds_colsum, st);
+  if (part && !deferred) return launch_reduce_partials(part, total, D, D, segs[0].ds_colsum, st);
   return 0;
 }
 int launch_pool_bwd(const PoolArgs& p, hipStream_t st) { return launch_pool_bwd2(&p, 1, st); }

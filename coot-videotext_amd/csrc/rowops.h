@@ -69,9 +69,22 @@ int launch_infc_param_grads(const float* M, const float* W, const float* g0, con
 // Producers write per-workgroup partial sums into a stream-ordered scratch region instead of issuing hundreds of
 // fp32 atomics onto the same few addresses (cross-XCD atomics serialise at the memory side: a 40 us GEMM became
 // 265 us, profiles/README.md); out[c] += sum_p ws[p*ld + c] is then one tiny kernel.
-void set_partials_workspace(float* ws, size_t floats);   // thread-local, set by the orchestrator per call
+void set_partials_workspace(float* ws, size_t floats, size_t low_floats = 0);  // thread-local, set by the orchestrator per call;
+                                                                              // the first low_floats stay with the immediate users
 float* partials_workspace(size_t need_floats);            // nullptr if not available / too small
 int launch_reduce_partials(const float* ws, int nparts, long ld, int C, float* out, hipStream_t stream);
+
+// Deferred reductions: inside colsum_defer_begin() .. colsum_defer_flush() a producer keeps its partial rows in a region taken
+// from the TOP of the partials workspace (partials_workspace_top) and only RECORDS out[c] (+)= sum_p src[p * ld + c]; flush
+// runs all recorded reductions as ONE launch.  A reduction launch between two large kernels costs far more than its 5 us
+// (drain, launch, ramp-up): the local backward had three of them.  Outside a scope (or with the table / workspace full)
+// colsum_defer_add returns false and the producer launches its reduction itself.
+void colsum_defer_begin();
+float* partials_workspace_top(size_t need_floats);
+bool colsum_defer_add(float* dst, const float* src, long ld, int nparts, int n, int overwrite);
+int colsum_defer_room();  // free slots of the table (0 outside a scope)
+int colsum_defer_flush(hipStream_t stream);
+void colsum_defer_end();
 
 int launch_fill_f32(float* p, long n, float v, hipStream_t stream);
 // y += a * x

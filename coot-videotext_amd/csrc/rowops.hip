@@ -91,8 +91,67 @@ int launch_ln_fwd(const LnFwd& p, hipStream_t stream) {
 
 static thread_local float* g_part_ws = nullptr;
 static thread_local size_t g_part_floats = 0;
-void set_partials_workspace(float* ws, size_t floats) { g_part_ws = ws; g_part_floats = floats; }
-float* partials_workspace(size_t need) { return (g_part_ws && need <= g_part_floats) ? g_part_ws : nullptr; }
+static thread_local size_t g_part_top = 0;  // floats reserved at the top of the workspace by deferred reductions
+static thread_local size_t g_part_low = 0;   // floats at the start that deferred regions never touch
+void set_partials_workspace(float* ws, size_t floats, size_t low_floats) { g_part_ws = ws; g_part_floats = floats; g_part_top = 0; g_part_low = low_floats; }
+float* partials_workspace(size_t need) { return (g_part_ws && need + g_part_top <= g_part_floats) ? g_part_ws : nullptr; }
+
+// ---- deferred column-sum reductions (rowops.h) ----------------------------------------------------------------
+constexpr int DEFER_MAX = 24;
+struct DeferSeg { float* dst; const float* src; long ld; int nparts, n, overwrite; };
+struct DeferArgs { DeferSeg s[DEFER_MAX]; int nseg; };
+static thread_local bool g_defer = false;
+static thread_local DeferArgs g_defer_args;
+
+void colsum_defer_begin() { g_defer = true; g_defer_args.nseg = 0; g_part_top = 0; }
+void colsum_defer_end() { g_defer = false; g_defer_args.nseg = 0; g_part_top = 0; }
+float* partials_workspace_top(size_t need) {
+  if (!g_defer || !g_part_ws || g_defer_args.nseg >= DEFER_MAX) return nullptr;
+  need = (need + 63) & ~(size_t)63;
+  if (g_part_low + g_part_top + need > g_part_floats) return nullptr;  // the first g_part_low floats stay with the immediate users
+  g_part_top += need;
+  return g_part_ws + (g_part_floats - g_part_top);
+}
+int colsum_defer_room() { return g_defer ? DEFER_MAX - g_defer_args.nseg : 0; }
+bool colsum_defer_add(float* dst, const float* src, long ld, int nparts, int n, int overwrite) {
+  if (!g_defer || g_defer_args.nseg >= DEFER_MAX) return false;
+  g_defer_args.s[g_defer_args.nseg++] = DeferSeg{dst, src, ld, nparts, n, overwrite};
+  return true;
+}
+// 16 columns x 16 partial-row groups per workgroup (a serial walk over the partial rows is a chain of load latencies)
+__global__ __launch_bounds__(256) void colsum_defer_kernel(DeferArgs a) {
+  __shared__ float red[16][17];
+  const DeferSeg& sg = a.s[blockIdx.y];
+  const int cl = threadIdx.x & 15, pg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  if (blockIdx.x * 16 >= sg.n) return;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  if (c < sg.n) {
+    const float* src = sg.src + c;
+    int t = pg;
+    for (; t + 48 < sg.nparts; t += 64) {
+      v0 += src[(long)t * sg.ld]; v1 += src[(long)(t + 16) * sg.ld]; v2 += src[(long)(t + 32) * sg.ld]; v3 += src[(long)(t + 48) * sg.ld];
+    }
+    for (; t < sg.nparts; t += 16) v0 += src[(long)t * sg.ld];
+  }
+  red[pg][cl] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (pg == 0 && c < sg.n) {
+    float r = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) r += red[g][cl];
+    sg.dst[c] = sg.overwrite ? r : sg.dst[c] + r;
+  }
+}
+int colsum_defer_flush(hipStream_t stream) {
+  const int n = g_defer_args.nseg;
+  if (n == 0) { g_part_top = 0; return 0; }
+  int maxn = 0;
+  for (int i = 0; i < n; ++i) if (g_defer_args.s[i].n > maxn) maxn = g_defer_args.s[i].n;
+  hipLaunchKernelGGL(colsum_defer_kernel, dim3((maxn + 15) / 16, n), dim3(256), 0, stream, g_defer_args);
+  g_defer_args.nseg = 0; g_part_top = 0;
+  COOT_CHECK_LAUNCH("colsum_defer");
+  return 0;
+}
 
 // out_k[c] += sum_p ws[p*ld + k*seg + c] for up to three outputs k (seg columns each).
 // grid = (column blocks of 64, part chunks): every block sums <= 64 parts (16 independent loads per thread), the
