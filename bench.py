@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="library A/B switch name=value (coot_set_option), repeatable")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (phase calls + RCCL collectives) even with one rank")
     ap.add_argument("--step-stamps", action="store_true", help="print a HIP-event timeline of one training step to stderr")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--mode", default="native", choices=["native", "autograd", "graph"],
@@ -116,9 +117,10 @@ def main():
         k, v = kv.split("=")
         cva.lib.check(lib.coot_set_option(k.encode(), int(v)), "coot_set_option")
     dp = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world)
         dp = cdist.DataParallelContext()
     w = cva.synthetic.WORKLOADS[args.workload]

@@ -59,6 +59,21 @@ int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int
   return launch_contrastive_fused(vs, dvs, n_high, n_low, d_high, d_low, w_pair, w_self, cfg->margin, loss, scratch, scratch_bytes, st);
 }
 
+int coot_contrastive_fwd_bwd_dp(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low, const float* const sets[6],
+                                const int64_t ld[6], float* loss, float* const d_own[6], int own_high0, int own_high, int own_low0, int own_low,
+                                void* scratch, size_t scratch_bytes, coot_stream_t stream) {
+  COOT_REQUIRE(cfg && sets && ld && loss && d_own && scratch, "contrastive_dp: null pointer");
+  COOT_REQUIRE(own_high0 >= 0 && own_high0 + own_high <= n_high && own_low0 >= 0 && own_low0 + own_low <= n_low, "contrastive_dp: window outside the batch");
+  const float w_pair[3] = {cfg->weight_high, cfg->weight_low, cfg->weight_context};
+  const float w_self[3] = {0.5f * cfg->weight_high_internal, 0.5f * cfg->weight_low_internal,
+                           cfg->weight_context_internal != 0.f ? 0.5f * cfg->weight_low_internal : 0.f};
+  long ldv[6];
+  for (int i = 0; i < 6; ++i) { COOT_REQUIRE(sets[i] && d_own[i] && ld[i] % 4 == 0, "contrastive_dp: set %d", i); ldv[i] = (long)ld[i]; }
+  const int window[4] = {own_high0, own_high, own_low0, own_low};
+  return launch_contrastive_fused(sets, d_own, n_high, n_low, d_high, d_low, w_pair, w_self, cfg->margin, loss, scratch, scratch_bytes,
+                                  (hipStream_t)stream, ldv, window);
+}
+
 int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* clip_lens, const int64_t* sent_lens,
                            const int64_t* idx_clip, const int64_t* idx_sent, int B, int Cc, int Cs, int D, float weight,
                            float inv_batch, float* loss, float* rows_clip, float* rows_sent, float* dclip, float* dsent,

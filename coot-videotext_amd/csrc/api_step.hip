@@ -328,7 +328,8 @@ size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_di
 
 int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, const coot_step_batch* x, const coot_step_dims* d,
                       float* local_v, float* local_t, float* glob_v, float* glob_t, float* resh_v, float* resh_t, void* workspace,
-                      size_t workspace_bytes, int train, uint64_t seed, coot_stream_t main_s, coot_stream_t side_v, coot_stream_t side_t) {
+                      size_t workspace_bytes, int train, uint64_t seed, int packs_fresh, coot_stream_t main_s, coot_stream_t side_v,
+                      coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
   COOT_REQUIRE(!A.overflow, "step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
@@ -336,9 +337,9 @@ int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, c
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
-                   local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv));
+                   local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, !packs_fresh));
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
-                   local_t, glob_t, resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st));
+                   local_t, glob_t, resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st, !packs_fresh));
   RUN(g_hops.hop(2, sv, sm));
   RUN(g_hops.hop(3, st, sm));
   return 0;
@@ -363,6 +364,35 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* b, 
                     W.sz_st, train, seed + 1000, st));
   RUN(g_hops.hop(2, sv, sm));
   RUN(g_hops.hop(3, st, sm));
+  return 0;
+}
+
+// optimizer update of the four networks (video side on side_v, text side on side_t, one launch each) + optional repack of the
+// bf16 weight packs; main is ordered after both
+int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* b, int64_t step, int repack, coot_stream_t main_s,
+                     coot_stream_t side_v, coot_stream_t side_t) {
+  RUN(check_cfg(*cfg));
+  COOT_REQUIRE(step >= 1, "step_update: step counts from 1");
+  hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
+  RUN(g_hops.hop(0, sm, sv));
+  RUN(g_hops.hop(1, sm, st));
+  const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
+  RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
+  if (repack) for (int i : vnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_v));
+  RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
+  if (repack) for (int i : tnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_t));
+  RUN(g_hops.hop(4, sv, sm));
+  RUN(g_hops.hop(5, st, sm));
+  return 0;
+}
+
+// idx[0 .. B) / idx[B .. 2B): one valid clip / sentence position per video (th.multinomial(mask, 1), coot/loss_fn.py:306-314)
+int coot_sample_cycle_indices(const int64_t* clip_num, const int64_t* sent_num, int B, uint64_t seed, int64_t* idx, coot_stream_t stream) {
+  COOT_REQUIRE(clip_num && sent_num && idx && B >= 0, "sample_cycle_indices: bad arguments");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)clip_num,
+                     (const long long*)sent_num, B, (unsigned long long)seed, (long long*)idx);
+  COOT_CHECK_LAUNCH("sample_idx");
   return 0;
 }
 

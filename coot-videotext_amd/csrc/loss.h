@@ -27,7 +27,11 @@ int launch_cyclecons(const CycleArgs& a, hipStream_t st);
 // clip_emb, sent_emb, vid_ctx, par_ctx (dv all null = forward only; gradients are ACCUMULATED).  w_pair[p] / w_self[p]:
 // alignment / cluster weight of pair p (high, low, context); w_self already carries the 1/2 of compute_cluster_loss.
 size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_low);
+// ldv (optional): row strides of the six input sets (default dense).  window (optional) = {high row0, high rows, low row0, low
+// rows}: only these rows of the per-video sets (0, 1, 4, 5) / per-clip sets (2, 3) receive gradients, dv[] are compact
+// [rows, d] arrays (data parallel: the loss is over the gathered batch, a rank keeps the rows of its own videos).
 int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
-                             const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st);
+                             const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st,
+                             const long* ldv = nullptr, const int* window = nullptr);
 
 }  // namespace coot

@@ -19,7 +19,7 @@
 
 namespace coot {
 
-struct ClPair { const float* va; const float* vb; bf16_t *a, *b, *aT, *bT; float *inva, *invb; float *dab, *daa, *dbb; int N, Np, d; };
+struct ClPair { const float* va; const float* vb; long lda, ldb; bf16_t *a, *b, *aT, *bT; float *inva, *invb; float *dab, *daa, *dbb; int N, Np, d; };
 struct ClNormArgs { ClPair p[3]; int row0[4]; };
 
 __global__ __launch_bounds__(256) void cl_norm_kernel(ClNormArgs A) {
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void cl_norm_kernel(ClNormArgs A) {
     const int ch = lane + 64 * q;
     xa[q] = f32x4_t{0.f, 0.f, 0.f, 0.f}; xb[q] = xa[q];
     if (ch < nch) {
-      xa[q] = *reinterpret_cast<const f32x4_t*>(P.va + (long)row * d + ch * 4);
-      xb[q] = *reinterpret_cast<const f32x4_t*>(P.vb + (long)row * d + ch * 4);
+      xa[q] = *reinterpret_cast<const f32x4_t*>(P.va + (long)row * P.lda + ch * 4);
+      xb[q] = *reinterpret_cast<const f32x4_t*>(P.vb + (long)row * P.ldb + ch * 4);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sa += xa[q][j] * xa[q][j]; sb += xb[q][j] * xb[q][j]; }
@@ -83,6 +83,7 @@ struct ClHalf {
   float* c1;                                           // [N]      #{j : m + S_ij - S_ii > 0}
   float* loss_part;                                    // [nblk]   sum of hinge values of the strip (only if primary)
   int N, Np, d, blk0, primary;
+  int w0, wn;                                          // rows whose dX strip is needed (data parallel: this rank's rows)
 };
 struct ClHalfArgs { ClHalf h[CL_MAX_HALF]; int nh; int nblk; float margin; };
 
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
     for (int w = 0; w < CL_NW; ++w) t += lred[w];
     H.loss_part[rb] = t;
   }
+  if (i0 + 16 <= H.w0 || i0 >= H.w0 + H.wn) return;  // nobody reads the gradient strip of another rank's rows
   // ---- dX strip [16, d] = G strip [16, Np] . Y [Np, d]: A operand = G (LDS), B operand = Y^T rows (k contiguous) ----
   const int nf = d / 16;
   for (int f0 = wave; f0 < nf; f0 += CL_NW * 3) {
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
 
 // per set: up to 3 contributions  coef * dX_h[i] + dcoef * (c1_p[i] + c1_q[i]) * other[i]   (other = bf16 normalised rows)
 struct ClContrib { const float* dX; float coef; const float* c1p; const float* c1q; float dcoef; const bf16_t* other; };
-struct ClSet { const float* v; const float* inv; float* dv; int N, d, nc, row0; ClContrib c[3]; };
+struct ClSet { const float* v; long ldv; const float* inv; float* dv; int N, d, nc, row0, w0, wn; ClContrib c[3]; };  // dv: rows [w0, w0 + wn) only, compact
 struct ClFinishArgs { ClSet s[6]; int rows; const float* loss_part[CL_MAX_HALF]; int loss_n[CL_MAX_HALF]; float loss_coef[CL_MAX_HALF]; int nl; float* loss; };
 
 __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
   const ClSet& S = A.s[si];
   if (!S.dv) return;
   const int row = grow - S.row0, d = S.d;
+  if (row < S.w0 || row >= S.w0 + S.wn) return;  // data-parallel: a rank keeps the gradient rows of its own videos / clips
   const float inv = S.inv[row];
   float gdc[3];
   for (int t = 0; t < S.nc; ++t) gdc[t] = -S.c[t].dcoef * (S.c[t].c1p[row] + S.c[t].c1q[row]);
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
         const f32x4_t of = {bflo(ob[0]), bfhi(ob[0]), bflo(ob[1]), bfhi(ob[1])};
         g[q] += S.c[t].coef * dx + gdc[t] * of;
       }
-      a[q] = *reinterpret_cast<const f32x4_t*>(S.v + o) * inv;
+      a[q] = *reinterpret_cast<const f32x4_t*>(S.v + (long)row * S.ldv + ch * 4) * inv;
       dot += a[q][0] * g[q][0] + a[q][1] * g[q][1] + a[q][2] * g[q][2] + a[q][3] * g[q][3];
     }
   }
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
   for (int q = 0; q < MAXC; ++q) {
     const int ch = lane + 64 * q;
     if (ch < nch) {
-      float* o = S.dv + (long)row * d + ch * 4;
+      float* o = S.dv + (long)(row - S.w0) * d + ch * 4;
       *reinterpret_cast<f32x4_t*>(o) = *reinterpret_cast<const f32x4_t*>(o) + (g[q] - a[q] * dot) * inv;
     }
   }
@@ -313,7 +316,8 @@ size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_
 
 // weights: w_pair[p] (alignment), w_self[p] (already includes the 1/2 of compute_cluster_loss)
 int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
-                             const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st) {
+                             const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st,
+                             const long* ldv, const int* window) {
   {
     const bool hi_on = w_pair[0] != 0.f || w_self[0] != 0.f, lo_on = w_pair[1] != 0.f || w_self[1] != 0.f || w_pair[2] != 0.f || w_self[2] != 0.f;
     COOT_REQUIRE((!hi_on || d_high % 32 == 0) && (!lo_on || d_low % 32 == 0), "contrastive: embedding dims must be multiples of 32 (%d, %d)", d_high, d_low);
@@ -326,7 +330,7 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
   ClNormArgs na; int rows = 0;
   for (int p = 0; p < 3; ++p) {
     ClPair& P = na.p[p]; const PairBufs& b = L.p[p];
-    P.va = v[2 * p]; P.vb = v[2 * p + 1]; P.a = b.a; P.b = b.b; P.aT = b.aT; P.bT = b.bT; P.inva = b.inva; P.invb = b.invb;
+    P.va = v[2 * p]; P.vb = v[2 * p + 1]; P.lda = ldv ? ldv[2 * p] : ds[p]; P.ldb = ldv ? ldv[2 * p + 1] : ds[p]; P.a = b.a; P.b = b.b; P.aT = b.aT; P.bT = b.bT; P.inva = b.inva; P.invb = b.invb;
     P.dab = b.dab; P.daa = b.daa; P.dbb = b.dbb; P.N = Ns[p]; P.Np = pad16(Ns[p]); P.d = ds[p];
     na.row0[p] = rows; rows += P.Np;
   }
@@ -351,6 +355,8 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
       H.YT = (q == 0 || q == 3) ? b.bT : b.aT;
       H.diag = q < 2 ? b.dab : (q == 2 ? b.daa : b.dbb);
       H.dX = hb.dX; H.c1 = hb.c1; H.loss_part = hb.lp; H.N = N; H.Np = Np; H.d = d; H.blk0 = nblk; H.primary = (q != 1);
+      H.w0 = 0; H.wn = N;
+      if (window) { H.w0 = window[p == 1 ? 2 : 0]; H.wn = window[p == 1 ? 3 : 1]; }
       if (H.primary) {
         fa.loss_part[fa.nl] = hb.lp; fa.loss_n[fa.nl] = Np / 16; fa.loss_coef[fa.nl] = (q == 0 ? w_pair[p] : w_self[p]) / ((float)N * (float)N);
         ++fa.nl;
@@ -372,7 +378,9 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
   for (int s = 0; s < 6; ++s) {
     const int p = s / 2, isb = s & 1;
     ClSet& S = fa.s[s]; const PairBufs& b = L.p[p];
-    S.v = v[s]; S.inv = isb ? b.invb : b.inva; S.dv = bwd ? dv[s] : nullptr; S.N = Ns[p]; S.d = ds[p]; S.nc = 0; S.row0 = frows;
+    S.v = v[s]; S.ldv = ldv ? ldv[s] : ds[p]; S.inv = isb ? b.invb : b.inva; S.dv = bwd ? dv[s] : nullptr; S.N = Ns[p]; S.d = ds[p]; S.nc = 0; S.row0 = frows;
+    S.w0 = 0; S.wn = Ns[p];
+    if (window) { S.w0 = window[p == 1 ? 2 : 0]; S.wn = window[p == 1 ? 3 : 1]; }  // {high row0, high rows, low row0, low rows}
     frows += Ns[p];
     if (!bwd) continue;
     const float n2 = (float)Ns[p] * (float)Ns[p];

@@ -140,10 +140,18 @@ class TransformerHip(nn.Module):
         """Pre-assign every param.grad as a view of one flat fp32 gradient arena (zeroed), so the
         autograd accumulation lands in place and a fused optimizer / one all-reduce can use it."""
         if self._grad_flat is None or self._grad_flat.device != self._flat.device:
-            self._grad_flat = torch.zeros_like(self._flat)
-            for (name, off, shape), p in zip(self.table, self._params):
-                p.grad = self._grad_flat[off:off + p.numel()].view(shape)
+            self.rebind_flat_grads(torch.zeros_like(self._flat))
         return self._grad_flat
+
+    def rebind_flat_grads(self, storage: torch.Tensor) -> None:
+        """Use `storage` (fp32, numel == self.numel, e.g. a slice of one arena shared by the four networks so that the
+        data-parallel step zeroes and all-reduces ONE tensor) as the gradient arena; the current gradients are copied over."""
+        assert storage.dtype == torch.float32 and storage.numel() == self.numel and storage.device == self._flat.device
+        if self._grad_flat is not None and self._grad_flat.device == storage.device and self._grad_flat.data_ptr() != storage.data_ptr():
+            storage.copy_(self._grad_flat)
+        self._grad_flat = storage
+        for (name, off, shape), p in zip(self.table, self._params):
+            p.grad = self._grad_flat[off:off + p.numel()].view(shape)
 
     def _param_version(self) -> int:
         return sum(p._version for p in self._params)

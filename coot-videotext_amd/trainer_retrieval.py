@@ -393,73 +393,80 @@ class RetrievalTrainer:
         if clip_counts is None:
             clip_counts = dp.global_counts(Nc, dev)
         key = (st.dims_key, tuple(vid_counts), tuple(clip_counts))
+        gb, gn = sum(vid_counts), sum(clip_counts)
         if getattr(st, "dp_key", None) != key:
             f32 = dict(dtype=torch.float32, device=dev)
             st.emb = [torch.empty(B + Nc, D, **f32), torch.empty(B + Nc, D, **f32), torch.empty(B, 2 * D, **f32), torch.empty(B, 2 * D, **f32),
                       torch.empty(B, d.Cmax_clip, D, **f32), torch.empty(B, d.Cmax_sent, D, **f32)]
-            st.demb = [torch.zeros_like(t) for t in st.emb]
-            gb, gn = sum(vid_counts), sum(clip_counts)
-            st.sets = [torch.empty(gb, 2 * D, **f32), torch.empty(gb, 2 * D, **f32), torch.empty(gn, D, **f32), torch.empty(gn, D, **f32),
-                       torch.empty(gb, D, **f32), torch.empty(gb, D, **f32)]
-            st.dsets = [torch.zeros_like(t) for t in st.sets]
+            # every buffer the step zeroes, in ONE allocation (one fill per step instead of thirteen): the gradients wrt this rank's
+            # embeddings (same shapes as st.emb) and the three loss words
+            sizes = [t.numel() for t in st.emb] + [4]
+            st.zbuf = torch.zeros(sum(sizes), **f32)
+            views, off = [], 0
+            for t_, n_ in zip(st.emb + [None], sizes):
+                views.append(st.zbuf[off:off + n_].view(t_.shape) if t_ is not None else st.zbuf[off:off + n_])
+                off += n_
+            st.demb, st.losses = views[:6], views[6][:3]
             st.loss_scratch = torch.empty(lib.coot_contrastive_scratch_bytes(gb, gn, 2 * D, D), dtype=torch.uint8, device=dev)
+            st.cyc_idx = torch.empty(2 * B, dtype=torch.int64, device=dev)
             st.dp_key = key
+        if getattr(st, "gall", None) is None or st.gall.device != dev:
+            # ONE gradient arena for the four networks + the cycle-consistency loss word: one fill and ONE all-reduce per step
+            st.gall = torch.zeros(sum(n.numel for n in st.nets) + 4, **dict(dtype=torch.float32, device=dev))
+            off = 0
+            for i, n in enumerate(st.nets):
+                n.rebind_flat_grads(st.gall[off:off + n.numel])
+                st.bufs.grads[i] = n._grad_flat.data_ptr()
+                off += n.numel
+            st.cc_word = st.gall[off:off + 1]
         local_v, local_t, glob_v, glob_t, resh_v, resh_t = st.emb
+        d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t = st.demb
         main = torch.cuda.current_stream()
         sv, stt = main, st.streams[1]  # video side on the caller's stream (no hop), text on a side stream
-        for n in st.nets:
-            n._grad_flat.zero_()
-        for g in st.demb + st.dsets:
-            g.zero_()
-        st.losses.zero_()
+        sp = main.cuda_stream
+        st.gall.zero_()
+        st.zbuf.zero_()
         ws, wsn = st.ws.data_ptr(), st.ws.numel()
+        fresh = int(all(n.pack_is_fresh() for n in st.nets))
         _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *[t.data_ptr() for t in st.emb], ws, wsn,
-                                         train, int(seed), main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_forward")
-        # ---- exchange: two packed all-gathers (per-video sets, per-clip sets) --------------------------------------
-        high = torch.cat([glob_v, glob_t, local_v[:B], local_t[:B]], dim=1)
-        low = torch.cat([local_v[B:], local_t[B:]], dim=1)
+                                         train, int(seed), fresh, main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_forward")
+        # ---- exchange: two packed all-gathers (per-video sets, per-clip sets); the loss reads the gathered buffers in place ----
         from .dist import gather_rows_nograd
+        high = torch.cat([glob_v, glob_t, local_v[:B], local_t[:B]], dim=1)      # [B, 2D | 2D | D | D]
+        low = torch.cat([local_v[B:], local_t[B:]], dim=1)                        # [Nc, D | D]
         high_all = gather_rows_nograd(high, vid_counts, dp.group)
         low_all = gather_rows_nograd(low, clip_counts, dp.group)
-        st.sets[0].copy_(high_all[:, :2 * D]); st.sets[1].copy_(high_all[:, 2 * D:4 * D])
-        st.sets[4].copy_(high_all[:, 4 * D:5 * D]); st.sets[5].copy_(high_all[:, 5 * D:])
-        st.sets[2].copy_(low_all[:, :D]); st.sets[3].copy_(low_all[:, D:])
-        sp = main.cuda_stream
-        _lib.check(lib.coot_contrastive_fwd_bwd(C.byref(st.cfg.contr), sum(vid_counts), sum(clip_counts), 2 * D, D,
-                                                *[t.data_ptr() for t in st.sets], st.losses[1:2].data_ptr(),
-                                                *[t.data_ptr() for t in st.dsets], st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
-                   "coot_contrastive_fwd_bwd")
+        wh, wl, e4 = 6 * D, 2 * D, 4
+        hp, lp = high_all.data_ptr(), low_all.data_ptr()
+        sets = (C.c_void_p * 6)(hp, hp + 2 * D * e4, lp, lp + D * e4, hp + 4 * D * e4, hp + 5 * D * e4)  # vid, par, clip, sent, vid_ctx, par_ctx
+        lds = (C.c_int64 * 6)(wh, wh, wl, wl, wh, wh)
         v0, c0 = sum(vid_counts[:dp.rank]), sum(clip_counts[:dp.rank])
-        d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t = st.demb
-        d_glob_v.copy_(st.dsets[0][v0:v0 + B]); d_glob_t.copy_(st.dsets[1][v0:v0 + B])
-        d_local_v[B:].copy_(st.dsets[2][c0:c0 + Nc]); d_local_t[B:].copy_(st.dsets[3][c0:c0 + Nc])
-        d_local_v[:B].copy_(st.dsets[4][v0:v0 + B]); d_local_t[:B].copy_(st.dsets[5][v0:v0 + B])
+        down = (C.c_void_p * 6)(d_glob_v.data_ptr(), d_glob_t.data_ptr(), d_local_v[B:].data_ptr(), d_local_t[B:].data_ptr(),
+                                d_local_v.data_ptr(), d_local_t.data_ptr())
+        _lib.check(lib.coot_contrastive_fwd_bwd_dp(C.byref(st.cfg.contr), gb, gn, 2 * D, D, C.byref(sets), C.byref(lds), st.losses[1:2].data_ptr(),
+                                                   C.byref(down), v0, B, c0, Nc, st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
+                   "coot_contrastive_fwd_bwd_dp")
         use_cc = st.cfg.cc_weight != 0.0
         if use_cc:
-            g = torch.Generator(device=dev)
-            g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
-            idx_c = loss_fn.sample_cycle_indices(batch.clip_num, g)
-            idx_s = loss_fn.sample_cycle_indices(batch.sent_num, g)
+            _lib.check(lib.coot_sample_cycle_indices(batch.clip_num.data_ptr(), batch.sent_num.data_ptr(), B, int(seed), st.cyc_idx.data_ptr(), sp),
+                       "coot_sample_cycle_indices")
             _lib.check(lib.coot_cyclecons_fwd_bwd(resh_v.data_ptr(), resh_t.data_ptr(), batch.clip_num.data_ptr(), batch.sent_num.data_ptr(),
-                                                  idx_c.data_ptr(), idx_s.data_ptr(), B, d.Cmax_clip, d.Cmax_sent, D, float(st.cfg.cc_weight),
-                                                  1.0 / float(sum(vid_counts)), st.losses[2:3].data_ptr(), None, None, d_resh_v.data_ptr(),
-                                                  d_resh_t.data_ptr(), sp), "coot_cyclecons_fwd_bwd")
+                                                  st.cyc_idx.data_ptr(), st.cyc_idx[B:].data_ptr(), B, d.Cmax_clip, d.Cmax_sent, D,
+                                                  float(st.cfg.cc_weight), 1.0 / float(gb), st.cc_word.data_ptr(), None, None,
+                                                  d_resh_v.data_ptr(), d_resh_t.data_ptr(), sp), "coot_cyclecons_fwd_bwd")
         _lib.check(lib.coot_step_backward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), local_v.data_ptr(), local_t.data_ptr(),
                                           resh_v.data_ptr(), resh_t.data_ptr(), d_local_v.data_ptr(), d_local_t.data_ptr(), d_glob_v.data_ptr(),
                                           d_glob_t.data_ptr(), d_resh_v.data_ptr() if use_cc else None, d_resh_t.data_ptr() if use_cc else None,
                                           ws, wsn, train, int(seed), main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_backward")
-        # cycle-consistency is a per-rank partial sum of a global mean: reduce it with the gradients (one extra word)
-        dp.allreduce_grads([n._grad_flat for n in st.nets] + [st.losses[2:3]], getattr(self, "comm_stream", None))
-        st.losses[0:1].copy_(st.losses[1:2] + st.losses[2:3])
+        # cycle-consistency is a per-rank partial sum of a global mean: its loss word lives at the end of the gradient arena
+        dp.allreduce_grads([st.gall], None)
+        st.losses[2:3].copy_(st.cc_word)
+        torch.add(st.losses[1:2], st.losses[2:3], out=st.losses[0:1])
         if do_optimizer:
-            for i, n in enumerate(st.nets):
-                args = (st.bufs.params[i], st.bufs.grads[i], st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i], n.numel, st.cfg.lr,
-                        st.cfg.beta1, st.cfg.beta2, st.cfg.eps, st.cfg.weight_decay, max(st.step, 1))
-                if st.cfg.optimizer == 1:
-                    _lib.check(lib.coot_radam_step(*args, st.cfg.radam_degentosgd, sp), "coot_radam_step")
-                else:
-                    _lib.check(lib.coot_adam_step(*args, sp), "coot_adam_step")
-            self.model_mgr.mark_weights_dirty()
+            _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), 1, main.cuda_stream, sv.cuda_stream,
+                                            stt.cuda_stream), "coot_step_update")
+            for n in st.nets:
+                n.mark_packed()
         self.total_step += 1
         return st.losses[0], st.losses[1], st.losses[2]
 

@@ -115,6 +115,16 @@ int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int
                              float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes,
                              coot_stream_t stream);
 
+/* The same loss for data-parallel training: sets[i] are the six GATHERED sets (row stride ld[i] floats: they may be column
+ * slices of the all-gather buffers), the loss is the mean over the global batch; gradients are produced only for this
+ * rank's rows — [own_high0, own_high0 + own_high) of the per-video sets (0 vid_emb, 1 par_emb, 4 vid_ctx, 5 par_ctx),
+ * [own_low0, own_low0 + own_low) of the per-clip sets (2 clip_emb, 3 sent_emb) — accumulated into the compact arrays
+ * d_own[i] [own rows, d]. */
+int coot_contrastive_fwd_bwd_dp(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low,
+                                const float* const sets[6], const int64_t ld[6], float* loss, float* const d_own[6],
+                                int own_high0, int own_high, int own_low0, int own_low, void* scratch,
+                                size_t scratch_bytes, coot_stream_t stream);
+
 /* CycleConsistencyLoss.forward + get_total_loss(num_samples=1) (coot/loss_fn.py:143-319).
  * idx_* are the th.multinomial draws (one valid position per video).  loss += weight *
  * inv_batch * sum_b (l_clip[b, idx_clip[b]] + l_sent[b, idx_sent[b]]); rows_* optional [B, C]. */
@@ -179,6 +189,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* bufs, 
 int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
                       const coot_step_dims* dims, float* local_v, float* local_t, float* glob_v, float* glob_t,
                       float* resh_v, float* resh_t, void* workspace, size_t workspace_bytes, int train, uint64_t seed,
+                      int packs_fresh /* the bf16 weight packs are current (coot_step_update repacked them): skip the packing */,
                       coot_stream_t main_stream, coot_stream_t side_v, coot_stream_t side_t);
 int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
                        const coot_step_dims* dims, const float* local_v, const float* local_t, const float* resh_v,
@@ -186,6 +197,14 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* buf
                        const float* d_glob_t, const float* d_resh_v, const float* d_resh_t, void* workspace,
                        size_t workspace_bytes, int train, uint64_t seed, coot_stream_t main_stream, coot_stream_t side_v,
                        coot_stream_t side_t);
+/* Optimizer update of the four networks after the gradient all-reduce (cfg->optimizer; `step` 1-based): one launch per side on
+ * side_v / side_t, then (repack != 0) the bf16 weight packs are rebuilt so that the next coot_step_forward may skip the packing. */
+int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* bufs, int64_t step, int repack,
+                     coot_stream_t main_stream, coot_stream_t side_v, coot_stream_t side_t);
+/* One valid clip / sentence position per video for the cycle-consistency loss (th.multinomial(mask, 1), coot/loss_fn.py:306-314),
+ * drawn on the device: idx[0 .. B) from clip_num, idx[B .. 2B) from sent_num. */
+int coot_sample_cycle_indices(const int64_t* clip_num, const int64_t* sent_num, int B, uint64_t seed, int64_t* idx,
+                              coot_stream_t stream);
 int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream);
 /* RAdam of nntrainer/optimization.py:79-181 on one flat arena: decoupled decay weight_decay * decay_mask,
