@@ -110,6 +110,7 @@ struct Hops {
   int wait(int slot, hipStream_t to) { return check_hip(hipStreamWaitEvent(to, ev[slot], 0), "streamWait"); }
 };
 thread_local Hops g_hops;
+thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller events: video / text global backward done
 
 // One extra stream per side for the early weight-gradient flush of the local network's backward (gemm.h: tn_batch_flush_aux)
 int g_tn_aux_sides = 0;  // coot_set_option("tn_aux", bits): 1 = video side, 2 = text side.  Measured: 136.6k -> 133k (video) / 131k (both)
@@ -172,6 +173,9 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   RUN(coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
                    b.grads[gi], dhid, dfeat, saved_g, sz_g, scratch, sz_scratch, train, seed + 11 * gi, nullptr, st));
   g_stamps.mark(li == 0 ? "video: global backward done" : "text: global backward done", st);
+  // data parallel: the global network's gradients are final here — the caller's communication stream may start reducing them
+  // under the local backward (coot_step_set_global_done_events)
+  if (g_glob_done[li == 0 ? 0 : 1]) RUN(check_hip(hipEventRecord((hipEvent_t)g_glob_done[li == 0 ? 0 : 1], st), "eventRecord"));
   RUN(launch_axpy_f32(d_local, dhid, (long)d.B * D, 1.0f, st));                               // context grad += dhidden
   RUN(launch_pack_bwd(dfeat, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));  // item grads += unpack(global input grad)
   if (d_resh) RUN(launch_pack_bwd(d_resh, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));
@@ -471,6 +475,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
 }
 
 void coot_step_stamps_enable(int on) { g_stamps.on = on != 0; }
+int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
 void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
 
 // text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.

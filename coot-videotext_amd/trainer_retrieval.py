@@ -120,6 +120,14 @@ class RetrievalTrainer:
             self.optimizer = make_optimizer(cfg.optimizer, params, capturable=on_gpu)  # capturable: HIP-graph safe
         self.cc_generator: Optional[torch.Generator] = None
         self.total_step = 0
+        # epoch-loop state (nntrainer/trainer_configs.py:16-40, the fields train_model needs; kept in memory — checkpoint files,
+        # metric meters and tensorboard are the reference's control plane and stay there)
+        self.current_epoch = 0
+        self.det_best_field_current: float = 0.0
+        self.det_best_field_best: Optional[float] = None
+        self.infos_val_epochs: list = []
+        self.infos_val_is_good: list = []
+        self.lr_scheduler = None
 
     # ---- loss hooks ------------------------------------------------------------------------------------
     def compute_align_loss(self, visual_emb: torch.Tensor, text_emb: torch.Tensor) -> torch.Tensor:
@@ -412,13 +420,24 @@ class RetrievalTrainer:
             st.dp_key = key
         if getattr(st, "gall", None) is None or st.gall.device != dev:
             # ONE gradient arena for the four networks + the cycle-consistency loss word: one fill and ONE all-reduce per step
+            # layout: [video global | text global | video local | text local | cc word] — the global networks' gradients are
+            # final after the global backward and are reduced on a communication stream under the local backward
             st.gall = torch.zeros(sum(n.numel for n in st.nets) + 4, **dict(dtype=torch.float32, device=dev))
             off = 0
-            for i, n in enumerate(st.nets):
+            for i in (1, 3, 0, 2):
+                n = st.nets[i]
                 n.rebind_flat_grads(st.gall[off:off + n.numel])
                 st.bufs.grads[i] = n._grad_flat.data_ptr()
                 off += n.numel
+                if i == 3:
+                    st.g_glob = st.gall[:off]
+                    off_loc = off
             st.cc_word = st.gall[off:off + 1]
+            st.g_loc = st.gall[off_loc:off + 1]  # local networks + the cycle-consistency word
+            st.comm = torch.cuda.Stream()
+            st.ev_glob = (torch.cuda.Event(), torch.cuda.Event())
+            for e in st.ev_glob:
+                e.record()  # creates the underlying hipEvent
         local_v, local_t, glob_v, glob_t, resh_v, resh_t = st.emb
         d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t = st.demb
         main = torch.cuda.current_stream()
@@ -454,12 +473,20 @@ class RetrievalTrainer:
                                                   st.cyc_idx.data_ptr(), st.cyc_idx[B:].data_ptr(), B, d.Cmax_clip, d.Cmax_sent, D,
                                                   float(st.cfg.cc_weight), 1.0 / float(gb), st.cc_word.data_ptr(), None, None,
                                                   d_resh_v.data_ptr(), d_resh_t.data_ptr(), sp), "coot_cyclecons_fwd_bwd")
+        lib.coot_step_set_global_done_events(st.ev_glob[0].cuda_event, st.ev_glob[1].cuda_event)
         _lib.check(lib.coot_step_backward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), local_v.data_ptr(), local_t.data_ptr(),
                                           resh_v.data_ptr(), resh_t.data_ptr(), d_local_v.data_ptr(), d_local_t.data_ptr(), d_glob_v.data_ptr(),
                                           d_glob_t.data_ptr(), d_resh_v.data_ptr() if use_cc else None, d_resh_t.data_ptr() if use_cc else None,
                                           ws, wsn, train, int(seed), main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_backward")
-        # cycle-consistency is a per-rank partial sum of a global mean: its loss word lives at the end of the gradient arena
-        dp.allreduce_grads([st.gall], None)
+        # gradient all-reduce: the global networks' half on the communication stream as soon as both global backward passes are
+        # done (events recorded inside coot_step_backward: it overlaps the local backward), the local half + the cycle-consistency
+        # word (a per-rank partial sum of a global mean) behind the backward on the main stream
+        lib.coot_step_set_global_done_events(None, None)  # the events belong to this trainer: no other step may record them
+        st.comm.wait_event(st.ev_glob[0]); st.comm.wait_event(st.ev_glob[1])
+        with torch.cuda.stream(st.comm):
+            dist.all_reduce(st.g_glob, op=dist.ReduceOp.SUM, group=dp.group)
+        dist.all_reduce(st.g_loc, op=dist.ReduceOp.SUM, group=dp.group)
+        main.wait_stream(st.comm)
         st.losses[2:3].copy_(st.cc_word)
         torch.add(st.losses[1:2], st.losses[2:3], out=st.losses[0:1])
         if do_optimizer:
@@ -472,6 +499,92 @@ class RetrievalTrainer:
 
     # ---- validation (coot/trainer_retrieval.py:312-477, metrics part) ---------------------------------------
     @torch.no_grad()
+    # ---- epoch loop (coot/trainer_retrieval.py:235-310 and the nntrainer/trainer_base.py hooks it calls) --------------
+    def check_is_val_epoch(self) -> bool:
+        """nntrainer/trainer_base.py:312-325."""
+        v = self.cfg.val
+        do_val = self.current_epoch % v.val_freq == 0 and v.val_freq > -1 and self.current_epoch >= v.val_start
+        return do_val or self.current_epoch == self.cfg.train.num_epochs
+
+    def check_is_new_best(self, result: float) -> bool:
+        """nntrainer/trainer_base.py:327-353, :632-669: better than the old best by det_best_threshold_value (relative or
+        absolute), smaller or bigger depending on det_best_compare_mode; the first result is always a new best."""
+        v = self.cfg.val
+        best, eps = self.det_best_field_best, float(v.det_best_threshold_value)
+        if v.det_best_compare_mode not in ("min", "max"):
+            raise ValueError(f"Compare mode for determining best field not understood: {v.det_best_compare_mode}")
+        if v.det_best_threshold_mode not in ("rel", "abs"):
+            raise ValueError(f"Threshold mode for metric comparison not understood: {v.det_best_threshold_mode}")
+        if best is None:
+            is_best = True
+        elif v.det_best_compare_mode == "min":
+            is_best = result < (best * (1 - eps) if v.det_best_threshold_mode == "rel" else best - eps)
+        else:
+            is_best = result > (best * (1 + eps) if v.det_best_threshold_mode == "rel" else best + eps)
+        self.det_best_field_current = result
+        if is_best:
+            self.det_best_field_best = result
+        return is_best
+
+    def find_best_epoch(self) -> int:
+        """The last validated epoch that was a new best, -1 before any validation (nntrainer/experiment_organization.py:79-102,
+        read from the in-memory flags instead of the trainer-state file of the last checkpoint)."""
+        good = [e for e, g in zip(self.infos_val_epochs, self.infos_val_is_good) if g]
+        return good[-1] if good else -1
+
+    def check_early_stop(self) -> bool:
+        """nntrainer/trainer_base.py:285-310: stop after det_best_terminate_after epochs without a new best (-1: never)."""
+        current = self.current_epoch - 1
+        best = self.find_best_epoch()
+        if best == -1:
+            best = current
+        after = self.cfg.val.det_best_terminate_after
+        return after > -1 and current - best >= after  # the reference's '>= after' with after = -1 is guarded by its config assert
+
+    def train_model(self, train_loader, val_loader, native: Optional[bool] = None, on_epoch_end=None) -> Dict[str, list]:
+        """Train epochs until done or early-stopped (coot/trainer_retrieval.py:235-310).  ``train_loader`` /
+        ``val_loader``: sized iterables of RetrievalDataBatchTuple already resident on the device.  Every step is
+        train_step_native (one C call) on a GPU; the schedule (lr_scheduler.py) runs on the host between steps and hands the
+        library one scalar.  Returns the per-epoch history {"epoch", "lr", "train_loss", "val"}."""
+        from . import lr_scheduler as lrs
+        assert self.optimizer is not None, "trainer was built with is_test=True"
+        if native is None:
+            native = any(p.is_cuda for g in self.optimizer.param_groups for p in g["params"])
+        steps_per_epoch = len(train_loader)
+        if self.lr_scheduler is None:
+            self.lr_scheduler = lrs.make_lr_scheduler(self.optimizer, lrs.SchedulerConfig(self.cfg.raw["lr_scheduler"]),
+                                                      float(self.cfg.optimizer.lr), self.cfg.train.num_epochs, steps_per_epoch)
+        hist: Dict[str, list] = {"epoch": [], "lr": [], "train_loss": [], "val": []}
+        for _epoch in range(self.current_epoch, self.cfg.train.num_epochs):
+            if self.check_early_stop():
+                break
+            self.model_mgr.set_all_models_train()
+            loss_sum = None
+            for batch in train_loader:
+                out = self.train_step_native(batch) if native else self.train_step(batch)
+                loss = out[0].detach()
+                loss_sum = loss.clone() if loss_sum is None else loss_sum + loss  # device-side: no sync per step
+                self.lr_scheduler.step()
+            do_val, is_best, val = self.check_is_val_epoch(), False, None
+            if do_val:
+                v = self.cfg.val
+                val_clips = bool(v.val_clips) and v.val_clips_freq > 0 and self.current_epoch % v.val_clips_freq == 0
+                val = self.validate_epoch(val_loader, val_clips=val_clips)
+                field = v.det_best_field
+                if field not in ("val_score_at_1", "val_loss", "val_clip_sent_score_at_1"):
+                    raise NotImplementedError(f"best field {field} not known")
+                is_best = self.check_is_new_best(val["loss"] if field == "val_loss" else val[field])
+                self.infos_val_epochs.append(self.current_epoch)
+                self.infos_val_is_good.append(is_best)
+            self.lr_scheduler.step_epoch(do_val, is_best)
+            hist["epoch"].append(self.current_epoch); hist["lr"].append(self.lr_scheduler.current_lr)
+            hist["train_loss"].append(float(loss_sum) / max(steps_per_epoch, 1) if loss_sum is not None else float("nan"))
+            hist["val"].append(val)
+            if on_epoch_end is not None:
+                on_epoch_end(self, do_val, is_best, val)
+            self.current_epoch += 1
+        return hist
+
     def validate_epoch(self, data_loader, val_clips: bool = True):
         self.model_mgr.set_all_models_eval()
         coll: Dict[str, list] = {k: [] for k in ("vid_emb", "par_emb", "clip_emb", "sent_emb")}

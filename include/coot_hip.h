@@ -197,6 +197,11 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* buf
                        const float* d_glob_t, const float* d_resh_v, const float* d_resh_t, void* workspace,
                        size_t workspace_bytes, int train, uint64_t seed, coot_stream_t main_stream, coot_stream_t side_v,
                        coot_stream_t side_t);
+/* Data parallel: hipEvent_t handles (or NULL) that coot_step_backward records on the video / text stream as soon as that side's
+ * GLOBAL network backward is enqueued — its parameter gradients (networks 1 and 3) are final from there on, so a communication
+ * stream can wait on the events and reduce them while the local backward (two thirds of the pass) still runs.  Thread-local,
+ * stays set until changed. */
+int coot_step_set_global_done_events(void* ev_video, void* ev_text);
 /* Optimizer update of the four networks after the gradient all-reduce (cfg->optimizer; `step` 1-based): one launch per side on
  * side_v / side_t, then (repack != 0) the bf16 weight packs are rebuilt so that the next coot_step_forward may skip the packing. */
 int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* bufs, int64_t step, int repack,

@@ -279,6 +279,56 @@ def gen_radam():
     print("wrote radam")
 
 
+LR_SCHEDULE_CASES = [  # (name, scheduler config, steps per epoch, epochs)
+    ("anet", dict(name="reduce_opw", warmup_type="epoch", warmup_epochs=3, rop_factor=0.1, rop_patience=2, rop_cooldown=3,
+                  rop_min_lr_factor=0), 5, 40),
+    ("yc2", dict(name="reduce_opw", warmup_type="epoch", warmup_epochs=0, rop_factor=0.1, rop_patience=5, rop_cooldown=3,
+                 rop_min_lr_factor=0), 3, 60),
+    ("stepwarm", dict(name="reduce_opw", warmup_type="step", warmup_epochs=2, rop_factor=0.5, rop_patience=1, rop_cooldown=1,
+                      rop_min_lr_factor=0.01), 7, 50),
+    ("nowarm", dict(name="reduce_opw", warmup_type="none", warmup_epochs=4, rop_factor=0.3, rop_patience=0, rop_cooldown=0,
+                    rop_min_lr_factor=0.05), 2, 30),
+    ("const", dict(name="none", warmup_type="step", warmup_epochs=3), 4, 8),
+]
+
+
+def lr_schedule_flags(case_idx, epochs):
+    """Per epoch: (validated?, new best?) — drawn so that plateaus of every length up to 8 occur."""
+    rs = np.random.RandomState(100 + case_idx)
+    is_val = rs.rand(epochs) < 0.85
+    improved = rs.rand(epochs) < 0.3
+    return is_val, improved & is_val
+
+
+def gen_lr_schedule():
+    """nntrainer/lr_scheduler.py driven the way the trainer drives it (step() per train step, step_epoch() per epoch): the
+    learning rate of both parameter groups and current_lr after EVERY call, for the shipped ANet / YC2 schedules and three
+    more covering per-step warmup, no warmup, a minimum LR factor and the constant schedule."""
+    from nntrainer import lr_scheduler
+    out = {}
+    for ci, (name, sc, spe, epochs) in enumerate(LR_SCHEDULE_CASES):
+        pa, pb = th.nn.Parameter(th.zeros(3)), th.nn.Parameter(th.zeros(2))
+        opt = th.optim.Adam([dict(params=[pa], lr=1e-3), dict(params=[pb], lr=2.5e-4)], lr=1e-3)
+        sched = lr_scheduler.make_lr_scheduler(opt, lr_scheduler.SchedulerConfig(dict(sc)), 1e-3, epochs, spe)
+        is_val, improved = lr_schedule_flags(ci, epochs)
+        rows = [[opt.param_groups[0]["lr"], opt.param_groups[1]["lr"], sched.current_lr]]
+        for e in range(epochs):
+            for _ in range(spe):
+                sched.step()
+                rows.append([opt.param_groups[0]["lr"], opt.param_groups[1]["lr"], sched.current_lr])
+            sched.step_epoch(bool(is_val[e]), bool(improved[e]))
+            rows.append([opt.param_groups[0]["lr"], opt.param_groups[1]["lr"], sched.current_lr])
+        out[name] = np.array(rows, dtype=np.float64)
+        out[name + "_reductions"] = np.int64(getattr(sched, "reduce_steps", 0))
+    import json
+    out["cases_json"] = np.array(json.dumps([[n, sc, spe, ep] for n, sc, spe, ep in LR_SCHEDULE_CASES]))
+    for ci, (name, _sc, _spe, epochs) in enumerate(LR_SCHEDULE_CASES):
+        is_val, improved = lr_schedule_flags(ci, epochs)
+        out[name + "_flags"] = np.stack([is_val, improved]).astype(np.int8)
+    np.savez_compressed(os.path.join(OUT, "lr_schedule.npz"), **out)
+    print("wrote lr_schedule")
+
+
 def gen_mask_semantics():
     """Numeric version of tests_nntrainer/test_transformers.py:22-79: perturbing masked inputs
     must not change un-masked outputs of the encoder; we store outputs before/after."""
@@ -306,6 +356,11 @@ def gen_mask_semantics():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]  # e.g. "lr_schedule": regenerate just that fixture
+    if only:
+        for name in only:
+            globals()["gen_" + name]()
+        return
     small = O.NetConfig(input_dim=40, hidden_dim=32, num_heads=4, ff_dim=32, pool_hidden=64)
     gen_single_net("net_local_small", small, N=5, L=7, seed=11, with_ctx=False)
     smallg = O.NetConfig(input_dim=32, hidden_dim=32, num_heads=4, ff_dim=32, pool_hidden=64,
@@ -321,6 +376,7 @@ def main():
              seed=31, full_grads=False)
     gen_retrieval_metrics()
     gen_radam()
+    gen_lr_schedule()
     gen_mask_semantics()
 
 

@@ -161,3 +161,83 @@ def test_radam_optimizer_matches_reference_trajectory(cva):
     sec.name = "sgd"
     with pytest.raises(NotImplementedError):
         make_optimizer(sec, [dict(params=p, decay_mult=1.0)])
+
+
+def test_lr_schedule_matches_reference(cva, golden_dir):
+    """lr_scheduler.py against nntrainer/lr_scheduler.py driven the way the trainer drives it (tests/golden/lr_schedule.npz,
+    oracle/gen_golden.py: gen_lr_schedule): the learning rate of both parameter groups and current_lr after EVERY step() /
+    step_epoch() call of the shipped ANet / YC2 schedules, per-step warmup, no warmup, a minimum LR factor, the constant
+    schedule.  Host arithmetic in double precision: exact to rounding (1e-15 relative)."""
+    import json
+    import torch
+    from coot_videotext_amd import lr_scheduler as lrs
+    g = np.load(os.path.join(golden_dir, "lr_schedule.npz"))
+    for name, sc, spe, epochs in json.loads(str(g["cases_json"])):
+        pa, pb = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))
+        opt = torch.optim.Adam([dict(params=[pa], lr=1e-3), dict(params=[pb], lr=2.5e-4)], lr=1e-3)
+        sched = lrs.make_lr_scheduler(opt, lrs.SchedulerConfig(sc), 1e-3, epochs, spe)
+        flags = g[name + "_flags"]
+        rows = [[opt.param_groups[0]["lr"], opt.param_groups[1]["lr"], sched.current_lr]]
+        for e in range(epochs):
+            for _ in range(spe):
+                sched.step()
+                rows.append([opt.param_groups[0]["lr"], opt.param_groups[1]["lr"], sched.current_lr])
+            sched.step_epoch(bool(flags[0, e]), bool(flags[1, e]))
+            rows.append([opt.param_groups[0]["lr"], opt.param_groups[1]["lr"], sched.current_lr])
+        got, ref = np.array(rows), g[name]
+        assert got.shape == ref.shape
+        assert np.allclose(got, ref, rtol=1e-14, atol=0), (name, np.abs(got / np.maximum(ref, 1e-300) - 1).max())
+        assert getattr(sched, "reduce_steps", 0) == int(g[name + "_reductions"])
+    # the schedule reduced at least twice in the plateau cases (the fixture exercises what it claims to)
+    assert int(g["anet_reductions"]) >= 2 and int(g["stepwarm_reductions"]) >= 3
+    # a step the trainer did not announce is an error (nntrainer/lr_scheduler.py:213-223), and so is an unknown schedule name
+    with pytest.raises(AssertionError):
+        for _ in range(spe + 1):
+            sched.step()
+    with pytest.raises(ValueError):
+        lrs.make_lr_scheduler(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]), lrs.SchedulerConfig(
+            dict(name="cosine", warmup_type="none", warmup_epochs=0)), 1e-3, 1, 1)
+    # state round trip
+    sd = sched.state_dict()
+    assert "optimizer" not in sd and sd["current_epoch"] == sched.current_epoch
+
+
+def test_train_model_epoch_loop_early_stop_and_schedule(cva):
+    """RetrievalTrainer.train_model (coot/trainer_retrieval.py:235-310 + the nntrainer/trainer_base.py hooks :285-353,
+    :461-499) with scripted steps and validation results: new-best rule with the relative threshold, plateau reductions of the
+    ANet schedule, early stop after det_best_terminate_after epochs, the learning rate every step sees."""
+    import torch
+    from coot_videotext_amd.trainer_retrieval import RetrievalTrainer
+    cfg = cva.load_named_config("anet_coot")
+    tr = object.__new__(RetrievalTrainer)
+    tr.cfg = cfg
+    p = torch.nn.Parameter(torch.zeros(2))
+    tr.optimizer = torch.optim.Adam([p], lr=float(cfg.optimizer.lr))
+    tr.lr_scheduler, tr.current_epoch, tr.det_best_field_best, tr.det_best_field_current = None, 0, None, 0.0
+    tr.infos_val_epochs, tr.infos_val_is_good = [], []
+    tr.model_mgr = type("M", (), dict(set_all_models_train=lambda self: None))()
+    seen_lr = []
+    # validation score: rises for 5 epochs, then a gain below the relative threshold (1e-4), then flat
+    scores = [0.10, 0.12, 0.15, 0.20, 0.30] + [0.30 * (1 + 5e-5)] + [0.30] * 100
+
+    def train_step(batch):
+        seen_lr.append(tr.optimizer.param_groups[0]["lr"])
+        return (torch.tensor(1.0), torch.tensor(0.9), torch.tensor(0.1))
+
+    def validate_epoch(loader, val_clips=True):
+        assert val_clips is False  # anet: val_clips false
+        return {"val_score_at_1": scores[tr.current_epoch], "loss": 1.0}
+
+    tr.train_step, tr.validate_epoch = train_step, validate_epoch
+    hist = tr.train_model([0, 1, 2], [0], native=False)
+    # last new best: epoch 4 -> epochs 0 .. 20 run (bad epochs = 20 - 4 = 16 stops epoch 21)
+    assert hist["epoch"] == list(range(21)) and tr.current_epoch == 21
+    assert tr.infos_val_is_good == [True] * 5 + [False] * 16 and abs(tr.det_best_field_best - 0.30) < 1e-12
+    base = float(cfg.optimizer.lr)
+    # warmup by epoch: epochs 0, 1, 2 train at 1/3, 2/3, 3/3 of the base LR
+    assert np.allclose(seen_lr[:9], [base / 3] * 3 + [base * 2 / 3] * 3 + [base] * 3, rtol=1e-12)
+    # plateau: bad epochs 5, 6, 7 (> patience 2) -> x0.1 from epoch 8; cooldown 8-10, bad 11-13 -> x0.01 from 14; 17-19 -> x0.001 from 20
+    per_epoch = np.array(seen_lr).reshape(21, 3)[:, 0]
+    want = [base / 3, base * 2 / 3] + [base] * 6 + [base * 0.1] * 6 + [base * 0.1 ** 2] * 6 + [base * 0.1 ** 3]
+    assert np.allclose(per_epoch, want, rtol=1e-12), per_epoch
+    assert np.allclose(hist["train_loss"], 1.0)

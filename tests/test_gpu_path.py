@@ -504,6 +504,63 @@ def test_native_step_trains_with_dropout_and_cycle_loss(env):
     assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.05
 
 
+def test_train_model_native_epochs(env):
+    """train_model (coot/trainer_retrieval.py:235-310) on the GPU: native steps, the ANet schedule's epoch warmup reaching the
+    library (coot_step_config.lr), device retrieval validation feeding the new-best rule, early stop.  The step with
+    lr = base / 3 must move the parameters a third as far as Adam's first step at the base rate does (|dp| = lr for every
+    element with a non-negligible gradient: Adam's first update is lr * sign(g))."""
+    torch, cva = env
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.01)
+    cfg.raw["lr_scheduler"] = dict(name="reduce_opw", warmup_type="epoch", warmup_epochs=3, rop_factor=0.1, rop_patience=0,
+                                   rop_cooldown=0, rop_min_lr_factor=0)
+    cfg.train.num_epochs = 12
+    for k, v in dict(val_freq=1, val_start=0, val_clips=True, val_clips_freq=1, det_best_field="val_clip_sent_score_at_1",
+                     det_best_compare_mode="max", det_best_threshold_mode="rel", det_best_threshold_value=1e-4,
+                     det_best_terminate_after=3).items():
+        setattr(cfg.val, k, v)
+    tr = cva.RetrievalTrainer(cfg, mgr)
+    train = [cva.synthetic.make_batch(20 + i, 8, [1, 2, 3, 4, 2, 1, 2, 3], 12, 10, 9, 6, dims[0], dims[1], ragged=True) for i in range(3)]
+    val = [cva.synthetic.make_batch(40 + i, 6, [1, 2, 3, 4, 2, 1], 12, 10, 9, 6, dims[0], dims[1], ragged=True) for i in range(2)]
+    p0 = mgr.model_dict["net_video_local"]._flat.detach().clone()
+    lrs_seen = []
+    orig = tr.train_step_native
+
+    def spy(batch, **kw):
+        out = orig(batch, **kw)
+        lrs_seen.append(float(tr._native.cfg.lr))
+        return out
+
+    tr.train_step_native = spy
+    first_dp = []
+
+    def on_epoch_end(t, do_val, is_best, val_out):
+        if t.current_epoch == 0:
+            first_dp.append((mgr.model_dict["net_video_local"]._flat.detach() - p0).abs().clone())
+        assert do_val and set(val_out) >= {"v2p", "p2v", "c2s", "s2c", "val_score_at_1", "val_clip_sent_score_at_1", "loss"}
+
+    hist = tr.train_model(train, val, on_epoch_end=on_epoch_end)
+    base = float(cfg.optimizer.lr)
+    n_ep = len(hist["epoch"])
+    assert 4 <= n_ep <= 12 and tr.current_epoch == n_ep
+    assert np.allclose(lrs_seen[:9], [base / 3] * 3 + [base * 2 / 3] * 3 + [base] * 3, rtol=1e-6)
+    assert all(np.isfinite(hist["train_loss"])) and hist["train_loss"][2] < hist["train_loss"][0]
+    # early stop: exactly det_best_terminate_after epochs after the last new best, unless the epoch budget ended first
+    last_best = [e for e, g in zip(tr.infos_val_epochs, tr.infos_val_is_good) if g][-1]
+    assert n_ep == min(12, last_best + 3 + 1)
+    # plateau with patience 0: every validated epoch after warmup without a new best multiplies the LR by 0.1
+    bad_after_warmup = sum(1 for e, g in zip(tr.infos_val_epochs, tr.infos_val_is_good) if not g and e >= 2)
+    assert abs(hist["lr"][-1] - base * 0.1 ** bad_after_warmup) <= 1e-12
+    # three Adam steps at lr = base / 3: no element moved further than 3 * base / 3 (+ weight decay, ~1e-8), and the elements
+    # with a steady gradient moved close to that bound — the warmup LR really reached the update kernel
+    d = first_dp[0]
+    # (bias-corrected |m| / sqrt(v) can exceed 1 by 0.4 % within the first three steps: bound 1.01)
+    assert float(d.max()) <= base * 1.01 + 1e-7 and float(d.max()) >= base * 0.9
+    assert float((d > 0.5 * base).float().mean()) > 0.05
+
+
 def test_native_dp_step_matches_single_gpu_native(env):
     """The data-parallel native step (phase calls + RCCL collectives, here a 1-rank nccl group) must produce the same
     gradients, losses and updated parameters as the single-call native step (dropout 0, no cycle loss => no RNG)."""
