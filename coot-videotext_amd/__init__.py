@@ -14,3 +14,5 @@ from .model_retrieval import (RetrievalDataBatchTuple, RetrievalModelManager, Re
 from .nets import TransformerHip, pack_by_count  # noqa: F401
 from .retrieval import compute_retrieval, compute_retrieval_cosine  # noqa: F401
 from .trainer_retrieval import RetrievalTrainer, make_optimizer  # noqa: F401
+from . import lr_scheduler  # noqa: F401,E402
+from .dataset_retrieval import BatchArena, DeviceLoader, RetrievalDataPointTuple, collate_fn  # noqa: F401,E402

@@ -322,7 +322,9 @@ class RetrievalTrainer:
             Nc, Lc, _ = batch.clip_feat.shape
             st.dims = _lib.StepDims(B, Nc, Lv, Lc, batch.par_feat.shape[1], batch.sent_feat.shape[1], batch.max_clip_num, batch.max_sent_num)
             assert batch.sent_feat.shape[0] == Nc and batch.par_feat.shape[0] == B
-            st.ws = torch.empty(lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims)), dtype=torch.uint8, device=dev)
+            need = lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims))
+            if getattr(st, "ws", None) is None or st.ws.numel() < need:  # ragged batches change shape every step: grow only
+                st.ws = torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev)
             st.dims_key = key
         x = _lib.StepBatch()
         for f in ("vid_feat", "clip_feat", "par_feat", "sent_feat"):

@@ -133,6 +133,16 @@ int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* 
                            int Cc, int Cs, int D, float weight, float inv_batch, float* loss, float* rows_clip,
                            float* rows_sent, float* dclip, float* dsent, coot_stream_t stream);
 
+/* ---- input side: batch collation into a staging arena ---------------------------------------------
+ * One feature level of RetrievalDataset.collate_fn (coot/dataset_retrieval.py:335-463: the zero-padded tensor + the bool
+ * mask the loops at :362-364, :378-380, :404-414, :438-452 fill): n sequences, seq[i] -> fp32 [rows[i], dim], are written to
+ * dst [n, max_rows, dim] (fp32 copy, or bf16 round-to-nearest-even when dst_bf16 != 0), rows beyond rows[i] zeroed;
+ * mask [n, max_rows] bytes (optional): 0 = data, 1 = padding.  Host-only: dst is normally a slice of ONE pinned arena that
+ * carries all four levels, lengths and masks and goes to the device with one hipMemcpyAsync on a copy stream.  threads > 1
+ * splits the sequences over that many host threads. */
+int coot_collate_level(const float* const* seq, const int64_t* rows, int64_t n, int64_t dim, int64_t max_rows, int dst_bf16,
+                       void* dst, uint8_t* mask, int threads);
+
 /* ---- retrieval ranking on the device -----------------------------------------------------------
  * validate_epoch's metric tail (coot/trainer_retrieval.py:397-402, :425-436) + nntrainer/retrieval.py:31-98 for one pair
  * of embedding sets emb1, emb2 [N, d] fp32 (e.g. vid_emb / par_emb of the whole validation set), both directions:

@@ -790,3 +790,21 @@ def make_batch(seed: int, B: int, counts, Lv: int, Lc: int, Lp: int, Ls: int, Dv
         L = b[f"{k}_feat"].shape[1]
         b[f"{k}_feat_mask"] = np.arange(L)[None, :] >= b[f"{k}_feat_len"][:, None]
     return b
+
+
+# ---- input side: seeded data points for the collation tests (shared by oracle/gen_golden.py and tests/) ----------------
+def make_datapoints(seed, B, dv, dt, max_frames=9, max_words=7, max_clips=4):
+    """B synthetic videos in the layout of RetrievalDataset.__getitem__ (coot/dataset_retrieval.py:261-333): a dict per
+    video with key, vid_feat [Lv, dv], clip_feat_list ([Lc_i, dv] per clip), par_feat [sum of sentence lengths, dt] and
+    sent_feat_len_list — sentences are slices of the paragraph features there, so only the lengths are stored."""
+    rs = np.random.RandomState(seed)
+    pts = []
+    for b in range(B):
+        c = int(rs.randint(1, max_clips + 1))
+        lv = int(rs.randint(1, max_frames + 1))
+        clip_lens = [int(rs.randint(1, max_frames + 1)) for _ in range(c)]
+        sent_lens = [int(rs.randint(1, max_words + 1)) for _ in range(c)]
+        pts.append(dict(key=f"v_{seed}_{b}", vid_feat=rs.randn(lv, dv).astype(np.float32),
+                        clip_feat_list=[rs.randn(n, dv).astype(np.float32) for n in clip_lens],
+                        par_feat=rs.randn(sum(sent_lens), dt).astype(np.float32), sent_feat_len_list=sent_lens))
+    return pts

@@ -329,6 +329,31 @@ def gen_lr_schedule():
     print("wrote lr_schedule")
 
 
+def gen_collate():
+    """RetrievalDataset.collate_fn (coot/dataset_retrieval.py:335-463; it never touches self) on seeded data points: every
+    tensor of the batch it returns.  Two batches: ragged, and a single video with a single clip."""
+    from coot.dataset_retrieval import RetrievalDataPointTuple, RetrievalDataset
+    out = {}
+    for name, (seed, B, dv, dt) in dict(ragged=(5, 6, 12, 10), single=(6, 1, 8, 4)).items():
+        pts = []
+        for d in O.make_datapoints(seed, B, dv, dt):
+            par = th.from_numpy(d["par_feat"])
+            sents, ptr = [], 0
+            for n in d["sent_feat_len_list"]:
+                sents.append(par[ptr:ptr + n]); ptr += n
+            clips = [th.from_numpy(c) for c in d["clip_feat_list"]]
+            pts.append(RetrievalDataPointTuple(d["key"], d["key"], ["w"] * len(clips), th.from_numpy(d["vid_feat"]),
+                                               d["vid_feat"].shape[0], par, par.shape[0], len(clips), clips,
+                                               [c.shape[0] for c in clips], len(clips), sents, d["sent_feat_len_list"]))
+        batch = RetrievalDataset.collate_fn(None, pts)
+        for k, v in batch.dict().items():
+            if isinstance(v, th.Tensor):
+                out[f"{name}_{k}"] = v.numpy()
+        out[f"{name}_args"] = np.array([seed, B, dv, dt])
+    np.savez_compressed(os.path.join(OUT, "collate.npz"), **out)
+    print("wrote collate")
+
+
 def gen_mask_semantics():
     """Numeric version of tests_nntrainer/test_transformers.py:22-79: perturbing masked inputs
     must not change un-masked outputs of the encoder; we store outputs before/after."""
@@ -377,6 +402,7 @@ def main():
     gen_retrieval_metrics()
     gen_radam()
     gen_lr_schedule()
+    gen_collate()
     gen_mask_semantics()
 
 

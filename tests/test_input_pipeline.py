@@ -1,0 +1,143 @@
+"""Input side: collation into one arena (coot_collate_level, host code of libcoot_hip.so) and the device staging
+loader, against batches RetrievalDataset.collate_fn itself produced (tests/golden/collate.npz, oracle/gen_golden.py:
+gen_collate).  Byte work: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import coot_oracle as O
+
+FIELDS = ("vid_feat", "vid_feat_mask", "vid_feat_len", "par_feat", "par_feat_mask", "par_feat_len", "clip_num", "clip_feat",
+          "clip_feat_mask", "clip_feat_len", "sent_num", "sent_feat", "sent_feat_mask", "sent_feat_len")
+
+
+def _points(seed, B, dv, dt, as_torch=False, **kw):
+    import torch
+    from coot_videotext_amd.dataset_retrieval import RetrievalDataPointTuple
+    pts = []
+    for d in O.make_datapoints(seed, B, dv, dt, **kw):
+        conv = (lambda a: torch.from_numpy(a)) if as_torch else (lambda a: a)
+        clips = [conv(c) for c in d["clip_feat_list"]]
+        par = conv(d["par_feat"])
+        sents, ptr = [], 0
+        for n in d["sent_feat_len_list"]:
+            sents.append(par[ptr:ptr + n]); ptr += n
+        pts.append(RetrievalDataPointTuple(d["key"], d["key"], ["w"] * len(clips), conv(d["vid_feat"]), d["vid_feat"].shape[0], par,
+                                           par.shape[0], len(clips), clips, [c.shape[0] for c in clips], len(clips), sents,
+                                           d["sent_feat_len_list"]))
+    return pts
+
+
+@pytest.mark.parametrize("as_torch", [False, True])
+def test_collate_matches_reference_batches(golden_dir, as_torch):
+    from coot_videotext_amd.dataset_retrieval import collate_fn
+    g = np.load(os.path.join(golden_dir, "collate.npz"))
+    for name in ("ragged", "single"):
+        seed, B, dv, dt = (int(v) for v in g[name + "_args"])
+        batch = collate_fn(_points(seed, B, dv, dt, as_torch=as_torch))
+        for f in FIELDS:
+            got, ref = getattr(batch, f).numpy(), g[f"{name}_{f}"]
+            assert got.dtype == ref.dtype and got.shape == ref.shape, (name, f, got.dtype, ref.dtype, got.shape, ref.shape)
+            assert np.array_equal(got, ref), (name, f)
+        assert batch.max_clip_num == int(g[f"{name}_clip_num"].max()) and batch.max_sent_num == int(g[f"{name}_sent_num"].max())
+        assert batch.key == [f"v_{seed}_{b}" for b in range(B)]
+
+
+def test_collate_arena_reuse_threads_and_bf16():
+    """One arena reused across batches of different shapes (stale bytes of the bigger batch must not leak into the padding of
+    the smaller one), the threaded path (> 1 MB), and bf16 staging = torch's round-to-nearest-even cast of the fp32 batch,
+    special values included."""
+    import torch
+    from coot_videotext_amd.dataset_retrieval import BatchArena, collate_fn
+    arena = BatchArena(pin=False)
+    big = _points(3, 16, 256, 64, max_frames=40, max_words=30)
+    b1 = collate_fn(big, arena, threads=4)
+    assert b1.clip_feat.numel() * 4 > (1 << 20)  # the clip level takes the threaded path
+    ref1 = collate_fn(big, None, threads=1)
+    for f in FIELDS:
+        assert torch.equal(getattr(b1, f), getattr(ref1, f)), f
+    snap = {f: getattr(ref1, f).clone() for f in FIELDS}
+    small = _points(4, 3, 256, 64, max_frames=5, max_words=4)
+    b2 = collate_fn(small, arena, threads=4)
+    ref2 = collate_fn(small, None)
+    for f in FIELDS:
+        assert torch.equal(getattr(b2, f), getattr(ref2, f)), f
+        assert torch.equal(getattr(ref1, f), snap[f])  # its own arena: untouched
+    # padding really is zero / masked and lengths agree with the masks
+    assert float(b2.clip_feat[b2.clip_feat_mask].abs().sum()) == 0.0
+    assert torch.equal((~b2.clip_feat_mask).sum(1), b2.clip_feat_len) and torch.equal((~b2.sent_feat_mask).sum(1), b2.sent_feat_len)
+    # bf16 staging
+    special = np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, np.inf, -np.inf, np.nan, 1e-40, 3.3895314e38, -2.5, 65504.0],
+                       dtype=np.float32)
+    pts = _points(8, 4, 12, 12)
+    pts[0].vid_feat[0, :12] = special
+    bb = collate_fn(pts, None, bf16=True)
+    bf = collate_fn(pts, None, bf16=False)
+    for f in ("vid_feat", "clip_feat", "par_feat", "sent_feat"):
+        got, want = getattr(bb, f), getattr(bf, f).to(torch.bfloat16)
+        assert got.dtype == torch.bfloat16
+        nan = torch.isnan(want)  # NaN payloads are not specified (torch's vectorised cast and the scalar one differ): NaN stays NaN
+        assert torch.equal(torch.isnan(got), nan)
+        assert np.array_equal(got.view(torch.int16)[~nan].numpy(), want.view(torch.int16)[~nan].numpy()), f
+    assert torch.equal(bb.vid_feat_mask, bf.vid_feat_mask) and torch.equal(bb.sent_feat_len, bf.sent_feat_len)
+
+
+def test_collate_level_rejects_bad_arguments():
+    import ctypes as C
+    import coot_videotext_amd as cva
+    lib = cva.lib.load()
+    src = np.zeros((3, 4), np.float32)
+    dst = np.zeros((1, 2, 4), np.float32)
+    seq = (C.c_void_p * 1)(src.ctypes.data)
+    rows = (C.c_int64 * 1)(3)  # longer than max_rows = 2
+    rc = lib.coot_collate_level(seq, rows, 1, 4, 2, 0, dst.ctypes.data, None, 1)
+    assert rc != 0 and b"max_rows" in lib.coot_last_error()
+    rows = (C.c_int64 * 1)(2)
+    assert lib.coot_collate_level(seq, rows, 1, 0, 2, 0, dst.ctypes.data, None, 1) != 0
+    assert lib.coot_collate_level(seq, rows, 1, 4, 2, 0, dst.ctypes.data, None, 1) == 0
+    with pytest.raises(AssertionError):
+        from coot_videotext_amd.dataset_retrieval import collate_fn
+        collate_fn([])
+
+
+@pytest.mark.gpu
+def test_device_loader_stages_batches_and_feeds_training():
+    """DeviceLoader: every batch arrives on the device bit-identical to the host collation, in order, with arenas rotating
+    (more batches than slots); bf16 staging arrives as the fp32 widening of the bf16 cast; train_model consumes it."""
+    import torch
+    import coot_videotext_amd as cva
+    from coot_videotext_amd.dataset_retrieval import DeviceLoader, collate_fn
+    from tests import helpers as H
+    assert torch.cuda.is_available()
+    dims = (64, 48, 64, 4, 64, 128)
+    lists = [_points(50 + i, 6, dims[0], dims[1], max_frames=12, max_words=9, as_torch=bool(i % 2)) for i in range(7)]
+    loader = DeviceLoader(lists, depth=2)
+    assert len(loader) == 7
+    seen = 0
+    keep = []
+    for i, db in enumerate(loader):
+        hb = collate_fn(lists[i])
+        keep.append(db)  # views of rotating arenas: compare now, and hold on to them to prove later batches do not need them
+        for f in FIELDS:
+            assert getattr(db, f).is_cuda and torch.equal(getattr(db, f).cpu(), getattr(hb, f)), (i, f)
+        assert db.key == hb.key and db.max_clip_num == hb.max_clip_num
+        seen += 1
+    assert seen == 7
+    for i, db in enumerate(DeviceLoader(lists[:3], depth=1, bf16=True)):
+        hb = collate_fn(lists[i])
+        assert db.clip_feat.dtype == torch.float32
+        assert torch.equal(db.clip_feat.cpu(), hb.clip_feat.to(torch.bfloat16).float()) and torch.equal(db.sent_feat_mask.cpu(), hb.sent_feat_mask)
+    # training straight from the loader (two epochs over 4 batches)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.01)
+    cfg.raw["lr_scheduler"] = dict(name="none", warmup_type="none", warmup_epochs=0)
+    cfg.train.num_epochs = 2
+    for k, v in dict(val_freq=1, val_start=0, val_clips=False, val_clips_freq=1, det_best_field="val_score_at_1",
+                     det_best_compare_mode="max", det_best_threshold_mode="rel", det_best_threshold_value=1e-4,
+                     det_best_terminate_after=16).items():
+        setattr(cfg.val, k, v)
+    tr = cva.RetrievalTrainer(cfg, mgr)
+    hist = tr.train_model(DeviceLoader(lists[:4], depth=2), DeviceLoader(lists[4:6], depth=1))
+    assert len(hist["epoch"]) == 2 and all(np.isfinite(hist["train_loss"])) and hist["val"][1]["val_score_at_1"] >= 0
