@@ -110,6 +110,7 @@ struct Hops {
   int wait(int slot, hipStream_t to) { return check_hip(hipStreamWaitEvent(to, ev[slot], 0), "streamWait"); }
 };
 thread_local Hops g_hops;
+thread_local int g_resh_wait_slot = -1;  // hop slot the video side waits on before it reads d_resh (coot_train_step), -1: none
 thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller events: video / text global backward done
 
 // One extra stream per side for the early weight-gradient flush of the local network's backward (gemm.h: tn_batch_flush_aux)
@@ -178,6 +179,9 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   if (g_glob_done[li == 0 ? 0 : 1]) RUN(check_hip(hipEventRecord((hipEvent_t)g_glob_done[li == 0 ? 0 : 1], st), "eventRecord"));
   RUN(launch_axpy_f32(d_local, dhid, (long)d.B * D, 1.0f, st));                               // context grad += dhidden
   RUN(launch_pack_bwd(dfeat, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));  // item grads += unpack(global input grad)
+  // the cycle-consistency gradients come from the other stream; they are first needed HERE, a whole global backward after the
+  // contrastive loss — waiting only now keeps the cross-stream hop off the critical path
+  if (d_resh && g_resh_wait_slot >= 0 && li == 0) RUN(g_hops.wait(g_resh_wait_slot, st));
   if (d_resh) RUN(launch_pack_bwd(d_resh, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));
   const int side = li == 0 ? 0 : 1;
   set_tn_aux_stream(((g_tn_aux_sides >> side) & 1) ? g_aux.get(side) : nullptr);
@@ -454,11 +458,13 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   RUN(g_hops.hop(3, sv, st));  // text backward needs the contrastive gradients
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses);  // total = contrastive + cycle-consistency (not needed by the backward)
   COOT_CHECK_LAUNCH("loss_total");
-  if (cc) RUN(g_hops.wait(7, sv));  // video backward needs d_resh_v (recorded on the text stream before it waited for the contrastive loss)
   const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
-  RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d, W.local_v,
-                    W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv,
-                    W.scratch_v, W.sz_sv, train, seed, sv));
+  g_resh_wait_slot = cc ? 7 : -1;  // d_resh_v was recorded on the text stream (slot 7); side_backward waits where it is first read
+  const int rc_v = side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
+                                 W.local_v, W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv,
+                                 W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, sv);
+  g_resh_wait_slot = -1;
+  RUN(rc_v);
   if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
   if (repack) for (int i : vnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_v));
   g_stamps.mark("video: updated", sv);
