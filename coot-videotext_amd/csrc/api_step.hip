@@ -251,11 +251,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) opt_update_range(k, p, g, m, v, decay, i, n);
 }
 
-struct AdamSegs { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; const float* decay[4]; long n[4]; int blk0[5]; };
+struct AdamSegs { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; const float* decay[4]; long n[4]; int blk0[5]; float* losses; };
 __global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, OptK k) {
   int s = 0;
 #pragma unroll
   for (int t = 1; t < 4; ++t) if ((int)blockIdx.x >= sg.blk0[t]) s = t;
+  // rider: total = contrastive + cycle-consistency (both final long before any update; was a 1-thread launch in front of the text backward)
+  if (sg.losses && blockIdx.x == 0 && threadIdx.x == 0) sg.losses[0] = sg.losses[1] + sg.losses[2];
   const long n = sg.n[s];
   const long i = ((long)(blockIdx.x - sg.blk0[s]) * 256 + threadIdx.x) * 4;
   if (i >= n) return;
@@ -286,8 +288,10 @@ OptK opt_scalars(int optimizer, int radam_degentosgd, float lr, float beta1, flo
 __global__ void loss_total_kernel(float* losses) { losses[0] = losses[1] + losses[2]; }
 
 // Adam update of `count` parameter arenas in ONE launch (four dependent 13 us launches used to end the step)
-int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int* nets, int count, int64_t step, hipStream_t st) {
+int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int* nets, int count, int64_t step, hipStream_t st,
+              float* losses = nullptr) {
   AdamSegs sg;
+  sg.losses = losses;
   int blk = 0;
   for (int k = 0; k < 4; ++k) {
     const int i = nets[k < count ? k : count - 1];
@@ -456,8 +460,6 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
                                W.sz_loss, side_v));
   g_stamps.mark("video: contrastive done", sv);
   RUN(g_hops.hop(3, sv, st));  // text backward needs the contrastive gradients
-  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses);  // total = contrastive + cycle-consistency (not needed by the backward)
-  COOT_CHECK_LAUNCH("loss_total");
   const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
   g_resh_wait_slot = cc ? 7 : -1;  // d_resh_v was recorded on the text stream (slot 7); side_backward waits where it is first read
   const int rc_v = side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
@@ -471,7 +473,12 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, W.local_t,
                     W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt,
                     W.scratch_t, W.sz_st, train, seed + 1000, st));
-  if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
+  // total = contrastive + cycle-consistency (not needed by the backward): rides on the text side's update launch
+  if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st, losses));
+  else {
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses);
+    COOT_CHECK_LAUNCH("loss_total");
+  }
   if (repack) for (int i : tnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_t));
   g_stamps.mark("text: updated", st);
   RUN(g_hops.hop(4, sv, sm));
