@@ -556,6 +556,7 @@ int coot_version(void) { return 1; }
 int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)dev_u64; return 0; }
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
 extern "C" void coot_step_tn_aux(int sides);
+extern "C" void coot_step_defer_global_tn(int on);
 int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
   if (!strcmp(name, "step_stamps")) { coot_step_stamps_enable(value); return 0; }
@@ -567,6 +568,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "tn_aux")) { coot_step_tn_aux(value); return 0; }
+  if (!strcmp(name, "defer_global_tn")) { coot_step_defer_global_tn(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   if (!strcmp(name, "fused_fwd_small")) { g_fused_fwd_small = value; return 0; }
@@ -913,7 +915,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     l.dx32 = dfeats; l.lddx32 = Din; l.dgain = G + L.n_gain; l.dbias = G + L.n_bias;
     if (!dfeats) { l.dx = dz_other; l.lddx = D; }
     RUN(launch_ln_bwd(l, st));
-    RUN(tn_batch_flush(st));
+    RUN(tn_batch_flush_end(st));  // global networks inside the train step: deferred to the aux stream (gemm.h), else a plain flush
     RUN(colsum_defer_flush(st));
   }
   RUN(tn_batch_join(st));

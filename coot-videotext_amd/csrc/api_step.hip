@@ -43,6 +43,7 @@ struct StepWs {
 };
 
 inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+inline size_t align256(size_t a) { return (a + 255) & ~(size_t)255; }
 
 void layout_step(const coot_step_config& c, const coot_step_dims& d, Bump& A, StepWs& W) {
   const size_t D = c.net[0].hidden_dim;
@@ -51,8 +52,10 @@ void layout_step(const coot_step_config& c, const coot_step_dims& d, Bump& A, St
   W.sz_lt = coot_net_saved_bytes(&c.net[2], d.B, d.Lp, d.Nc, d.Ls);
   W.sz_gt = coot_net_saved_bytes(&c.net[3], d.B, d.Cmax_sent, 0, 0);
   W.saved_lv = A.get(W.sz_lv); W.saved_gv = A.get(W.sz_gv); W.saved_lt = A.get(W.sz_lt); W.saved_gt = A.get(W.sz_gt);
-  W.sz_sv = max2(coot_net_scratch_bytes(&c.net[0], d.B, d.Lv, d.Nc, d.Lc), coot_net_scratch_bytes(&c.net[1], d.B, d.Cmax_clip, 0, 0));
-  W.sz_st = max2(coot_net_scratch_bytes(&c.net[2], d.B, d.Lp, d.Nc, d.Ls), coot_net_scratch_bytes(&c.net[3], d.B, d.Cmax_sent, 0, 0));
+  // backward: the global network's scratch sits BEHIND the local network's (side_backward) — its weight-gradient GEMMs run on an
+  // aux stream next to the local backward and still read their operands there
+  W.sz_sv = align256(coot_net_scratch_bytes(&c.net[0], d.B, d.Lv, d.Nc, d.Lc)) + coot_net_scratch_bytes(&c.net[1], d.B, d.Cmax_clip, 0, 0);
+  W.sz_st = align256(coot_net_scratch_bytes(&c.net[2], d.B, d.Lp, d.Nc, d.Ls)) + coot_net_scratch_bytes(&c.net[3], d.B, d.Cmax_sent, 0, 0);
   W.scratch_v = A.get(W.sz_sv); W.scratch_t = A.get(W.sz_st);
   W.sz_loss = coot_contrastive_scratch_bytes(d.B, d.Nc, 2 * (int)D, (int)D);
   W.loss_scratch = A.get(W.sz_loss);
@@ -89,7 +92,7 @@ int check_cfg(const coot_step_config& c) {
 // streams vanish), the losses run on the video stream, and every hop left on the critical path waits for the text side,
 // which has slack.
 struct Hops {
-  static constexpr int N = 8;
+  static constexpr int N = 10;
   hipEvent_t ev[N]; bool made = false;
   int init() {
     if (made) return 0;
@@ -114,6 +117,11 @@ thread_local int g_resh_wait_slot = -1;  // hop slot the video side waits on bef
 thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller events: video / text global backward done
 
 // One extra stream per side for the early weight-gradient flush of the local network's backward (gemm.h: tn_batch_flush_aux)
+// coot_set_option("defer_global_tn", 0/1): the global networks' weight gradients on the aux stream, next to the local backward.
+// Measured (A/B in one session): 173.0k -> 167.5k clip-pairs/s — the global backward does not get shorter (its chain is bound by
+// the dependent launches, the 36-workgroup TN launch overlapped with them anyway) and the aux launch slows the local backward's
+// first kernels.  Off.
+int g_defer_global_tn = 0;
 int g_tn_aux_sides = 0;  // coot_set_option("tn_aux", bits): 1 = video side, 2 = text side.  Measured: 136.6k -> 133k (video) / 131k (both)
                           // clip-pairs/s — the local backward is area bound, two half batches of weight gradients are less efficient than one
 struct AuxStreams {
@@ -171,25 +179,43 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
                   size_t sz_scratch, int train, uint64_t seed, hipStream_t st) {
   const int D = c.net[0].hidden_dim;
   g_stamps.mark(li == 0 ? "video: backward starts" : "text: backward starts", st);
-  RUN(coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
-                   b.grads[gi], dhid, dfeat, saved_g, sz_g, scratch, sz_scratch, train, seed + 11 * gi, nullptr, st));
+  const int side = li == 0 ? 0 : 1;
+  // scratch: [local network | global network].  The global network's weight gradients (one batched TN launch, 36 workgroups)
+  // are not needed before the optimizer: they go to this side's aux stream and run next to the local backward (which leaves
+  // 56 CUs idle in its largest kernel) instead of in front of it; joined below.
+  const size_t sz_loc = align256(coot_net_scratch_bytes(&c.net[li], d.B, Lctx, d.Nc, Litem));
+  const size_t sz_glob = coot_net_scratch_bytes(&c.net[gi], d.B, Cmax, 0, 0);
+  COOT_REQUIRE(sz_loc + sz_glob <= sz_scratch, "step backward: scratch too small (%zu < %zu)", sz_scratch, sz_loc + sz_glob);
+  const bool defer = g_defer_global_tn != 0;
+  set_tn_aux_stream(defer ? g_aux.get(side) : nullptr);
+  set_tn_defer(defer);
+  const int rc_g = coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
+                                b.grads[gi], dhid, dfeat, saved_g, sz_g, (char*)scratch + sz_loc, sz_glob, train, seed + 11 * gi, nullptr, st);
+  set_tn_defer(false);
+  set_tn_aux_stream(nullptr);
+  RUN(rc_g);
   g_stamps.mark(li == 0 ? "video: global backward done" : "text: global backward done", st);
-  // data parallel: the global network's gradients are final here — the caller's communication stream may start reducing them
-  // under the local backward (coot_step_set_global_done_events)
-  if (g_glob_done[li == 0 ? 0 : 1]) RUN(check_hip(hipEventRecord((hipEvent_t)g_glob_done[li == 0 ? 0 : 1], st), "eventRecord"));
+  // data parallel: the global network's gradients are final here (behind the deferred weight-gradient launch, if any) — the
+  // caller's communication stream may start reducing them under the local backward (coot_step_set_global_done_events)
+  if (g_glob_done[side]) {
+    hipStream_t ds = tn_deferred_pending() ? tn_deferred_stream() : nullptr;
+    if (ds) RUN(g_hops.hop(8 + side, st, ds));  // ... and behind everything the pass enqueued on `st` after that launch
+    RUN(check_hip(hipEventRecord((hipEvent_t)g_glob_done[side], ds ? ds : st), "eventRecord"));
+  }
   RUN(launch_axpy_f32(d_local, dhid, (long)d.B * D, 1.0f, st));                               // context grad += dhidden
   RUN(launch_pack_bwd(dfeat, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));  // item grads += unpack(global input grad)
   // the cycle-consistency gradients come from the other stream; they are first needed HERE, a whole global backward after the
   // contrastive loss — waiting only now keeps the cross-stream hop off the critical path
   if (d_resh && g_resh_wait_slot >= 0 && li == 0) RUN(g_hops.wait(g_resh_wait_slot, st));
   if (d_resh) RUN(launch_pack_bwd(d_resh, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));
-  const int side = li == 0 ? 0 : 1;
   set_tn_aux_stream(((g_tn_aux_sides >> side) & 1) ? g_aux.get(side) : nullptr);
   const int rc = coot_net_bwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
-                              nullptr, d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_scratch, train, seed + 11 * li, nullptr,
+                              nullptr, d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_loc, train, seed + 11 * li, nullptr,
                               st);
   set_tn_aux_stream(nullptr);
+  const int rc_j = tn_deferred_join(st);  // the optimizer / the end of the pass needs the global network's weight gradients
   RUN(rc);
+  RUN(rc_j);
   g_stamps.mark(li == 0 ? "video: local backward done" : "text: local backward done", st);
   return 0;
 }
@@ -490,6 +516,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
 void coot_step_stamps_enable(int on) { g_stamps.on = on != 0; }
 int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
 void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
+void coot_step_defer_global_tn(int on) { g_defer_global_tn = on; }
 
 // text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.
 int coot_debug_step_stamps(char* buf, int buf_bytes) {

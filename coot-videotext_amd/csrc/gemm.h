@@ -65,6 +65,12 @@ void tn_batch_end();
 void set_tn_aux_stream(hipStream_t aux);
 int tn_batch_flush_aux(hipStream_t st);  // flush what is recorded so far on the aux stream, ordered after `st`
 int tn_batch_join(hipStream_t st);       // `st` waits for the aux flushes of the current scope
+// the last flush of a scope, not joined by it (gemm.hip): used for the global networks' weight gradients
+void set_tn_defer(bool on);
+int tn_batch_flush_end(hipStream_t st);  // = tn_batch_flush(st) unless set_tn_defer(true) and an aux stream is set
+bool tn_deferred_pending();
+hipStream_t tn_deferred_stream();        // the stream the deferred flush runs on (nullptr if there is none)
+int tn_deferred_join(hipStream_t st);    // `st` waits for the deferred flush, if any
 // 1 (default): batched problems with Mo % 384 == 0 use the 384 x 128 output tiles; 0: always 128 x 128 (A/B switch)
 void set_tn_wide(int on);
 void set_xcd_order(int bits);  // XCD-aware workgroup -> tile order: 1 = gemm_nt, 4 = short attention (A/B switch)

@@ -1033,6 +1033,32 @@ int tn_batch_join(hipStream_t st) {
   return check_hip(hipStreamWaitEvent(st, g_tn_ev[1], 0), "streamWait");
 }
 
+// Deferred flush: the LAST flush of a scope whose results nothing on `st` needs for a long while (the global network's weight
+// gradients: final consumers are the optimizer and the gradient all-reduce, a whole local backward later).  It goes to the aux
+// stream like tn_batch_flush_aux(), but the scope's tn_batch_join() does not wait for it: the owner of the aux stream calls
+// tn_deferred_join(st) where the results are needed (and tn_deferred_record(ev) to publish "done" to another stream).
+static thread_local bool g_tn_defer = false, g_tn_deferred = false;
+static thread_local hipStream_t g_tn_deferred_stream = nullptr;
+void set_tn_defer(bool on) { g_tn_defer = on; }
+int tn_batch_flush_end(hipStream_t st) {
+  if (g_tn_defer && g_tn_aux && g_tn_aux != st && g_tn_collect && g_tn_nitems > 0) {
+    int rc = tn_batch_flush_aux(st);
+    if (rc) return rc;
+    g_tn_aux_pending = false;
+    g_tn_deferred = true;
+    g_tn_deferred_stream = g_tn_aux;
+    return 0;
+  }
+  return tn_batch_flush(st);
+}
+bool tn_deferred_pending() { return g_tn_deferred; }
+hipStream_t tn_deferred_stream() { return g_tn_deferred ? g_tn_deferred_stream : nullptr; }
+int tn_deferred_join(hipStream_t st) {
+  if (!g_tn_deferred) return 0;
+  g_tn_deferred = false;
+  return check_hip(hipStreamWaitEvent(st, g_tn_ev[1], 0), "streamWait");
+}
+
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
   COOT_REQUIRE(g.A && g.B && g.C, "gemm_tn: null operand");
   COOT_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.Mo % 8 == 0 && g.No % 8 == 0 && g.zA % 8 == 0 && g.zB % 8 == 0,

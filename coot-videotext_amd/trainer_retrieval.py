@@ -8,7 +8,7 @@ the overrides a ``HipRetrievalTrainer(RetrievalTrainer)`` subclass carries (INTE
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple
 
 import math
 import os
@@ -587,18 +587,31 @@ class RetrievalTrainer:
             self.current_epoch += 1
         return hist
 
-    def validate_epoch(self, data_loader, val_clips: bool = True):
+    @torch.no_grad()
+    def validate_epoch(self, data_loader, val_clips: bool = True, save_embs: bool = False, save_path: Optional[str] = None):
+        """coot/trainer_retrieval.py:312-477 (metric part): eval forward of every batch, both losses, retrieval metrics of
+        the collected embeddings; with ``save_embs`` also the embedding export of :404-415 — the dictionary under
+        ``out["embeddings"]`` carries exactly the datasets of the reference's ``embeddings_<epoch>.h5`` (``clip_num``,
+        ``sent_num`` — written from clip_num there too, :360 —, ``key``, and for each of vid_emb / par_emb / clip_emb /
+        sent_emb / vid_context / par_context the L2-normalised rows plus ``<name>_before_norm``); ``save_path`` writes it
+        (``.h5`` through h5py when that is importable — the consumers' format, mart/recursive_caption_dataset.py:159-201 —
+        otherwise ``.npz`` with the same keys)."""
         self.model_mgr.set_all_models_eval()
-        coll: Dict[str, list] = {k: [] for k in ("vid_emb", "par_emb", "clip_emb", "sent_emb")}
-        losses = []
+        keys = ["vid_emb", "par_emb", "clip_emb", "sent_emb"] + (["vid_context", "par_context"] if save_embs else [])
+        coll: Dict[str, list] = {k: [] for k in keys}
+        losses, save_clip_num, save_key = [], [], []
         for batch in data_loader:
             visual_data = self.model_mgr.encode_visual(batch)
             text_data = self.model_mgr.encode_text(batch)
             contr = self.compute_total_constrastive_loss(visual_data, text_data)
             cc = self.compute_cyclecons_loss(visual_data, text_data)
             losses.append(contr + cc)
-            coll["vid_emb"].append(visual_data.vid_emb); coll["par_emb"].append(text_data.par_emb)
-            coll["clip_emb"].append(visual_data.clip_emb); coll["sent_emb"].append(text_data.sent_emb)
+            both = {**visual_data.__dict__, **text_data.__dict__}
+            for k in keys:
+                coll[k].append(both[k])
+            if save_embs:
+                save_clip_num.append(batch.clip_num)
+                save_key.extend(batch.key)
         data = {k: torch.cat(v, 0).float() for k, v in coll.items()}
         # The reference moves every batch to the host, normalises there (manual L2 without eps, :397-402) and ranks with one
         # numpy argsort per row (nntrainer/retrieval.py:68-98).  Here the embeddings never leave the GPU: normalisation,
@@ -609,4 +622,34 @@ class RetrievalTrainer:
             c2s, s2c, cs_sum = compute_retrieval_device(data["clip_emb"], data["sent_emb"], normalize=True)
             out.update({"c2s": c2s, "s2c": s2c, "val_clip_sent_score_at_1": cs_sum})
         out["loss"] = float(torch.stack(losses).mean())
+        if save_embs:
+            clip_num = torch.cat(save_clip_num).cpu().numpy()
+            emb: Dict[str, Any] = {"clip_num": clip_num, "sent_num": clip_num.copy(), "key": list(save_key)}
+            for k in keys:  # one D2H copy per tensor, after the last batch (the reference copies every batch of every key)
+                x = data[k]
+                emb[k] = (x / (x * x).sum(dim=-1).sqrt().unsqueeze(-1)).cpu().numpy()
+                emb[f"{k}_before_norm"] = x.cpu().numpy()
+            out["embeddings"] = emb
+            if save_path is not None:
+                out["embeddings_file"] = save_embeddings(emb, save_path)
         return out
+
+
+def save_embeddings(emb: Dict[str, Any], path: str) -> str:
+    """Write the export dictionary of validate_epoch(save_embs=True): HDF5 with the reference's dataset names when h5py is
+    importable (coot/trainer_retrieval.py:404-415), else numpy ``.npz`` with the same keys (``key`` as a unicode array)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        h5py = None
+    base = path[:-3] if path.endswith(".h5") else (path[:-4] if path.endswith(".npz") else path)
+    if h5py is not None:
+        fn = base + ".h5"
+        with h5py.File(fn, mode="w") as h5:
+            for k, v in emb.items():
+                h5[k] = v
+        return fn
+    fn = base + ".npz"
+    np.savez(fn, **{k: (np.array(v) if k == "key" else v) for k, v in emb.items()})
+    return fn

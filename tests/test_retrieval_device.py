@@ -112,3 +112,46 @@ def test_validate_epoch_uses_device_ranking(env):
     for k in ("r1", "r5", "r10", "r50", "medr"):
         assert abs(out["v2p"][k] - r12[k]) < 1e-6 and abs(out["p2v"][k] - r21[k]) < 1e-6, (k, out["v2p"], r12)
     assert abs(out["val_score_at_1"] - s1) < 1e-6 and np.isfinite(out["loss"])
+
+
+def test_validate_epoch_embedding_export(env, tmp_path):
+    """save_embs (coot/trainer_retrieval.py:404-415): the datasets of the reference's embeddings_<epoch>.h5 — keys, clip_num
+    twice (sent_num is written from clip_num there), unit-norm rows next to the raw ones — and the file round trip."""
+    torch, cva = env
+    from tests import helpers as H
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.05) for i in range(4)]
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.0)
+    tr = cva.RetrievalTrainer(cfg, mgr, is_test=True)
+    counts = [1, 2, 3, 4, 2, 1]
+    batches = [cva.synthetic.make_batch(10 + i, 6, counts, 12, 10, 9, 6, dims[0], dims[1], ragged=True) for i in range(2)]
+    for i, b in enumerate(batches):
+        b.key = [f"vid{i}_{j}" for j in range(6)]
+    out = tr.validate_epoch(batches, val_clips=False, save_embs=True, save_path=str(tmp_path / "embeddings_0.h5"))
+    emb = out["embeddings"]
+    names = ["vid_emb", "par_emb", "clip_emb", "sent_emb", "vid_context", "par_context"]
+    assert set(emb) == {"clip_num", "sent_num", "key"} | set(names) | {n + "_before_norm" for n in names}
+    assert emb["key"] == [f"vid{i}_{j}" for i in range(2) for j in range(6)]
+    assert np.array_equal(emb["clip_num"], np.array(counts * 2)) and np.array_equal(emb["sent_num"], emb["clip_num"])
+    mgr.set_all_models_eval()
+    with torch.no_grad():
+        v = [mgr.encode_visual(b) for b in batches]
+        t = [mgr.encode_text(b) for b in batches]
+    want = {"vid_emb": [x.vid_emb for x in v], "clip_emb": [x.clip_emb for x in v], "vid_context": [x.vid_context for x in v],
+            "par_emb": [x.par_emb for x in t], "sent_emb": [x.sent_emb for x in t], "par_context": [x.par_context for x in t]}
+    for n in names:
+        raw = torch.cat(want[n], 0).float().cpu().numpy()
+        assert emb[n + "_before_norm"].shape == raw.shape and np.array_equal(emb[n + "_before_norm"], raw), n
+        assert np.abs(np.sqrt((emb[n].astype(np.float64) ** 2).sum(-1)) - 1).max() < 1e-6
+        assert np.allclose(emb[n], raw / np.sqrt((raw * raw).sum(-1, keepdims=True)), rtol=1e-6, atol=1e-7)
+    assert emb["clip_emb"].shape[0] == sum(counts) * 2 and emb["vid_emb"].shape == (12, 2 * dims[2])
+    fn = out["embeddings_file"]
+    assert os.path.exists(fn)
+    if fn.endswith(".npz"):
+        z = np.load(fn)
+        assert set(z.files) == set(emb) and np.array_equal(z["vid_emb"], emb["vid_emb"]) and list(z["key"]) == emb["key"]
+    else:
+        import h5py
+        with h5py.File(fn, "r") as h5:
+            assert set(h5.keys()) == set(emb) and np.array_equal(h5["vid_emb"][()], emb["vid_emb"])
