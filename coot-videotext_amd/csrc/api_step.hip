@@ -202,12 +202,11 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
     if (ds) RUN(g_hops.hop(8 + side, st, ds));  // ... and behind everything the pass enqueued on `st` after that launch
     RUN(check_hip(hipEventRecord((hipEvent_t)g_glob_done[side], ds ? ds : st), "eventRecord"));
   }
-  RUN(launch_axpy_f32(d_local, dhid, (long)d.B * D, 1.0f, st));                               // context grad += dhidden
-  RUN(launch_pack_bwd(dfeat, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));  // item grads += unpack(global input grad)
   // the cycle-consistency gradients come from the other stream; they are first needed HERE, a whole global backward after the
   // contrastive loss — waiting only now keeps the cross-stream hop off the critical path
   if (d_resh && g_resh_wait_slot >= 0 && li == 0) RUN(g_hops.wait(g_resh_wait_slot, st));
-  if (d_resh) RUN(launch_pack_bwd(d_resh, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, st));
+  // context grad += dhidden, item grads += unpack(global input grad) + unpack(cycle-consistency grad): one launch
+  RUN(launch_pack_bwd_join(dfeat, d_resh, dhid, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, d_local, st));
   set_tn_aux_stream(((g_tn_aux_sides >> side) & 1) ? g_aux.get(side) : nullptr);
   const int rc = coot_net_bwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
                               nullptr, d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_loc, train, seed + 11 * li, nullptr,

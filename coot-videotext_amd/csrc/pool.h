@@ -41,6 +41,8 @@ int launch_pack_fwd(const float* emb, const long long* counts, int B, int Cmax, 
                     long long* lens, hipStream_t st);
 // d_emb[ptr+c,:] += d_out[b,c,:]
 int launch_pack_bwd(const float* dout, const long long* counts, int B, int Cmax, int D, float* demb, hipStream_t st);
+int launch_pack_bwd_join(const float* dout1, const float* dout2, const float* dctx, const long long* counts, int B, int Cmax, int D,
+                         float* demb_items, float* demb_ctx, hipStream_t st);
 
 int launch_cast_bf16_f32(const bf16_t* src, long lds, int R, int C, float* dst, long ldd, hipStream_t st);
 int launch_cast_f32_bf16(const float* src, long lds, int R, int C, bf16_t* dst, long ldd, hipStream_t st);

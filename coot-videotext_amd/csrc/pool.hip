@@ -297,6 +297,30 @@ __global__ __launch_bounds__(256) void pack_bwd_kernel(const float* dout, const 
     demb[(ptr + c) * D + d] += dout[((long)b * Cmax + c) * D + d];
   }
 }
+// the hand-over from a global network's backward to its local network's in ONE launch (was axpy + pack_bwd + pack_bwd, three
+// dependent 5 us launches): item rows += unpack(dout1) (+ unpack(dout2)), context rows += dctx
+__global__ __launch_bounds__(256) void pack_bwd_join_kernel(const float* dout1, const float* dout2, const float* dctx, const long long* counts,
+                                                            int B, int Cmax, int D, float* demb_items, float* demb_ctx) {
+  const int b = blockIdx.x;
+  const long ptr = pack_prefix(counts, b);
+  const int cnt = (int)counts[b];
+  for (int i = threadIdx.x; i < cnt * D; i += 256) {
+    const int c = i / D, d = i % D;
+    const long src = ((long)b * Cmax + c) * D + d;
+    float v = dout1[src];
+    if (dout2) v += dout2[src];
+    demb_items[(ptr + c) * D + d] += v;
+  }
+  if (dctx) for (int d = threadIdx.x; d < D; d += 256) demb_ctx[(long)b * D + d] += dctx[(long)b * D + d];
+}
+int launch_pack_bwd_join(const float* dout1, const float* dout2, const float* dctx, const long long* counts, int B, int Cmax, int D,
+                         float* demb_items, float* demb_ctx, hipStream_t st) {
+  COOT_REQUIRE(dout1 && counts && demb_items && (!dctx || demb_ctx), "pack bwd join: null pointer");
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(pack_bwd_join_kernel, dim3(B), dim3(256), 0, st, dout1, dout2, dctx, counts, B, Cmax, D, demb_items, demb_ctx);
+  COOT_CHECK_LAUNCH("pack_bwd_join");
+  return 0;
+}
 int launch_pack_bwd(const float* dout, const long long* counts, int B, int Cmax, int D, float* demb, hipStream_t st) {
   COOT_REQUIRE(dout && counts && demb, "pack bwd: null pointer");
   if (B <= 0) return 0;
