@@ -15,12 +15,21 @@
 
 namespace {
 
-inline uint16_t f32_to_bf16_rne(float f) {
-  uint32_t u;
-  std::memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;  // NaN stays NaN (canonical quiet NaN; rounding the payload could carry into infinity)
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even; NaN stays NaN (canonical quiet NaN: rounding the payload could carry into infinity).
+// Branch-free so that the row loop vectorises; compiled for AVX-512 / AVX2 / baseline and picked at load time (the staging
+// thread converts 65 M elements per ActivityNet batch: the scalar loop was the bound of the bf16 staging path).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define COOT_HOST_CLONES  // hipcc also parses this file for gfx950: host function multiversioning does not exist there
+#else
+#define COOT_HOST_CLONES __attribute__((target_clones("arch=x86-64-v4", "arch=x86-64-v3", "default")))
+#endif
+COOT_HOST_CLONES void convert_bf16_rne(const float* __restrict__ s, uint16_t* __restrict__ o, int64_t n) {
+  for (int64_t k = 0; k < n; ++k) {
+    uint32_t u;
+    std::memcpy(&u, s + k, 4);
+    const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    o[k] = (u & 0x7fffffffu) > 0x7f800000u ? (uint16_t)0x7fc0 : (uint16_t)r;
+  }
 }
 
 void collate_range(const float* const* seq, const int64_t* rows, int64_t i0, int64_t i1, int64_t dim, int64_t max_rows, int dst_bf16,
@@ -30,9 +39,7 @@ void collate_range(const float* const* seq, const int64_t* rows, int64_t i0, int
     const int64_t r = rows[i];
     char* d = (char*)dst + (size_t)i * max_rows * dim * esz;
     if (dst_bf16) {
-      const float* s = seq[i];
-      uint16_t* o = (uint16_t*)d;
-      for (int64_t k = 0; k < r * dim; ++k) o[k] = f32_to_bf16_rne(s[k]);
+      convert_bf16_rne(seq[i], (uint16_t*)d, r * dim);
     } else if (r > 0) {
       std::memcpy(d, seq[i], (size_t)r * dim * 4);
     }

@@ -168,7 +168,7 @@ class DeviceLoader:
     batch on a copy stream, the consumer's stream waits on its event only.  A device arena is rewritten only after the work
     the consumer enqueued on it (everything up to its next ``next()``) has finished; a host arena only after its copy has."""
 
-    def __init__(self, source: Iterable, depth: int = 2, device: str = "cuda", bf16: bool = False, threads: int = 4):
+    def __init__(self, source: Iterable, depth: int = 2, device: str = "cuda", bf16: bool = False, threads: int = 8):
         assert depth >= 1
         self.source, self.depth, self.device, self.bf16, self.threads = source, depth, torch.device(device), bf16, threads
         self.copy_stream = torch.cuda.Stream(device=self.device)
