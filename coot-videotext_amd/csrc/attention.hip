@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // backward, part 1: dQ (and delta = rowsum(dO * O)), one wave per 16 queries
 // ---------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, const int bx) {
   const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP, NK = DH / 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[KC * RP];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t Kt[DH * TP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = bx * 64 + wave * 16;
   const int Lq = a.Lq, Lk = a.Lk;
   const int nvalid = (int)a.lens[n];
   const long qbase = (long)n * Lq, kbase = (long)n * Lk;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
 // backward, part 2: dK, dV, one wave per 16 keys, loop over query chunks
 // ---------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_kv_body(const AttnArgs& a, const int bx) {
   const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;  // once per kernel, not per element
   constexpr int RP = AttnSmem<DH>::RP, TP = AttnSmem<DH>::TP, NK = DH / 16;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[KC * RP];
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
   __shared__ float lse_s[KC], delta_s[KC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.z, h = blockIdx.y;
-  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int k0 = bx * 64 + wave * 16;
   const int Lq = a.Lq, Lk = a.Lk;
   const int nvalid = (int)a.lens[n];
   const long qbase = (long)n * Lq, kbase = (long)n * Lk;
@@ -301,7 +301,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     if (threadIdx.x < KC) {
       const int qr = qc + threadIdx.x;
       lse_s[threadIdx.x] = qr < Lq ? a.lse[(qbase + qr) * a.H + h] : 0.f;
-      delta_s[threadIdx.x] = qr < Lq ? a.delta[(qbase + qr) * a.H + h] : 0.f;
+    }
+    {  // delta_q = <dO_q, O_q> over this head, recomputed here (4 threads per query row) instead of read from the query-tile
+       // blocks' output: the key tiles then depend on nothing those blocks write and both run in ONE launch
+      const int ql = threadIdx.x >> 2, part = threadIdx.x & 3, qr = qc + ql;
+      float dl = 0.f;
+      if (qr < Lq) {
+        const bf16_t* dop = a.dout + (qbase + qr) * a.lddo + h * DH + part * (DH / 4);
+        const bf16_t* op = a.o + (qbase + qr) * a.ldo + h * DH + part * (DH / 4);
+#pragma unroll
+        for (int e = 0; e < DH / 4; e += 4) {
+          const s16x4_t d4 = *reinterpret_cast<const s16x4_t*>(dop + e);
+          const s16x4_t o4 = *reinterpret_cast<const s16x4_t*>(op + e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dl += bf2f((bf16_t)d4[j]) * bf2f((bf16_t)o4[j]);
+        }
+      }
+      dl += __shfl_xor(dl, 1, 64);
+      dl += __shfl_xor(dl, 2, 64);
+      if (part == 0) delta_s[ql] = dl;
     }
     __syncthreads();
     s16x4_t pf[4], dsf[4];
@@ -663,6 +681,11 @@ static int attn_fwd_t(const AttnArgs& a_in, hipStream_t st) {
   return 0;
 }
 template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, int nq) {
+  if ((int)blockIdx.x < nq) attn_bwd_q_body<DH>(a, (int)blockIdx.x);
+  else attn_bwd_kv_body<DH>(a, (int)blockIdx.x - nq);
+}
+template <int DH>
 static int attn_bwd_t(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.xcd_order = get_xcd_order() & 4;
@@ -673,12 +696,11 @@ static int attn_bwd_t(const AttnArgs& a_in, hipStream_t st) {
     COOT_CHECK_LAUNCH("attn_short_bwd");
     return 0;
   }
-  dim3 gq((a.Lq + 63) / 64, a.H, a.Nseq);
-  hipLaunchKernelGGL(attn_bwd_q_kernel<DH>, gq, dim3(256), 0, st, a);
-  COOT_CHECK_LAUNCH("attn_bwd_q");
-  dim3 gk((a.Lk + 63) / 64, a.H, a.Nseq);
-  hipLaunchKernelGGL(attn_bwd_kv_kernel<DH>, gk, dim3(256), 0, st, a);
-  COOT_CHECK_LAUNCH("attn_bwd_kv");
+  // dQ tiles and dK/dV tiles in ONE launch (x < nq: query tiles, else key tiles; the key tiles recompute delta themselves) — on
+  // the global networks' context layer (1 query per video) the two were dependent 7 us launches on the critical path
+  const int nq = (a.Lq + 63) / 64, nk = (a.Lk + 63) / 64;
+  hipLaunchKernelGGL(attn_bwd_kernel<DH>, dim3(nq + nk, a.H, a.Nseq), dim3(256), 0, st, a, nq);
+  COOT_CHECK_LAUNCH("attn_bwd");
   return 0;
 }
 
