@@ -601,19 +601,20 @@ size_t coot_net_wpack_bytes(const coot_net_config* cfg) {
   Arena A(nullptr, 0); WPack W; layout_wpack(c, A, W); return A.off + 256;
 }
 
-int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpack, coot_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+// Records the pack jobs of one network into `jobs`, offsets relative to (P0, wpack0) — a base at or below every network of the
+// launch, so one launch can carry several networks (coot_nets_pack_weights); a full job table is flushed on the way.
+static int pack_net_jobs(const coot_net_config* cfg, const float* P, void* wpack, const float* P0, void* wpack0, PackJobs& jobs, hipStream_t st) {
   coot_net_config c; RUN(norm_cfg(cfg, &c));
+  const int64_t pd = P - P0;  // >= 0
   NetLayout L; build_layout(c, L);
   Arena A(wpack, (size_t)-1); WPack W; layout_wpack(c, A, W);
   const int D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
-  PackJobs jobs;
-  auto flush = [&]() -> int { int rc = launch_pack_jobs(P, wpack, jobs, st); jobs.n = 0; jobs.mv = PackMatvec(); return rc; };
+  auto flush = [&]() -> int { int rc = launch_pack_jobs(P0, wpack0, jobs, st); jobs.n = 0; jobs.mv = PackMatvec(); return rc; };
   auto add = [&](int64_t src_off, long lds, int R, int Cc, bf16_t* dst, long ldd, int transpose, int64_t colscale_off) -> int {
     if (jobs.n == 56) RUN(flush());
     PackJob& j = jobs.j[jobs.n++];
-    j.src_off = src_off; j.dst_byte_off = (char*)dst - (char*)wpack; j.R = R; j.C = Cc; j.lds = lds; j.ldd = ldd;
-    j.transpose = transpose; j.p48 = 0; j.colscale_off = colscale_off;
+    j.src_off = src_off + pd; j.dst_byte_off = (char*)dst - (char*)wpack0; j.R = R; j.C = Cc; j.lds = lds; j.ldd = ldd;
+    j.transpose = transpose; j.p48 = 0; j.colscale_off = colscale_off >= 0 ? colscale_off + pd : -1;
     return 0;
   };
   // logical [N, K] = src (transpose == 0) or src^T (transpose == 1), written in the P48 layout of the fused kernels
@@ -670,8 +671,25 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
       }
     }
   }
-  RUN(flush());
   return 0;
+}
+
+int coot_nets_pack_weights(int n, const coot_net_config* const* cfgs, const float* const* Ps, void* const* wpacks, coot_stream_t stream) {
+  COOT_REQUIRE(n >= 1 && cfgs && Ps && wpacks, "nets_pack_weights: bad arguments");
+  const float* P0 = Ps[0]; char* w0 = (char*)wpacks[0];
+  for (int i = 1; i < n; ++i) { if (Ps[i] < P0) P0 = Ps[i]; if ((char*)wpacks[i] < w0) w0 = (char*)wpacks[i]; }
+  for (int i = 0; i < n; ++i)
+    COOT_REQUIRE(((const char*)Ps[i] - (const char*)P0) % 4 == 0 && ((char*)wpacks[i] - w0) % 16 == 0, "nets_pack_weights: unaligned arenas");
+  PackJobs jobs;
+  for (int i = 0; i < n; ++i) {
+    if (jobs.mv.W && cfgs[i]->use_input_fc) { RUN(launch_pack_jobs(P0, w0, jobs, (hipStream_t)stream)); jobs.n = 0; jobs.mv = PackMatvec(); }  // one rider per launch
+    RUN(pack_net_jobs(cfgs[i], Ps[i], wpacks[i], P0, w0, jobs, (hipStream_t)stream));
+  }
+  return launch_pack_jobs(P0, w0, jobs, (hipStream_t)stream);
+}
+int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpack, coot_stream_t stream) {
+  const coot_net_config* cfgs[1] = {cfg}; const float* Ps[1] = {P}; void* ws[1] = {wpack};
+  return coot_nets_pack_weights(1, cfgs, Ps, ws, stream);
 }
 
 size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int Lseq, int N2, int L2) {

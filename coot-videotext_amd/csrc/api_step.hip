@@ -124,6 +124,13 @@ thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller even
 int g_defer_global_tn = 0;
 int g_tn_aux_sides = 0;  // coot_set_option("tn_aux", bits): 1 = video side, 2 = text side.  Measured: 136.6k -> 133k (video) / 131k (both)
                           // clip-pairs/s — the local backward is area bound, two half batches of weight gradients are less efficient than one
+// bf16 weight packs of `count` networks in one launch
+int pack_nets(const coot_step_config& c, const coot_step_buffers& b, const int* nets, int count, void* stream) {
+  const coot_net_config* cfgs[4]; const float* Ps[4]; void* ws[4];
+  for (int k = 0; k < count; ++k) { cfgs[k] = &c.net[nets[k]]; Ps[k] = b.params[nets[k]]; ws[k] = b.wpack[nets[k]]; }
+  return coot_nets_pack_weights(count, cfgs, Ps, ws, stream);
+}
+
 struct AuxStreams {
   hipStream_t s[2] = {nullptr, nullptr};
   hipStream_t get(int side) {
@@ -156,8 +163,7 @@ int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, 
                  void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, int train, uint64_t seed, hipStream_t st, bool pack = true) {
   const int D = c.net[0].hidden_dim;
   if (pack) {
-    RUN(coot_net_pack_weights(&c.net[li], b.params[li], b.wpack[li], st));
-    RUN(coot_net_pack_weights(&c.net[gi], b.params[gi], b.wpack[gi], st));
+    { const int two[2] = {li, gi}; RUN(pack_nets(c, b, two, 2, st)); }
   }
   g_stamps.mark(li == 0 ? "video: weights packed" : "text: weights packed", st);
   RUN(coot_net_fwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
@@ -415,9 +421,9 @@ int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* b, in
   RUN(g_hops.hop(1, sm, st));
   const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
   RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
-  if (repack) for (int i : vnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_v));
+  if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
   RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
-  if (repack) for (int i : tnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_t));
+  if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
   RUN(g_hops.hop(4, sv, sm));
   RUN(g_hops.hop(5, st, sm));
   return 0;
@@ -493,7 +499,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   g_resh_wait_slot = -1;
   RUN(rc_v);
   if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
-  if (repack) for (int i : vnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_v));
+  if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
   g_stamps.mark("video: updated", sv);
   RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, W.local_t,
                     W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt,
@@ -504,7 +510,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
     hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses);
     COOT_CHECK_LAUNCH("loss_total");
   }
-  if (repack) for (int i : tnets) RUN(coot_net_pack_weights(&cfg->net[i], b->params[i], b->wpack[i], side_t));
+  if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
   g_stamps.mark("text: updated", st);
   RUN(g_hops.hop(4, sv, sm));
   RUN(g_hops.hop(5, st, sm));

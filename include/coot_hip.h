@@ -62,6 +62,10 @@ int coot_net_out_dim(const coot_net_config* cfg);
 /* ---- bf16 weight pack (once per optimizer step) ---------------------------------------------- */
 size_t coot_net_wpack_bytes(const coot_net_config* cfg);
 int coot_net_pack_weights(const coot_net_config* cfg, const float* params, void* wpack, coot_stream_t stream);
+/* The same for n networks in ONE launch (the train step rebuilds the packs of a side's local + global network right after
+ * their update: one launch instead of two dependent ones at the end of the step). */
+int coot_nets_pack_weights(int n, const coot_net_config* const* cfgs, const float* const* params, void* const* wpacks,
+                           coot_stream_t stream);
 
 /* ---- one network forward / backward -----------------------------------------------------------
  * Replaces TransformerLegacy.forward (nntrainer/models/transformer_legacy.py:200-288) and its
