@@ -36,6 +36,10 @@ SMALL_LOCAL2 = O.NetConfig(input_dim=48, hidden_dim=96, num_heads=2, ff_dim=64, 
 SMALL_GLOBAL = O.NetConfig(input_dim=64, hidden_dim=64, num_heads=4, ff_dim=64, use_input_fc=False, use_context=True,
                            pooler="avg_special")
 ANET_LOCAL = O.NetConfig(input_dim=2048, hidden_dim=384, num_heads=8, ff_dim=384, pool_hidden=768, pool_heads=2)
+# the other input widths of the shipped configs: text features 1536 (all three), YouCook2 video features 512 (100m) / 4096 (2d3d)
+TEXT_LOCAL = O.NetConfig(input_dim=1536, hidden_dim=384, num_heads=8, ff_dim=384, pool_hidden=768, pool_heads=2)
+YC2_100M_LOCAL = O.NetConfig(input_dim=512, hidden_dim=384, num_heads=8, ff_dim=384, pool_hidden=768, pool_heads=2)
+YC2_2D3D_LOCAL = O.NetConfig(input_dim=4096, hidden_dim=384, num_heads=8, ff_dim=384, pool_hidden=768, pool_heads=2)
 ANET_GLOBAL = O.NetConfig(input_dim=384, hidden_dim=384, num_heads=8, ff_dim=384, use_input_fc=False, use_context=True,
                           pooler="avg_special")
 
@@ -43,7 +47,8 @@ ANET_GLOBAL = O.NetConfig(input_dim=384, hidden_dim=384, num_heads=8, ff_dim=384
 @pytest.mark.parametrize("name,cfg,N,L,with_ctx", [
     ("small_local", SMALL_LOCAL, 5, 7, False), ("small_local_2layer", SMALL_LOCAL2, 4, 70, False),
     ("small_global", SMALL_GLOBAL, 4, 5, True), ("anet_local", ANET_LOCAL, 6, 80, False),
-    ("anet_global", ANET_GLOBAL, 5, 9, True)])
+    ("anet_global", ANET_GLOBAL, 5, 9, True), ("text_local", TEXT_LOCAL, 7, 16, False),
+    ("yc2_100m_local", YC2_100M_LOCAL, 4, 60, False), ("yc2_2d3d_local", YC2_2D3D_LOCAL, 3, 33, False)])
 def test_net_fwd_bwd(env, name, cfg, N, L, with_ctx):
     torch, cva = env
     P = O.make_params(cfg, 11)
@@ -613,7 +618,8 @@ def test_native_dp_step_matches_single_gpu_native(env):
 
 @pytest.mark.parametrize("name,cfg,N,L,with_ctx,train", [
     ("anet_local", ANET_LOCAL, 7, 80, False, False), ("anet_local_train", ANET_LOCAL, 5, 37, False, True),
-    ("anet_global", ANET_GLOBAL, 40, 9, True, False)])
+    ("anet_global", ANET_GLOBAL, 40, 9, True, False), ("text_local_train", TEXT_LOCAL, 9, 16, False, True),
+    ("yc2_100m_local_train", YC2_100M_LOCAL, 5, 41, False, True), ("yc2_2d3d_local", YC2_2D3D_LOCAL, 3, 70, False, False)])
 def test_fused_chain_matches_per_op_kernels(env, name, cfg, N, L, with_ctx, train):
     """The fused token-tile chains (fused.hip: out-proj ... LN2 + GenPool score MLP in one launch) against the per-op
     kernels they replace, same inputs / weights / dropout seed: the two paths have the same rounding points, so pooled
