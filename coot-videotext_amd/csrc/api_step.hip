@@ -113,6 +113,7 @@ struct Hops {
   int wait(int slot, hipStream_t to) { return check_hip(hipStreamWaitEvent(to, ev[slot], 0), "streamWait"); }
 };
 thread_local Hops g_hops;
+thread_local const uint64_t* g_step_seed_dev = nullptr;  // device base seed of a replayable step (StepState::seed below), else null
 thread_local int g_resh_wait_slot = -1;  // hop slot the video side waits on before it reads d_resh (coot_train_step), -1: none
 thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller events: video / text global backward done
 
@@ -167,11 +168,11 @@ int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, 
   }
   g_stamps.mark(li == 0 ? "video: weights packed" : "text: weights packed", st);
   RUN(coot_net_fwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
-                   nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, nullptr, st));
+                   nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, g_step_seed_dev, st));
   g_stamps.mark(li == 0 ? "video: local forward done" : "text: local forward done", st);
   RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
   RUN(coot_net_fwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0,
-                   local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi, nullptr, st));
+                   local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi, g_step_seed_dev, st));
   g_stamps.mark(li == 0 ? "video: global forward done" : "text: global forward done", st);
   return 0;
 }
@@ -196,7 +197,7 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   set_tn_aux_stream(defer ? g_aux.get(side) : nullptr);
   set_tn_defer(defer);
   const int rc_g = coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
-                                b.grads[gi], dhid, dfeat, saved_g, sz_g, (char*)scratch + sz_loc, sz_glob, train, seed + 11 * gi, nullptr, st);
+                                b.grads[gi], dhid, dfeat, saved_g, sz_g, (char*)scratch + sz_loc, sz_glob, train, seed + 11 * gi, g_step_seed_dev, st);
   set_tn_defer(false);
   set_tn_aux_stream(nullptr);
   RUN(rc_g);
@@ -215,7 +216,7 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   RUN(launch_pack_bwd_join(dfeat, d_resh, dhid, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, d_local, st));
   set_tn_aux_stream(((g_tn_aux_sides >> side) & 1) ? g_aux.get(side) : nullptr);
   const int rc = coot_net_bwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
-                              nullptr, d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_loc, train, seed + 11 * li, nullptr,
+                              nullptr, d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_loc, train, seed + 11 * li, g_step_seed_dev,
                               st);
   set_tn_aux_stream(nullptr);
   const int rc_j = tn_deferred_join(st);  // the optimizer / the end of the pass needs the global network's weight gradients
@@ -226,9 +227,11 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
 }
 
 // idx[b] uniform in [0, len[b])  — th.multinomial(mask, 1) of coot/loss_fn.py:306-314 on the device
-__global__ void sample_idx_kernel(const long long* lens_a, const long long* lens_b, int B, unsigned long long seed, long long* idx) {
+__global__ void sample_idx_kernel(const long long* lens_a, const long long* lens_b, int B, unsigned long long seed, long long* idx,
+                                  const unsigned long long* seed_dev = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * B) return;
+  seed = eff_seed(seed, seed_dev);
   const long long len = i < B ? lens_a[i] : lens_b[i - B];
   const unsigned r = rng_u32(seed, 0xCCu, (unsigned long long)i);
   long long v = (long long)(((unsigned long long)r * (unsigned long long)len) >> 32);
@@ -283,7 +286,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 }
 
 struct AdamSegs { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; const float* decay[4]; long n[4]; int blk0[5]; float* losses; };
-__global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, OptK k) {
+__global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, OptK k_arg, const OptK* k_dev) {
+  const OptK k = k_dev ? *k_dev : k_arg;
   int s = 0;
 #pragma unroll
   for (int t = 1; t < 4; ++t) if ((int)blockIdx.x >= sg.blk0[t]) s = t;
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, OptK k) {
   opt_update_range(k, sg.p[s], sg.g[s], sg.m[s], sg.v[s], sg.decay[s], i, n);
 }
 
-// host side of the rules above; optimizer: 0 = Adam, 1 = RAdam
-OptK opt_scalars(int optimizer, int radam_degentosgd, float lr, float beta1, float beta2, float eps, float wd, int64_t step) {
+// the scalars of the rules above (host, or thread 0 of step_state_kernel); optimizer: 0 = Adam, 1 = RAdam
+__host__ __device__ OptK opt_scalars(int optimizer, int radam_degentosgd, float lr, float beta1, float beta2, float eps, float wd, int64_t step) {
   OptK k; k.lr = lr; k.b1 = beta1; k.b2 = beta2; k.eps = eps; k.wd = wd; k.a = 0.f; k.b = 0.f;
   const double b1t = pow((double)beta1, (double)step), b2t = pow((double)beta2, (double)step);
   if (optimizer == 0) {
@@ -318,6 +322,18 @@ OptK opt_scalars(int optimizer, int radam_degentosgd, float lr, float beta1, flo
 
 __global__ void loss_total_kernel(float* losses) { losses[0] = losses[1] + losses[2]; }
 
+// Per-step scalars in DEVICE memory, for a train step that is captured once and replayed as a hipGraph (a replay cannot change
+// kernel arguments): the dropout base seed, the optimizer step count with the scalars derived from it, the learning rate (the
+// host rewrites that word when the schedule changes it).  step_state_kernel is the first node of the step: it advances the
+// counters exactly as the host does between two eager steps, so eager and replayed steps draw the same masks and take the same
+// update.  coot_step_set_device_state(ptr): non-null switches coot_train_step to this mode (its seed argument becomes a salt).
+struct StepState { unsigned long long seed, step; float lr; int pad; OptK k; };
+thread_local StepState* g_state_dev = nullptr;
+__global__ void step_state_kernel(StepState* s, int optimizer, int degen, float b1, float b2, float eps, float wd, unsigned long long seed_inc) {
+  s->step += 1; s->seed += seed_inc;
+  s->k = opt_scalars(optimizer, degen, s->lr, b1, b2, eps, wd, (int64_t)s->step);
+}
+
 // Adam update of `count` parameter arenas in ONE launch (four dependent 13 us launches used to end the step)
 int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int* nets, int count, int64_t step, hipStream_t st,
               float* losses = nullptr) {
@@ -333,7 +349,7 @@ int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int
   }
   sg.blk0[4] = blk;
   const OptK k = opt_scalars(cfg.optimizer, cfg.radam_degentosgd, cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, step);
-  hipLaunchKernelGGL(adam4_kernel, dim3(blk), dim3(256), 0, st, sg, k);
+  hipLaunchKernelGGL(adam4_kernel, dim3(blk), dim3(256), 0, st, sg, k, g_state_dev ? (const OptK*)&g_state_dev->k : (const OptK*)nullptr);
   COOT_CHECK_LAUNCH("adam4");
   return 0;
 }
@@ -453,6 +469,12 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   const bool pack_first = (do_optimizer & COOT_STEP_PACKS_FRESH) == 0;
   g_stamps.begin();
   g_stamps.mark("step starts", sm);
+  if (g_state_dev) {  // replayable step: counters and optimizer scalars advance on the device, before the two sides fork
+    COOT_REQUIRE(optimize, "train_step: the device step state is for optimizer steps");
+    hipLaunchKernelGGL(step_state_kernel, dim3(1), dim3(1), 0, sm, g_state_dev, cfg->optimizer, cfg->radam_degentosgd, cfg->beta1, cfg->beta2,
+                       cfg->eps, cfg->weight_decay, (unsigned long long)7919);
+    COOT_CHECK_LAUNCH("step_state");
+  }
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
@@ -476,7 +498,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   if (cc) {  // cycle-consistency -> losses[2] on the text stream, next to the contrastive loss on the video stream
     RUN(g_hops.hop(6, sv, st));
     hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * d->B + 255) / 256), dim3(256), 0, st, (const long long*)x->clip_num,
-                       (const long long*)x->sent_num, d->B, (unsigned long long)seed, W.idx);
+                       (const long long*)x->sent_num, d->B, (unsigned long long)seed, W.idx, (const unsigned long long*)g_step_seed_dev);
     COOT_CHECK_LAUNCH("sample_idx");
     RUN(coot_cyclecons_fwd_bwd(W.resh_v, W.resh_t, x->clip_num, x->sent_num, (const int64_t*)W.idx, (const int64_t*)(W.idx + d->B), d->B,
                                d->Cmax_clip, d->Cmax_sent, D, cfg->cc_weight, 1.0f / (float)d->B, losses + 2, nullptr, nullptr, W.d_resh_v,
@@ -519,6 +541,12 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
 }
 
 void coot_step_stamps_enable(int on) { g_stamps.on = on != 0; }
+size_t coot_step_device_state_bytes(void) { return sizeof(StepState); }
+int coot_step_set_device_state(void* state) {
+  g_state_dev = (StepState*)state;
+  g_step_seed_dev = state ? (const uint64_t*)&g_state_dev->seed : nullptr;
+  return 0;
+}
 int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
 void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
 void coot_step_defer_global_tn(int on) { g_defer_global_tn = on; }

@@ -338,8 +338,85 @@ class RetrievalTrainer:
             setattr(x, f, t_.data_ptr())
         return st, x
 
+    # ---- the native step as a replayed hipGraph ----------------------------------------------------------------------
+    _GRAPH_FEATS = ("vid_feat", "clip_feat", "par_feat", "sent_feat")
+    _GRAPH_LENS = ("vid_feat_len", "clip_feat_len", "par_feat_len", "sent_feat_len", "clip_num", "sent_num")
+
+    def _graph_state_bytes(self, st, lr: float) -> bytes:
+        import struct
+        seed = (torch.initial_seed() * 1000003 + 7919 * self.total_step) & 0xFFFFFFFFFFFFFFFF  # the kernel adds 7919 first
+        return struct.pack("<QQfi", seed, int(st.step), float(lr), 0)
+
+    def _train_step_native_graph(self, batch: RetrievalDataBatchTuple):
+        """coot_train_step captured ONCE per batch shape and replayed (torch.cuda.CUDAGraph around the C call): a dependent
+        launch costs 1.7 us in a replay against 3.1 us launched one by one (tools/micro/launchgap.hip), and the step is a
+        chain of ~150 of them.  Per-step scalars (dropout seed, optimizer step count and its scalars, learning rate) live in a
+        device state block the step's first node advances (coot_step_set_device_state), the batch is copied into static
+        buffers.  Same masks, same update as the eager native step (tests/test_gpu_path.py).  Falls back to the eager call
+        for the first step of a shape (lazy state is created outside a capture)."""
+        lib = _lib.load()
+        st, x = self._native_setup(batch)
+        lr = float(self.optimizer.param_groups[0]["lr"]) if self.optimizer is not None else float(st.cfg.lr)
+        ptrs = tuple(int(st.bufs.params[i]) for i in range(4)) + tuple(int(st.bufs.wpack[i]) for i in range(4))
+        key = (st.dims_key, ptrs, st.ws.data_ptr())
+        graphs = st.__dict__.setdefault("graphs", {})
+        g = graphs.get(key)
+        if g is None:
+            if st.step == 0 or not all(n.pack_is_fresh() for n in st.nets):
+                return None  # caller runs the eager step (creates lazy state, leaves fresh packs); captured on the next call
+            g = type("NativeGraph", (), {})()
+            dev = batch.vid_feat.device
+            nbytes = int(lib.coot_step_device_state_bytes())
+            assert nbytes >= 24
+            g.state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            g.static = {f: getattr(batch, f).clone() for f in self._GRAPH_FEATS + self._GRAPH_LENS}
+            g.x = _lib.StepBatch()
+            for f in self._GRAPH_FEATS:
+                setattr(g.x, f, g.static[f].data_ptr())
+            for f, src in (("vid_len", "vid_feat_len"), ("clip_len", "clip_feat_len"), ("par_len", "par_feat_len"),
+                           ("sent_len", "sent_feat_len"), ("clip_num", "clip_num"), ("sent_num", "sent_num")):
+                setattr(g.x, f, g.static[src].data_ptr())
+            g.dims = _lib.StepDims(*[getattr(st.dims, f[0]) for f in st.dims._fields_])
+            g.cfg = _lib.StepConfig.from_buffer_copy(st.cfg)
+            g.cfg.lr = 0.0  # unused: the learning rate is read from the state block
+            g.mirror = None
+            g.last_batch, g.last_versions = None, None
+            flags = _lib.STEP_OPTIMIZER | _lib.STEP_REPACK | _lib.STEP_PACKS_FRESH
+            torch.cuda.synchronize()
+            lib.coot_step_set_device_state(g.state.data_ptr())
+            try:
+                g.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g.graph):
+                    cur = torch.cuda.current_stream()
+                    _lib.check(lib.coot_train_step(C.byref(g.cfg), C.byref(st.bufs), C.byref(g.x), C.byref(g.dims), st.losses.data_ptr(),
+                                                   st.ws.data_ptr(), st.ws.numel(), 1, 0, 1, flags, cur.cuda_stream, cur.cuda_stream,
+                                                   st.streams[1].cuda_stream), "coot_train_step (capture)")
+            finally:
+                lib.coot_step_set_device_state(None)
+            graphs[key] = g
+        if not all(n.pack_is_fresh() for n in st.nets):
+            return None
+        # inputs -> static buffers (skipped when the caller passes the very same, unmodified batch object again)
+        versions = tuple(getattr(batch, f)._version for f in self._GRAPH_FEATS + self._GRAPH_LENS)
+        if batch is not g.last_batch or versions != g.last_versions:
+            for f in self._GRAPH_FEATS + self._GRAPH_LENS:
+                g.static[f].copy_(getattr(batch, f), non_blocking=True)
+            g.last_batch, g.last_versions = batch, versions
+        # device counters: rewritten only when the host moved on without the graph (eager steps in between) or the LR changed
+        want = (self.total_step, st.step, lr)
+        if g.mirror != want:
+            hdr = torch.frombuffer(bytearray(self._graph_state_bytes(st, lr)), dtype=torch.uint8)
+            g.state[:24].copy_(hdr)
+        g.graph.replay()
+        st.step += 1
+        self.total_step += 1
+        g.mirror = (self.total_step, st.step, lr)
+        for n in st.nets:
+            n.mark_packed()
+        return st.losses[0], st.losses[1], st.losses[2]
+
     def train_step_native(self, batch: RetrievalDataBatchTuple, do_optimizer: bool = True, seed: Optional[int] = None,
-                          vid_counts=None, clip_counts=None):
+                          vid_counts=None, clip_counts=None, use_graph: bool = False):
         """One optimisation step as ONE call into libcoot_hip.so (coot_train_step): forward of both sides on two
         HIP streams, losses, backward, fused Adam — no Python between the kernel launches.  Returns views of the
         device loss vector (total, contrastive, cycle-consistency).  With ``self.dp`` set the step runs as native phases
@@ -349,6 +426,10 @@ class RetrievalTrainer:
         lib = _lib.load()
         if getattr(self, "dp", None) is not None:
             return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts)
+        if use_graph and do_optimizer and seed is None and self.model_mgr.is_train:
+            out = self._train_step_native_graph(batch)
+            if out is not None:
+                return out
         st, x = self._native_setup(batch)
         if self.optimizer is not None:
             st.cfg.lr = float(self.optimizer.param_groups[0]["lr"])

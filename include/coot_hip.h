@@ -211,6 +211,15 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* buf
                        const float* d_glob_t, const float* d_resh_v, const float* d_resh_t, void* workspace,
                        size_t workspace_bytes, int train, uint64_t seed, coot_stream_t main_stream, coot_stream_t side_v,
                        coot_stream_t side_t);
+/* Replayable step (hipGraph): with a device state block set (coot_step_device_state_bytes() bytes: { uint64 seed; uint64
+ * step; float lr; int pad; 32 bytes of optimizer scalars }), coot_train_step reads its per-step scalars from DEVICE memory — its
+ * first node advances them (step += 1, seed += 7919, optimizer scalars from step and lr) exactly as the host does between two
+ * eager steps; the seed argument becomes a salt (pass 0), the step argument is ignored.  The call can then be captured once
+ * (hipStreamBeginCapture on `main`, side_v == main) and replayed: dependent launches cost 1.7 us in a replay against 3.1 us
+ * launched one by one (tools/micro/launchgap.hip).  The host initialises seed / step / lr before the first step and rewrites
+ * lr when the schedule changes it.  NULL returns to argument-driven steps.  Thread-local. */
+size_t coot_step_device_state_bytes(void);
+int coot_step_set_device_state(void* state);
 /* Data parallel: hipEvent_t handles (or NULL) that coot_step_backward records on the video / text stream as soon as that side's
  * GLOBAL network backward is enqueued — its parameter gradients (networks 1 and 3) are final from there on, so a communication
  * stream can wait on the events and reduce them while the local backward (two thirds of the pass) still runs.  Thread-local,

@@ -407,6 +407,44 @@ def test_native_step_repack_is_equivalent_to_packing_at_start(env):
     assert float(torch.nn.functional.cosine_similarity(va.flatten(), vb.flatten(), dim=0)) > 1 - 1e-5
 
 
+def test_native_step_graph_replay_matches_eager(env):
+    """train_step_native(use_graph=True): coot_train_step captured once and replayed as a hipGraph, per-step scalars (dropout
+    seed, Adam step count and scalars, learning rate) advanced on the device by the step's first node — against the eager
+    native step on the same batches and seeds, dropout and the cycle loss ON: same masks, same update (tolerances of the
+    repack test above: fp32-atomics summation order).  Two alternating batch objects (static input buffers), a learning-rate
+    change between replays, and an eager step in the middle (host and device counters re-synchronise)."""
+    torch, cva = env
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    counts = [1, 2, 3, 4, 2, 1]
+    batches = [cva.synthetic.make_batch(7 + i, 6, counts, 12, 10, 9, 6, dims[0], dims[1], ragged=False) for i in range(2)]
+    plan = [True, True, True, True, False, True, True]  # use_graph per step (step 0 falls back to eager: nothing to replay yet)
+    res = []
+    for graph in (False, True):
+        torch.manual_seed(1234)
+        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.05, cc_weight=0.01)
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg_x, mgr)
+        losses = []
+        for it, ug in enumerate(plan):
+            if it == 3:
+                for grp in tr.optimizer.param_groups:
+                    grp["lr"] = 3e-4
+            out = tr.train_step_native(batches[it % 2], use_graph=graph and ug)
+            losses.append([float(v) for v in out])
+        if graph:
+            assert len(tr._native.graphs) == 1 and tr._native.step == len(plan) and tr.total_step == len(plan)
+        torch.cuda.synchronize()
+        res.append((losses, [n._flat.clone() for n in mgr.model_dict.values()]))
+    (la, pa), (lb, pb) = res
+    assert np.allclose(la, lb, rtol=2e-5, atol=2e-6), (la, lb)
+    assert all(abs(l[0] - l[1] - l[2]) < 1e-5 for l in lb)
+    for a, b in zip(pa, pb):
+        d = (a - b).abs()
+        assert float((d > 1e-6).float().mean()) < 4e-3 and float(d.max()) <= 8.1e-3, (float((d > 1e-6).float().mean()), float(d.max()))
+
+
 def test_fused_adam_matches_torch_adam(env):
     """coot_adam_step on identical gradients vs torch.optim.Adam (coupled weight decay with a per-element decay mask =
     the reference's bias decay_mult 0, nntrainer/optimization.py:45-74, model_manager_base.py:152-154)."""
