@@ -141,3 +141,49 @@ def test_device_loader_stages_batches_and_feeds_training():
     tr = cva.RetrievalTrainer(cfg, mgr)
     hist = tr.train_model(DeviceLoader(lists[:4], depth=2), DeviceLoader(lists[4:6], depth=1))
     assert len(hist["epoch"]) == 2 and all(np.isfinite(hist["train_loss"])) and hist["val"][1]["val_score_at_1"] >= 0
+
+
+def _collate_numpy(pts):
+    """Plain restatement of RetrievalDataset.collate_fn (coot/dataset_retrieval.py:335-463) with numpy loops: the checker for
+    the randomised shapes below (the reference-generated fixture pins two batches; this pins the layout rule for many)."""
+    B = len(pts)
+    dv, dt = pts[0].vid_feat.shape[-1], pts[0].par_feat.shape[-1]
+    vl = [p.vid_feat_len for p in pts]; pl = [p.par_feat_len for p in pts]
+    vid = np.zeros((B, max(vl), dv), np.float32); vmask = np.ones((B, max(vl)), bool)
+    par = np.zeros((B, max(pl), dt), np.float32); pmask = np.ones((B, max(pl)), bool)
+    for b, p in enumerate(pts):
+        vid[b, :vl[b]] = p.vid_feat; vmask[b, :vl[b]] = False
+        par[b, :pl[b]] = p.par_feat; pmask[b, :pl[b]] = False
+    cl = [c.shape[0] for p in pts for c in p.clip_feat_list]
+    clip = np.zeros((len(cl), max(cl), dv), np.float32); cmask = np.ones((len(cl), max(cl)), bool)
+    i = 0
+    for p in pts:
+        for c in p.clip_feat_list:
+            clip[i, :c.shape[0]] = c; cmask[i, :c.shape[0]] = False; i += 1
+    sl = [n for p in pts for n in p.sent_feat_len_list]
+    sent = np.zeros((len(sl), max(sl), dt), np.float32); smask = np.ones((len(sl), max(sl)), bool)
+    i = 0
+    for b, p in enumerate(pts):
+        ptr = 0
+        for n in p.sent_feat_len_list:
+            sent[i, :n] = par[b, ptr:ptr + n]; smask[i, :n] = False; i += 1; ptr += n
+    return dict(vid_feat=vid, vid_feat_mask=vmask, vid_feat_len=np.array(vl), par_feat=par, par_feat_mask=pmask, par_feat_len=np.array(pl),
+                clip_num=np.array([p.clip_num for p in pts]), clip_feat=clip, clip_feat_mask=cmask, clip_feat_len=np.array(cl),
+                sent_num=np.array([p.sent_num for p in pts]), sent_feat=sent, sent_feat_mask=smask, sent_feat_len=np.array(sl))
+
+
+def test_collate_random_shapes_match_layout_rule():
+    """40 random batches (1-9 videos, 1-6 clips, 1-23 frames / 1-11 words, odd feature widths) through ONE reused arena with
+    1-5 threads: every field equals the loop restatement of the reference's collate rule."""
+    from coot_videotext_amd.dataset_retrieval import BatchArena, collate_fn
+    rs = np.random.RandomState(77)
+    arena = BatchArena(pin=False)
+    for trial in range(40):
+        B, dv, dt = int(rs.randint(1, 10)), int(rs.choice([4, 12, 20, 36])), int(rs.choice([4, 8, 28]))
+        pts = _points(1000 + trial, B, dv, dt, max_frames=int(rs.randint(1, 24)), max_words=int(rs.randint(1, 12)),
+                      max_clips=int(rs.randint(1, 7)))
+        want = _collate_numpy(pts)
+        got = collate_fn(pts, arena, threads=int(rs.randint(1, 6)))
+        for f in FIELDS:
+            g = getattr(got, f).numpy()
+            assert g.shape == want[f].shape and np.array_equal(g, want[f]), (trial, f)
