@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (phase calls + RCCL collectives) even with one rank")
     ap.add_argument("--step-stamps", action="store_true", help="print a HIP-event timeline of one training step to stderr")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
-    ap.add_argument("--mode", default="native", choices=["native", "native-graph", "autograd", "graph"],
+    ap.add_argument("--mode", default="native", choices=["native", "native-graph", "native-phases", "autograd", "graph"],
                     help="native: one C call per step (default); native-graph: that call captured once and replayed as a hipGraph; "
                          "autograd: torch autograd Functions; graph: autograd step in a HIP graph")
     return ap.parse_args()
@@ -152,8 +152,8 @@ def main():
         batch.global_max_synced = True  # fixed shapes: every rank has the same Cmax, no MAX all-reduce needed
 
         def step(graph=None):
-            if mode in ("native", "native-graph") and graph is None:  # N > 1: native phases with the RCCL collectives between them
-                return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, use_graph=(mode == "native-graph"))[0]
+            if mode in ("native", "native-graph", "native-phases") and graph is None:  # N > 1: native phases with the RCCL collectives between them
+                return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, use_graph={"native-graph": True, "native-phases": "phases"}.get(mode, False))[0]
             return trainer.train_step(batch, vid_counts, clip_counts, use_graph=(mode == "graph") if graph is None else graph)[0]
 
     def barrier():

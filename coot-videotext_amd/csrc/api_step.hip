@@ -540,6 +540,79 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   return 0;
 }
 
+// One phase of coot_train_step on ONE stream — the same calls in the same order, cut where the two sides meet — so that each
+// piece is a LINEAR chain of launches: captured and replayed as its own hipGraph on its own stream it keeps the two sides as
+// concurrent as two eager streams are (the whole step captured as one two-branch graph replays slower than it runs eagerly,
+// profiles/README.md), while every dependent launch inside costs a graph node (1.7 us) instead of a stream launch (3.1 us).
+// The caller orders the phases with events:  0 -> {1, 2};  {1, 2} -> 3;  1 -> 4;  {3, 4} -> {5, 6};  0 needs the device state.
+//   0 device step state (counters, optimizer scalars)   1 video forward            2 text forward + zero fills
+//   3 contrastive loss                                  4 cycle-consistency loss   5 video backward + update + packs
+//   6 text backward + update (+ total loss) + packs
+int coot_train_step_phase(const coot_step_config* cfg, const coot_step_buffers* b, const coot_step_batch* x, const coot_step_dims* d,
+                          float* losses, void* workspace, size_t workspace_bytes, int train, uint64_t seed, int64_t step, int do_optimizer,
+                          int phase, coot_stream_t stream) {
+  RUN(check_cfg(*cfg));
+  COOT_REQUIRE(losses && phase >= 0 && phase <= 6, "train_step_phase: bad arguments");
+  Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
+  COOT_REQUIRE(!A.overflow, "train_step_phase: workspace too small (%zu < %zu)", workspace_bytes, A.off);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = cfg->net[0].hidden_dim;
+  const bool optimize = (do_optimizer & COOT_STEP_OPTIMIZER) != 0, repack = optimize && (do_optimizer & COOT_STEP_REPACK) != 0;
+  const bool pack_first = (do_optimizer & COOT_STEP_PACKS_FRESH) == 0;
+  const bool cc = cfg->cc_weight != 0.f;
+  const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
+  switch (phase) {
+    case 0:
+      COOT_REQUIRE(g_state_dev && optimize, "train_step_phase 0: needs the device step state and an optimizer step");
+      hipLaunchKernelGGL(step_state_kernel, dim3(1), dim3(1), 0, s, g_state_dev, cfg->optimizer, cfg->radam_degentosgd, cfg->beta1, cfg->beta2,
+                         cfg->eps, cfg->weight_decay, (unsigned long long)7919);
+      COOT_CHECK_LAUNCH("step_state");
+      return 0;
+    case 1:
+      return side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
+                          W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, s, pack_first);
+    case 2:
+      RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
+                       W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, s,
+                       pack_first));
+      for (int i = 0; i < 4; ++i)
+        RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), s), "memset grads"));
+      RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, s), "memset embedding grads"));
+      return check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), s), "memset losses");
+    case 3:
+      return coot_contrastive_fwd_bwd(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
+                                      W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
+                                      W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t,
+                                      W.loss_scratch, W.sz_loss, stream);
+    case 4:
+      if (!cc) return 0;
+      hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * d->B + 255) / 256), dim3(256), 0, s, (const long long*)x->clip_num,
+                         (const long long*)x->sent_num, d->B, (unsigned long long)seed, W.idx, (const unsigned long long*)g_step_seed_dev);
+      COOT_CHECK_LAUNCH("sample_idx");
+      return coot_cyclecons_fwd_bwd(W.resh_v, W.resh_t, x->clip_num, x->sent_num, (const int64_t*)W.idx, (const int64_t*)(W.idx + d->B), d->B,
+                                    d->Cmax_clip, d->Cmax_sent, D, cfg->cc_weight, 1.0f / (float)d->B, losses + 2, nullptr, nullptr,
+                                    W.d_resh_v, W.d_resh_t, stream);
+    case 5:
+      RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
+                        W.local_v, W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv,
+                        W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, s));
+      if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, s));
+      if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, stream));
+      return 0;
+    default:
+      RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
+                        W.local_t, W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt,
+                        W.saved_gt, W.sz_gt, W.scratch_t, W.sz_st, train, seed + 1000, s));
+      if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, s, losses));
+      else {
+        hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, s, losses);
+        COOT_CHECK_LAUNCH("loss_total");
+      }
+      if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, stream));
+      return 0;
+  }
+}
+
 void coot_step_stamps_enable(int on) { g_stamps.on = on != 0; }
 size_t coot_step_device_state_bytes(void) { return sizeof(StepState); }
 int coot_step_set_device_state(void* state) {

@@ -407,7 +407,8 @@ def test_native_step_repack_is_equivalent_to_packing_at_start(env):
     assert float(torch.nn.functional.cosine_similarity(va.flatten(), vb.flatten(), dim=0)) > 1 - 1e-5
 
 
-def test_native_step_graph_replay_matches_eager(env):
+@pytest.mark.parametrize("how", [True, "phases"])
+def test_native_step_graph_replay_matches_eager(env, how):
     """train_step_native(use_graph=True): coot_train_step captured once and replayed as a hipGraph, per-step scalars (dropout
     seed, Adam step count and scalars, learning rate) advanced on the device by the step's first node — against the eager
     native step on the same batches and seeds, dropout and the cycle loss ON: same masks, same update (tolerances of the
@@ -431,7 +432,7 @@ def test_native_step_graph_replay_matches_eager(env):
             if it == 3:
                 for grp in tr.optimizer.param_groups:
                     grp["lr"] = 3e-4
-            out = tr.train_step_native(batches[it % 2], use_graph=graph and ug)
+            out = tr.train_step_native(batches[it % 2], use_graph=(how if (graph and ug) else False))
             losses.append([float(v) for v in out])
         if graph:
             assert len(tr._native.graphs) == 1 and tr._native.step == len(plan) and tr.total_step == len(plan)
