@@ -354,6 +354,19 @@ int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int
   return 0;
 }
 
+// The cycle-consistency loss scores ONE valid position per video and direction (coot/loss_fn.py:306-314).  Normally drawn on the
+// device from the step seed; a caller that has to reproduce a given draw (parity tests against the reference's th.multinomial
+// sequence) injects the 2B indices with coot_step_set_cycle_indices.
+thread_local const int64_t* g_cc_idx_inject = nullptr;
+int draw_cycle_indices(const coot_step_batch& x, const coot_step_dims& d, uint64_t seed, long long* idx, hipStream_t s) {
+  if (g_cc_idx_inject)
+    return check_hip(hipMemcpyAsync(idx, g_cc_idx_inject, 2 * (size_t)d.B * sizeof(long long), hipMemcpyDeviceToDevice, s), "cycle indices");
+  hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * d.B + 255) / 256), dim3(256), 0, s, (const long long*)x.clip_num, (const long long*)x.sent_num,
+                     d.B, (unsigned long long)seed, idx, (const unsigned long long*)g_step_seed_dev);
+  COOT_CHECK_LAUNCH("sample_idx");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -497,9 +510,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   const bool cc = cfg->cc_weight != 0.f;
   if (cc) {  // cycle-consistency -> losses[2] on the text stream, next to the contrastive loss on the video stream
     RUN(g_hops.hop(6, sv, st));
-    hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * d->B + 255) / 256), dim3(256), 0, st, (const long long*)x->clip_num,
-                       (const long long*)x->sent_num, d->B, (unsigned long long)seed, W.idx, (const unsigned long long*)g_step_seed_dev);
-    COOT_CHECK_LAUNCH("sample_idx");
+    RUN(draw_cycle_indices(*x, *d, seed, W.idx, st));
     RUN(coot_cyclecons_fwd_bwd(W.resh_v, W.resh_t, x->clip_num, x->sent_num, (const int64_t*)W.idx, (const int64_t*)(W.idx + d->B), d->B,
                                d->Cmax_clip, d->Cmax_sent, D, cfg->cc_weight, 1.0f / (float)d->B, losses + 2, nullptr, nullptr, W.d_resh_v,
                                W.d_resh_t, side_t));
@@ -586,9 +597,7 @@ int coot_train_step_phase(const coot_step_config* cfg, const coot_step_buffers* 
                                       W.loss_scratch, W.sz_loss, stream);
     case 4:
       if (!cc) return 0;
-      hipLaunchKernelGGL(sample_idx_kernel, dim3((2 * d->B + 255) / 256), dim3(256), 0, s, (const long long*)x->clip_num,
-                         (const long long*)x->sent_num, d->B, (unsigned long long)seed, W.idx, (const unsigned long long*)g_step_seed_dev);
-      COOT_CHECK_LAUNCH("sample_idx");
+      RUN(draw_cycle_indices(*x, *d, seed, W.idx, s));
       return coot_cyclecons_fwd_bwd(W.resh_v, W.resh_t, x->clip_num, x->sent_num, (const int64_t*)W.idx, (const int64_t*)(W.idx + d->B), d->B,
                                     d->Cmax_clip, d->Cmax_sent, D, cfg->cc_weight, 1.0f / (float)d->B, losses + 2, nullptr, nullptr,
                                     W.d_resh_v, W.d_resh_t, stream);
@@ -620,6 +629,7 @@ int coot_step_set_device_state(void* state) {
   g_step_seed_dev = state ? (const uint64_t*)&g_state_dev->seed : nullptr;
   return 0;
 }
+int coot_step_set_cycle_indices(const int64_t* idx) { g_cc_idx_inject = idx; return 0; }
 int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
 void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
 void coot_step_defer_global_tn(int on) { g_defer_global_tn = on; }

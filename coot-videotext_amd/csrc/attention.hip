@@ -658,6 +658,101 @@ __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-query attention (the context block of the global networks, nntrainer/models/transformer_legacy.py:251-267: the local
+// network's context vector attends to <= 64 clip / sentence tokens): ONE wave per (sequence, head), lane = key, everything in
+// fp32 registers from the bf16 q / k / v.  The backward recomputes the probabilities and takes delta = sum_k P_k dP_k from the
+// very products it differentiates, so sum_k dS_k = 0 to fp32 round-off.  (delta = <dO, O> with the bf16-rounded O leaves a
+// residue eps; dq = sum_k dS_k K_k then carries eps * mean(K), and the keys of a global network share a large common component:
+// measured cos 0.96 against the reference on the q / k projection gradients of tf_context at the benchmark shapes.)
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__device__ __forceinline__ void load_row(const bf16_t* p, float (&r)[DH]) {
+#pragma unroll
+  for (int c = 0; c < DH; c += 4) {
+    const s16x4_t v = *reinterpret_cast<const s16x4_t*>(p + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[c + j] = bf2f((bf16_t)v[j]);
+  }
+}
+template <int DH>
+__device__ __forceinline__ void store_row(bf16_t* p, const float (&r)[DH]) {
+#pragma unroll
+  for (int c = 0; c < DH; c += 4) {
+    const u32x2_t pk = {pack2bf(r[c], r[c + 1]), pack2bf(r[c + 2], r[c + 3])};
+    *reinterpret_cast<u32x2_t*>(p + c) = pk;
+  }
+}
+template <int DH>
+__global__ __launch_bounds__(256) void attn_q1_fwd_kernel(AttnArgs a) {
+  const int lane = threadIdx.x & 63, pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= a.Nseq * a.H) return;
+  const int n = pair / a.H, h = pair - n * a.H, Lk = a.Lk, nvalid = (int)a.lens[n];
+  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;
+  float qv[DH], kv[DH];
+  load_row<DH>(a.q + (long)n * a.ldq + h * DH, qv);
+  float sv = 0.f;
+  if (lane < Lk) {
+    load_row<DH>(a.k + ((long)n * Lk + lane) * a.ldk + h * DH, kv);
+#pragma unroll
+    for (int c = 0; c < DH; ++c) sv += qv[c] * kv[c];
+    sv *= a.scale;
+    if (lane >= nvalid) sv = kMaskFill;
+  }
+  const float m = wave_max(lane < Lk ? sv : -3.0e38f);
+  const float e = lane < Lk ? __expf(sv - m) : 0.f;
+  const float sum = wave_sum(e);
+  float p = e / sum;
+  if (a.drop.thr && lane < Lk) p *= attn_drop(dkey, (unsigned)(n * a.H + h), lane, (unsigned)(Lk + 1) >> 1, a.drop.thr, a.drop.inv_keep);
+  float o = 0.f;
+  const bf16_t* vcol = a.v + (long)n * Lk * a.ldv + h * DH + (lane < DH ? lane : 0);
+  for (int l = 0; l < Lk; ++l) o += __shfl(p, l, 64) * bf2f(vcol[(long)l * a.ldv]);
+  if (lane < DH) a.o[(long)n * a.ldo + h * DH + lane] = f2bf(o);
+  if (lane == 0) a.lse[(long)n * a.H + h] = m + __logf(sum);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_q1_bwd_kernel(AttnArgs a) {
+  const int lane = threadIdx.x & 63, pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= a.Nseq * a.H) return;
+  const int n = pair / a.H, h = pair - n * a.H, Lk = a.Lk, nvalid = (int)a.lens[n];
+  const unsigned dkey = a.drop.thr ? drop_site_key(a.drop.seed, a.drop.seed_ptr, a.drop.site) : 0u;
+  float qv[DH], dov[DH], row[DH];
+  load_row<DH>(a.q + (long)n * a.ldq + h * DH, qv);
+  load_row<DH>(a.dout + (long)n * a.lddo + h * DH, dov);
+  const float lse = a.lse[(long)n * a.H + h];
+  float p = 0.f, dp = 0.f, dr = 1.f;
+  if (lane < Lk) {
+    load_row<DH>(a.k + ((long)n * Lk + lane) * a.ldk + h * DH, row);
+    float sv = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) sv += qv[c] * row[c];
+    sv *= a.scale;
+    if (lane >= nvalid) sv = kMaskFill;
+    p = __expf(sv - lse);
+    load_row<DH>(a.v + ((long)n * Lk + lane) * a.ldv + h * DH, row);
+#pragma unroll
+    for (int c = 0; c < DH; ++c) dp += dov[c] * row[c];
+    if (a.drop.thr) dr = attn_drop(dkey, (unsigned)(n * a.H + h), lane, (unsigned)(Lk + 1) >> 1, a.drop.thr, a.drop.inv_keep);
+  }
+  const float pd = p * dr;                       // dropped probability: what multiplied V in the forward
+  const float delta = wave_sum(pd * dp);         // = <dO, O> in exact arithmetic
+  const float ds = (lane < nvalid) ? p * (dr * dp - delta) * a.scale : 0.f;  // masked_fill blocks the gradient
+  if (lane < Lk) {
+#pragma unroll
+    for (int c = 0; c < DH; ++c) row[c] = ds * qv[c];
+    store_row<DH>(a.dk + ((long)n * Lk + lane) * a.lddk + h * DH, row);
+#pragma unroll
+    for (int c = 0; c < DH; ++c) row[c] = pd * dov[c];
+    store_row<DH>(a.dv + ((long)n * Lk + lane) * a.lddv + h * DH, row);
+  }
+  float dq = 0.f;
+  const bf16_t* kcol = a.k + (long)n * Lk * a.ldk + h * DH + (lane < DH ? lane : 0);
+  for (int l = 0; l < Lk; ++l) dq += __shfl(ds, l, 64) * bf2f(kcol[(long)l * a.ldk]);
+  if (lane < DH) a.dq[(long)n * a.lddq + h * DH + lane] = f2bf(dq);
+}
+static bool attn_q1_ok(const AttnArgs& a) { return a.Lq == 1 && a.Lk >= 1 && a.Lk <= 64 && a.Nseq2 == 0; }
+
 static int g_attn_short = 1;
 void set_attn_short(int on) { g_attn_short = on; }
 static bool attn_short_ok(const AttnArgs& a) {
@@ -669,6 +764,11 @@ template <int DH>
 static int attn_fwd_t(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.xcd_order = get_xcd_order() & 4;
+  if (attn_q1_ok(a)) {
+    hipLaunchKernelGGL(attn_q1_fwd_kernel<DH>, dim3((a.Nseq * a.H + 3) / 4), dim3(256), 0, st, a);
+    COOT_CHECK_LAUNCH("attn_q1_fwd");
+    return 0;
+  }
   if (attn_short_ok(a)) {
     const int nw = ((a.Nseq2 > 0 && a.L2 > a.Lk ? a.L2 : a.Lk) + 15) / 16;
     hipLaunchKernelGGL(attn_short_fwd_kernel<DH>, dim3(short_grid(a)), dim3(64 * nw), (size_t)2 * nw * 16 * AttnSmem<DH>::RP * sizeof(bf16_t), st, a);
@@ -689,6 +789,11 @@ template <int DH>
 static int attn_bwd_t(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.xcd_order = get_xcd_order() & 4;
+  if (attn_q1_ok(a)) {
+    hipLaunchKernelGGL(attn_q1_bwd_kernel<DH>, dim3((a.Nseq * a.H + 3) / 4), dim3(256), 0, st, a);
+    COOT_CHECK_LAUNCH("attn_q1_bwd");
+    return 0;
+  }
   if (attn_short_ok(a)) {
     const int nw = ((a.Nseq2 > 0 && a.L2 > a.Lk ? a.L2 : a.Lk) + 15) / 16;
     hipLaunchKernelGGL(attn_short_bwd_kernel<DH>, dim3(short_grid(a)), dim3(64 * nw),

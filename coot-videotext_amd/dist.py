@@ -90,6 +90,14 @@ class DataParallelContext:
         dist.all_gather_into_tensor(out, t, group=self.group)
         return [int(v) for v in out.tolist()]
 
+    def gather_rows_nograd(self, x: torch.Tensor, counts: List[int]) -> torch.Tensor:
+        """All-gather of row blocks (counts[r] rows from rank r), no autograd: the native step slices gradients itself."""
+        return gather_rows_nograd(x, counts, self.group)
+
+    def all_reduce_sum(self, t: torch.Tensor) -> None:
+        """In-place sum over ranks on the current stream."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def gather_embeddings(self, vis, txt, clip_counts: Optional[List[int]] = None, vid_counts: Optional[List[int]] = None):
         """Returns the six full-batch embedding sets (vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx).
         Row counts per rank may be passed when known on the host (fixed-shape batches) to avoid two tiny

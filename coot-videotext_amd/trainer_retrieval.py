@@ -225,7 +225,21 @@ class RetrievalTrainer:
             out = self._step_impl(batch, vid_counts, clip_counts)
         self._graph, self._graph_out = graph, out
 
+    def _sync_global_max(self, batch) -> None:
+        """Data parallel: every rank pads its packed clip / sentence embeddings to the GLOBAL max count per video (one
+        all-reduce(MAX) of two ints per batch) — avg_special pooling sums the padded rows (nntrainer/models/poolers.py:237), so the
+        global embeddings depend on Cmax and must see the full batch's value.  Fixed-shape callers set
+        batch.global_max_synced themselves and skip the collective."""
+        dp = getattr(self, "dp", None)
+        if dp is None or getattr(batch, "global_max_synced", False):
+            return
+        if batch.max_clip_num is None or batch.max_sent_num is None:
+            batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
+        batch.max_clip_num, batch.max_sent_num = dp.global_max_pair(batch.max_clip_num, batch.max_sent_num, batch.vid_feat.device)
+        batch.global_max_synced = True
+
     def _step_impl(self, batch, vid_counts=None, clip_counts=None):
+        self._sync_global_max(batch)
         nets = list(self.model_mgr.model_dict.values())
         if getattr(self, "_seed_dev", None) is None:
             self._seed_dev = torch.zeros(1, dtype=torch.int64, device=batch.vid_feat.device)
@@ -467,7 +481,7 @@ class RetrievalTrainer:
         return st.losses[0], st.losses[1], st.losses[2]
 
     def train_step_native(self, batch: RetrievalDataBatchTuple, do_optimizer: bool = True, seed: Optional[int] = None,
-                          vid_counts=None, clip_counts=None, use_graph=False):
+                          vid_counts=None, clip_counts=None, use_graph=False, cc_indices: Optional[torch.Tensor] = None):
         """One optimisation step as ONE call into libcoot_hip.so (coot_train_step): forward of both sides on two
         HIP streams, losses, backward, fused Adam — no Python between the kernel launches.  Returns views of the
         device loss vector (total, contrastive, cycle-consistency).  With ``self.dp`` set the step runs as native phases
@@ -476,7 +490,7 @@ class RetrievalTrainer:
         reference's LR schedulers keep working."""
         lib = _lib.load()
         if getattr(self, "dp", None) is not None:
-            return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts)
+            return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts, cc_indices)
         if use_graph and do_optimizer and seed is None and self.model_mgr.is_train:
             out = self._train_step_native_graph(batch, phases=(use_graph == "phases"))
             if out is not None:
@@ -496,30 +510,32 @@ class RetrievalTrainer:
             flags |= _lib.STEP_OPTIMIZER | _lib.STEP_REPACK
         if all(n.pack_is_fresh() for n in st.nets):
             flags |= _lib.STEP_PACKS_FRESH
-        _lib.check(lib.coot_train_step(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(st.dims), st.losses.data_ptr(),
-                                       st.ws.data_ptr(), st.ws.numel(), train, int(seed), max(st.step, 1), flags,
-                                       main.cuda_stream, main.cuda_stream, st.streams[1].cuda_stream), "coot_train_step")
+        if cc_indices is not None:  # a given draw of the cycle-consistency positions ([2B] int64: clips, then sentences)
+            assert cc_indices.dtype == torch.int64 and cc_indices.is_cuda and cc_indices.numel() == 2 * st.dims.B
+            lib.coot_step_set_cycle_indices(cc_indices.data_ptr())
+        try:
+            _lib.check(lib.coot_train_step(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(st.dims), st.losses.data_ptr(),
+                                           st.ws.data_ptr(), st.ws.numel(), train, int(seed), max(st.step, 1), flags,
+                                           main.cuda_stream, main.cuda_stream, st.streams[1].cuda_stream), "coot_train_step")
+        finally:
+            if cc_indices is not None:
+                lib.coot_step_set_cycle_indices(None)
         if do_optimizer:  # the library rebuilt the bf16 packs right after its Adam update
             for n in st.nets:
                 n.mark_packed()
         self.total_step += 1
         return st.losses[0], st.losses[1], st.losses[2]
 
-    def _train_step_native_dp(self, batch, do_optimizer=True, seed=None, vid_counts=None, clip_counts=None):
+    def _train_step_native_dp(self, batch, do_optimizer=True, seed=None, vid_counts=None, clip_counts=None, cc_indices=None):
         """Data-parallel native step: this rank's videos through coot_step_forward (C, two streams), ONE
         packed all-gather per embedding level over RCCL, the contrastive loss on the full gathered batch (every rank
         keeps the gradient rows of its own videos — no collective for embedding gradients), the per-video
         cycle-consistency loss scaled by 1 / global batch, coot_step_backward (C), all-reduce(SUM) of the flat gradient
         arenas, fused Adam.  Same kernels and the same C sequencing as the single-GPU native step."""
-        import torch.distributed as dist
         lib = _lib.load()
-        dp = self.dp
+        dp = self.dp  # every collective of the step goes through this object (dist.DataParallelContext)
         dev = batch.vid_feat.device
-        if not getattr(batch, "global_max_synced", False):
-            if batch.max_clip_num is None or batch.max_sent_num is None:
-                batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
-            batch.max_clip_num, batch.max_sent_num = dp.global_max_pair(batch.max_clip_num, batch.max_sent_num, dev)
-            batch.global_max_synced = True
+        self._sync_global_max(batch)
         st, x = self._native_setup(batch)
         if self.optimizer is not None:
             st.cfg.lr = float(self.optimizer.param_groups[0]["lr"])
@@ -584,11 +600,10 @@ class RetrievalTrainer:
         _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *[t.data_ptr() for t in st.emb], ws, wsn,
                                          train, int(seed), fresh, main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_forward")
         # ---- exchange: two packed all-gathers (per-video sets, per-clip sets); the loss reads the gathered buffers in place ----
-        from .dist import gather_rows_nograd
         high = torch.cat([glob_v, glob_t, local_v[:B], local_t[:B]], dim=1)      # [B, 2D | 2D | D | D]
         low = torch.cat([local_v[B:], local_t[B:]], dim=1)                        # [Nc, D | D]
-        high_all = gather_rows_nograd(high, vid_counts, dp.group)
-        low_all = gather_rows_nograd(low, clip_counts, dp.group)
+        high_all = dp.gather_rows_nograd(high, vid_counts)
+        low_all = dp.gather_rows_nograd(low, clip_counts)
         wh, wl, e4 = 6 * D, 2 * D, 4
         hp, lp = high_all.data_ptr(), low_all.data_ptr()
         sets = (C.c_void_p * 6)(hp, hp + 2 * D * e4, lp, lp + D * e4, hp + 4 * D * e4, hp + 5 * D * e4)  # vid, par, clip, sent, vid_ctx, par_ctx
@@ -601,8 +616,11 @@ class RetrievalTrainer:
                    "coot_contrastive_fwd_bwd_dp")
         use_cc = st.cfg.cc_weight != 0.0
         if use_cc:
-            _lib.check(lib.coot_sample_cycle_indices(batch.clip_num.data_ptr(), batch.sent_num.data_ptr(), B, int(seed), st.cyc_idx.data_ptr(), sp),
-                       "coot_sample_cycle_indices")
+            if cc_indices is not None:  # a given draw ([2B] int64: this rank's clip positions, then its sentence positions)
+                st.cyc_idx.copy_(cc_indices)
+            else:
+                _lib.check(lib.coot_sample_cycle_indices(batch.clip_num.data_ptr(), batch.sent_num.data_ptr(), B, int(seed),
+                                                         st.cyc_idx.data_ptr(), sp), "coot_sample_cycle_indices")
             _lib.check(lib.coot_cyclecons_fwd_bwd(resh_v.data_ptr(), resh_t.data_ptr(), batch.clip_num.data_ptr(), batch.sent_num.data_ptr(),
                                                   st.cyc_idx.data_ptr(), st.cyc_idx[B:].data_ptr(), B, d.Cmax_clip, d.Cmax_sent, D,
                                                   float(st.cfg.cc_weight), 1.0 / float(gb), st.cc_word.data_ptr(), None, None,
@@ -618,8 +636,8 @@ class RetrievalTrainer:
         lib.coot_step_set_global_done_events(None, None)  # the events belong to this trainer: no other step may record them
         st.comm.wait_event(st.ev_glob[0]); st.comm.wait_event(st.ev_glob[1])
         with torch.cuda.stream(st.comm):
-            dist.all_reduce(st.g_glob, op=dist.ReduceOp.SUM, group=dp.group)
-        dist.all_reduce(st.g_loc, op=dist.ReduceOp.SUM, group=dp.group)
+            dp.all_reduce_sum(st.g_glob)
+        dp.all_reduce_sum(st.g_loc)
         main.wait_stream(st.comm)
         st.losses[2:3].copy_(st.cc_word)
         torch.add(st.losses[1:2], st.losses[2:3], out=st.losses[0:1])
@@ -631,8 +649,6 @@ class RetrievalTrainer:
         self.total_step += 1
         return st.losses[0], st.losses[1], st.losses[2]
 
-    # ---- validation (coot/trainer_retrieval.py:312-477, metrics part) ---------------------------------------
-    @torch.no_grad()
     # ---- epoch loop (coot/trainer_retrieval.py:235-310 and the nntrainer/trainer_base.py hooks it calls) --------------
     def check_is_val_epoch(self) -> bool:
         """nntrainer/trainer_base.py:312-325."""

@@ -240,6 +240,10 @@ int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* bufs,
  * drawn on the device: idx[0 .. B) from clip_num, idx[B .. 2B) from sent_num. */
 int coot_sample_cycle_indices(const int64_t* clip_num, const int64_t* sent_num, int B, uint64_t seed, int64_t* idx,
                               coot_stream_t stream);
+/* Injects the draw instead: idx[0 .. B) clip positions, idx[B .. 2B) sentence positions (device memory, read at every
+ * coot_train_step / phase 4 until reset with NULL).  For reproducing a given th.multinomial sequence of the reference
+ * (coot/loss_fn.py:306-314 consumes the global torch RNG, which no device kernel can replay).  Thread-local. */
+int coot_step_set_cycle_indices(const int64_t* idx);
 int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream);
 /* RAdam of nntrainer/optimization.py:79-181 on one flat arena: decoupled decay weight_decay * decay_mask,

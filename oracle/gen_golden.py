@@ -176,18 +176,21 @@ def gen_single_net(name, cfg_o: O.NetConfig, N, L, seed, with_ctx):
     print("wrote", name, {k: v.shape for k, v in out.items() if not k.startswith("grad:")})
 
 
-def gen_full(name, dims, B, counts, Ls, seed, full_grads):
+def gen_full(name, dims, B, counts, Ls, seed, full_grads, ragged=True, cc_weight=None, sub_step=97, scale=0.05,
+             store_reshape=True):
     """encode_visual + encode_text + total contrastive + cycle-consistency, fwd and bwd."""
     dv, dt, hidden, heads, ff, pool_hidden = dims
     Lv, Lc, Lp, Lsent = Ls
     cfg = ref_config(*dims)
+    if cc_weight is not None:
+        cfg.train.loss_cycle_cons = cc_weight
     ocfgs = oracle_cfgs(*dims)
     th.manual_seed(0)
     mgr = model_retrieval.RetrievalModelManager(cfg)
     for i, k in enumerate(NET_KEYS):
-        load_params(mgr.model_dict[k], O.make_params(ocfgs[i], seed + 10 * i))
+        load_params(mgr.model_dict[k], O.make_params(ocfgs[i], seed + 10 * i, scale=scale))
     mgr.set_all_models_eval()
-    b = O.make_batch(seed + 100, B, counts, Lv, Lc, Lp, Lsent, dv, dt, ragged=True, corr=0.5)
+    b = O.make_batch(seed + 100, B, counts, Lv, Lc, Lp, Lsent, dv, dt, ragged=ragged, corr=0.5)
     batch = to_batch(b)
     vis = mgr.encode_visual(batch)
     txt = mgr.encode_text(batch)
@@ -215,8 +218,14 @@ def gen_full(name, dims, B, counts, Ls, seed, full_grads):
                sent_emb_mask=txt.sent_emb_mask, sent_emb_lens=txt.sent_emb_lens,
                contr_loss=contr, cc_loss=cc, cc_rows_clip=lrow_c, cc_rows_sent=lrow_s)
     out = {k: v.detach().numpy() for k, v in out.items()}
+    if not store_reshape:  # the padded [B, Cmax, D] copies are pack_by_count(clip_emb / sent_emb): derivable, large
+        del out["clip_emb_reshape"], out["sent_emb_reshape"]
     out["cc_idx_clip"], out["cc_idx_sent"] = ic, isent
     out["meta"] = np.array([seed, B, Lv, Lc, Lp, Lsent, dv, dt, hidden, heads, ff, pool_hidden])
+    out["ragged"] = np.array(int(ragged))
+    out["cc_weight"] = np.array(float(cfg.train.loss_cycle_cons))
+    out["sub_step"] = np.array(sub_step)
+    out["param_scale"] = np.array(scale)
     out["counts"] = np.asarray(counts)
     for k in NET_KEYS:
         for n, p in mgr.model_dict[k].named_parameters():
@@ -227,7 +236,7 @@ def gen_full(name, dims, B, counts, Ls, seed, full_grads):
                 out[f"grad:{k}:{n}"] = g
             else:
                 out[f"gnorm:{k}:{n}"] = np.array(np.linalg.norm(g.astype(np.float64)))
-                out[f"gsub:{k}:{n}"] = subsample(g)
+                out[f"gsub:{k}:{n}"] = subsample(g, sub_step)
     # retrieval metrics on these embeddings (nntrainer/retrieval.py)
     for (a, c, tag) in (("vid_emb", "par_emb", "vp"), ("clip_emb", "sent_emb", "cs")):
         e1 = out[a] / np.sqrt((out[a] ** 2).sum(-1, keepdims=True))
@@ -379,6 +388,39 @@ def gen_mask_semantics():
     print("wrote mask_semantics")
 
 
+ANET_DIMS = (2048, 1536, 384, 8, 384, 768)
+
+
+def anet_like_counts(seed, B):
+    """Clips per video with the shape of the ActivityNet annotation statistics (mean 3.74, p95 7, max 27)."""
+    rs = np.random.RandomState(seed)
+    return np.minimum(27, 1 + rs.negative_binomial(2, 0.42, B)).astype(np.int64)
+
+
+def gen_bench_anet():
+    """BASELINE.json configs[1] exactly as bench.py runs it: 64 videos x 4 clips, Lv = Lc = 80, Lp = 64, Ls = 16 (fixed shape)."""
+    gen_full("bench_anet", ANET_DIMS, B=64, counts=[4] * 64, Ls=(80, 80, 64, 16), seed=41, full_grads=False, ragged=False,
+             sub_step=197, store_reshape=False)
+
+
+def gen_bench_anet_ragged():
+    """Same dims, ragged: clip counts ~ ANet annotation statistics, frame / word counts uniform up to the maxima."""
+    gen_full("bench_anet_ragged", ANET_DIMS, B=64, counts=anet_like_counts(43, 64), Ls=(80, 80, 64, 30), seed=43,
+             full_grads=False, ragged=True, sub_step=197, store_reshape=False)
+
+
+def gen_bench_yc2_100m():
+    """synthetic.WORKLOADS['yc2_100m'] (yc2_100m_coot.yaml: Dv 512, 16 videos x 8 clips, cycle weight 0.001)."""
+    gen_full("bench_yc2_100m", (512, 1536, 384, 8, 384, 768), B=16, counts=[8] * 16, Ls=(80, 20, 96, 12), seed=47,
+             full_grads=False, ragged=False, cc_weight=0.001, sub_step=197, store_reshape=False)
+
+
+def gen_bench_yc2_2d3d():
+    """synthetic.WORKLOADS['yc2_2d3d'] (yc2_2d3d_coot.yaml: Dv 4096, 64 videos x 8 clips)."""
+    gen_full("bench_yc2_2d3d", (4096, 1536, 384, 8, 384, 768), B=64, counts=[8] * 64, Ls=(80, 20, 96, 12), seed=53,
+             full_grads=False, ragged=False, cc_weight=0.001, sub_step=197, store_reshape=False)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]  # e.g. "lr_schedule": regenerate just that fixture
@@ -399,6 +441,10 @@ def main():
     # full path, ActivityNet paper dims (d_model 384, 8 heads, Dv 2048, Dt 1536), sub-sampled grads
     gen_full("full_anet", (2048, 1536, 384, 8, 384, 768), B=6, counts=[3, 1, 4, 2, 2, 5], Ls=(20, 16, 18, 9),
              seed=31, full_grads=False)
+    gen_bench_anet()
+    gen_bench_anet_ragged()
+    gen_bench_yc2_100m()
+    gen_bench_yc2_2d3d()
     gen_retrieval_metrics()
     gen_radam()
     gen_lr_schedule()
