@@ -534,6 +534,13 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
   return 0;
 }
 
+static int g_use_glob_fused = 1;  // coot_set_option("glob_fused", 0/1): context networks as one launch per pass (fused.hip: glob_fwd_kernel)
+// the shape every shipped global network has: d_model 384, 8 heads, no input FC, one encoder layer + one context layer, avg_special
+static bool glob_fused_ok(const coot_net_config& c, const Segs& sg) {
+  return g_use_fused && g_use_glob_fused && fused_layer_ok(c) && c.num_heads == 8 && c.use_context && !c.use_input_fc && c.pooler != 0 &&
+         c.num_layers == 1 && c.ctx_num_layers == 1 && sg.n == 1 && glob_fwd_supported(sg.L[0]);
+}
+
 static LayerBufs self_bufs(const LayerS& s, int D) {
   LayerBufs b; b.q = s.qkv; b.ldq = 3 * D; b.k = s.qkv + D; b.ldk = 3 * D; b.v = s.qkv + 2 * D; b.ldv = 3 * D;
   b.ctx = s.ctx; b.r1 = s.r1; b.z1 = s.z1; b.h1 = s.h1; b.a1 = s.a1; b.r2 = s.r2; b.z2 = s.z2; b.lse = s.lse;
@@ -562,6 +569,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "step_stamps")) { coot_step_stamps_enable(value); return 0; }
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
   if (!strcmp(name, "fused_bwd")) { g_use_fused_bwd = value; return 0; }
+  if (!strcmp(name, "glob_fused")) { g_use_glob_fused = value; return 0; }
   if (!strcmp(name, "fused_infc")) { g_use_fused_infc = value; return 0; }
   if (!strcmp(name, "gemm_small")) { set_gemm_small(value); return 0; }
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
@@ -749,6 +757,24 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     l.pe = pe; l.pe_L = Lseq; l.y = S.z0; l.ldy = D;
     RUN(launch_ln_fwd(l, st));
     if (sg.n > 1) { l.x = feats2; l.R = T - T0; l.pe_L = L2; l.y = S.z0 + (size_t)T0 * D; RUN(launch_ln_fwd(l, st)); }
+  }
+  if (glob_fused_ok(c, sg) && W.layers[0].f_wqkv && W.ctx[0].f_wqkv) {
+    // the whole context network in ONE launch (fused.hip: glob_fwd_kernel); saves the same tensors as the per-op path below
+    GlobFwd f; f.B = N; f.Cmax = Lseq; f.x = feats; f.lens = (const long long*)lengths; f.hidden = hidden; f.pe = pe;
+    f.n_gain = P + L.n_gain; f.n_bias = P + L.n_bias; f.z0 = S.z0; f.cq_in = S.cq_in; f.pooled = pooled; f.per_token = per_token; f.train = train; f.tstamps = g_fz_tstamps;
+    auto fill = [&](GlobLayerFwd& g, const LayerP& lp, const LayerW& lw, const LayerBufs& b, float pdrop, unsigned site_base) {
+      g.wqkv = lw.f_wqkv; g.wo = lw.f_wo; g.w1 = lw.f_w1; g.w2 = lw.f_w2;
+      g.bqkv = P + lp.bq; g.bo = P + lp.bo; g.ln1g = P + lp.ln1g; g.ln1b = P + lp.ln1b; g.b1 = P + lp.b1; g.b2 = P + lp.b2;
+      g.ln2g = P + lp.ln2g; g.ln2b = P + lp.ln2b;
+      g.q = b.q; g.ldq = b.ldq; g.k = b.k; g.ldk = b.ldk; g.v = b.v; g.ldv = b.ldv;
+      g.ctx = b.ctx; g.r1 = b.r1; g.z1 = b.z1; g.h1 = b.h1; g.a1 = b.a1; g.r2 = b.r2; g.z2 = b.z2; g.lse = b.lse;
+      g.d_attn = mkdrop(train, pdrop, seed, site_base + SITE_ATTN); g.d_postln = mkdrop(train, pdrop, seed, site_base + SITE_POSTLN);
+      g.d_ff1 = mkdrop(train, pdrop, seed, site_base + SITE_FF1); g.d_ff2 = mkdrop(train, pdrop, seed, site_base + SITE_FF2);
+    };
+    fill(f.self, L.layers[0], W.layers[0], self_bufs(S.layers[0], D), c.dropout, 0u);
+    fill(f.ctx, L.ctx[0], W.ctx[0], ctx_bufs(S.ctx[0], D), c.ctx_dropout, 16u * 8);
+    COOT_REQUIRE((c.dropout > 0.f) == (c.ctx_dropout > 0.f) || !train, "net_fwd: the fused context network takes dropout on both layers or on none");
+    return launch_glob_fwd(f, st);
   }
   const bf16_t* z = S.z0;
   const bool pool_fused = g_use_fused && fused_pool_ok(c) && W.f_pw1 && !c.use_context && T >= g_fused_min_rows;

@@ -94,6 +94,39 @@ struct QkvBwd {
 };
 int launch_qkv_bwd(const QkvBwd& p, hipStream_t st);
 
+// ---- global (video / paragraph level) network, the whole forward in ONE launch --------------------------------------------
+// TransformerLegacy.forward of a context network (nntrainer/models/transformer_legacy.py:200-288 with use_input_fc off,
+// use_context on, pooler avg_special; d_model 384, 8 heads, one encoder layer, one context layer — every shipped config):
+// LayerNorm + positional encoding, self-attention encoder layer, context block (one query per sequence, :251-267),
+// avg_special pooling (poolers.py:232-241).  A workgroup owns G = 32 / Cmax whole sequences (<= 32 token rows): their tokens
+// stay in LDS from the input LayerNorm to the pooled output, the twelve 384-wide weight matrices stream from L2, attention
+// runs on the LDS tiles in fp32.  Was 10 dependent launches of 5-30 us on 64-256 rows with the chip idle.
+// Writes exactly the tensors the per-op path saves for the backward pass (same buffers, same layout).
+struct GlobLayerFwd {
+  const bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;  // P48 packs ([1152 x 384], 3 x [384 x 384])
+  const float *bqkv = nullptr, *bo = nullptr, *ln1g = nullptr, *ln1b = nullptr, *b1 = nullptr, *b2 = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+  bf16_t* q = nullptr; long ldq = 0; bf16_t* k = nullptr; long ldk = 0; bf16_t* v = nullptr; long ldv = 0;  // saved projections
+  bf16_t *ctx = nullptr, *r1 = nullptr, *z1 = nullptr, *h1 = nullptr, *a1 = nullptr, *r2 = nullptr, *z2 = nullptr; float* lse = nullptr;
+  DropCfg d_attn, d_postln, d_ff1, d_ff2;
+};
+struct GlobFwd {
+  int B = 0, Cmax = 0;            // sequences (videos), padded items (clips) per sequence; Cmax <= 32
+  const float* x = nullptr;       // [B, Cmax, 384] fp32, zero padded
+  const long long* lens = nullptr;  // [B] valid items
+  const float* hidden = nullptr;  // [B, 384] context vectors of the local network
+  const float* pe = nullptr;      // [>= Cmax, 384]
+  const float *n_gain = nullptr, *n_bias = nullptr;
+  GlobLayerFwd self, ctx;
+  bf16_t *z0 = nullptr, *cq_in = nullptr;  // saved: LN(x) + pe [B Cmax, 384], bf16(hidden) [B, 384]
+  float* pooled = nullptr;        // [B, 768] = avg_special | context block output
+  float* per_token = nullptr;     // optional [B Cmax, 384] fp32 copy of the encoder output
+  int train = 0;
+  int tiles = 0, warm_per_xcd = 0;  // set by launch_glob_fwd
+  unsigned long long* tstamps = nullptr;  // profiling aid: block 0 phase stamps (tools/glob_stamps.py)
+};
+int launch_glob_fwd(const GlobFwd& p, hipStream_t st);
+bool glob_fwd_supported(int Cmax);
+
 constexpr int FZ_BWD_NCS = 9 * FZ_D;  // floats per tile in PreAttnBwd::part
 int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st);
 

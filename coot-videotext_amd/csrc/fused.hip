@@ -272,6 +272,14 @@ __device__ __forceinline__ DropK resolve_drop(const DropCfg& d, unsigned long lo
   DropK k; k.key = drop_key(d.seed + base, d.site); k.thr = d.thr; k.inv_keep = d.inv_keep; return k;
 }
 
+// dropout mask of one attention probability: the map of attention.hip (attn_drop), so that this file's in-tile attention and
+// the attention kernels draw the same masks for the same (seed, site, sequence, head, query, key)
+__device__ __forceinline__ float attn_drop_f(unsigned key, unsigned row, int k, unsigned lk_half, unsigned thr, float inv_keep) {
+  const unsigned h = drop_hash((row * lk_half + ((unsigned)k >> 1)) ^ key);
+  const unsigned u = (k & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return u >= (thr >> 16) ? inv_keep : 0.0f;
+}
+
 template <bool DROP>
 __device__ __forceinline__ void apply_drop(const DropK& d, unsigned long long idx0, float (&v)[8]) {
   if constexpr (DROP) {
@@ -285,9 +293,9 @@ __device__ __forceinline__ void apply_drop(const DropK& d, unsigned long long id
 // COOT LayerNorm (nntrainer/models/normalizations.py:98-101) of every tile row, in place.  Wave w owns rows
 // [2 RF w, 2 RF w + 2 RF); 16 lanes share a row (4 rows per wave in flight): lane j holds the three 8-element chunks at
 // columns 8 j, 128 + 8 j, 256 + 8 j (16-byte LDS / global accesses), reductions are 4 DPP steps.
-template <int RF, bool DROP, bool OUT32>
+template <int RF, bool DROP, bool OUT32, bool MASK = false>
 __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const float* bias, int row0, int T, bf16_t* out, float* out32,
-                                        long ld32, const DropK& drop) {
+                                        long ld32, const DropK& drop) {  // MASK: rows >= T are not stored to `out` either (tiles that do not own whole 32-row blocks)
   asm volatile("" : "+s"(row0));  // see ln_bwd_tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
   constexpr int RW = 2 * RF, ITR = (RW + 3) / 4;
@@ -327,7 +335,7 @@ __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const flo
       }
       const u32x4_t o = pack8(y);
       *reinterpret_cast<u32x4_t*>(ar + m * 128) = o;
-      gst16(out, (unsigned)(row * FZ_D + m * 128 + j16 * 8) * 2u, o);
+      if (!MASK || row < T) gst16(out, (unsigned)(row * FZ_D + m * 128 + j16 * 8) * 2u, o);
       if constexpr (OUT32) {
         if (row < T) {
           float* o32 = out32 + (long)row * ld32 + m * 128 + j16 * 8;
@@ -744,6 +752,287 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   stamp();
 }
 
+// ---- global network forward in one launch (fused.h: GlobFwd) ---------------------------------------------------------------
+
+// Attention on LDS tiles, fp32 VALU (the problems are tiny: <= 32 keys of 48 channels per (query, head)).  Two threads per
+// (query row r, head h): each takes 24 of the head's 48 channels.  Scores go through Sc[pair][32] (the staging buffer).
+//   SELF: query r belongs to sequence r / Lk (position r % Lk), its keys are that sequence's rows; mask row id as attn_short
+//   else: one query per sequence r (the context block), keys = rows [r Lk, r Lk + Lk); mask row id as attn_q1
+// Output: bf16 into Os (zeros for rows >= nq), and for rows < nq into o_glob / lse_glob (global row = grow0 + r).
+template <bool SELF, bool DROP>
+__device__ __forceinline__ void tile_attn(const bf16_t* Qs, const bf16_t* Ks, const bf16_t* Vs, bf16_t* Os, float* Sc, int nq, int Lk,
+                                          int seq0, const long long* lens, float scale, const DropK& dk, bf16_t* o_glob, float* lse_glob,
+                                          int grow0) {
+  const int tid = threadIdx.x, pair = tid >> 1, half = tid & 1, r = pair >> 3, h = pair & 7;
+  const bool on = r < nq;
+  const int sl = on ? (SELF ? r / Lk : r) : 0;
+  const int kr0 = sl * Lk;
+  const int nvalid = on ? (int)lens[seq0 + sl] : 0;
+  const int coff = h * 48 + half * 24;
+  float q[24];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) unpack8(*reinterpret_cast<const u32x4_t*>(&Qs[(on ? r : 0) * APITCH + coff + c * 8]), &q[c * 8]);
+  float m = -3.0e38f;
+  for (int j = 0; j < Lk; ++j) {
+    float kk[24];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) unpack8(*reinterpret_cast<const u32x4_t*>(&Ks[(kr0 + j) * APITCH + coff + c * 8]), &kk[c * 8]);
+    float sv = 0.f;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) sv += q[c] * kk[c];
+    sv += __shfl_xor(sv, 1, 64);
+    sv *= scale;
+    if (j >= nvalid) sv = kMaskFill;
+    if (half == 0) Sc[pair * 32 + j] = sv;  // both threads of the pair hold the same value; the partner (the next lane) reads it below
+    m = fmaxf(m, sv);
+  }
+  // the partner's reads below follow these writes in the same wave's LDS queue (DS operations of a wave execute in order);
+  // the fence only keeps the compiler from moving them
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float sum = 0.f;
+  for (int j = 0; j < Lk; ++j) sum += __expf(Sc[pair * 32 + j] - m);
+  const float lse = m + __logf(sum);
+  float o[24];
+#pragma unroll
+  for (int c = 0; c < 24; ++c) o[c] = 0.f;
+  const unsigned mrow = SELF ? (unsigned)(((seq0 + sl) * 8 + h) * Lk + (r - kr0)) : (unsigned)((seq0 + sl) * 8 + h);
+  for (int j = 0; j < Lk; ++j) {
+    float pj = __expf(Sc[pair * 32 + j] - lse);
+    if constexpr (DROP) pj *= attn_drop_f(dk.key, mrow, j, (unsigned)(Lk + 1) >> 1, dk.thr, dk.inv_keep);
+    float vv[24];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) unpack8(*reinterpret_cast<const u32x4_t*>(&Vs[(kr0 + j) * APITCH + coff + c * 8]), &vv[c * 8]);
+#pragma unroll
+    for (int c = 0; c < 24; ++c) o[c] += pj * vv[c];
+  }
+  if (r < 32) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const u32x4_t pk = on ? pack8(&o[c * 8]) : u32x4_t{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4_t*>(&Os[r * APITCH + coff + c * 8]) = pk;
+      if (on) gst16(o_glob, (unsigned)((grow0 + r) * FZ_D + coff + c * 8) * 2u, pk);
+    }
+    if (on && half == 0) lse_glob[(long)(grow0 + r) * 8 + h] = lse;
+  }
+}
+
+// L2 warm-up.  A 32-row tile chain streams all twelve 384 x 384 weight matrices (3.5 MB) through ONE CU; with only 8-64 such
+// workgroups on the chip each is alone on its XCD's L2 and, cold, pulls them from HBM / Infinity Cache at the rate one CU can
+// (measured ~30 GB/s: 115 us for the pass, whatever the launch count).  The otherwise idle CUs of the XCD fetch them instead:
+// helper workgroup h of n on an XCD touches the 8 KB pieces h, h + n, ... of the eight P48 arrays in the order of use, so the
+// chain finds them in L2 (block b runs on XCD b % 8: an affinity assumed for speed only, correctness does not depend on it).
+__device__ __forceinline__ void l2_prefetch(const bf16_t* const (&ws)[8], int h, int n) {
+  constexpr unsigned SZQKV = 3u * FZ_D * FZ_D * 2u, SZ = FZ_D * FZ_D * 2u, PIECE = 8192u;  // bytes; 512 threads x 16 B
+  unsigned x = 0;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const unsigned bytes = (a & 3) == 0 ? SZQKV : SZ;
+    for (unsigned piece = (unsigned)h; piece * PIECE < bytes; piece += (unsigned)n) {
+      const u32x4_t v = gld16(ws[a], piece * PIECE + threadIdx.x * 16u);
+      x ^= v[0];
+    }
+  }
+  asm volatile("" :: "v"(x));  // the loads must be issued; their values are not needed
+}
+
+// out-proj + residual + LN1 (+ dropout) + FF1 + GELU + FF2 + residual + LN2 on the 32-row tile in As (rows [row0, rowEnd) are
+// real; nothing is stored for the others).  The chain of post_attn_fwd_kernel with row masks and global parameter vectors.
+template <bool DROP, bool OUT32>
+__device__ __forceinline__ void glob_chain_fwd(bf16_t* As, float* Stg, const GlobLayerFwd& L, const bf16_t* xres, int row0, int rowEnd,
+                                               float* z2_f32, long ldz2_f32, unsigned long long sbase) {
+  constexpr int RF = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const DropK d_postln = resolve_drop(L.d_postln, sbase), d_ff1 = resolve_drop(L.d_ff1, sbase), d_ff2 = resolve_drop(L.d_ff2, sbase);
+  f32x4_t acc[RF][3];
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, L.wo + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, L.bo,
+      [&](int row, int col) { return PreRes{row < rowEnd ? gld16(xres, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
+      [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
+        float r[8];
+        unpack8(pr.res, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+        if (row < rowEnd) gst16(L.r1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+      }, true);
+  ln_tile<RF, DROP, false, true>(As, L.ln1g, L.ln1b, row0, rowEnd, L.z1, nullptr, 0, d_postln);
+  __syncthreads();
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, L.w1 + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, L.b1, [&](int, int) { return PreNone{}; },
+      [&](int row, int col, float (&v)[8], const PreNone&, int) {
+        apply_drop<DROP>(d_ff1, (unsigned long long)row * FZ_D + col, v);
+        if (row < rowEnd) gst16(L.h1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        if (row < rowEnd) gst16(L.a1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+      }, true);
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, L.w2 + wave * GSZ, acc, lane);
+  __syncthreads();  // z1 (stored by this workgroup in ln_tile) is read back as the residual
+  epilogue<RF, 8>(acc, Stg, As, row0, L.b2,
+      [&](int row, int col) { return PreRes{row < rowEnd ? gld16(L.z1, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
+      [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
+        float r[8];
+        unpack8(pr.res, r);
+        apply_drop<DROP>(d_ff2, (unsigned long long)row * FZ_D + col, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+        if (row < rowEnd) gst16(L.r2, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+      }, true);
+  {
+    const DropK none;
+    ln_tile<RF, false, OUT32, true>(As, L.ln2g, L.ln2b, row0, rowEnd, L.z2, z2_f32, ldz2_f32, none);
+  }
+  __syncthreads();
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
+  constexpr int RF = 2, BT = 32;
+  // LDS: token tile | q | k | v tiles (bf16 [32][400]) | fp32 staging [32][388], also the attention score buffer [256][32]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BT * APITCH * 2 + BT * SPITCH * 4];
+  static_assert(BT * SPITCH * 4 >= 256 * 32 * 4, "the staging buffer holds the attention scores [256 pairs][32 keys]");
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Qs = As + BT * APITCH;
+  bf16_t* Ks = Qs + BT * APITCH;
+  bf16_t* Vs = Ks + BT * APITCH;
+  float* Stg = reinterpret_cast<float*>(smem + 4 * BT * APITCH * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Cm = p.Cmax, G = 32 / Cm;
+  if ((int)blockIdx.x >= p.tiles) {  // L2 warm-up workgroups (see launch_glob_fwd)
+    const bf16_t* ws[8] = {p.self.wqkv, p.self.wo, p.self.w1, p.self.w2, p.ctx.wqkv, p.ctx.wo, p.ctx.w1, p.ctx.w2};
+    l2_prefetch(ws, ((int)blockIdx.x - p.tiles) >> 3, p.warm_per_xcd);
+    return;
+  }
+  const int v0 = blockIdx.x * G, nv = (p.B - v0) < G ? (p.B - v0) : G;
+  const int row0 = v0 * Cm, nrows = nv * Cm, rowEnd = row0 + nrows;
+  unsigned long long sbase = 0;
+  if constexpr (DROP) { if (p.self.d_ff1.seed_ptr) sbase = *p.self.d_ff1.seed_ptr; }
+  const float scale = 0.14433756729740643f;  // 1 / sqrt(48)
+  f32x4_t acc[RF][3];
+  int tsn = 0;
+  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  stamp();
+
+  // ---- z0 = LayerNorm(x) + pe (transformer_legacy.py:222-241; padded items are zero rows: LN gives bias + pe there) ----
+  {
+    const int j16 = lane & 15, g = lane >> 4, rl = wave * 4 + g, row = row0 + rl;
+    const bool on = rl < nrows;
+    float x[3][8];
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      if (on) load8f(p.x + (long)row * FZ_D + m * 128 + j16 * 8, x[m]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[m][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[m][e];
+    }
+    const float mean = row16_sum(s) * (1.0f / 384.0f);
+    float qq = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[m][e] -= mean; qq += x[m][e] * x[m][e]; }
+    const float rs = 1.0f / (sqrtf(row16_sum(qq) * (1.0f / 383.0f)) + kLnEps);
+    const int pos = rl % Cm;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int col = m * 128 + j16 * 8;
+      float gn[8], bi[8], pe[8], y[8];
+      load8f(p.n_gain + col, gn); load8f(p.n_bias + col, bi); load8f(p.pe + (long)pos * FZ_D + col, pe);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = on ? x[m][e] * rs * gn[e] + bi[e] + pe[e] : 0.f;
+      const u32x4_t o = pack8(y);
+      *reinterpret_cast<u32x4_t*>(&As[rl * APITCH + col]) = o;
+      if (on) gst16(p.z0, (unsigned)(row * FZ_D + col) * 2u, o);
+    }
+  }
+  __syncthreads();
+  stamp();
+
+  // ---- self-attention encoder layer -------------------------------------------------------------------------------------
+#pragma unroll 1
+  for (int q = 0; q < 3; ++q) {
+    zero_acc<RF>(acc);
+    gemm_pass<RF, 12>(As, p.self.wqkv + (q * 8 + wave) * GSZ, acc, lane);
+    bf16_t* dst = q == 0 ? Qs : (q == 1 ? Ks : Vs);
+    epilogue<RF, 8>(acc, Stg, dst, row0, p.self.bqkv + q * FZ_D, [&](int, int) { return PreNone{}; },
+        [&](int row, int col, float (&v)[8], const PreNone&, int) {
+          if (row < rowEnd) gst16(p.self.q, (unsigned)(row * (3 * FZ_D) + q * FZ_D + col) * 2u, pack8(v));
+        }, true);
+    stamp();
+  }
+  __syncthreads();
+  {
+    const DropK dk = resolve_drop(p.self.d_attn, sbase);
+    tile_attn<true, DROP>(Qs, Ks, Vs, As, Stg, nrows, Cm, v0, p.lens, scale, dk, p.self.ctx, p.self.lse, row0);
+  }
+  __syncthreads();
+  stamp();
+  if (p.per_token) glob_chain_fwd<DROP, true>(As, Stg, p.self, p.z0, row0, rowEnd, p.per_token, FZ_D, sbase);
+  else glob_chain_fwd<DROP, false>(As, Stg, p.self, p.z0, row0, rowEnd, nullptr, 0, sbase);
+  stamp();
+
+  // ---- avg_special pooling (poolers.py:237-238): the sum runs over ALL Cmax rows, padded ones included -----------------------
+  if (tid < FZ_D) {
+    for (int gv = 0; gv < nv; ++gv) {
+      float a = 0.f;
+      for (int j = 0; j < Cm; ++j) a += bf2f(As[(gv * Cm + j) * APITCH + tid]);
+      p.pooled[(long)(v0 + gv) * (2 * FZ_D) + tid] = a / (float)p.lens[v0 + gv];
+    }
+  }
+
+  // ---- context block (transformer_legacy.py:251-267): keys / values from the encoder output, one query per sequence ----------
+#pragma unroll 1
+  for (int q = 1; q < 3; ++q) {
+    zero_acc<RF>(acc);
+    gemm_pass<RF, 12>(As, p.ctx.wqkv + (q * 8 + wave) * GSZ, acc, lane);
+    bf16_t* dst = q == 1 ? Ks : Vs;
+    bf16_t* gdst = q == 1 ? p.ctx.k : p.ctx.v;
+    const int ldkv = (int)(q == 1 ? p.ctx.ldk : p.ctx.ldv);
+    epilogue<RF, 8>(acc, Stg, dst, row0, p.ctx.bqkv + q * FZ_D, [&](int, int) { return PreNone{}; },
+        [&](int row, int col, float (&v)[8], const PreNone&, int) {
+          if (row < rowEnd) gst16(gdst, (unsigned)(row * ldkv + col) * 2u, pack8(v));
+        }, true);
+  }
+  __syncthreads();  // every wave is done with the encoder output in As
+  stamp();
+  {  // query tile: row gv = bf16(hidden[v0 + gv]); 48 16-byte chunks per row
+    for (int c = tid; c < BT * 48; c += 512) {
+      const int rl = c / 48, ch = c - rl * 48;
+      u32x4_t o = {0u, 0u, 0u, 0u};
+      if (rl < nv) {
+        float h[8];
+        load8f(p.hidden + (long)(v0 + rl) * FZ_D + ch * 8, h);
+        o = pack8(h);
+        gst16(p.cq_in, (unsigned)((v0 + rl) * FZ_D + ch * 8) * 2u, o);
+      }
+      *reinterpret_cast<u32x4_t*>(&As[rl * APITCH + ch * 8]) = o;
+    }
+  }
+  __syncthreads();
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, p.ctx.wqkv + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, Qs, v0, p.ctx.bqkv, [&](int, int) { return PreNone{}; },
+      [&](int row, int col, float (&v)[8], const PreNone&, int) {
+        if (row < v0 + nv) gst16(p.ctx.q, (unsigned)(row * (int)p.ctx.ldq + col) * 2u, pack8(v));
+      }, true);
+  __syncthreads();
+  stamp();
+  {
+    const DropK dk = resolve_drop(p.ctx.d_attn, sbase);
+    tile_attn<false, DROP>(Qs, Ks, Vs, As, Stg, nv, Cm, v0, p.lens, scale, dk, p.ctx.ctx, p.ctx.lse, v0);
+  }
+  __syncthreads();
+  stamp();
+  glob_chain_fwd<DROP, true>(As, Stg, p.ctx, p.cq_in, v0, v0 + nv, p.pooled + FZ_D, 2 * FZ_D, sbase);
+  stamp();
+}
+
 // ---- input FC (K = Din, streamed) + GELU + pe + QKV -----------------------------------------------------------------
 constexpr int XPITCH = 80;  // bf16 elements per row of a 64-column slab (160 B: conflict-free fragment reads)
 
@@ -1070,6 +1359,28 @@ int launch_qkv_bwd(const QkvBwd& p_in, hipStream_t st) {
 }  // namespace coot
 
 namespace coot {
+bool glob_fwd_supported(int Cmax) { return Cmax >= 1 && Cmax <= 32; }
+int launch_glob_fwd(const GlobFwd& p_in, hipStream_t st) {
+  COOT_REQUIRE(p_in.x && p_in.lens && p_in.hidden && p_in.pe && p_in.n_gain && p_in.n_bias && p_in.z0 && p_in.cq_in && p_in.pooled, "glob_fwd: null pointer");
+  COOT_REQUIRE(glob_fwd_supported(p_in.Cmax), "glob_fwd: %d items per sequence (max 32)", p_in.Cmax);
+  if (p_in.B <= 0) return 0;
+  GlobFwd p = p_in;
+  const int G = 32 / p.Cmax, tiles = (p.B + G - 1) / G;
+  p.tiles = tiles;
+  p.warm_per_xcd = tiles >= 128 ? 0 : (tiles > 64 ? 8 : 16);  // helper workgroups per XCD (0: the chains fill the chip themselves)
+  const bool drop = p.self.d_attn.thr || p.self.d_postln.thr || p.self.d_ff1.thr || p.self.d_ff2.thr;
+  if (drop) COOT_REQUIRE(p.self.d_attn.thr && p.self.d_postln.thr && p.self.d_ff1.thr && p.self.d_ff2.thr && p.ctx.d_attn.thr && p.ctx.d_postln.thr &&
+                         p.ctx.d_ff1.thr && p.ctx.d_ff2.thr, "glob_fwd: dropout on some sites only");
+  const double T = (double)p.B * p.Cmax;
+  void* ts = timing_begin(TIMING_GLOB, 2.0 * 384.0 * 384.0 * (8.0 * T + 4.0 * p.B), 0, st);
+  // grid: the chains first (block b -> XCD b % 8), then warm_per_xcd helpers for each of the 8 XCDs
+  const int grid = tiles + 8 * p.warm_per_xcd;
+  if (drop) hipLaunchKernelGGL(glob_fwd_kernel<true>, dim3(grid), dim3(NTHR), 0, st, p);
+  else hipLaunchKernelGGL(glob_fwd_kernel<false>, dim3(grid), dim3(NTHR), 0, st, p);
+  timing_end(ts, st);
+  COOT_CHECK_LAUNCH("glob_fwd");
+  return 0;
+}
 int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st) {
   COOT_REQUIRE(p.xhat && p.win && p.bin && p.pe && p.wqkv && p.bqkv && p.h0 && p.z0 && p.qkv, "infc_qkv_fwd: null pointer");
   COOT_REQUIRE(p.Din % 64 == 0 && p.Din >= 128 && p.L1 > 0 && p.L2 > 0, "infc_qkv_fwd: Din = %d must be a multiple of 64", p.Din);

@@ -792,6 +792,49 @@ def make_batch(seed: int, B: int, counts, Lv: int, Lc: int, Lp: int, Ls: int, Dv
     return b
 
 
+def make_latent_batch(seed: int, B: int, counts, Lv: int, Lc: int, Lp: int, Ls: int, Dv: int, Dt: int, latent: int = 32,
+                      noise: float = 0.5, map_seed: int = 12345):
+    """Seeded batch with a LEARNABLE video-text correspondence (SURVEY 8d retrieval-parity set): every clip / sentence pair shares
+    a latent code u ~ N(0, I_latent); its frames are A u + noise, its words B u + noise (A, B fixed by map_seed, the same for
+    every batch); the frames of a video / the words of its paragraph are those of its clips / sentences, sub-sampled to Lv / Lp.
+    A few hundred contrastive steps make retrieval far better than chance, unlike make_batch's weak mean-feature coupling."""
+    rs = np.random.RandomState(seed)
+    rm = np.random.RandomState(map_seed)
+    A = rm.randn(latent, Dv) / math.sqrt(latent)
+    Bm = rm.randn(latent, Dt) / math.sqrt(latent)
+    counts = np.full(B, counts, dtype=np.int64) if np.isscalar(counts) else np.asarray(counts, dtype=np.int64)
+    Nc = int(counts.sum())
+    u = rs.randn(Nc, latent)
+    clip_len = rs.randint(max(1, Lc // 4), Lc + 1, size=Nc).astype(np.int64); clip_len[rs.randint(0, Nc)] = Lc
+    sent_len = rs.randint(max(1, Ls // 3), Ls + 1, size=Nc).astype(np.int64); sent_len[rs.randint(0, Nc)] = Ls
+
+    def seqs(n, L, D, ln, base):
+        x = base[:, None, :] + noise * rs.randn(n, L, D)
+        x[np.arange(L)[None, :] >= ln[:, None]] = 0.0
+        return x
+
+    clip_feat = seqs(Nc, Lc, Dv, clip_len, u @ A)
+    sent_feat = seqs(Nc, Ls, Dt, sent_len, u @ Bm)
+    vid_len = np.minimum(Lv, np.maximum(1, [int(clip_len[s:s + c].sum()) for s, c in zip(np.cumsum(counts) - counts, counts)])).astype(np.int64)
+    par_len = np.minimum(Lp, np.maximum(1, [int(sent_len[s:s + c].sum()) for s, c in zip(np.cumsum(counts) - counts, counts)])).astype(np.int64)
+    vid_feat, par_feat = np.zeros((B, Lv, Dv)), np.zeros((B, Lp, Dt))
+    ptr = 0
+    for b, c in enumerate(counts):
+        fr = np.concatenate([clip_feat[ptr + i, :clip_len[ptr + i]] for i in range(c)])
+        wd = np.concatenate([sent_feat[ptr + i, :sent_len[ptr + i]] for i in range(c)])
+        iv = np.linspace(0, len(fr) - 1, vid_len[b]).round().astype(int)
+        ip = np.linspace(0, len(wd) - 1, par_len[b]).round().astype(int)
+        vid_feat[b, :vid_len[b]] = fr[iv]
+        par_feat[b, :par_len[b]] = wd[ip]
+        ptr += c
+    b_ = dict(vid_feat=vid_feat, vid_feat_len=vid_len, par_feat=par_feat, par_feat_len=par_len, clip_num=counts.copy(),
+              clip_feat=clip_feat, clip_feat_len=clip_len, sent_num=counts.copy(), sent_feat=sent_feat, sent_feat_len=sent_len)
+    for k in ("vid", "par", "clip", "sent"):
+        L = b_[f"{k}_feat"].shape[1]
+        b_[f"{k}_feat_mask"] = np.arange(L)[None, :] >= b_[f"{k}_feat_len"][:, None]
+    return b_
+
+
 # ---- input side: seeded data points for the collation tests (shared by oracle/gen_golden.py and tests/) ----------------
 def make_datapoints(seed, B, dv, dt, max_frames=9, max_words=7, max_clips=4):
     """B synthetic videos in the layout of RetrievalDataset.__getitem__ (coot/dataset_retrieval.py:261-333): a dict per

@@ -236,7 +236,8 @@ def gen_full(name, dims, B, counts, Ls, seed, full_grads, ragged=True, cc_weight
                 out[f"grad:{k}:{n}"] = g
             else:
                 out[f"gnorm:{k}:{n}"] = np.array(np.linalg.norm(g.astype(np.float64)))
-                out[f"gsub:{k}:{n}"] = subsample(g, sub_step)
+                # vectors (biases, LayerNorm parameters) in full: a stride-197 sample of 384 numbers is two numbers
+                out[f"gsub:{k}:{n}"] = subsample(g, sub_step if g.size > 4096 else 1)
     # retrieval metrics on these embeddings (nntrainer/retrieval.py)
     for (a, c, tag) in (("vid_emb", "par_emb", "vp"), ("clip_emb", "sent_emb", "cs")):
         e1 = out[a] / np.sqrt((out[a] ** 2).sum(-1, keepdims=True))
@@ -421,6 +422,91 @@ def gen_bench_yc2_2d3d():
              full_grads=False, ragged=False, cc_weight=0.001, sub_step=197, store_reshape=False)
 
 
+RK_DIMS = (2048, 1536, 384, 8, 384, 768)
+RK_N, RK_BATCH, RK_LS = 1024, 64, (40, 40, 32, 12)   # validation videos, batch, (Lv, Lc, Lp, Ls)
+
+
+def rk_batch(seed, B=RK_BATCH):
+    """One seeded batch of the R@K parity set: ANet-like clip counts, ragged lengths, every clip / sentence pair generated from a
+    shared latent code (O.make_latent_batch), so that a briefly trained model retrieves far above chance."""
+    Lv, Lc, Lp, Ls = RK_LS
+    return O.make_latent_batch(seed, B, anet_like_counts(seed + 1, B), Lv, Lc, Lp, Ls, RK_DIMS[0], RK_DIMS[1])
+
+
+def quantize_state(sd):
+    """int8 per-tensor quantisation of a state dict (the fixture must stay small): returns (q, scale) per tensor and the
+    de-quantised fp32 state BOTH implementations load."""
+    q, deq = {}, {}
+    for k, v in sd.items():
+        a = v.detach().numpy().astype(np.float32)
+        if k.endswith("embedding.pe"):
+            continue
+        sc = float(np.abs(a).max()) / 127.0 or 1.0
+        qi = np.clip(np.round(a / sc), -127, 127).astype(np.int8)
+        q[k] = (qi, np.float32(sc))
+        deq[k] = qi.astype(np.float32) * np.float32(sc)
+    return q, deq
+
+
+def gen_rk_parity(train_steps=160):
+    """SURVEY 8d retrieval-parity set: 1 024 videos (~3 800 clips), correlated features, a 'trained-like' state = the reference
+    trained for `train_steps` Adam steps on seeded batches of the same distribution (its own modules, losses and optimizer
+    settings, dropout on), then int8-quantised so the fixture stays small.  Stored: the quantised state, and R@1/5/10/50,
+    MedR, MeanR of the REFERENCE's eval embeddings with that state (both directions, both levels) through
+    nntrainer/retrieval.py, plus a few embedding rows."""
+    cfg = ref_config(*RK_DIMS)
+    ocfgs = oracle_cfgs(*RK_DIMS)
+    th.manual_seed(0)
+    mgr = model_retrieval.RetrievalModelManager(cfg)     # reference init (truncnorm 0.01)
+    tr = _FakeTrainer(cfg)
+    params = [p for k in NET_KEYS for p in mgr.model_dict[k].parameters() if p.requires_grad]
+    opt = th.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-5)
+    mgr.set_all_models_train()
+    import time
+    t0 = time.time()
+    for step in range(train_steps):
+        batch = to_batch(rk_batch(5000 + 7 * step))
+        opt.zero_grad()
+        vis, txt = mgr.encode_visual(batch), mgr.encode_text(batch)
+        loss = tr.compute_total_constrastive_loss(vis, txt) + tr.compute_cyclecons_loss(vis, txt)
+        loss.backward()
+        opt.step()
+        if step % 20 == 0:
+            print(f"  rk_parity train step {step}: loss {float(loss):.4f} ({time.time() - t0:.0f} s)", flush=True)
+    out = {}
+    for k in NET_KEYS:
+        q, deq = quantize_state(mgr.model_dict[k].state_dict())
+        sd = mgr.model_dict[k].state_dict()
+        for n, v in deq.items():
+            sd[n] = th.from_numpy(v)
+        mgr.model_dict[k].load_state_dict(sd)
+        for n, (qi, sc) in q.items():
+            out[f"q:{k}:{n}"] = qi
+            out[f"s:{k}:{n}"] = sc
+    mgr.set_all_models_eval()
+    embs = {k: [] for k in ("vid_emb", "par_emb", "clip_emb", "sent_emb")}
+    with th.no_grad():
+        for i in range(RK_N // RK_BATCH):
+            batch = to_batch(rk_batch(900000 + 13 * i))
+            vis, txt = mgr.encode_visual(batch), mgr.encode_text(batch)
+            for k, v in (("vid_emb", vis.vid_emb), ("par_emb", txt.par_emb), ("clip_emb", vis.clip_emb), ("sent_emb", txt.sent_emb)):
+                embs[k].append(v.numpy())
+    E = {k: np.concatenate(v) for k, v in embs.items()}
+    for (a, c, tag) in (("vid_emb", "par_emb", "vp"), ("clip_emb", "sent_emb", "cs")):
+        e1 = E[a] / np.sqrt((E[a] ** 2).sum(-1, keepdims=True))      # coot/trainer_retrieval.py:401-402 (no eps)
+        e2 = E[c] / np.sqrt((E[c] ** 2).sum(-1, keepdims=True))
+        r1, r2, s1 = retrieval.compute_retrieval({"a": e1, "b": e2}, "a", "b", print_fn=lambda *_: None)[:3]
+        keys = ("r1", "r5", "r10", "r50", "medr", "meanr")
+        out[f"ret_{tag}"] = np.array([r1[k] for k in keys] + [r2[k] for k in keys] + [s1])
+        print(f"  rk_parity {tag}: N = {len(e1)}  " + "  ".join(f"{k} {r1[k]:.4f}/{r2[k]:.4f}" for k in keys))
+    out["n_clips"] = np.array(len(E["clip_emb"]))
+    for k in E:
+        out["rows:" + k] = E[k][::37].astype(np.float32)
+    out["meta"] = np.array([RK_N, RK_BATCH, *RK_LS, *RK_DIMS, train_steps])
+    np.savez_compressed(os.path.join(OUT, "rk_parity.npz"), **out)
+    print("wrote rk_parity")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]  # e.g. "lr_schedule": regenerate just that fixture
@@ -445,6 +531,7 @@ def main():
     gen_bench_anet_ragged()
     gen_bench_yc2_100m()
     gen_bench_yc2_2d3d()
+    gen_rk_parity()
     gen_retrieval_metrics()
     gen_radam()
     gen_lr_schedule()

@@ -80,7 +80,8 @@ def _check_grads(g, grads_by_net: dict, tag):
                 if np.linalg.norm(got) > 1e-3 * gmax:
                     bad.append((key, "zero-grad", float(np.linalg.norm(got))))
                 continue
-            c = H.cosine_flat(got.reshape(-1)[::step], g["gsub:" + key])
+            ref = g["gsub:" + key]
+            c = H.cosine_flat(got.reshape(-1)[::(1 if ref.size == got.size else step)], ref)
             nr = float(np.linalg.norm(got.astype(np.float64))) / gn
             n_checked += 1
             if c < 0.995 or abs(nr - 1) > 0.02:

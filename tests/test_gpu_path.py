@@ -139,7 +139,8 @@ def test_full_path_anet_golden(env, golden_dir):
                 if np.linalg.norm(got) > 1e-3 * gmax:
                     bad.append((k, n, "zero-grad", float(np.linalg.norm(got))))
                 continue
-            c = H.cosine_flat(got.reshape(-1)[::97], g[f"gsub:{k}:{n}"])
+            ref = g[f"gsub:{k}:{n}"]
+            c = H.cosine_flat(got.reshape(-1)[::(1 if ref.size == got.size else 97)], ref)
             nr = float(np.linalg.norm(got)) / gn
             print(f"[golden] grad {k}:{n} cos(sub)={c:.4f} norm ratio={nr:.4f}")
             if not (c > 0.98 and 0.95 < nr < 1.05):
@@ -689,5 +690,44 @@ def test_fused_chain_matches_per_op_kernels(env, name, cfg, N, L, with_ctx, trai
     print(f"[{name}] fused vs per-op: pooled rel err {ep:.2e}, tokens {et:.2e}")
     assert ep < 5e-3 and et < 5e-3
     # key-projection bias: the true gradient is zero (softmax shift invariance), both paths hold round-off noise there
+    bad, table = H.grad_report([(n, g) for n, g in g1.items() if "key_projection.bias" not in n], g0, cos_min=0.999, ratio_tol=0.01)
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("N,L,train", [(64, 4, False), (64, 4, True), (13, 9, True), (5, 27, False), (7, 32, True), (40, 1, True)])
+def test_global_network_single_launch_matches_per_op_kernels(env, N, L, train):
+    """The context networks as ONE launch per pass (fused.hip: glob_fwd_kernel; coot_set_option("glob_fused", 1), the default)
+    against the per-op kernels it replaces: same inputs, weights and dropout seed -> same masks, same rounding points up to the
+    fp32 attention arithmetic; pooled output, per-token output and every gradient (the backward reads the tensors the forward
+    saved) agree.  Ragged lengths, sequences per workgroup from 1 (L = 27, 32) to 32 (L = 1)."""
+    torch, cva = env
+    lib = cva.lib.load()
+    cfg = ANET_GLOBAL
+    P = O.make_params(cfg, 41)
+    x, lens, hid, R = _inputs(cfg, N, L, 42 + N, True)
+    res = []
+    for fused in (0, 1):
+        cva.lib.check(lib.coot_set_option(b"glob_fused", fused))
+        try:
+            net = H.make_hip_net(cfg, P, dropout=0.1 if train else 0.0)
+            net.train(train)
+            xt = torch.from_numpy(x).float().cuda().requires_grad_(True)
+            ht = torch.from_numpy(hid).float().cuda().requires_grad_(True)
+            mask = torch.from_numpy(np.arange(L)[None, :] >= lens[:, None]).cuda()
+            pooled, tok = net(xt, mask, torch.from_numpy(lens).cuda(), ht, seed=4321)
+            (pooled * torch.from_numpy(R).float().cuda()).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            cva.lib.check(lib.coot_set_option(b"glob_fused", 1))
+        res.append((pooled.detach().cpu().numpy(), tok.detach().cpu().numpy(), xt.grad.cpu().numpy(), ht.grad.cpu().numpy(),
+                    {n: p.grad.detach().cpu().numpy() for n, p in net.named_parameters() if p.requires_grad}))
+    (p0, t0, dx0, dh0, g0), (p1, t1, dx1, dh1, g1) = res
+    valid = np.arange(L)[None, :] < lens[:, None]
+    ep, et = H.rel_err(p1, p0), H.rel_err(t1, t0)
+    print(f"[global N={N} L={L} train={train}] one launch vs per-op: pooled rel err {ep:.2e}, tokens {et:.2e}")
+    # the in-tile attention keeps the probabilities in fp32 (the attention kernels round them to bf16 for the MFMA): the two
+    # paths differ by bf16 rounding noise of the per-token outputs, the level both have against the oracle (test_net_fwd_bwd)
+    assert ep < 5e-3 and et < 1.5e-2
+    assert H.cosine_flat(dx1[valid], dx0[valid]) > 0.999 and H.cosine_flat(dh1, dh0) > 0.999
     bad, table = H.grad_report([(n, g) for n, g in g1.items() if "key_projection.bias" not in n], g0, cos_min=0.999, ratio_tol=0.01)
     assert not bad, "\n".join(bad)
