@@ -8,12 +8,15 @@ B = 64 videos x 4 clips/GPU, Lc = Lv = 80 frames, Ls = 16 / Lp = 64 tokens, Dv =
 bf16 MFMA operands, fp32 accumulation/statistics/master weights; dropout ON as in training).  Inputs are
 resident in HBM before the timed region.  Weak scaling: per-GPU batch fixed, global batch = 64 N videos.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--workload anet|yc2_100m|yc2_2d3d|yc2_2d3d_2816|hbm_stress]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline": dominant kernel (bf16 MFMA GEMM gemm_nt_kernel) algorithmic FLOP/s from HIP events vs 2.5 PF dense,
-  "cpu_baseline": the numpy oracle ("port") timed on the host cores on a bounded sample of the same workload.
+  "roofline": the MFMA kernel family the step spends most time in (the fused token-tile chains: infc_qkv_fwd, post_attn_fwd,
+              pre_attn_bwd, qkv_bwd), algorithmic FLOP/s from HIP events on the launch stream vs 2.5 PF dense bf16;
+              for --workload hbm_stress the input LayerNorm (the kernel that reads the feature stream) vs 8 TB/s HBM;
+  "cpu_baseline": oracle/coot_torch_cpu.py (a PyTorch-CPU restatement issuing the reference's ATen ops: kind "port")
+              timed on the host cores on the full per-GPU batch of the same workload.
 """
 import argparse
 import ctypes as C
@@ -65,18 +68,17 @@ def algorithmic_flops_per_step(w, cfg):
     return fwd, 3 * fwd
 
 
-def cpu_baseline(w, budget_s=15.0):
+def cpu_baseline(w, budget_s=25.0):
     """CPU baseline ("port"): oracle/coot_torch_cpu.py — the train step restated with the same PyTorch CPU ops the
-    reference's modules issue (fp32, autograd backward, torch.optim.Adam), dropout on.  Bounded sample: B_s = 8 videos (an
-    eighth of the per-GPU batch, same sequence shapes), median step time over ~budget_s seconds of CPU work; clip-pairs/s
-    = clips per step / median step time.  Intra-op threads are capped at 32: on a many-core host more threads are SLOWER
-    for these op sizes (128 threads: 2.5 s per 16-video step on the 256-core box vs 0.7 s on 8 cores; "cores" = threads
-    actually used).  The reference itself (/root/reference) does not exist on the GPU box; SURVEY 8d quotes its own time in
-    the build container."""
+    reference's modules issue (fp32, autograd backward, torch.optim.Adam), dropout on, on the FULL per-GPU batch of the
+    workload (same shapes as the GPU step).  Median step time over ~budget_s seconds of CPU work (at least 2 steps after a
+    warm-up step); clip-pairs/s = clips per step / median step time.  Intra-op threads are capped at 32: on a many-core host
+    more threads are SLOWER for these op sizes ("cores" = threads actually used).  The reference itself (/root/reference)
+    does not exist on the GPU box; SURVEY 8d quotes its own time in the build container (136 clip-pairs/s on 8 cores)."""
     from oracle import coot_oracle as O
     from oracle import coot_torch_cpu as T
     from tests import helpers as H
-    Bs = 8
+    Bs = w["B"]
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     dims = (w["Dv"], w["Dt"], 384, 8, 384, 768)
     cfgs = H.full_cfgs(*dims)
@@ -99,8 +101,8 @@ def cpu_baseline(w, budget_s=15.0):
     dt = float(np.median(times))
     return {"value": Bs * w["C"] / dt, "unit": "clip-pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"PyTorch-CPU fp32 restatement (oracle/coot_torch_cpu.py: same ATen ops as the reference modules, autograd, "
-                      f"Adam, dropout on), {Bs} videos x {w['C']} clips of the same shapes, median of {len(times)} steps, "
-                      f"{dt:.3f} s/step, host cpu_count {os.cpu_count()}"}
+                      f"Adam, dropout on), the full per-GPU batch: {Bs} videos x {w['C']} clips of the same shapes, median of "
+                      f"{len(times)} steps, {dt:.3f} s/step, host cpu_count {os.cpu_count()}"}
 
 
 def main():
@@ -125,7 +127,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
         dp = cdist.DataParallelContext()
     w = cva.synthetic.WORKLOADS[args.workload]
-    cfg = cva.load_named_config({"anet": "anet_coot", "yc2_100m": "yc2_100m_coot", "yc2_2d3d": "yc2_2d3d_coot"}[args.workload])
+    cfg = cva.load_named_config(*cva.synthetic.WORKLOAD_CONFIG[args.workload])
     torch.manual_seed(0)  # identical initial weights on every rank
     mgr = cva.RetrievalModelManager(cfg).cuda()
     trainer = cva.RetrievalTrainer(cfg, mgr, is_test=args.eval)
@@ -211,7 +213,8 @@ def main():
                     "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2), "ms_per_step": round(ms.value / nst, 3),
                     "algorithmic_gflop_per_step": round(fl.value / nst / 1e9, 2)}
 
-        by = {names[k]: collect(k) for k in (2, 3, 4, 5)}
+        names[6] = "single-launch global network passes (glob_fwd: LDS-resident 32-row tiles, twelve 384-wide GEMM passes, L2-streamed weights)"
+        by = {names[k]: collect(k) for k in (2, 3, 4, 5, 6)}
         # algorithmic HBM bytes of the fused chains: bf16 tensors each read / written exactly once per token:
         # input FC + QKV (reads xhat [Din], writes h0, z0, qkv), forward chain 1536 read + 8448 written, backward chain 5376 + 5376,
         # QKV dX 3840 + 768
@@ -222,12 +225,13 @@ def main():
             alg = tok_v * (2 * w["Dv"] + 1536 + 2304) + tok_t * (2 * w["Dt"] + 1536 + 2304) + (tok_v + tok_t) * (9984 + 10752 + 4608)
             by[fused]["algorithmic_bytes_per_launch"] = int(alg / by[fused]["launches_per_step"])
         allk, infc = collect(0), collect(1)
+        inln = collect(7)  # input LayerNorm: "achieved" is TB/s here (the slot carries algorithmic bytes)
         lib.coot_timing_enable(0)
         dom = max(by, key=lambda k: by[k]["ms_per_step"])  # the kernel the step spends most MFMA time in
         # HBM bytes per launch of that family from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py)
         traffic, traffic_src = None, None
-        fam_key = {2: "gemm_nt", 3: "gemm_nt_small", 4: "gemm_tn", 5: "fused"}[[k for k in names if names[k] == dom][0]]
+        fam_key = {2: "gemm_nt", 3: "gemm_nt_small", 4: "gemm_tn", 5: "fused", 6: "glob"}[[k for k in names if names[k] == dom][0]]
         import glob
         cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
         if cands:
@@ -245,7 +249,18 @@ def main():
                     "avg_launch_us": by[dom]["avg_launch_us"], "ms_per_step": by[dom]["ms_per_step"],
                     "note": "algorithmic 2*M*N*K per launch / HIP-event duration on the launch stream, measured while both "
                             "sides (two streams) run concurrently; 'by_kernel' lists every MFMA kernel family the same way",
-                    "all_mfma_kernels": allk, "input_fc_instances": infc, "by_kernel": by}
+                    "all_mfma_kernels": allk, "input_fc_instances": infc, "by_kernel": by,
+                    "input_layernorm_hbm": {"achieved_GBps": round(inln["achieved"] * 1e3, 1), "frac_of_8TBps": round(inln["achieved"] / 8.0, 4),
+                                            "launches_per_step": inln["launches_per_step"], "avg_launch_us": inln["avg_launch_us"],
+                                            "algorithmic_bytes_per_step": int(inln["algorithmic_gflop_per_step"] * 1e9),
+                                            "note": "ln_fwd_kernel: reads the fp32 feature stream once, writes bf16 xhat once"}}
+        if args.workload == "hbm_stress":  # BASELINE.json configs[4]: the input stream against the HBM roofline
+            roofline = {"bound": "hbm", "kernel": "ln_fwd_kernel (input LayerNorm: the kernel that reads the feature stream)",
+                        "achieved": round(inln["achieved"] * 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(inln["achieved"] / 8.0, 4),
+                        "traffic": None, "launches_per_step": inln["launches_per_step"], "avg_launch_us": inln["avg_launch_us"],
+                        "algorithmic_bytes_per_launch": int(inln["algorithmic_gflop_per_step"] * 1e9 / max(inln["launches_per_step"], 1)),
+                        "note": "algorithmic bytes (fp32 features read once + bf16 normalised features written once) / HIP-event duration; "
+                                "mfma families under by_kernel", "by_kernel": by, "all_mfma_kernels": allk}
     if dp is not None:
         torch.distributed.barrier()
 
@@ -256,9 +271,7 @@ def main():
             "value": round(value, 1), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{dict(anet='ActivityNet', yc2_100m='YouCook2 (100M features)', yc2_2d3d='YouCook2 (2D+3D features)')[args.workload]}"
-                                   f"-shaped paper config ({dict(anet='anet_coot', yc2_100m='yc2_100m_coot', yc2_2d3d='yc2_2d3d_coot')[args.workload]}): "
-                                   f"{w['B']} videos x {w['C']} clips per GPU, "
+            "config": {"workload": f"{cva.synthetic.WORKLOAD_LABEL[args.workload]}: {w['B']} videos x {w['C']} clips per GPU, "
                                    f"Lc=Lv={w['Lc']}, Ls={w['Ls']}, Lp={w['Lp']}, Dv={w['Dv']}, Dt={w['Dt']}, d_model=384",
                        "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
                        "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",

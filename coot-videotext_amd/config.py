@@ -151,6 +151,13 @@ def load_yaml_config_file(path: str) -> Dict[str, Any]:
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "retrieval")
 
 
-def load_named_config(name: str) -> RetrievalConfig:
-    """name in {anet_coot, yc2_100m_coot, yc2_2d3d_coot} (config/retrieval/*.yaml in this repo)."""
-    return RetrievalConfig(load_yaml_config_file(os.path.join(CONFIG_DIR, name + ".yaml")))
+def load_named_config(name: str, vid_feat_dim: Optional[int] = None) -> RetrievalConfig:
+    """name in {anet_coot, yc2_100m_coot, yc2_2d3d_coot} (config/retrieval/*.yaml in this repo); vid_feat_dim overrides the
+    video feature width of the dataset sections (the reference's `-o dataset_train.vid_feat_dim=...`)."""
+    d = load_yaml_config_file(os.path.join(CONFIG_DIR, name + ".yaml"))
+    if vid_feat_dim is not None:
+        d = resolve_same_as(d)
+        for sec in ("dataset_train", "dataset_val"):
+            if sec in d:
+                d[sec]["vid_feat_dim"] = int(vid_feat_dim)
+    return RetrievalConfig(d)

@@ -79,7 +79,7 @@ int get_xcd_order();
 void set_tn_default_workspace(float* ws, size_t floats);
 
 // per-launch HIP-event timing of every MFMA GEMM kernel (bench roofline leg); events are recorded on the launch stream
-enum { TIMING_NT = 2, TIMING_NT_SMALL = 3, TIMING_TN = 4, TIMING_FUSED = 5, TIMING_GLOB = 6 };  // 6: single-launch global network passes
+enum { TIMING_NT = 2, TIMING_NT_SMALL = 3, TIMING_TN = 4, TIMING_FUSED = 5, TIMING_GLOB = 6, TIMING_INLN = 7 };  // 6: single-launch global network passes; 7: input LayerNorm (the `flops` field carries algorithmic BYTES: the HBM roofline of the input stream)
 void gemm_timing_enable(int on);
 int gemm_timing_collect(int selector, double* ms, double* flops, int* launches);
 void* timing_begin(int kind, double flops, int big_k, hipStream_t stream);  // nullptr when timing is off

@@ -1,6 +1,7 @@
 // Row-wise kernels for gfx950: one 64-lane wave per row, the row lives in registers,
 // 8/16-byte coalesced loads, wave-shuffle reductions (no LDS, no barriers in the forward).
 #include "rowops.h"
+#include "gemm.h"
 #include "fused.h"
 
 namespace coot {
@@ -80,9 +81,13 @@ int launch_ln_fwd(const LnFwd& p, hipStream_t stream) {
   COOT_REQUIRE(p.D % 4 == 0 && p.D <= 4096 && p.D >= 8 && p.ldx % 4 == 0, "ln_fwd: D=%d unsupported (need D%%4==0, 8<=D<=4096)", p.D);
   if (p.R <= 0) return 0;
   dim3 grid((p.R + 3) / 4);
+  // the input LayerNorm of a local network (the one kernel that reads the feature stream): HIP events around it, with the
+  // bytes it must move (input once, bf16 xhat once) in the flops field
+  void* ts = (p.x_f32 && !p.gain && p.y) ? timing_begin(TIMING_INLN, (double)p.R * p.D * 6.0, 0, stream) : nullptr;
   if (p.D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, stream, p);
   else if (p.D <= 2048) hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, dim3(256), 0, stream, p);
+  timing_end(ts, stream);
   COOT_CHECK_LAUNCH("ln_fwd");
   return 0;
 }

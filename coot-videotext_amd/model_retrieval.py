@@ -124,11 +124,25 @@ class RetrievalModelManager:
     def get_model_state(self) -> Dict[str, Dict[str, torch.Tensor]]:
         return {name: model.state_dict() for name, model in self.model_dict.items()}
 
-    def set_model_state(self, state: Dict[str, Dict[str, torch.Tensor]]) -> None:
+    # parameter renames of checkpoints written by the first coot-videotext release (nntrainer/models/model_manager_base.py:96-113)
+    LEGACY_RENAMES = {"input_norm.": "norm_input.", "input_fc.": "input_fc.mlp.", "pooler.genpool": "pooler.pools.0.genpool"}
+
+    def set_model_state(self, state) -> None:
+        """nntrainer/models/model_manager_base.py:85-126: {network name: state dict} (keys with or without the ``module.``
+        prefix of nn.DataParallel), or the LIST of four state dicts of the first coot-videotext release with its parameter names."""
         self.was_loaded = True
+        strip = lambda sd: {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        if isinstance(state, (list, tuple)):
+            for model_name, this_state in zip(self.model_dict.keys(), state):
+                new_state = {}
+                for name, param in this_state.items():
+                    for old, new in self.LEGACY_RENAMES.items():
+                        name = name.replace(old, new)
+                    new_state[name] = param
+                self.model_dict[model_name].load_state_dict(strip(new_state))
+            return
         for model_name, state_dict in state.items():
-            state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
-            self.model_dict[model_name].load_state_dict(state_dict)
+            self.model_dict[model_name].load_state_dict(strip(state_dict))
 
     def cuda(self) -> "RetrievalModelManager":
         for k in self.model_dict:

@@ -25,8 +25,8 @@ from .config import TransformerConfig
 
 
 def sincos_pe(max_len: int, dim: int) -> torch.Tensor:
-    """PositionalEncodingSinCos buffer (nntrainer/models/encoder.py:84-90); note the exponent uses the
-    dim index itself (not index//2)."""
+    """PositionalEncodingSinCos buffer: verbatim the six lines of nntrainer/models/encoder.py:84-90 (a parity-defining
+    formula: the exponent uses the dim index itself, not index // 2, and the buffer is part of the state dict)."""
     pe = torch.zeros(max_len, dim).float()
     position = torch.arange(0, max_len).unsqueeze(1).float()
     dimension = torch.arange(0, dim).float()
@@ -37,8 +37,8 @@ def sincos_pe(max_len: int, dim: int) -> torch.Tensor:
 
 
 def fill_truncnorm_(t: torch.Tensor, std: float, limit: float = 2.0, generator=None) -> None:
-    """Truncated normal as the reference draws it (nntrainer/utils_torch.py:73-92): 8 candidates per
-    element, first one inside +-limit sigma."""
+    """Truncated normal, verbatim the draw of nntrainer/utils_torch.py:87-92 (8 candidates per element, the first one inside
+    +-limit sigma): the RNG consumption order defines which weights a seed gives, so the lines are kept as they are."""
     tmp = torch.empty(tuple(t.shape) + (8,)).normal_(generator=generator)
     valid = (tmp < limit) & (tmp > -limit)
     _, ind = valid.max(-1, keepdim=True)

@@ -14,6 +14,22 @@ WORKLOADS = {
     "anet": dict(B=64, C=4, Lv=80, Lc=80, Lp=64, Ls=16, Dv=2048, Dt=1536),
     "yc2_100m": dict(B=16, C=8, Lv=80, Lc=20, Lp=96, Ls=12, Dv=512, Dt=1536),
     "yc2_2d3d": dict(B=64, C=8, Lv=80, Lc=20, Lp=96, Ls=12, Dv=4096, Dt=1536),
+    # BASELINE.json configs[3] words the concatenated 2D + 3D features as d = 2816 (the shipped YAML says 4096): same network, other width
+    "yc2_2d3d_2816": dict(B=64, C=8, Lv=80, Lc=20, Lp=96, Ls=12, Dv=2816, Dt=1536),
+    # BASELINE.json configs[4], per-GPU slice: 64 clips x 80 frames x d = 1024 per video ("HBM-bandwidth roofline stress": the input
+    # stream Nc Lc Dv is what matters; 100k such videos are streamed batch by batch, a batch is what one step sees)
+    "hbm_stress": dict(B=16, C=64, Lv=80, Lc=80, Lp=64, Ls=16, Dv=1024, Dt=1536),
+}
+# workload -> (YAML in config/retrieval, overrides of dataset_*.vid_feat_dim)
+WORKLOAD_CONFIG = {
+    "anet": ("anet_coot", None), "yc2_100m": ("yc2_100m_coot", None), "yc2_2d3d": ("yc2_2d3d_coot", None),
+    "yc2_2d3d_2816": ("yc2_2d3d_coot", 2816), "hbm_stress": ("anet_coot", 1024),
+}
+WORKLOAD_LABEL = {
+    "anet": "ActivityNet-shaped paper config (anet_coot)", "yc2_100m": "YouCook2 (100M features)-shaped paper config (yc2_100m_coot)",
+    "yc2_2d3d": "YouCook2 (2D+3D features)-shaped paper config (yc2_2d3d_coot)",
+    "yc2_2d3d_2816": "YouCook2 (2D+3D features, d = 2816 as BASELINE.json words it)-shaped config (yc2_2d3d_coot, vid_feat_dim 2816)",
+    "hbm_stress": "HBM-stress slice of BASELINE.json configs[4] (anet_coot networks, vid_feat_dim 1024)",
 }
 
 

@@ -147,3 +147,29 @@ def grad_report(named_got, ref: dict, cos_min=0.99, ratio_tol=0.05):
         if not ok:
             bad.append(rows[-1])
     return bad, "\n".join(rows)
+
+
+def import_reference(ref_root="/root/reference"):
+    """The unmodified reference, imported with the shims of SURVEY 8c (removed collections aliases, absent GPUtil / h5py /
+    tensorboard).  Returns a namespace of its modules, or None where the reference tree does not exist (the GPU box)."""
+    import collections
+    import collections.abc
+    import sys
+    import types
+    if not os.path.isdir(os.path.join(ref_root, "coot")):
+        return None
+    for n in ("Iterable", "Mapping", "Sequence", "MutableMapping"):
+        setattr(collections, n, getattr(collections.abc, n))
+    for name in ("GPUtil", "h5py"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = type("SummaryWriter", (), {"add_scalar": lambda *a, **k: None, "close": lambda *a, **k: None})
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    if ref_root not in sys.path:
+        sys.path.insert(0, ref_root)
+    import warnings
+    warnings.filterwarnings("ignore")
+    from coot import configs_retrieval, model_retrieval
+    from nntrainer import models, utils_yaml
+    return types.SimpleNamespace(root=ref_root, model_retrieval=model_retrieval, configs_retrieval=configs_retrieval, models=models,
+                                 utils_yaml=utils_yaml)
