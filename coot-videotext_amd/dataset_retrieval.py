@@ -187,7 +187,15 @@ class DeviceLoader:
         hb = collate_fn(item, self.host[k], self.bf16, self.threads) if isinstance(item, list) else item
         nbytes = hb.arena.nbytes
         if self.dev[k].numel() < nbytes:
-            self.dev[k] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=self.device)
+            # (Re)allocate ON the copy stream: the caching allocator may hand out a block the consumer's stream freed while kernels
+            # reading it are still queued there; a block allocated under the copy stream is only re-used in that stream's order,
+            # and record_stream tells the allocator that the consumer's stream reads it too.  The copy stream first waits for
+            # everything the consumer has enqueued so far (the old arena of this slot may still be in use until then).
+            consumer = torch.cuda.current_stream(self.device)
+            self.copy_stream.wait_stream(consumer)
+            with torch.cuda.stream(self.copy_stream):
+                self.dev[k] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=self.device)
+            self.dev[k].record_stream(consumer)
         if self.consumed[k] is not None:
             self.copy_stream.wait_event(self.consumed[k])
         with torch.cuda.stream(self.copy_stream):

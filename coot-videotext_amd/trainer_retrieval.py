@@ -192,26 +192,43 @@ class RetrievalTrainer:
         shapes; a new batch of the same shapes is copied into the captured input buffers)."""
         if not use_graph:
             return self._step_impl(batch, vid_counts, clip_counts)
-        g = getattr(self, "_graph", None)
-        if g is None or not self._graph_matches(batch):
-            self._capture(batch, vid_counts, clip_counts)
-        elif batch is not self._graph_batch:
+        if isinstance(self.optimizer, RAdam):
+            # its step count and rectification scalars are host values: a replay would freeze them (the native step keeps them in a
+            # device block instead: train_step_native(use_graph=True))
+            raise NotImplementedError("train_step(use_graph=True) supports torch.optim.Adam only; use train_step_native for RAdam")
+        lr = float(self.optimizer.param_groups[0]["lr"])
+        key = self._graph_key(batch, lr)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get(key)
+        if g is None:  # one graph per (batch shapes, learning rate): ragged batches and LR schedule steps re-capture, they never re-use a stale graph
+            g = graphs[key] = self._capture(batch, vid_counts, clip_counts)
+        if batch is not g["batch"]:
             for name, value in batch.__dict__.items():
                 if torch.is_tensor(value):
-                    getattr(self._graph_batch, name).copy_(value, non_blocking=True)
-        self._graph.replay()
+                    getattr(g["batch"], name).copy_(value, non_blocking=True)
+        g["graph"].replay()
         self.total_step += 1
-        return self._graph_out
+        return g["out"]
 
-    def _graph_matches(self, batch) -> bool:
-        ref = self._graph_batch
-        return all((not torch.is_tensor(v)) or (v.shape == getattr(ref, k).shape) for k, v in batch.__dict__.items()) \
-            and batch.max_clip_num == ref.max_clip_num and batch.max_sent_num == ref.max_sent_num
+    @staticmethod
+    def _graph_key(batch, lr: float):
+        return (tuple((k, tuple(v.shape)) for k, v in sorted(batch.__dict__.items()) if torch.is_tensor(v)), batch.max_clip_num,
+                batch.max_sent_num, lr)
 
-    def _capture(self, batch, vid_counts, clip_counts, warmup: int = 3) -> None:
-        """Whole-step capture: eager warm-up on a side stream (allocator, RCCL, lazy inits), then one capture."""
+    def _capture(self, batch, vid_counts, clip_counts, warmup: int = 3):
+        """Whole-step capture.  The eager warm-up (allocator, RCCL, lazy optimizer state) runs on a SNAPSHOT: parameters,
+        optimizer state, step counters and the dropout seed are restored afterwards, so the first call for a shape applies exactly
+        one update — the replay's — like every other call.  (The warm-up used to be three real optimizer steps per capture.)"""
         if batch.max_clip_num is None or batch.max_sent_num is None:
             raise RuntimeError("graph capture needs batch.max_clip_num / max_sent_num on the host (no device sync inside a graph)")
+        import copy
+        nets = list(self.model_mgr.model_dict.values())
+        if getattr(self, "_seed_dev", None) is None:
+            self._step_prepare_seed(batch, nets)
+        had_state = len(self.optimizer.state) > 0
+        # parameters first: the warm-up steps below (and, without optimizer state yet, the steps that create it) all move them
+        snap = dict(params=[n._flat.detach().clone() for n in nets], total_step=self.total_step, seed=self._seed_dev.clone())
+        snap["opt"] = copy.deepcopy(self.optimizer.state_dict()) if had_state else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -219,11 +236,39 @@ class RetrievalTrainer:
                 self._step_impl(batch, vid_counts, clip_counts)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._graph_batch = batch
+
+        def restore():
+            with torch.no_grad():
+                for n, p0 in zip(nets, snap["params"]):
+                    n._flat.copy_(p0)
+            if had_state:
+                # in place, so that the state tensors the graph captured stay the optimizer's
+                cur = self.optimizer.state_dict()["state"]
+                for idx, st in snap["opt"]["state"].items():
+                    for name, val in st.items():
+                        if torch.is_tensor(val):
+                            cur[idx][name].copy_(val)
+            else:
+                for st in self.optimizer.state.values():
+                    for name, val in st.items():
+                        if torch.is_tensor(val):
+                            val.zero_()
+            self.total_step = snap["total_step"]
+            self._seed_dev.copy_(snap["seed"])
+            self.model_mgr.mark_weights_dirty()
+
+        restore()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self._step_impl(batch, vid_counts, clip_counts)
-        self._graph, self._graph_out = graph, out
+        # the capture itself executed nothing, but host-side bookkeeping of _step_impl ran: put the counters back
+        self.total_step = snap["total_step"]
+        return dict(graph=graph, out=out, batch=batch)
+
+    def _step_prepare_seed(self, batch, nets) -> None:
+        self._seed_dev = torch.zeros(1, dtype=torch.int64, device=batch.vid_feat.device)
+        for net in nets:
+            net.seed_dev = self._seed_dev
 
     def _sync_global_max(self, batch) -> None:
         """Data parallel: every rank pads its packed clip / sentence embeddings to the GLOBAL max count per video (one
@@ -242,9 +287,7 @@ class RetrievalTrainer:
         self._sync_global_max(batch)
         nets = list(self.model_mgr.model_dict.values())
         if getattr(self, "_seed_dev", None) is None:
-            self._seed_dev = torch.zeros(1, dtype=torch.int64, device=batch.vid_feat.device)
-            for net in nets:
-                net.seed_dev = self._seed_dev
+            self._step_prepare_seed(batch, nets)
         self._seed_dev += 1  # device-side dropout seed: advances on every step, also under graph replay
         flat_grads = [net.bind_flat_grads() for net in nets]
         for net, g in zip(nets, flat_grads):
@@ -324,6 +367,13 @@ class RetrievalTrainer:
             st.step = 0
             st.dims_key = None
             self._native = st
+            pending = self.__dict__.pop("_native_pending", None)
+            if pending is not None:  # optimizer state loaded before the first native step (load_optimizer_state_dict)
+                st.step = int(pending["step"])
+                for dst, src in zip(st.m, pending["m"]):
+                    dst.copy_(src)
+                for dst, src in zip(st.v, pending["v"]):
+                    dst.copy_(src)
         for i, n in enumerate(nets):  # arenas move when a module is re-flattened (.cuda()/load): refresh every call
             st.bufs.params[i], st.bufs.grads[i], st.bufs.wpack[i] = n._flat.data_ptr(), n._grad_flat.data_ptr(), n._wpack.data_ptr()
             st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i] = st.m[i].data_ptr(), st.v[i].data_ptr(), st.decay[i].data_ptr()
@@ -351,6 +401,37 @@ class RetrievalTrainer:
             assert t_.dtype == torch.int64 and t_.is_contiguous(), src
             setattr(x, f, t_.data_ptr())
         return st, x
+
+    # ---- optimizer state of either path, for optimizer_<epoch>.pth (nntrainer/trainer_base.py:685-707) ------------------------
+    def optimizer_state_dict(self) -> Dict[str, Any]:
+        """What a checkpoint must hold to resume training: ``self.optimizer.state_dict()`` (the autograd path's torch optimizer)
+        and, when native steps have run, the library's optimizer state — the flat first / second moment arenas of the four
+        networks and the step count (coot_train_step keeps them outside torch.optim, so the torch state dict alone would
+        resume with zero moments and bias-correction step 1)."""
+        out: Dict[str, Any] = {"optimizer": self.optimizer.state_dict() if self.optimizer is not None else None, "total_step": self.total_step}
+        st = getattr(self, "_native", None)
+        if st is not None:
+            out["native"] = {"step": int(st.step), "m": [t.detach().cpu().clone() for t in st.m], "v": [t.detach().cpu().clone() for t in st.v]}
+        return out
+
+    def load_optimizer_state_dict(self, state: Dict[str, Any], batch_for_setup: Optional[RetrievalDataBatchTuple] = None) -> None:
+        """Inverse of optimizer_state_dict.  The native state is created lazily by the first native step; when it does not exist
+        yet the loaded moments are kept and installed by _native_setup."""
+        if state.get("optimizer") is not None and self.optimizer is not None:
+            self.optimizer.load_state_dict(state["optimizer"])
+        self.total_step = int(state.get("total_step", self.total_step))
+        nat = state.get("native")
+        if nat is None:
+            return
+        st = getattr(self, "_native", None)
+        if st is None:
+            self._native_pending = nat
+            return
+        st.step = int(nat["step"])
+        for dst, src in zip(st.m, nat["m"]):
+            dst.copy_(src)
+        for dst, src in zip(st.v, nat["v"]):
+            dst.copy_(src)
 
     # ---- the native step as a replayed hipGraph ----------------------------------------------------------------------
     _GRAPH_FEATS = ("vid_feat", "clip_feat", "par_feat", "sent_feat")

@@ -792,8 +792,14 @@ def make_batch(seed: int, B: int, counts, Lv: int, Lc: int, Lp: int, Ls: int, Dv
     return b
 
 
+def anet_like_counts(seed, B):
+    """Clips per video with the shape of the ActivityNet annotation statistics (mean 3.74, p95 7, max 27)."""
+    rs = np.random.RandomState(seed)
+    return np.minimum(27, 1 + rs.negative_binomial(2, 0.42, B)).astype(np.int64)
+
+
 def make_latent_batch(seed: int, B: int, counts, Lv: int, Lc: int, Lp: int, Ls: int, Dv: int, Dt: int, latent: int = 32,
-                      noise: float = 0.5, map_seed: int = 12345):
+                      noise: float = 0.5, map_seed: int = 12345, clusters: int = 0, spread: float = 1.0):
     """Seeded batch with a LEARNABLE video-text correspondence (SURVEY 8d retrieval-parity set): every clip / sentence pair shares
     a latent code u ~ N(0, I_latent); its frames are A u + noise, its words B u + noise (A, B fixed by map_seed, the same for
     every batch); the frames of a video / the words of its paragraph are those of its clips / sentences, sub-sampled to Lv / Lp.
@@ -805,6 +811,11 @@ def make_latent_batch(seed: int, B: int, counts, Lv: int, Lc: int, Lp: int, Ls: 
     counts = np.full(B, counts, dtype=np.int64) if np.isscalar(counts) else np.asarray(counts, dtype=np.int64)
     Nc = int(counts.sum())
     u = rs.randn(Nc, latent)
+    if clusters > 0:
+        # confusable neighbours: every code sits near one of `clusters` shared centres (fixed by map_seed), `spread` of its norm
+        # is its own — retrieval inside a cluster has to resolve the small individual part (near-ties, as in real data)
+        centres = rm.randn(clusters, latent)
+        u = math.sqrt(max(0.0, 1.0 - spread * spread)) * centres[rs.randint(0, clusters, size=Nc)] + spread * u
     clip_len = rs.randint(max(1, Lc // 4), Lc + 1, size=Nc).astype(np.int64); clip_len[rs.randint(0, Nc)] = Lc
     sent_len = rs.randint(max(1, Ls // 3), Ls + 1, size=Nc).astype(np.int64); sent_len[rs.randint(0, Nc)] = Ls
 

@@ -241,3 +241,52 @@ def test_train_model_epoch_loop_early_stop_and_schedule(cva):
     want = [base / 3, base * 2 / 3] + [base] * 6 + [base * 0.1] * 6 + [base * 0.1 ** 2] * 6 + [base * 0.1 ** 3]
     assert np.allclose(per_epoch, want, rtol=1e-12), per_epoch
     assert np.allclose(hist["train_loss"], 1.0)
+
+
+def test_embedding_export_hdf5_branch_with_a_recording_h5py(tmp_path, monkeypatch):
+    """save_embeddings' HDF5 branch (coot/trainer_retrieval.py:404-415: ``with h5py.File(filename, mode="w") as h5: h5[name] =
+    array``).  h5py is not installed in this image, so the branch runs against a recording stand-in with h5py's call surface
+    (File(path, mode=...) as a context manager, item assignment): what is checked is the call pattern, the dataset names the
+    consumers read (mart/recursive_caption_dataset.py:159-201, test_embeddings_retrieval.py:21-38) and the value types h5py
+    accepts (numeric ndarrays, a list of str for ``key``) — the file format itself is h5py's business."""
+    import sys
+    import types
+    from coot_videotext_amd.trainer_retrieval import save_embeddings
+    written = {}
+
+    class _File:
+        def __init__(self, path, mode="r"):
+            assert mode == "w"
+            self.path, self.d = path, {}
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            written[self.path] = self.d
+            open(self.path, "wb").close()
+            return False
+
+        def __setitem__(self, k, v):
+            assert isinstance(k, str) and k not in self.d
+            if isinstance(v, (list, tuple)):   # h5py stores a list of str as a variable-length string dataset
+                assert all(isinstance(x, str) for x in v)
+            else:
+                assert isinstance(v, np.ndarray) and v.dtype.kind in "fiu", (k, type(v))
+            self.d[k] = v
+
+    fake = types.ModuleType("h5py")
+    fake.File = _File
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    names = ["vid_emb", "par_emb", "clip_emb", "sent_emb", "vid_context", "par_context"]
+    rs = np.random.RandomState(0)
+    emb = {"clip_num": np.array([2, 1, 3]), "sent_num": np.array([2, 1, 3]), "key": ["a", "b", "c"]}
+    for n in names:
+        raw = rs.randn(6 if n in ("clip_emb", "sent_emb") else 3, 8).astype(np.float32)
+        emb[n + "_before_norm"] = raw
+        emb[n] = raw / np.sqrt((raw * raw).sum(-1, keepdims=True))
+    fn = save_embeddings(emb, str(tmp_path / "embeddings_7.h5"))
+    assert fn.endswith("embeddings_7.h5") and os.path.exists(fn)
+    d = written[fn]
+    assert set(d) == {"clip_num", "sent_num", "key"} | set(names) | {n + "_before_norm" for n in names}
+    assert d["key"] == ["a", "b", "c"] and np.array_equal(d["vid_emb"], emb["vid_emb"])

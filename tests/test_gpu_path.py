@@ -688,7 +688,8 @@ def test_fused_chain_matches_per_op_kernels(env, name, cfg, N, L, with_ctx, trai
     (p0, t0, g0), (p1, t1, g1) = res
     ep, et = H.rel_err(p1, p0), H.rel_err(t1, t0)
     print(f"[{name}] fused vs per-op: pooled rel err {ep:.2e}, tokens {et:.2e}")
-    assert ep < 5e-3 and et < 5e-3
+    # (context networks: the single-launch path keeps the attention probabilities in fp32, see the test of that path below)
+    assert ep < 5e-3 and et < (1.5e-2 if with_ctx else 5e-3)
     # key-projection bias: the true gradient is zero (softmax shift invariance), both paths hold round-off noise there
     bad, table = H.grad_report([(n, g) for n, g in g1.items() if "key_projection.bias" not in n], g0, cos_min=0.999, ratio_tol=0.01)
     assert not bad, "\n".join(bad)
@@ -731,3 +732,85 @@ def test_global_network_single_launch_matches_per_op_kernels(env, N, L, train):
     assert H.cosine_flat(dx1[valid], dx0[valid]) > 0.999 and H.cosine_flat(dh1, dh0) > 0.999
     bad, table = H.grad_report([(n, g) for n, g in g1.items() if "key_projection.bias" not in n], g0, cos_min=0.999, ratio_tol=0.01)
     assert not bad, "\n".join(bad)
+
+
+def test_autograd_graph_step_is_one_update_per_call(env):
+    """train_step(use_graph=True) (the autograd step captured as one HIP graph): the capture's eager warm-up runs on a snapshot, so
+    every call — the first one for a shape included — applies exactly ONE optimizer update; a learning-rate change between calls
+    re-captures instead of replaying the old rate; RAdam (host-side step scalars) is refused."""
+    torch, cva = env
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    counts = [1, 2, 3, 4, 2, 1]
+    batch = cva.synthetic.make_batch(7, 6, counts, 12, 10, 9, 6, dims[0], dims[1], ragged=False)
+    res = []
+    for graph in (False, True):
+        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg_x, mgr)
+        losses = []
+        for it in range(4):
+            if it == 2:
+                for grp in tr.optimizer.param_groups:
+                    grp["lr"] = 2e-4
+            losses.append(float(tr.train_step(batch, use_graph=graph)[0]))
+        torch.cuda.synchronize()
+        assert tr.total_step == 4
+        if graph:
+            assert len(tr._graphs) == 2  # one per learning rate
+        res.append((losses, [n._flat.clone() for n in mgr.model_dict.values()]))
+    (la, pa), (lb, pb) = res
+    assert np.allclose(la, lb, rtol=2e-3, atol=2e-5), (la, lb)  # loss BEFORE each update: equal only if the update counts are
+    for a, b in zip(pa, pb):
+        d = (a - b).abs()
+        assert float((d > 1e-6).float().mean()) < 2e-2 and float(d.max()) <= 2.5e-3, (float((d > 1e-6).float().mean()), float(d.max()))
+    cfg_r, mgr_r = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+    cfg_r.optimizer.name = "radam"
+    tr_r = cva.RetrievalTrainer(cfg_r, mgr_r)
+    with pytest.raises(NotImplementedError):
+        tr_r.train_step(batch, use_graph=True)
+
+
+def test_native_optimizer_state_round_trip(env):
+    """optimizer_state_dict / load_optimizer_state_dict: a run resumed from (model state, optimizer state) after two native steps
+    continues exactly like the uninterrupted run (Adam moments and the bias-correction step count live in the library, not in
+    torch.optim: without them the third step would restart from zero moments)."""
+    torch, cva = env
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batch = cva.synthetic.make_batch(7, 6, [1, 2, 3, 4, 2, 1], 12, 10, 9, 6, dims[0], dims[1], ragged=True)
+    cfg_a, mgr_a = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+    mgr_a.set_all_models_train()
+    ta = cva.RetrievalTrainer(cfg_a, mgr_a)
+    for it in range(2):
+        ta.train_step_native(batch)
+    torch.cuda.synchronize()
+    ckpt_model = {k: {n: v.detach().cpu().clone() for n, v in sd.items()} for k, sd in mgr_a.get_model_state().items()}
+    ckpt_opt = ta.optimizer_state_dict()
+    assert ckpt_opt["native"]["step"] == 2 and float(ckpt_opt["native"]["v"][0].abs().max()) > 0
+    ta.train_step_native(batch)
+    # resumed run
+    cfg_b, mgr_b = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+    mgr_b.set_model_state(ckpt_model)
+    mgr_b.cuda()
+    mgr_b.set_all_models_train()
+    tb = cva.RetrievalTrainer(cfg_b, mgr_b)
+    tb.load_optimizer_state_dict(ckpt_opt)       # before the first native step: installed when the native state is created
+    tb.train_step_native(batch)
+    # cold restart for contrast: same parameters, no optimizer state
+    cfg_c, mgr_c = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+    mgr_c.set_model_state(ckpt_model)
+    mgr_c.cuda()
+    mgr_c.set_all_models_train()
+    tc = cva.RetrievalTrainer(cfg_c, mgr_c)
+    tc.train_step_native(batch)
+    torch.cuda.synchronize()
+    assert tb._native.step == 3 and tb.total_step == 3
+    d_resumed = max(float((a._flat - b._flat).abs().max()) for a, b in zip(mgr_a.model_dict.values(), mgr_b.model_dict.values()))
+    d_cold = max(float((a._flat - c._flat).abs().max()) for a, c in zip(mgr_a.model_dict.values(), mgr_c.model_dict.values()))
+    print(f"resumed vs uninterrupted: max |dp| {d_resumed:.2e}; cold restart: {d_cold:.2e}")
+    assert d_resumed <= 2.1e-3 and d_cold > 3 * max(d_resumed, 1e-5) or d_resumed < 1e-6
+    frac = np.mean([float(((a._flat - b._flat).abs() > 1e-6).float().mean()) for a, b in zip(mgr_a.model_dict.values(), mgr_b.model_dict.values())])
+    assert frac < 5e-3, frac
