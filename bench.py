@@ -44,10 +44,26 @@ def parse():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (phase calls + RCCL collectives) even with one rank")
     ap.add_argument("--step-stamps", action="store_true", help="print a HIP-event timeline of one training step to stderr")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
+    ap.add_argument("--padded", action="store_true", help="ragged workloads: run the reference's padded layout instead of packed (varlen) rows")
     ap.add_argument("--mode", default="native", choices=["native", "native-graph", "native-phases", "autograd", "graph"],
                     help="native: one C call per step (default); native-graph: that call captured once and replayed as a hipGraph; "
                          "autograd: torch autograd Functions; graph: autograd step in a HIP graph")
     return ap.parse_args()
+
+
+def algorithmic_flops_ragged(lens, D=384):
+    """The same count from the real lengths of a ragged batch: tokens beyond a sequence's length are not useful work
+    (len tokens, len^2 attention); lens = dict of numpy arrays vid / clip / par / sent lengths and clip counts per video."""
+    def loc(din, l):
+        l = l.astype(np.float64)
+        return float((l * (2 * din * D + 18 * D * D) + 4 * l * l * D).sum())
+
+    fwd = loc(lens["Dv"], lens["clip"]) + loc(lens["Dv"], lens["vid"]) + loc(lens["Dt"], lens["sent"]) + loc(lens["Dt"], lens["par"])
+    Cn = lens["counts"].astype(np.float64)
+    fwd += 2 * float((Cn * (12 * D * D + 4 * Cn * D) + Cn * 4 * D * D + 8 * D * D + 4 * Cn * D).sum())
+    B, Nc = len(Cn), float(Cn.sum())
+    fwd += 2 * (3 * B * B * 768 + 3 * Nc * Nc * D + B * B * D)
+    return fwd, 3 * fwd
 
 
 def algorithmic_flops_per_step(w, cfg):
@@ -83,7 +99,8 @@ def cpu_baseline(w, budget_s=25.0):
     dims = (w["Dv"], w["Dt"], 384, 8, 384, 768)
     cfgs = H.full_cfgs(*dims)
     Ps = [T.to_torch_params(O.make_params(cfgs[i], 5 + 10 * i, dtype=np.float32)) for i in range(4)]
-    b = O.make_batch(1, Bs, w["C"], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=False, dtype=np.float32)
+    counts = w["C"] if w["C"] else O.anet_like_counts(4321, Bs)   # C = 0: the ragged workload (the CPU path pads, as the reference does)
+    b = O.make_batch(1, Bs, counts, w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=not w["C"], dtype=np.float32)
     idx = np.zeros(Bs, dtype=np.int64)
     opt = torch.optim.Adam([v for P in Ps for k, v in P.items() if v.requires_grad], lr=1e-3, weight_decay=2e-5)
 
@@ -99,9 +116,9 @@ def cpu_baseline(w, budget_s=25.0):
         one()
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
-    return {"value": Bs * w["C"] / dt, "unit": "clip-pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    return {"value": float(np.sum(b["clip_num"])) / dt, "unit": "clip-pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"PyTorch-CPU fp32 restatement (oracle/coot_torch_cpu.py: same ATen ops as the reference modules, autograd, "
-                      f"Adam, dropout on), the full per-GPU batch: {Bs} videos x {w['C']} clips of the same shapes, median of "
+                      f"Adam, dropout on), the full per-GPU batch: {Bs} videos, {int(np.sum(b['clip_num']))} clips of the same shapes, median of "
                       f"{len(times)} steps, {dt:.3f} s/step, host cpu_count {os.cpu_count()}"}
 
 
@@ -134,10 +151,18 @@ def main():
     if dp is not None:
         trainer.dp = dp
         trainer.comm_stream = torch.cuda.Stream()
-    batch = cva.synthetic.make_batch(1234 + rank, w["B"], w["C"], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=False)
+    ragged = w["C"] == 0
+    if ragged:  # every rank knows every rank's clip counts (seeded): no collective for the shard sizes or the global Cmax
+        all_counts = [cva.synthetic.anet_like_counts(4321 + r, w["B"]) for r in range(world)]
+        batch = cva.synthetic.make_batch(1234 + rank, w["B"], all_counts[rank], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=True,
+                                         packed=not args.padded)
+        batch.max_clip_num = batch.max_sent_num = int(max(c.max() for c in all_counts))
+        clip_counts = [int(c.sum()) for c in all_counts]
+    else:
+        batch = cva.synthetic.make_batch(1234 + rank, w["B"], w["C"], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=False)
+        clip_counts = [w["B"] * w["C"]] * world
     vid_counts = [w["B"]] * world
-    clip_counts = [w["B"] * w["C"]] * world
-    clip_pairs = w["B"] * w["C"] * world
+    clip_pairs = sum(clip_counts)
 
     if args.eval:
         mgr.set_all_models_eval()
@@ -218,8 +243,11 @@ def main():
         # algorithmic HBM bytes of the fused chains: bf16 tensors each read / written exactly once per token:
         # input FC + QKV (reads xhat [Din], writes h0, z0, qkv), forward chain 1536 read + 8448 written, backward chain 5376 + 5376,
         # QKV dX 3840 + 768
-        tok_v = w["B"] * w["Lv"] + w["B"] * w["C"] * w["Lc"]
-        tok_t = w["B"] * w["Lp"] + w["B"] * w["C"] * w["Ls"]
+        if ragged and not args.padded:  # rows the kernels process: the valid tokens
+            tok_v = int(batch.vid_feat_len.sum() + batch.clip_feat_len.sum()); tok_t = int(batch.par_feat_len.sum() + batch.sent_feat_len.sum())
+        else:
+            tok_v = batch.vid_feat.shape[0] * batch.vid_feat.shape[1] + batch.clip_feat.shape[0] * batch.clip_feat.shape[1]
+            tok_t = batch.par_feat.shape[0] * batch.par_feat.shape[1] + batch.sent_feat.shape[0] * batch.sent_feat.shape[1]
         fused = names[5]
         if by[fused]["launches_per_step"]:
             alg = tok_v * (2 * w["Dv"] + 1536 + 2304) + tok_t * (2 * w["Dt"] + 1536 + 2304) + (tok_v + tok_t) * (9984 + 10752 + 4608)
@@ -265,17 +293,28 @@ def main():
         torch.distributed.barrier()
 
     if rank == 0:
-        fwd_flops, train_flops = algorithmic_flops_per_step(w, cfg)
+        if ragged:
+            lens = {"vid": batch.vid_feat_len.cpu().numpy(), "clip": batch.clip_feat_len.cpu().numpy(), "par": batch.par_feat_len.cpu().numpy(),
+                    "sent": batch.sent_feat_len.cpu().numpy(), "counts": batch.clip_num.cpu().numpy(), "Dv": w["Dv"], "Dt": w["Dt"]}
+            fwd_flops, train_flops = algorithmic_flops_ragged(lens)   # rank 0's shard; x world below
+        else:
+            fwd_flops, train_flops = algorithmic_flops_per_step(w, cfg)
         out = {
             "metric": "clip-pairs/sec (COOT retrieval " + ("eval forward" if args.eval else "train step") + ", whole job)",
             "value": round(value, 1), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{cva.synthetic.WORKLOAD_LABEL[args.workload]}: {w['B']} videos x {w['C']} clips per GPU, "
+            "config": {"workload": f"{cva.synthetic.WORKLOAD_LABEL[args.workload]}: {w['B']} videos x "
+                                   f"{(str(w['C']) + ' clips') if not ragged else (str(clip_counts[0]) + ' clips in total (rank 0)')} per GPU, "
                                    f"Lc=Lv={w['Lc']}, Ls={w['Ls']}, Lp={w['Lp']}, Dv={w['Dv']}, Dt={w['Dt']}, d_model=384",
                        "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
                        "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",
                        "launch": "eval" if args.eval else mode,
+                       **({"token_layout": "padded to the batch maxima (the reference's layout)" if args.padded else "packed (cu_seqlens): valid tokens only",
+                           "valid_tokens": [int(batch.vid_feat_len.sum() + batch.clip_feat_len.sum()), int(batch.par_feat_len.sum() + batch.sent_feat_len.sum())],
+                           "padded_tokens": [batch.vid_feat.shape[0] * batch.vid_feat.shape[1] + batch.clip_feat.shape[0] * batch.clip_feat.shape[1],
+                                             batch.par_feat.shape[0] * batch.par_feat.shape[1] + batch.sent_feat.shape[0] * batch.sent_feat.shape[1]]}
+                          if ragged else {}),
                        "final_loss": round(loss_val, 5)},
             "per_gpu": round(value / world, 1), "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
             "algorithmic_tflops_per_s": round((fwd_flops if args.eval else train_flops) * world / (ms_per_step * 1e-3) / 1e12, 2),

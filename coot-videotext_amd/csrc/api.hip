@@ -191,6 +191,7 @@ struct CtxS {
 };
 struct Saved {
   bf16_t *xhat = nullptr, *h0 = nullptr, *z0 = nullptr;
+  int* pos = nullptr;  // packed rows: position of every row within its sequence
   std::vector<LayerS> layers; std::vector<CtxS> ctx;
   bf16_t* cq_in = nullptr;
   bf16_t *hp = nullptr, *ap = nullptr, *s = nullptr; float *smax = nullptr, *ssum = nullptr, *pooled = nullptr;
@@ -200,7 +201,7 @@ static void layout_saved(const coot_net_config& c, int N_in, long Ttok, Arena& A
   // tiles without row bounds checks; rows past T / N hold don't-care values that no kernel consumes.
   const size_t T = ((size_t)Ttok + 127) & ~(size_t)127, D = c.hidden_dim, F = c.ff_dim, H = c.num_heads;
   const size_t N = ((size_t)N_in + 127) & ~(size_t)127;
-  if (c.use_input_fc) { S.xhat = A.get<bf16_t>(T * c.input_dim); S.h0 = A.get<bf16_t>(T * D); }
+  if (c.use_input_fc) { S.xhat = A.get<bf16_t>(T * c.input_dim); S.h0 = A.get<bf16_t>(T * D); S.pos = A.get<int>(T); }
   S.z0 = A.get<bf16_t>(T * D);
   for (int i = 0; i < c.num_layers; ++i) {
     LayerS l;
@@ -310,8 +311,12 @@ struct LayerBufs {
 // sequence structure (attention, pooling, positional encoding) are segment aware.
 struct Segs {
   int n = 1; int N[2] = {0, 0}; int L[2] = {0, 0}; const long long* lens[2] = {nullptr, nullptr};
+  // packed (varlen) token rows: sequence i of the call (segment 0 first) is rows [cu[i], cu[i] + len) of every token matrix, no
+  // padding rows exist; Tp = cu[Ntot] on the host.  Null: the padded layout, row = n L + l per segment.
+  const int* cu = nullptr; int Tp = 0;
   int Ntot() const { return N[0] + (n > 1 ? N[1] : 0); }
-  int T() const { return N[0] * L[0] + (n > 1 ? N[1] * L[1] : 0); }
+  int Tpad() const { return N[0] * L[0] + (n > 1 ? N[1] * L[1] : 0); }
+  int T() const { return cu ? Tp : Tpad(); }
 };
 
 // self-attention over every segment (rows of segment s start at sum_{s'<s} N*L), or one cross-attention
@@ -320,6 +325,12 @@ static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipSt
   if (cross) {
     COOT_REQUIRE(sg.n == 1, "context networks take a single segment");
     a.lens = sg.lens[0]; a.Nseq = sg.N[0]; a.Lq = 1; a.Lk = sg.L[0];
+    return bwd ? launch_attn_bwd(a, st) : launch_attn_fwd(a, st);
+  }
+  if (sg.cu) {  // packed rows: the short kernels, every sequence at its own row offset (both segments in one launch)
+    COOT_REQUIRE(attn_short_path(sg.L[0]) && (sg.n == 1 || attn_short_path(sg.L[1])), "packed rows need the short attention kernels (L <= 128)");
+    a.cu = sg.cu; a.lens = sg.lens[0]; a.Nseq = sg.N[0]; a.Lq = sg.L[0]; a.Lk = sg.L[0];
+    if (sg.n == 2) { a.Nseq2 = sg.N[1]; a.L2 = sg.L[1]; a.lens2 = sg.lens[1]; a.seed2_delta = 0x9E3779B97F4A7C15ull; }
     return bwd ? launch_attn_bwd(a, st) : launch_attn_fwd(a, st);
   }
   if (sg.n == 2 && attn_short_path(sg.L[0]) && attn_short_path(sg.L[1])) {  // both segments in ONE launch of the short kernels
@@ -541,6 +552,17 @@ static bool glob_fused_ok(const coot_net_config& c, const Segs& sg) {
          c.num_layers == 1 && c.ctx_num_layers == 1 && sg.n == 1 && glob_fwd_supported(sg.L[0]);
 }
 
+static int g_use_packed = 1;  // coot_set_option("packed", 0/1): honour cu_seqlens (0: process the padded layout even when the caller passes them)
+// Packed (varlen) token rows are taken by the fused local-network path: input LayerNorm (gathers the rows), the token-tile chains
+// (row independent), the short attention and the pooling kernels (sequence offsets from cu_seqlens).  Forward and backward take the
+// same decision from the same arguments.
+static bool packed_ok(const coot_net_config& c, const WPack& W, const Segs& sg, const coot_packed_seqs* pk) {
+  if (!g_use_packed || !pk || !pk->cu_seqlens || pk->total_tokens <= 0) return false;
+  return g_use_fused && g_use_fused_infc && g_use_fused_bwd && c.use_input_fc && !c.use_context && fused_pool_ok(c) && W.f_in_w && W.f_pw1 &&
+         W.f_pw1_kn && c.input_dim % 64 == 0 && pk->total_tokens >= g_fused_min_rows && pk->total_tokens <= sg.Tpad() &&
+         attn_short_path(sg.L[0]) && (sg.n == 1 || attn_short_path(sg.L[1]));
+}
+
 static LayerBufs self_bufs(const LayerS& s, int D) {
   LayerBufs b; b.q = s.qkv; b.ldq = 3 * D; b.k = s.qkv + D; b.ldk = 3 * D; b.v = s.qkv + 2 * D; b.ldv = 3 * D;
   b.ctx = s.ctx; b.r1 = s.r1; b.z1 = s.z1; b.h1 = s.h1; b.a1 = s.a1; b.r2 = s.r2; b.z2 = s.z2; b.lse = s.lse;
@@ -570,6 +592,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
   if (!strcmp(name, "fused_bwd")) { g_use_fused_bwd = value; return 0; }
   if (!strcmp(name, "glob_fused")) { g_use_glob_fused = value; return 0; }
+  if (!strcmp(name, "packed")) { g_use_packed = value; return 0; }
   if (!strcmp(name, "fused_infc")) { g_use_fused_infc = value; return 0; }
   if (!strcmp(name, "gemm_small")) { set_gemm_small(value); return 0; }
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
@@ -713,7 +736,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
                  const int64_t* lengths, int N, int Lseq, const float* feats2, const int64_t* lengths2, int N2, int L2,
                  const float* hidden, float* pooled, float* per_token, void* saved,
                  size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed, const uint64_t* seed_dev,
-                 coot_stream_t stream) {
+                 coot_stream_t stream, const coot_packed_seqs* packed) {
   hipStream_t st = (hipStream_t)stream;
   struct SeedScope { SeedScope(const uint64_t* p) { g_seed_dev = (const unsigned long long*)p; } ~SeedScope() { g_seed_dev = nullptr; } } seedscope(seed_dev);
   coot_net_config c; RUN(norm_cfg(cfg, &c));
@@ -729,8 +752,12 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
-  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.T(), AS, S);
+  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);  // sized for the padded layout (>= the packed rows)
   COOT_REQUIRE(!AS.overflow, "net_fwd: saved buffer too small (%zu < %zu)", saved_bytes, AS.off);
+  if (packed_ok(c, W, sg, packed)) {
+    COOT_REQUIRE(!per_token, "net_fwd: per-token output is not available with packed rows");
+    sg.cu = packed->cu_seqlens; sg.Tp = packed->total_tokens;
+  }
   const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim, T0 = N * Lseq;
   const int out_dim = D * (c.use_context ? 2 : 1);
 
@@ -738,9 +765,11 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   if (c.use_input_fc) {
     LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T0; l.D = Din; l.y = S.xhat; l.ldy = Din;
     if (sg.n > 1) { l.x2 = feats2; l.R0 = T0; l.R = T; }  // both segments in one launch
+    if (sg.cu) { l.R = T; l.cu = sg.cu; l.nseq = Ntot; l.N0 = N; l.L0 = Lseq; l.L1 = L2; l.pos_out = S.pos; }  // gathers the valid rows
     RUN(launch_ln_fwd(l, st));
     if (W.f_in_w && W.layers[0].f_wqkv && g_use_fused && g_use_fused_infc && T >= g_fused_min_rows) {
       InfcQkvFwd f; f.T = T; f.Din = Din; f.xhat = S.xhat; f.win = W.f_in_w; f.bin = W.in_bias; f.pe = pe; f.T0 = T0; f.L1 = Lseq;
+      f.pos = sg.cu ? S.pos : nullptr;
       f.L2 = sg.n > 1 ? L2 : Lseq; f.wqkv = W.layers[0].f_wqkv; f.bqkv = P + L.layers[0].bq; f.h0 = S.h0; f.z0 = S.z0; f.qkv = S.layers[0].qkv;
       f.tstamps = g_fz_tstamps;
       RUN(launch_infc_qkv_fwd(f, st));
@@ -820,6 +849,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     PoolArgs ps[2];
     for (int sidx = 0; sidx < sg.n; ++sidx) {
       PoolArgs& p = ps[sidx]; p.s = S.s + row * D; p.lds = D; p.z = z + row * D; p.ldz = D; p.lens = sg.lens[sidx]; p.N = sg.N[sidx]; p.L = sg.L[sidx];
+      if (sg.cu) { p.s = S.s; p.z = z; p.cu = sg.cu + n0; }  // packed: global row offsets per sequence
       p.D = D; p.pooled = pooled + (size_t)n0 * out_dim; p.ldp = out_dim;
       p.pooled_copy = S.pooled + (size_t)n0 * D; p.smax = S.smax + (size_t)n0 * D; p.ssum = S.ssum + (size_t)n0 * D;
       p.drop_w = mkdrop(train, c.pool_dropout, seed + 977u * sidx, 16u * 15 + SITE_POOL3);
@@ -838,7 +868,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
                  const int64_t* lengths, int N, int Lseq, const float* feats2, const int64_t* lengths2, int N2, int L2,
                  const float* hidden, const float* dpooled, float* G, float* dhidden,
                  float* dfeats, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed,
-                 const uint64_t* seed_dev, coot_stream_t stream) {
+                 const uint64_t* seed_dev, coot_stream_t stream, const coot_packed_seqs* packed) {
   hipStream_t st = (hipStream_t)stream;
   struct SeedScope { SeedScope(const uint64_t* p) { g_seed_dev = (const unsigned long long*)p; } ~SeedScope() { g_seed_dev = nullptr; } } seedscope(seed_dev);
   coot_net_config c; RUN(norm_cfg(cfg, &c));
@@ -853,9 +883,10 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
-  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.T(), AS, S);
+  Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);
   COOT_REQUIRE(!AS.overflow, "net_bwd: saved buffer too small");
-  Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, Ntot, sg.T(), AX, X);
+  Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, Ntot, sg.Tpad(), AX, X);
+  if (packed_ok(c, W, sg, packed)) { sg.cu = packed->cu_seqlens; sg.Tp = packed->total_tokens; }  // the forward's decision
   COOT_REQUIRE(!AX.overflow, "net_bwd: scratch buffer too small (%zu < %zu)", scratch_bytes, AX.off);
   struct TnWs { TnWs(float* p, size_t n) { set_tn_default_workspace(p, n); } ~TnWs() { set_tn_default_workspace(nullptr, 0); } } tnws(X.tn_ws, X.tn_ws_floats);
   struct PartWs { PartWs(float* p, size_t n, size_t lo) { set_partials_workspace(p, n, lo); } ~PartWs() { set_partials_workspace(nullptr, 0); } } partws(X.part_ws, X.part_floats, X.part_low);
@@ -885,6 +916,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       p.drop_w = mkdrop(train, c.pool_dropout, seed + 977u * sidx, 16u * 15 + SITE_POOL3);
       p.drop_s = mkdrop(train, c.pool_dropout, seed, 16u * 15 + SITE_POOL2); p.drop_s_ld = D; p.drop_s_row0 = row;
       p.dpooled = dpooled + (size_t)n0 * out_dim; p.lddp = out_dim; p.ds = X.ds + row * D; p.ldds = D; p.dz = X.dzp + row * D; p.lddz = D;
+      if (sg.cu) { p.s = S.s; p.z = zL; p.ds = X.ds; p.dz = X.dzp; p.drop_s_row0 = 0; p.cu = sg.cu + n0; }  // packed: global row offsets
       p.ds_colsum = G + L.pb2;
       row += (long)sg.N[sidx] * sg.L[sidx]; n0 += sg.N[sidx];
     }

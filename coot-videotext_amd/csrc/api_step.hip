@@ -76,6 +76,15 @@ void layout_step(const coot_step_config& c, const coot_step_dims& d, Bump& A, St
   W.zero_bytes = A.off - z0;
 }
 
+// packed rows of a side (coot_step_batch.cu_vis / cu_txt + coot_step_dims.tok_vis / tok_txt), or "padded" (cu_seqlens = NULL)
+struct SidePacked { coot_packed_seqs v, t; };
+SidePacked side_packed(const coot_step_batch& x, const coot_step_dims& d) {
+  SidePacked p;
+  p.v.cu_seqlens = d.tok_vis > 0 ? x.cu_vis : nullptr; p.v.total_tokens = d.tok_vis;
+  p.t.cu_seqlens = d.tok_txt > 0 ? x.cu_txt : nullptr; p.t.total_tokens = d.tok_txt;
+  return p;
+}
+
 int check_cfg(const coot_step_config& c) {
   const int D = c.net[0].hidden_dim;
   COOT_REQUIRE(c.net[1].hidden_dim == D && c.net[2].hidden_dim == D && c.net[3].hidden_dim == D, "step: the four networks must share hidden_dim");
@@ -161,18 +170,20 @@ StepStamps g_stamps;
 int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, int gi, const float* ctx_feat, const int64_t* ctx_len,
                  int Lctx, const float* item_feat, const int64_t* item_len, int Litem, const int64_t* item_num, int Cmax,
                  const coot_step_dims& d, float* local_out, float* glob_out, float* resh, unsigned char* mask, long long* lens,
-                 void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, int train, uint64_t seed, hipStream_t st, bool pack = true) {
+                 void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, int train, uint64_t seed, hipStream_t st, bool pack = true,
+                 const coot_packed_seqs* pk = nullptr) {
   const int D = c.net[0].hidden_dim;
   if (pack) {
     { const int two[2] = {li, gi}; RUN(pack_nets(c, b, two, 2, st)); }
   }
   g_stamps.mark(li == 0 ? "video: weights packed" : "text: weights packed", st);
   RUN(coot_net_fwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
-                   nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, g_step_seed_dev, st));
+                   nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, g_step_seed_dev, st, pk));
   g_stamps.mark(li == 0 ? "video: local forward done" : "text: local forward done", st);
   RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
   RUN(coot_net_fwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0,
-                   local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi, g_step_seed_dev, st));
+                   local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi, g_step_seed_dev, st,
+                   nullptr));
   g_stamps.mark(li == 0 ? "video: global forward done" : "text: global forward done", st);
   return 0;
 }
@@ -183,7 +194,7 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
                   int Lctx, const float* item_feat, const int64_t* item_len, int Litem, const int64_t* item_num, int Cmax,
                   const coot_step_dims& d, const float* local_out, const float* resh, float* d_local, const float* d_glob,
                   const float* d_resh, float* dhid, float* dfeat, void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, void* scratch,
-                  size_t sz_scratch, int train, uint64_t seed, hipStream_t st) {
+                  size_t sz_scratch, int train, uint64_t seed, hipStream_t st, const coot_packed_seqs* pk = nullptr) {
   const int D = c.net[0].hidden_dim;
   g_stamps.mark(li == 0 ? "video: backward starts" : "text: backward starts", st);
   const int side = li == 0 ? 0 : 1;
@@ -197,7 +208,8 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   set_tn_aux_stream(defer ? g_aux.get(side) : nullptr);
   set_tn_defer(defer);
   const int rc_g = coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
-                                b.grads[gi], dhid, dfeat, saved_g, sz_g, (char*)scratch + sz_loc, sz_glob, train, seed + 11 * gi, g_step_seed_dev, st);
+                                b.grads[gi], dhid, dfeat, saved_g, sz_g, (char*)scratch + sz_loc, sz_glob, train, seed + 11 * gi, g_step_seed_dev, st,
+                                nullptr);
   set_tn_defer(false);
   set_tn_aux_stream(nullptr);
   RUN(rc_g);
@@ -217,7 +229,7 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   set_tn_aux_stream(((g_tn_aux_sides >> side) & 1) ? g_aux.get(side) : nullptr);
   const int rc = coot_net_bwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
                               nullptr, d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_loc, train, seed + 11 * li, g_step_seed_dev,
-                              st);
+                              st, pk);
   set_tn_aux_stream(nullptr);
   const int rc_j = tn_deferred_join(st);  // the optimizer / the end of the pass needs the global network's weight gradients
   RUN(rc);
@@ -404,14 +416,15 @@ int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, c
                       coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
+  const SidePacked pk = side_packed(*x, *d);
   COOT_REQUIRE(!A.overflow, "step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
-                   local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, !packs_fresh));
+                   local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, !packs_fresh, &pk.v));
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
-                   local_t, glob_t, resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st, !packs_fresh));
+                   local_t, glob_t, resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st, !packs_fresh, &pk.t));
   RUN(g_hops.hop(2, sv, sm));
   RUN(g_hops.hop(3, st, sm));
   return 0;
@@ -424,16 +437,17 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* b, 
                        coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
+  const SidePacked pk = side_packed(*x, *d);
   COOT_REQUIRE(!A.overflow, "step: workspace too small");
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d, local_v,
                     resh_v, d_local_v, d_glob_v, d_resh_v, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, W.scratch_v,
-                    W.sz_sv, train, seed, sv));
+                    W.sz_sv, train, seed, sv, &pk.v));
   RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, local_t,
                     resh_t, d_local_t, d_glob_t, d_resh_t, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, W.scratch_t,
-                    W.sz_st, train, seed + 1000, st));
+                    W.sz_st, train, seed + 1000, st, &pk.t));
   RUN(g_hops.hop(2, sv, sm));
   RUN(g_hops.hop(3, st, sm));
   return 0;
@@ -474,6 +488,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   RUN(check_cfg(*cfg));
   COOT_REQUIRE(losses, "train_step: losses pointer");
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
+  const SidePacked pk = side_packed(*x, *d);
   COOT_REQUIRE(!A.overflow, "train_step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
   COOT_REQUIRE(sv != st, "train_step: the two side streams must differ");
@@ -491,10 +506,10 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
-                   W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first));
+                   W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first, &pk.v));
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
                    W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st,
-                   pack_first));
+                   pack_first, &pk.t));
   // Zero the parameter gradients (4 arenas), the embedding gradients (one block) and the loss words at the END of the text
   // forward: the text side shares the chip with the three times larger video side and, started at the same time, finishes its
   // forward ~75 us earlier (HIP-event timeline), so the six fills are free there.  (At the head of the text stream they delayed
@@ -528,7 +543,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   g_resh_wait_slot = cc ? 7 : -1;  // d_resh_v was recorded on the text stream (slot 7); side_backward waits where it is first read
   const int rc_v = side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                                  W.local_v, W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv,
-                                 W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, sv);
+                                 W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, sv, &pk.v);
   g_resh_wait_slot = -1;
   RUN(rc_v);
   if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
@@ -536,7 +551,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   g_stamps.mark("video: updated", sv);
   RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, W.local_t,
                     W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt,
-                    W.scratch_t, W.sz_st, train, seed + 1000, st));
+                    W.scratch_t, W.sz_st, train, seed + 1000, st, &pk.t));
   // total = contrastive + cycle-consistency (not needed by the backward): rides on the text side's update launch
   if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st, losses));
   else {
@@ -565,6 +580,7 @@ int coot_train_step_phase(const coot_step_config* cfg, const coot_step_buffers* 
   RUN(check_cfg(*cfg));
   COOT_REQUIRE(losses && phase >= 0 && phase <= 6, "train_step_phase: bad arguments");
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
+  const SidePacked pk = side_packed(*x, *d);
   COOT_REQUIRE(!A.overflow, "train_step_phase: workspace too small (%zu < %zu)", workspace_bytes, A.off);
   hipStream_t s = (hipStream_t)stream;
   const int D = cfg->net[0].hidden_dim;
@@ -581,11 +597,11 @@ int coot_train_step_phase(const coot_step_config* cfg, const coot_step_buffers* 
       return 0;
     case 1:
       return side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
-                          W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, s, pack_first);
+                          W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, s, pack_first, &pk.v);
     case 2:
       RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
                        W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, s,
-                       pack_first));
+                       pack_first, &pk.t));
       for (int i = 0; i < 4; ++i)
         RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), s), "memset grads"));
       RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, s), "memset embedding grads"));
@@ -604,14 +620,14 @@ int coot_train_step_phase(const coot_step_config* cfg, const coot_step_buffers* 
     case 5:
       RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                         W.local_v, W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv,
-                        W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, s));
+                        W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, s, &pk.v));
       if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, s));
       if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, stream));
       return 0;
     default:
       RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
                         W.local_t, W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt,
-                        W.saved_gt, W.sz_gt, W.scratch_t, W.sz_st, train, seed + 1000, s));
+                        W.saved_gt, W.sz_gt, W.scratch_t, W.sz_st, train, seed + 1000, s, &pk.t));
       if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, s, losses));
       else {
         hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, s, losses);

@@ -21,6 +21,8 @@ struct AttnArgs {
   // matrices (rows Nseq * Lk ..): Nseq2 sequences of length L2 (e.g. 64 videos x 80 frames, then 256 clips x 80 frames) —
   // one launch for both (launch_attn_fwd/bwd fall back to one launch per segment when a segment is too long)
   int Nseq2 = 0, L2 = 0; const long long* lens2 = nullptr; unsigned long long seed2_delta = 0;
+  const int* cu = nullptr;                  // short kernels, packed rows: sequence n (both segments, n < Nseq + Nseq2) starts at row
+                                            // cu[n] and has lens[n] rows, all of them valid (no padding rows exist)
   DropCfg drop;                             // dropout on the attention probabilities
   // backward only
   const bf16_t* dout = nullptr; long lddo = 0;

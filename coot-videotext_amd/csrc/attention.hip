@@ -405,6 +405,14 @@ static inline int short_grid(const AttnArgs& a) { return ((a.Nseq + a.Nseq2 + 7)
 struct ShortSeq { int n, L, nvalid; long base; unsigned dkey; };
 __device__ __forceinline__ ShortSeq short_seq(const AttnArgs& a, int n) {
   ShortSeq s;
+  if (a.cu) {  // packed rows
+    const bool second = n >= a.Nseq;
+    s.n = second ? n - a.Nseq : n;
+    s.L = s.nvalid = (int)(second ? a.lens2[s.n] : a.lens[s.n]);
+    s.base = a.cu[n];
+    s.dkey = a.drop.thr ? drop_site_key(a.drop.seed + (second ? a.seed2_delta : 0ull), a.drop.seed_ptr, a.drop.site) : 0u;
+    return s;
+  }
   if (n >= a.Nseq) {
     s.n = n - a.Nseq; s.L = a.L2; s.nvalid = (int)a.lens2[s.n]; s.base = (long)a.Nseq * a.Lk + (long)s.n * a.L2;
     s.dkey = a.drop.thr ? drop_site_key(a.drop.seed + a.seed2_delta, a.drop.seed_ptr, a.drop.site) : 0u;

@@ -69,6 +69,7 @@ struct InfcQkvFwd {
   const bf16_t* win = nullptr;    // P48 [384 x Din] (LayerNorm gain folded)
   const float* bin = nullptr;     // [384] folded bias
   const float* pe = nullptr; int T0 = 0, L1 = 1, L2 = 1;  // pe[pos][384]; pos = row < T0 ? row % L1 : (row - T0) % L2
+  const int* pos = nullptr;       // packed rows: pos[row] (written by the input LayerNorm) instead
   const bf16_t* wqkv = nullptr; const float* bqkv = nullptr;
   bf16_t *h0 = nullptr, *z0 = nullptr, *qkv = nullptr;
   unsigned long long* tstamps = nullptr;  // profiling aid: block 0 phase stamps at slots 48.. (tools/fused_stamps.py)

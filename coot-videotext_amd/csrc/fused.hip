@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
   struct PrePe { f32x4_t a, b; };
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm,
       [&](int row, int col) {
-        const int pos = row < p.T0 ? row % p.L1 : (row - p.T0) % p.L2;
+        const int pos = p.pos ? (row < p.T ? p.pos[row] : 0) : (row < p.T0 ? row % p.L1 : (row - p.T0) % p.L2);
         const float* pp = p.pe + (long)pos * FZ_D + col;
         return PrePe{*reinterpret_cast<const f32x4_t*>(pp), *reinterpret_cast<const f32x4_t*>(pp + 4)};
       },

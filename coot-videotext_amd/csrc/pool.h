@@ -10,6 +10,7 @@ struct PoolArgs {
   const bf16_t* s = nullptr; long lds = 0;   // [N*L, D] pre-softmax scores (dropout2 already applied)
   const bf16_t* z = nullptr; long ldz = 0;   // [N*L, D] features being pooled
   const long long* lens = nullptr;           // [N]
+  const int* cu = nullptr;                   // packed rows: sequence n is rows [cu[n], cu[n] + lens[n]) of s / z / ds / dz (no padding rows)
   int N = 0, L = 0, D = 0;
   float* pooled = nullptr; long ldp = 0;     // [N, D] fp32 (may be a column slice of a wider matrix)
   float* pooled_copy = nullptr;              // optional dense [N, D] copy kept for the backward

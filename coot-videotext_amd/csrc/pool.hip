@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs2 pp) {
   const int n = (int)blockIdx.x - (second ? pp.n0 : 0), cpb = pool_cpb(p.D), rgs = 256 / cpb;
   const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, c = (blockIdx.y * cpb + cl) * 8;
   const int len = (int)p.lens[n];
-  const long r0 = (long)n * p.L;
+  const long r0 = p.cu ? (long)p.cu[n] : (long)n * p.L;
+  const int Lp = p.cu ? len : p.L;  // rows the sequence occupies (padded length, or its own when packed)
   float m[8], z[8], a[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; z[j] = 0.f; a[j] = 0.f; }
@@ -79,14 +80,14 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs2 pp) {
     float mm = -INFINITY;
     for (int g = 0; g < rgs; ++g) mm = fmaxf(mm, red[0][g * cpb * 8 + cc]);
     // rows >= len hold -INF (= -32752) after masked_fill (poolers.py:190)
-    if (len < p.L) mm = fmaxf(mm, kMaskFill);
+    if (len < Lp) mm = fmaxf(mm, kMaskFill);
     float zz = 0.f, aa = 0.f;
     for (int g = 0; g < rgs; ++g) {
       const float mg = red[0][g * cpb * 8 + cc];
       const float r = mg == -INFINITY ? 0.f : __expf(mg - mm);
       zz += red[1][g * cpb * 8 + cc] * r; aa += red[2][g * cpb * 8 + cc] * r;
     }
-    if (len < p.L) zz += (float)(p.L - len) * __expf(kMaskFill - mm);  // 0 in fp32 unless every row is masked
+    if (len < Lp) zz += (float)(Lp - len) * __expf(kMaskFill - mm);  // 0 in fp32 unless every row is masked
     const float pooled = aa / zz;
     const int ch = blockIdx.y * cpb * 8 + cc;
     p.pooled[(long)n * p.ldp + ch] = pooled;
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs2 pp) {
   const int n = (int)blockIdx.x - (second ? pp.n0 : 0), cpb = pool_cpb(p.D), rgs = 256 / cpb;
   const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, c = (blockIdx.y * cpb + cl) * 8;
   const int len = (int)p.lens[n];
-  const long r0 = (long)n * p.L;
+  const long r0 = p.cu ? (long)p.cu[n] : (long)n * p.L;
+  const int Lp = p.cu ? len : p.L;
   float cs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) cs[j] = 0.f;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs2 pp) {
       g[j] = p.dpooled[(long)n * p.lddp + c + j];
       gp[j] = g[j] * p.pooled[(long)n * p.ldp + c + j];
     }
-    for (int l0 = rg; l0 < p.L; l0 += rgs * POOL_RB) {
+    for (int l0 = rg; l0 < Lp; l0 += rgs * POOL_RB) {
       u32x4_t su[POOL_RB], fu[POOL_RB];
 #pragma unroll
       for (int b = 0; b < POOL_RB; ++b) {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs2 pp) {
 #pragma unroll
       for (int b = 0; b < POOL_RB; ++b) {
         const int l = l0 + b * rgs;
-        if (l < p.L) {
+        if (l < Lp) {
           float ds[8], dz[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) { ds[j] = 0.f; dz[j] = 0.f; }

@@ -18,6 +18,10 @@ struct LnFwd {
   bf16_t* y = nullptr; long ldy = 0;                         // bf16 out (optional)
   float* y32 = nullptr; long ldy32 = 0;                      // fp32 out (optional)
   DropCfg drop;                                              // dropout applied to the LN output
+  // packed (varlen) output rows: row r of the output is token (r - cu[n]) of sequence n (cu: nseq + 1 packed row starts); the
+  // source stays the padded [N, L, D] layout of the batch: sequences [0, N0) are rows n L0 + l of x, the others rows
+  // (n - N0) L1 + l of x2.  pos_out[r] = position of row r within its sequence (for the positional encoding further down).
+  const int* cu = nullptr; int nseq = 0, N0 = 0, L0 = 0, L1 = 0; int* pos_out = nullptr;
 };
 int launch_ln_fwd(const LnFwd& p, hipStream_t stream);
 

@@ -28,9 +28,17 @@ __global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.R) return;
   const int D = p.D, nch = D >> 2;
-  const bool second = p.x2 && row >= p.R0;
+  bool second = p.x2 && row >= p.R0;
+  long xrow = second ? row - p.R0 : row;
+  if (p.cu) {  // packed rows: find the sequence (largest n with cu[n] <= row), gather from the padded source
+    int lo = 0, hi = p.nseq;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.cu[mid] <= row) lo = mid; else hi = mid; }
+    const int l = row - p.cu[lo];
+    second = lo >= p.N0;
+    xrow = second ? (long)(lo - p.N0) * p.L1 + l : (long)lo * p.L0 + l;
+    if (p.pos_out && lane == 0) p.pos_out[row] = l;
+  }
   const void* xsrc = second ? p.x2 : p.x;
-  const long xrow = second ? row - p.R0 : row;
   f32x4_t v[NV];
   float s = 0.f;
 #pragma unroll

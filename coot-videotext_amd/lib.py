@@ -51,7 +51,13 @@ class StepConfig(C.Structure):
 
 
 class StepDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "Nc", "Lv", "Lc", "Lp", "Ls", "Cmax_clip", "Cmax_sent")]
+    """coot_step_dims; tok_vis / tok_txt: packed token totals (0 = padded layout)."""
+    _fields_ = [(n, C.c_int) for n in ("B", "Nc", "Lv", "Lc", "Lp", "Ls", "Cmax_clip", "Cmax_sent", "tok_vis", "tok_txt")]
+
+
+class PackedSeqs(C.Structure):
+    """coot_packed_seqs: device int32 row starts [nseq + 1] + their last entry on the host."""
+    _fields_ = [("cu_seqlens", C.c_void_p), ("total_tokens", C.c_int)]
 
 
 class StepBuffers(C.Structure):
@@ -60,7 +66,7 @@ class StepBuffers(C.Structure):
 
 class StepBatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("vid_feat", "clip_feat", "par_feat", "sent_feat", "vid_len", "clip_len",
-                                          "par_len", "sent_len", "clip_num", "sent_num")]
+                                          "par_len", "sent_len", "clip_num", "sent_num", "cu_vis", "cu_txt")]
 
 
 _lib = None
@@ -99,8 +105,9 @@ def load():
     lib.coot_net_saved_bytes.argtypes = [cfgp, i32, i32, i32, i32]
     lib.coot_net_scratch_bytes.restype = sz
     lib.coot_net_scratch_bytes.argtypes = [cfgp, i32, i32, i32, i32]
-    lib.coot_net_fwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp, vp]
-    lib.coot_net_bwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp, vp]
+    pkp = C.POINTER(PackedSeqs)
+    lib.coot_net_fwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp, vp, pkp]
+    lib.coot_net_bwd.argtypes = [cfgp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, u64, vp, vp, pkp]
     lib.coot_pack_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.coot_pack_bwd.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.coot_contrastive_scratch_bytes.restype = sz

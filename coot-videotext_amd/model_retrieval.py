@@ -41,6 +41,12 @@ class RetrievalDataBatchTuple:
     # host-side copies (optional): avoid the device sync of th.max(batch.clip_num) (model_retrieval.py:122)
     max_clip_num: Optional[int] = None
     max_sent_num: Optional[int] = None
+    # packed (varlen) token rows of the local networks (attach_packed_index): int32 device row starts [B + Nc + 1]
+    # (the B videos / paragraphs first, then the Nc clips / sentences) and their totals on the host.  None: padded processing.
+    cu_vis: Optional[torch.Tensor] = None
+    cu_txt: Optional[torch.Tensor] = None
+    tok_vis: int = 0
+    tok_txt: int = 0
 
     def dict(self) -> Dict[str, Any]:
         return dict(self.__dict__)
@@ -49,6 +55,26 @@ class RetrievalDataBatchTuple:
         for name, value in self.__dict__.items():
             if isinstance(value, torch.Tensor):
                 setattr(self, name, value.cuda(non_blocking=non_blocking))
+
+
+def packed_index(len_a: torch.Tensor, len_b: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """cu_seqlens of two sets of sequences through one local network (set a first): int32 [Na + Nb + 1] exclusive prefix sums of
+    the lengths on the lengths' device, and the total as a host int (one device -> host read unless the lengths live on the
+    host; loaders compute it from their host-side lengths)."""
+    lens = torch.cat([len_a.reshape(-1), len_b.reshape(-1)]).to(torch.int64)
+    cu = torch.zeros(lens.numel() + 1, dtype=torch.int32, device=lens.device)
+    cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    return cu, int(cu[-1])
+
+
+def attach_packed_index(batch: "RetrievalDataBatchTuple", device=None) -> "RetrievalDataBatchTuple":
+    """Adds cu_vis / cu_txt / tok_vis / tok_txt to a batch (from host copies of the four length vectors when they are given on the
+    host, else with one sync).  The local networks then skip every padding frame / word (coot_packed_seqs)."""
+    dev = device if device is not None else batch.vid_feat.device
+    batch.cu_vis, batch.tok_vis = packed_index(batch.vid_feat_len.cpu(), batch.clip_feat_len.cpu())
+    batch.cu_txt, batch.tok_txt = packed_index(batch.par_feat_len.cpu(), batch.sent_feat_len.cpu())
+    batch.cu_vis, batch.cu_txt = batch.cu_vis.to(dev), batch.cu_txt.to(dev)
+    return batch
 
 
 @dataclass
@@ -155,10 +181,10 @@ class RetrievalModelManager:
 
     # ---- coot/model_retrieval.py:86-197 --------------------------------------------------------------------
     def _encode(self, net_local, net_global, ctx_feat, ctx_mask, ctx_len, item_feat, item_mask, item_len, item_num,
-                cmax: Optional[int]):
+                cmax: Optional[int], packed=None):
         # both passes through the local network share one call (same weights): every GEMM / LayerNorm launch
         # covers the video-level AND the clip-level tokens
-        context, item_emb = net_local.forward_pair(ctx_feat, ctx_len, item_feat, item_len)
+        context, item_emb = net_local.forward_pair(ctx_feat, ctx_len, item_feat, item_len, packed=packed)
         if cmax is None:
             cmax = int(torch.max(item_num))
         if self.global_max_fn is not None:
@@ -172,12 +198,14 @@ class RetrievalModelManager:
         K = RetrievalNetworksConst
         out = self._encode(self.model_dict[K.NET_VIDEO_LOCAL], self.model_dict[K.NET_VIDEO_GLOBAL], batch.vid_feat,
                            batch.vid_feat_mask, batch.vid_feat_len, batch.clip_feat, batch.clip_feat_mask,
-                           batch.clip_feat_len, batch.clip_num, getattr(batch, "max_clip_num", None))
+                           batch.clip_feat_len, batch.clip_num, getattr(batch, "max_clip_num", None),
+                           (batch.cu_vis, batch.tok_vis) if getattr(batch, "cu_vis", None) is not None else None)
         return RetrievalVisualEmbTuple(*out)
 
     def encode_text(self, batch: RetrievalDataBatchTuple) -> RetrievalTextEmbTuple:
         K = RetrievalNetworksConst
         out = self._encode(self.model_dict[K.NET_TEXT_LOCAL], self.model_dict[K.NET_TEXT_GLOBAL], batch.par_feat,
                            batch.par_feat_mask, batch.par_feat_len, batch.sent_feat, batch.sent_feat_mask,
-                           batch.sent_feat_len, batch.sent_num, getattr(batch, "max_sent_num", None))
+                           batch.sent_feat_len, batch.sent_num, getattr(batch, "max_sent_num", None),
+                           (batch.cu_txt, batch.tok_txt) if getattr(batch, "cu_txt", None) is not None else None)
         return RetrievalTextEmbTuple(*out)

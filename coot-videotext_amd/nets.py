@@ -181,14 +181,16 @@ class TransformerHip(nn.Module):
         return pooled, tokens
 
     def forward_pair(self, features: torch.Tensor, lengths: torch.Tensor, features2: torch.Tensor, lengths2: torch.Tensor,
-                     seed: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     seed: Optional[int] = None, packed: Optional[Tuple[torch.Tensor, int]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Two sets of sequences through the same weights in ONE call (video frames + clip frames of a batch,
-        coot/model_retrieval.py:104,:120).  Returns (pooled_1 [N1, D], pooled_2 [N2, D])."""
-        pooled, _ = self._run(features, lengths, features2, lengths2, None, False, seed)
+        coot/model_retrieval.py:104,:120).  Returns (pooled_1 [N1, D], pooled_2 [N2, D]).
+        packed = (cu_seqlens, total): int32 device tensor [N1 + N2 + 1] of packed row starts (first set first) and its last entry as
+        a host int — the network then processes only the valid tokens (coot_packed_seqs, include/coot_hip.h); same outputs."""
+        pooled, _ = self._run(features, lengths, features2, lengths2, None, False, seed, packed)
         n1 = features.shape[0]
         return pooled[:n1], pooled[n1:]
 
-    def _run(self, features, lengths, features2, lengths2, hidden_state, want_tokens, seed):
+    def _run(self, features, lengths, features2, lengths2, hidden_state, want_tokens, seed, packed=None):
         if not features.is_cuda:
             raise RuntimeError("TransformerHip runs on an MI355X only (features must be a cuda tensor); "
                                "there is no CPU fallback")
@@ -198,13 +200,13 @@ class TransformerHip(nn.Module):
         if seed is None:
             self.call_counter += 1
             seed = (torch.initial_seed() * 1000003 + self.call_counter) & 0xFFFFFFFFFFFFFFFF
-        return _NetFn.apply(self, features, lengths, features2, lengths2, hidden_state, bool(want_tokens), int(seed),
+        return _NetFn.apply(self, features, lengths, features2, lengths2, hidden_state, bool(want_tokens), int(seed), packed,
                             *self._params)
 
 
 class _NetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net: TransformerHip, feats, lengths, feats2, lengths2, hidden, want_tokens, seed, *params):
+    def forward(ctx, net: TransformerHip, feats, lengths, feats2, lengths2, hidden, want_tokens, seed, packed, *params):
         lib = _lib.load()
         cfg = net.c_cfg
         feats = feats.contiguous().float()
@@ -224,11 +226,16 @@ class _NetFn(torch.autograd.Function):
         saved = torch.empty(lib.coot_net_saved_bytes(C.byref(cfg), N, L, N2, L2), dtype=torch.uint8, device=dev)
         train = 1 if net.training else 0
         pe = net.embedding.pe
+        pk = None
+        if packed is not None:
+            cu, total = packed
+            assert cu.dtype == torch.int32 and cu.is_cuda and cu.numel() == N + N2 + 1, "packed = (int32 device cu_seqlens [N + N2 + 1], total)"
+            pk = _lib.PackedSeqs(cu.data_ptr(), int(total))
         _lib.check(lib.coot_net_fwd(C.byref(cfg), _lib.ptr(net._flat), _lib.ptr(net._wpack), _lib.ptr(pe), _lib.ptr(feats),
                                     _lib.ptr(lengths), N, L, _lib.ptr(feats2), _lib.ptr(lengths2), N2, L2, _lib.ptr(hid),
                                     _lib.ptr(pooled), _lib.ptr(tokens), _lib.ptr(saved), saved.numel(), None, 0, train, seed,
-                                    _lib.ptr(net.seed_dev), _lib.stream_ptr()), "coot_net_fwd")
-        ctx.net, ctx.saved, ctx.seed, ctx.train = net, saved, seed, train
+                                    _lib.ptr(net.seed_dev), _lib.stream_ptr(), C.byref(pk) if pk is not None else None), "coot_net_fwd")
+        ctx.net, ctx.saved, ctx.seed, ctx.train, ctx.packed = net, saved, seed, train, packed
         ctx.feats, ctx.lengths, ctx.hid, ctx.feats2, ctx.lengths2 = feats, lengths, hid, feats2, lengths2
         ctx.need_dfeats = bool(ctx.needs_input_grad[1])
         ctx.need_dhid = hidden is not None
@@ -260,12 +267,14 @@ class _NetFn(torch.autograd.Function):
                                     _lib.ptr(feats), _lib.ptr(lengths), N, L, _lib.ptr(feats2), _lib.ptr(lengths2), N2, L2,
                                     _lib.ptr(hid), _lib.ptr(dpooled), _lib.ptr(gflat), _lib.ptr(dhid), _lib.ptr(dfeats),
                                     _lib.ptr(ctx.saved), ctx.saved.numel(), _lib.ptr(scratch), scratch.numel(), ctx.train,
-                                    ctx.seed, _lib.ptr(net.seed_dev), _lib.stream_ptr()), "coot_net_bwd")
+                                    ctx.seed, _lib.ptr(net.seed_dev), _lib.stream_ptr(),
+                                    C.byref(_lib.PackedSeqs(ctx.packed[0].data_ptr(), int(ctx.packed[1]))) if ctx.packed is not None else None),
+                   "coot_net_bwd")
         if direct:
             grads = (None,) * len(net.table)
         else:
             grads = tuple(gflat[off:off + math.prod(shape)].view(shape) for (_, off, shape) in net.table)
-        return (None, dfeats, None, None, None, dhid, None, None) + grads
+        return (None, dfeats, None, None, None, dhid, None, None, None) + grads
 
 
 class _PackFn(torch.autograd.Function):

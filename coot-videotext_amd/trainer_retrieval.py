@@ -380,11 +380,15 @@ class RetrievalTrainer:
             st.bufs.pe[i] = n.embedding.pe.data_ptr()
         if batch.max_clip_num is None or batch.max_sent_num is None:
             batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
-        key = (batch.vid_feat.shape, batch.clip_feat.shape, batch.par_feat.shape, batch.sent_feat.shape, batch.max_clip_num, batch.max_sent_num)
+        packed = getattr(batch, "cu_vis", None) is not None and getattr(batch, "cu_txt", None) is not None
+        tok_vis, tok_txt = (int(batch.tok_vis), int(batch.tok_txt)) if packed else (0, 0)
+        key = (batch.vid_feat.shape, batch.clip_feat.shape, batch.par_feat.shape, batch.sent_feat.shape, batch.max_clip_num, batch.max_sent_num,
+               tok_vis, tok_txt)
         if key != st.dims_key:
             B, Lv, _ = batch.vid_feat.shape
             Nc, Lc, _ = batch.clip_feat.shape
-            st.dims = _lib.StepDims(B, Nc, Lv, Lc, batch.par_feat.shape[1], batch.sent_feat.shape[1], batch.max_clip_num, batch.max_sent_num)
+            st.dims = _lib.StepDims(B, Nc, Lv, Lc, batch.par_feat.shape[1], batch.sent_feat.shape[1], batch.max_clip_num, batch.max_sent_num,
+                                    tok_vis, tok_txt)
             assert batch.sent_feat.shape[0] == Nc and batch.par_feat.shape[0] == B
             need = lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims))
             if getattr(st, "ws", None) is None or st.ws.numel() < need:  # ragged batches change shape every step: grow only
@@ -400,6 +404,9 @@ class RetrievalTrainer:
             t_ = getattr(batch, src)
             assert t_.dtype == torch.int64 and t_.is_contiguous(), src
             setattr(x, f, t_.data_ptr())
+        if packed:  # valid tokens only through the local networks (coot_packed_seqs)
+            assert batch.cu_vis.dtype == torch.int32 and batch.cu_vis.numel() == st.dims.B + st.dims.Nc + 1 and batch.cu_vis.is_cuda
+            x.cu_vis, x.cu_txt = batch.cu_vis.data_ptr(), batch.cu_txt.data_ptr()
         return st, x
 
     # ---- optimizer state of either path, for optimizer_<epoch>.pth (nntrainer/trainer_base.py:685-707) ------------------------

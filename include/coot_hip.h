@@ -74,6 +74,15 @@ int coot_nets_pack_weights(int n, const coot_net_config* const* cfgs, const floa
  * pooled [N, out_dim] fp32; per_token [N, L, hidden_dim] fp32 or NULL.
  * `saved` carries activations from fwd to bwd (coot_net_saved_bytes), `scratch` is temporary
  * (coot_net_scratch_bytes).  train != 0 enables dropout with the given seed. */
+/* Packed (variable-length) token rows, SURVEY 8f-2.  The reference pads every sequence of a batch to the batch maximum
+ * (coot/dataset_retrieval.py:335-463) and runs all padded frames / words through the local networks.  With `packed` set, a local
+ * network (input_fc + atn pooler) processes only the valid tokens: cu_seqlens[i] (DEVICE, int32, N + N2 + 1 entries, segment 1's
+ * sequences first, cu_seqlens[0] = 0) is the first packed row of sequence i, total_tokens = cu_seqlens[N + N2] (HOST copy: it sizes
+ * the launches).  The input stays the reference's padded feats (+ lengths): the input LayerNorm gathers the valid rows, the
+ * token-tile chains are row independent, attention / pooling / positional encoding take the sequence boundaries from cu_seqlens.
+ * Pooled outputs and all gradients equal the padded computation (padded rows carry exactly zero pooling weight, poolers.py:190).
+ * NULL (or a network / size the packed path does not cover): the padded layout.  Forward and backward take the same decision. */
+typedef struct coot_packed_seqs { const int32_t* cu_seqlens; int total_tokens; } coot_packed_seqs;
 size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int L, int N2, int L2);
 size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int L, int N2, int L2);
 /* Optional SECOND SEGMENT (feats2 [N2, L2, input_dim], lengths2 [N2]; N2 = 0 / NULL when unused): a second set
@@ -83,7 +92,8 @@ int coot_net_fwd(const coot_net_config* cfg, const float* params, const void* wp
                  const float* feats, const int64_t* lengths, int N, int L, const float* feats2,
                  const int64_t* lengths2, int N2, int L2, const float* hidden,
                  float* pooled, float* per_token, void* saved, size_t saved_bytes, void* scratch,
-                 size_t scratch_bytes, int train, uint64_t seed, const uint64_t* seed_dev, coot_stream_t stream);
+                 size_t scratch_bytes, int train, uint64_t seed, const uint64_t* seed_dev, coot_stream_t stream,
+                 const coot_packed_seqs* packed /* NULL: padded rows */);
 /* Dropout (train != 0) draws from a counter-based generator keyed by (seed + *seed_dev, site, element); seed_dev
  * is an optional DEVICE word the caller advances once per step — with it a captured HIP graph of the step draws new
  * masks on every replay; forward and backward of one step must see the same value.
@@ -94,7 +104,8 @@ int coot_net_bwd(const coot_net_config* cfg, const float* params, const void* wp
                  const int64_t* lengths2, int N2, int L2, const float* hidden,
                  const float* dpooled, float* grads, float* dhidden, float* dfeats, void* saved,
                  size_t saved_bytes, void* scratch, size_t scratch_bytes, int train, uint64_t seed,
-                 const uint64_t* seed_dev, coot_stream_t stream);
+                 const uint64_t* seed_dev, coot_stream_t stream,
+                 const coot_packed_seqs* packed /* the forward's */);
 
 /* ---- clip -> video packing: the python loop of coot/model_retrieval.py:121-136 ---------------- */
 int coot_pack_fwd(const float* emb, const int64_t* counts, int B, int Cmax, int D, float* out /*[B,Cmax,D]*/,
@@ -172,7 +183,11 @@ typedef struct coot_step_config {
   int optimizer;                                 /* 0 = torch.optim.Adam, 1 = the in-file RAdam (:79-181)     */
   int radam_degentosgd;                          /* RAdam degenerated_to_sgd (optimizer.radam_degentosgd)     */
 } coot_step_config;
-typedef struct coot_step_dims { int B, Nc, Lv, Lc, Lp, Ls, Cmax_clip, Cmax_sent; } coot_step_dims;
+typedef struct coot_step_dims {
+  int B, Nc, Lv, Lc, Lp, Ls, Cmax_clip, Cmax_sent;
+  int tok_vis, tok_txt;   /* packed rows (coot_packed_seqs): valid frames of the B videos + Nc clips, valid words of the B paragraphs +
+                             Nc sentences (host values; 0 = padded layout); used with coot_step_batch.cu_vis / cu_txt */
+} coot_step_dims;
 typedef struct coot_step_buffers {
   float* params[4]; float* grads[4]; void* wpack[4];       /* flat arenas (coot_net_param_info layout), bf16 pack */
   float* adam_m[4]; float* adam_v[4];                      /* Adam moments, same layout                            */
@@ -182,6 +197,8 @@ typedef struct coot_step_buffers {
 typedef struct coot_step_batch {                           /* RetrievalDataBatchTuple (coot/dataset_retrieval.py:64-102) */
   const float *vid_feat, *clip_feat, *par_feat, *sent_feat;
   const int64_t *vid_len, *clip_len, *par_len, *sent_len, *clip_num, *sent_num;
+  const int32_t *cu_vis, *cu_txt;  /* optional packed row starts [B + Nc + 1]: the B videos (paragraphs) first, then the Nc clips
+                                      (sentences); NULL = padded layout */
 } coot_step_batch;
 size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_dims* dims);
 /* One optimisation step in one call: grads zeroed, both sides encoded on side_v / side_t, contrastive +
