@@ -265,9 +265,9 @@ static void layout_scratch(const coot_net_config& c, int N, long Ttok, Arena& A,
   {
     size_t widest = 3 * D; if (F > widest) widest = F; if ((size_t)c.pool_hidden > widest) widest = c.pool_hidden;
     S.part_floats = (T / 64 + 1024) * widest;
-    if (S.part_floats < (T / 128) * (size_t)FZ_BWD_NCS) S.part_floats = (T / 128) * (size_t)FZ_BWD_NCS;
+    if (S.part_floats < (T / 64) * (size_t)FZ_BWD_NCS) S.part_floats = (T / 64) * (size_t)FZ_BWD_NCS;  // one partial row per (64-row) tile
     S.part_low = S.part_floats;  // immediate users; behind it: the regions of the deferred reductions of one layer (rowops.h):
-    S.part_floats += (T / 128 + 1) * ((size_t)FZ_BWD_NCS + D) + (size_t)N * D + 1024;  // fused backward chain, QKV dX, pooling
+    S.part_floats += (T / 64 + 1) * ((size_t)FZ_BWD_NCS + D) + (size_t)N * D + 1024;  // fused backward chain, QKV dX, pooling
     S.part_ws = A.get<float>(S.part_floats);
   }
   if (c.use_context) {
@@ -593,6 +593,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "fused_bwd")) { g_use_fused_bwd = value; return 0; }
   if (!strcmp(name, "glob_fused")) { g_use_glob_fused = value; return 0; }
   if (!strcmp(name, "packed")) { g_use_packed = value; return 0; }
+  if (!strcmp(name, "half_tiles")) { set_half_tiles(value); return 0; }
   if (!strcmp(name, "fused_infc")) { g_use_fused_infc = value; return 0; }
   if (!strcmp(name, "gemm_small")) { set_gemm_small(value); return 0; }
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }

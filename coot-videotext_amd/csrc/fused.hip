@@ -148,7 +148,8 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
   // NCG = 4: 192 output columns, wave = 4 * row half + column group; a round = 64 rows x 192 columns, staged as two
   //          32-row groups side by side (staging columns 0..191 and 192..383), so the tile pass is the same 3 chunks/thread.
   constexpr int RR = RF >= 2 ? 32 : 16, FR = RR / 16, RPR = (NCG == 8 ? RR : 2 * RR), ROUNDS = 16 * RF / RPR, CH = RR * 48, IT = CH / NTHR;
-  static_assert(CH % NTHR == 0 && IT == 3 && ROUNDS <= 4 && (NCG == 8 || (NCG == 4 && ROUNDS == 2 && RF == 8)), "tile pass geometry");
+  static_assert(CH % NTHR == 0 && IT == 3 && ROUNDS <= 4 && (NCG == 8 || (NCG == 4 && ((ROUNDS == 2 && RF == 8) || (ROUNDS == 1 && RF == 4)))),
+                "tile pass geometry");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = wave % NCG, rh = wave / NCG;
   int rl[IT], col[IT];
@@ -197,13 +198,18 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
         case 2: put(std::integral_constant<int, 2>{}); break;
         default: put(std::integral_constant<int, 3>{}); break;
       }
-    } else {
+    } else if constexpr (RF == 8) {
       if (rh == r) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + (a & 1) * 16 * SPITCH + (a >> 1) * 192 + b * 16) = acc[a][b];
       }
+    } else {  // RF == 4: one round, both 32-row halves side by side (row half rh at staging columns 192 rh)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4_t*>(sw + a * 16 * SPITCH + rh * 192 + b * 16) = acc[a][b];
     }
     const int rbase = row0 + r * RPR;
     FZ_PT(2);
@@ -485,19 +491,20 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 template <int RF, bool DROPY, bool MASKX>
 __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, const bf16_t* xsaved, int row0, int T, bf16_t* out_dx,
                                             bf16_t* out_dxm, const DropK& dy_drop, const DropK& dx_drop, float* red, float* part_dst) {
-  static_assert(RF == 8, "16 rows per wave, 4 per pass");
+  static_assert(RF == 8 || RF == 4, "2 RF rows per wave, 4 per pass");
+  constexpr int NIT = RF / 2, RW = 2 * RF;
   asm volatile("" : "+s"(row0));  // keep this call's per-thread offsets out of the other LayerNorm's live range (they were spilled across the chain)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
-  u32x4_t xs[4][3];  // the saved LN input of this lane's 4 rows, kept packed (all loads in flight together)
+  u32x4_t xs[NIT][3];  // the saved LN input of this lane's rows, kept packed (all loads in flight together)
 #pragma unroll
-  for (int it = 0; it < 4; ++it)
+  for (int it = 0; it < NIT; ++it)
 #pragma unroll
-    for (int m = 0; m < 3; ++m) xs[it][m] = gld16(xsaved, (unsigned)((row0 + wave * 16 + it * 4 + g) * FZ_D + m * 128 + j16 * 8) * 2u);
+    for (int m = 0; m < 3; ++m) xs[it][m] = gld16(xsaved, (unsigned)((row0 + wave * RW + it * 4 + g) * FZ_D + m * 128 + j16 * 8) * 2u);
   // pass A: row statistics (4 scalars per row)
-  float mean[4], rsv[4], hmean[4], k2[4];
+  float mean[NIT], rsv[NIT], hmean[NIT], k2[NIT];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rl = wave * 16 + it * 4 + g, row = row0 + rl;
+  for (int it = 0; it < NIT; ++it) {
+    const int rl = wave * RW + it * 4 + g, row = row0 + rl;
     bf16_t* ar = As + rl * APITCH + j16 * 8;
     float s = 0.f;
 #pragma unroll
@@ -543,8 +550,8 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
 #pragma unroll
     for (int e = 0; e < 8; ++e) { csg[e] = 0.f; csb[e] = 0.f; csx[e] = 0.f; }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int rl = wave * 16 + it * 4 + g, row = row0 + rl;
+    for (int it = 0; it < NIT; ++it) {
+      const int rl = wave * RW + it * 4 + g, row = row0 + rl;
       bf16_t* ar = As + rl * APITCH + j16 * 8 + m * 128;
       float x[8], dy[8], dx[8], dm[8];
       unpack8(xs[it][m], x);
@@ -626,9 +633,9 @@ __device__ __forceinline__ void colsum_flush(const float (&cs)[3][8], float* red
   if (tid < FZ_D) dst[tid] = tot;
 }
 
-template <bool DROP>
+template <int RF, bool DROP>
 __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
-  constexpr int RF = 8, BT = 128, RR = 32;
+  constexpr int BT = 16 * RF, RR = 32;
   constexpr long GSZ192 = 6L * 3 * 512;  // one 48-column weight group at K = 192
   // LDS: token tile | fp32 staging (also the LayerNorm column-sum buffer) | zero vector, ln2 gain, ln1 gain, column-sum buffer
   __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4 + 4 * FZ_D * 4];
@@ -1036,8 +1043,10 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
 // ---- input FC (K = Din, streamed) + GELU + pe + QKV -----------------------------------------------------------------
 constexpr int XPITCH = 80;  // bf16 elements per row of a 64-column slab (160 B: conflict-free fragment reads)
 
+template <int RF>
 __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
-  constexpr int RF = 8, BT = 128, RR = 32;
+  constexpr int BT = 16 * RF, RR = 32, CPT = RF / 4;  // CPT: 16-byte slab chunks per thread (BT rows x 64 columns over 512 threads)
+  static_assert(RF == 8 || RF == 4, "tile height");
   __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4 + 4 * FZ_D * 4];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);          // during the K loop: two [128][80] slabs of xhat
   float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
@@ -1050,7 +1059,7 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
   if (tid < FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[tid] = reinterpret_cast<const f32x4_t*>(p.bin)[tid];
   else if (tid < 4 * FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[tid] = reinterpret_cast<const f32x4_t*>(p.bqkv)[tid - FZ_D / 4];
   bf16_t* Xs = As;  // [2][BT * XPITCH]
-  // slab staging: 128 rows x 64 columns = 1024 16-byte chunks, two per thread (rows r and r + 64)
+  // slab staging: BT rows x 64 columns = 8 BT 16-byte chunks, CPT per thread (rows r, r + 64)
   const int sr = tid >> 3, sc = (tid & 7) * 8;
   const unsigned g0 = (unsigned)((row0 + sr) * Din + sc) * 2u, g1 = (unsigned)((row0 + sr + 64) * Din + sc) * 2u;
   // Software pipeline of the K loop (one 64-column slab = two k-blocks = 48 MFMAs per wave, ~0.6 us per slab and CU):
@@ -1059,10 +1068,13 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
   //   weights: a ring of three slabs (6 k-blocks), filled two slabs ahead of their use (L2 latency ~ one slab);
   //   one LDS-only barrier per slab (a __syncthreads() would also drain the prefetches: one memory round trip per slab).
   u32x4_t xr[2][2];
-  auto gload = [&](int set, int k0) { xr[set][0] = gld16(p.xhat, g0 + (unsigned)k0 * 2u); xr[set][1] = gld16(p.xhat, g1 + (unsigned)k0 * 2u); };
+  auto gload = [&](int set, int k0) {
+    xr[set][0] = gld16(p.xhat, g0 + (unsigned)k0 * 2u);
+    if constexpr (CPT == 2) xr[set][1] = gld16(p.xhat, g1 + (unsigned)k0 * 2u);
+  };
   auto sstore = [&](int set, int buf) {
     *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + sr * XPITCH + sc]) = xr[set][0];
-    *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + (sr + 64) * XPITCH + sc]) = xr[set][1];
+    if constexpr (CPT == 2) *reinterpret_cast<u32x4_t*>(&Xs[buf * BT * XPITCH + (sr + 64) * XPITCH + sc]) = xr[set][1];
   };
   f32x4_t acc[RF][3];
   zero_acc<RF>(acc);
@@ -1164,9 +1176,9 @@ __global__ __launch_bounds__(512) void qkv_fwd_kernel(QkvFwd p) {
   }
 }
 
-template <bool GELU>
+template <int RF, bool GELU>
 __global__ __launch_bounds__(512) void qkv_bwd_kernel(QkvBwd p) {
-  constexpr int RF = 8, BT = 128, RR = 32;
+  constexpr int BT = 16 * RF, RR = 32;
   __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);
   float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
@@ -1258,6 +1270,14 @@ __global__ __launch_bounds__(256) void colsum_scatter_kernel(ScatterArgs a) {
 
 }  // namespace
 
+// Tile height of the token-tile chains.  One workgroup per CU: a launch of <= 256 tiles is ONE wave of workgroups whose duration is
+// the per-tile latency, however few tiles there are.  Up to 16 384 tokens (the text side of every shipped config, ragged batches
+// with packed rows, small batches) 64-row tiles still fit in one wave and each takes about half as long; above, 128-row tiles
+// (half the weight traffic per token) stay one wave up to 32 768 tokens.  coot_set_option("half_tiles", 0) forces 128 rows.
+static int g_half_tiles = 1;
+void set_half_tiles(int on) { g_half_tiles = on; }
+bool half_tiles(int T) { return g_half_tiles && T <= 256 * 64; }
+
 int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   COOT_REQUIRE(p.ctx && p.xres && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.ln1g && p.ln1b && p.ln2g && p.ln2b && p.r1 && p.z1 &&
                p.h1 && p.a1 && p.r2 && p.z2, "post_attn_fwd: null pointer");
@@ -1274,6 +1294,9 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   if (small) {
     if (drop) hipLaunchKernelGGL((post_attn_fwd_kernel<2, true>), dim3((p.T + 31) / 32), dim3(NTHR), 0, st, p);
     else hipLaunchKernelGGL((post_attn_fwd_kernel<2, false>), dim3((p.T + 31) / 32), dim3(NTHR), 0, st, p);
+  } else if (half_tiles(p.T)) {
+    if (drop) hipLaunchKernelGGL((post_attn_fwd_kernel<4, true>), dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
+    else hipLaunchKernelGGL((post_attn_fwd_kernel<4, false>), dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
   } else if (drop) {
     hipLaunchKernelGGL((post_attn_fwd_kernel<8, true>), dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
   } else {
@@ -1293,7 +1316,8 @@ int launch_pre_attn_bwd(const PreAttnBwd& p_in, hipStream_t st) {
                "pre_attn_bwd: null pointer");
   COOT_REQUIRE(p.do_pool ? (p.ds && p.dzp && p.hp && p.pw2 && p.pw1 && p.dhp) : (p.dz2 != nullptr), "pre_attn_bwd: input gradient pointers");
   if (p.T <= 0) return 0;
-  const int tiles = (p.T + 127) / 128;
+  const bool half = half_tiles(p.T);
+  const int tiles = half ? (p.T + 63) / 64 : (p.T + 127) / 128;
   // the per-tile partial rows: kept until the pass's single reduction launch if the caller opened a deferred scope (rowops.h)
   float* top = colsum_defer_room() >= 8 ? partials_workspace_top((size_t)tiles * FZ_BWD_NCS) : nullptr;
   if (top) p.part = top;
@@ -1301,9 +1325,11 @@ int launch_pre_attn_bwd(const PreAttnBwd& p_in, hipStream_t st) {
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 384.0 * (p.do_pool ? 6.0 : 3.0), 0, st);
   if (drop) {
     COOT_REQUIRE(p.d_ff2.thr && p.d_ff1.thr && p.d_postln.thr && (!p.do_pool || p.d_pool1.thr) && p.dr2m, "pre_attn_bwd: dropout on some sites only");
-    hipLaunchKernelGGL(pre_attn_bwd_kernel<true>, dim3(tiles), dim3(NTHR), 0, st, p);
+    if (half) hipLaunchKernelGGL((pre_attn_bwd_kernel<4, true>), dim3(tiles), dim3(NTHR), 0, st, p);
+    else hipLaunchKernelGGL((pre_attn_bwd_kernel<8, true>), dim3(tiles), dim3(NTHR), 0, st, p);
   } else {
-    hipLaunchKernelGGL(pre_attn_bwd_kernel<false>, dim3(tiles), dim3(NTHR), 0, st, p);
+    if (half) hipLaunchKernelGGL((pre_attn_bwd_kernel<4, false>), dim3(tiles), dim3(NTHR), 0, st, p);
+    else hipLaunchKernelGGL((pre_attn_bwd_kernel<8, false>), dim3(tiles), dim3(NTHR), 0, st, p);
   }
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("pre_attn_bwd");
@@ -1338,15 +1364,21 @@ int launch_qkv_bwd(const QkvBwd& p_in, hipStream_t st) {
   COOT_REQUIRE(p.dqkv && p.wqkv && p.res && p.dz, "qkv_bwd: null pointer");
   COOT_REQUIRE(!p.aux || (p.colsum && p.part), "qkv_bwd: GELU' needs the column-sum buffers");
   if (p.T <= 0) return 0;
-  const int tiles = (p.T + 127) / 128;
+  const bool half = half_tiles(p.T);
+  const int tiles = half ? (p.T + 63) / 64 : (p.T + 127) / 128;
   bool deferred = false;
   if (p.aux) {  // per-tile column sums -> the pass's single deferred reduction, if a scope is open (rowops.h)
     float* top = partials_workspace_top((size_t)tiles * FZ_D);
     if (top && colsum_defer_add(p.colsum, top, FZ_D, tiles, FZ_D, p.colsum_overwrite)) { p.part = top; deferred = true; }
   }
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 1152.0, 0, st);
-  if (p.aux) hipLaunchKernelGGL(qkv_bwd_kernel<true>, dim3(tiles), dim3(NTHR), 0, st, p);
-  else hipLaunchKernelGGL(qkv_bwd_kernel<false>, dim3(tiles), dim3(NTHR), 0, st, p);
+  if (half) {
+    if (p.aux) hipLaunchKernelGGL((qkv_bwd_kernel<4, true>), dim3(tiles), dim3(NTHR), 0, st, p);
+    else hipLaunchKernelGGL((qkv_bwd_kernel<4, false>), dim3(tiles), dim3(NTHR), 0, st, p);
+  } else {
+    if (p.aux) hipLaunchKernelGGL((qkv_bwd_kernel<8, true>), dim3(tiles), dim3(NTHR), 0, st, p);
+    else hipLaunchKernelGGL((qkv_bwd_kernel<8, false>), dim3(tiles), dim3(NTHR), 0, st, p);
+  }
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("qkv_bwd");
   if (p.aux) {
@@ -1386,7 +1418,8 @@ int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st) {
   COOT_REQUIRE(p.Din % 64 == 0 && p.Din >= 128 && p.L1 > 0 && p.L2 > 0, "infc_qkv_fwd: Din = %d must be a multiple of 64", p.Din);
   if (p.T <= 0) return 0;
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * (p.Din + 1152.0), 0, st);
-  hipLaunchKernelGGL(infc_qkv_fwd_kernel, dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+  if (half_tiles(p.T)) hipLaunchKernelGGL(infc_qkv_fwd_kernel<4>, dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
+  else hipLaunchKernelGGL(infc_qkv_fwd_kernel<8>, dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("infc_qkv_fwd");
   return 0;

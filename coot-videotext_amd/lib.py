@@ -146,6 +146,12 @@ def load():
     lib.coot_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp]
     lib.coot_radam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, i32, vp]
     _lib = lib
+    # A/B switches from the environment (COOT_OPTIONS="name=value,name=value": coot_set_option), e.g. to run the test-suite on an
+    # alternative kernel path
+    for kv in filter(None, os.environ.get("COOT_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        if lib.coot_set_option(k.strip().encode(), int(v)) != 0:
+            raise RuntimeError(f"COOT_OPTIONS: {lib.coot_last_error().decode()}")
     return lib
 
 
