@@ -545,6 +545,7 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
   return 0;
 }
 
+static int g_use_glob_fused_bwd = 1;  // coot_set_option("glob_fused_bwd", 0/1): their backward likewise (glob_bwd_kernel + one batched weight-gradient GEMM)
 static int g_use_glob_fused = 1;  // coot_set_option("glob_fused", 0/1): context networks as one launch per pass (fused.hip: glob_fwd_kernel)
 // the shape every shipped global network has: d_model 384, 8 heads, no input FC, one encoder layer + one context layer, avg_special
 static bool glob_fused_ok(const coot_net_config& c, const Segs& sg) {
@@ -592,6 +593,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
   if (!strcmp(name, "fused_bwd")) { g_use_fused_bwd = value; return 0; }
   if (!strcmp(name, "glob_fused")) { g_use_glob_fused = value; return 0; }
+  if (!strcmp(name, "glob_fused_bwd")) { g_use_glob_fused_bwd = value; return 0; }
   if (!strcmp(name, "packed")) { g_use_packed = value; return 0; }
   if (!strcmp(name, "half_tiles")) { set_half_tiles(value); return 0; }
   if (!strcmp(name, "fused_infc")) { g_use_fused_infc = value; return 0; }
@@ -905,6 +907,53 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   bf16_t* dz = X.dzA;     // grad wrt the last layer's output tokens
   bf16_t* dz_other = X.dzB;
 
+  if (glob_fused_ok(c, sg) && g_use_glob_fused_bwd && W.layers[0].f_wqkv_kn && W.ctx[0].f_wqkv_kn) {
+    // the whole context network backward in ONE launch (fused.hip: glob_bwd_kernel) + the batched weight-gradient GEMM
+    COOT_REQUIRE(dhidden && hidden, "net_bwd: dhidden required for context networks");
+    GlobBwd f; f.B = N; f.Cmax = Lseq; f.x = feats; f.lens = lens; f.n_gain = P + L.n_gain; f.dpooled = dpooled; f.dx = dfeats; f.dhidden = dhidden;
+    f.g_n_gain = G + L.n_gain; f.g_n_bias = G + L.n_bias; f.tstamps = g_fz_tstamps ? g_fz_tstamps + 16 : nullptr;
+    struct Dy { bf16_t *dr2, *dr2m, *dh1, *dr1, *dq; long lddq; bf16_t* dk; long lddk; bf16_t* dv; long lddv; };
+    auto fill = [&](GlobLayerBwd& g, const LayerP& lp, const LayerW& lw, const LayerBufs& b, const Dy& d, float pdrop, unsigned site_base) {
+      g.wqkv_kn = lw.f_wqkv_kn; g.wo_kn = lw.f_wo_kn; g.w1_kn = lw.f_w1_kn; g.w2_kn = lw.f_w2_kn; g.ln1g = P + lp.ln1g; g.ln2g = P + lp.ln2g;
+      g.q = b.q; g.ldq = b.ldq; g.k = b.k; g.ldk = b.ldk; g.v = b.v; g.ldv = b.ldv; g.r1 = b.r1; g.h1 = b.h1; g.r2 = b.r2; g.lse = b.lse;
+      g.dr2 = d.dr2; g.dr2m = d.dr2m; g.dh1 = d.dh1; g.dr1 = d.dr1; g.dq = d.dq; g.lddq = d.lddq; g.dk = d.dk; g.lddk = d.lddk; g.dv = d.dv; g.lddv = d.lddv;
+      g.g_ln2g = G + lp.ln2g; g.g_ln2b = G + lp.ln2b; g.g_ln1g = G + lp.ln1g; g.g_ln1b = G + lp.ln1b;
+      g.d_attn = mkdrop(train, pdrop, seed, site_base + SITE_ATTN); g.d_postln = mkdrop(train, pdrop, seed, site_base + SITE_POSTLN);
+      g.d_ff1 = mkdrop(train, pdrop, seed, site_base + SITE_FF1); g.d_ff2 = mkdrop(train, pdrop, seed, site_base + SITE_FF2);
+    };
+    const LayerBufs bs = self_bufs(S.layers[0], D), bc = ctx_bufs(S.ctx[0], D);
+    const Dy ds{X.dr2, X.dr2m, X.dh1, X.dr1, X.dqkv, 3L * D, X.dqkv + D, 3L * D, X.dqkv + 2 * D, 3L * D};
+    const Dy dc{X.c_d1, X.c_d2, X.c_dh1, X.c_dr1, X.c_dq, (long)D, X.c_dkv, 2L * D, X.c_dkv + D, 2L * D};
+    fill(f.self, L.layers[0], W.layers[0], bs, ds, c.dropout, 0u);
+    fill(f.ctx, L.ctx[0], W.ctx[0], bc, dc, c.ctx_dropout, 16u * 8);
+    RUN(launch_glob_bwd(f, st));
+    // the weight gradients layer_bwd records, from the dY tensors the kernel wrote (one batched launch at the flush below)
+    auto tn = [&](const bf16_t* A, long lda, const bf16_t* Bm, long ldb, int Tr, int Mo, int No, float* Cw, float* a_colsum) {
+      GemmTN t; t.A = A; t.lda = lda; t.B = Bm; t.ldb = ldb; t.T = Tr; t.Mo = Mo; t.No = No; t.C = Cw; t.ldc = No; t.a_colsum = a_colsum;
+      return launch_gemm_tn(t, st);
+    };
+    const int F = c.ff_dim;
+    {  // context layer: rows = sequences for the chain and the query projection, tokens for the key / value projections
+      const LayerP& lp = L.ctx[0];
+      // (b2, b1, bo gradients = column sums of the A operands: taken by the GEMM that streams them)
+      RUN(tn(f.ctx.d_ff2.thr ? dc.dr2m : dc.dr2, D, bc.a1, F, N, D, F, G + lp.w2, G + lp.b2));
+      RUN(tn(dc.dh1, F, bc.z1, D, N, F, D, G + lp.w1, G + lp.b1));
+      RUN(tn(dc.dr1, D, bc.ctx, D, N, D, D, G + lp.wo, G + lp.bo));
+      RUN(tn(dc.dq, D, S.cq_in, D, N, D, D, G + lp.wqkv, G + lp.bq));
+      RUN(tn(dc.dk, 2 * D, zL, D, T, 2 * D, D, G + lp.wqkv + (size_t)D * D, G + lp.bk));
+    }
+    {
+      const LayerP& lp = L.layers[0];
+      RUN(tn(f.self.d_ff2.thr ? ds.dr2m : ds.dr2, D, bs.a1, F, T, D, F, G + lp.w2, G + lp.b2));
+      RUN(tn(ds.dh1, F, bs.z1, D, T, F, D, G + lp.w1, G + lp.b1));
+      RUN(tn(ds.dr1, D, bs.ctx, D, T, D, D, G + lp.wo, G + lp.bo));
+      RUN(tn(ds.dq, 3 * D, S.z0, D, T, 3 * D, D, G + lp.wqkv, G + lp.bq));
+    }
+    RUN(tn_batch_flush_end(st));
+    RUN(colsum_defer_flush(st));
+    RUN(tn_batch_join(st));
+    return 0;
+  }
   // pooling MLP dX + the last encoder layer's LN / FF / out-proj dX in one fused launch (fused.hip: pre_attn_bwd_kernel)
   const bool pool_bwd_fused = g_use_fused && g_use_fused_bwd && fused_pool_ok(c) && W.f_pw1_kn && !c.use_context && T >= g_fused_min_rows;
   if (c.pooler == 0) {

@@ -128,6 +128,38 @@ struct GlobFwd {
 int launch_glob_fwd(const GlobFwd& p, hipStream_t st);
 bool glob_fwd_supported(int Cmax);
 
+// ---- the same network, backward, in ONE launch (+ the batched weight-gradient GEMM the caller records) ------------------------
+// From the gradient of the pooled output [B, 768] down to the gradient wrt the packed input [B, Cmax, 384] and the context
+// vectors [B, 384]: context-block chain backward (LN2, FF2^T, GELU', FF1^T, LN1, out-proj^T), one-query attention backward,
+// q / k / v projection dX, avg_special backward, encoder-layer chain backward, self-attention backward, QKV dX, input LayerNorm
+// backward — on the same 32-row tiles as glob_fwd_kernel.  Writes every dY tensor the weight-gradient GEMMs read (the layout
+// of the per-op path's scratch buffers) and adds the bias / LayerNorm parameter gradients (column sums) into the gradient arena.
+struct GlobLayerBwd {
+  const bf16_t *wqkv_kn = nullptr, *wo_kn = nullptr, *w1_kn = nullptr, *w2_kn = nullptr;  // P48 packs, dX orientation
+  const float *ln1g = nullptr, *ln2g = nullptr;
+  const bf16_t* q = nullptr; long ldq = 0; const bf16_t* k = nullptr; long ldk = 0; const bf16_t* v = nullptr; long ldv = 0;  // saved
+  const bf16_t *r1 = nullptr, *h1 = nullptr, *r2 = nullptr; const float* lse = nullptr;                                        // saved
+  bf16_t *dr2 = nullptr, *dr2m = nullptr, *dh1 = nullptr, *dr1 = nullptr;  // written: operands of the weight-gradient GEMMs
+  bf16_t* dq = nullptr; long lddq = 0; bf16_t* dk = nullptr; long lddk = 0; bf16_t* dv = nullptr; long lddv = 0;
+  float *g_ln2g = nullptr, *g_ln2b = nullptr, *g_ln1g = nullptr, *g_ln1b = nullptr;  // += (the bias gradients b2 / b1 / bo are column sums
+                                                                                   // of dr2m / dh1 / dr1: the weight-gradient GEMM takes them)
+  DropCfg d_attn, d_postln, d_ff1, d_ff2;
+};
+struct GlobBwd {
+  int B = 0, Cmax = 0;
+  const float* x = nullptr;         // [B, Cmax, 384] the forward's input
+  const long long* lens = nullptr;
+  const float* n_gain = nullptr;
+  const float* dpooled = nullptr;   // [B, 768]
+  GlobLayerBwd self, ctx;
+  float* dx = nullptr;              // [B, Cmax, 384] fp32 (written)
+  float* dhidden = nullptr;         // [B, 384] fp32 (written)
+  float *g_n_gain = nullptr, *g_n_bias = nullptr;  // +=
+  int tiles = 0, warm_per_xcd = 0;  // set by launch_glob_bwd
+  unsigned long long* tstamps = nullptr;  // profiling aid: block 0 phase stamps at slots 16.. (tools/glob_stamps.py)
+};
+int launch_glob_bwd(const GlobBwd& p, hipStream_t st);
+
 constexpr int FZ_BWD_NCS = 9 * FZ_D;  // floats per tile in PreAttnBwd::part
 bool half_tiles(int T);          // the chains run on 64-row tiles for this many tokens (fused.hip)
 void set_half_tiles(int on);

@@ -1040,6 +1040,478 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
   stamp();
 }
 
+// ---- global network backward in one launch (fused.h: GlobBwd) ---------------------------------------------------------------
+
+// Column sums over the rows of a 32-row tile held one row per 16-lane group (lane j16 holds columns 128 m + 8 j16 .. + 8 of the
+// three 128-column chunks): NQ quantities, dst[q][384] += (global atomics: at most 64 workgroups per launch add one row each).
+// One 128-column chunk at a time through red[32 rows][NQ x 128] (plain LDS stores, NQ x 128 threads add the 32 rows): the
+// register route (xor-shuffles over the 4 row groups of a wave = 48 NQ ds_bpermute per lane) made a LayerNorm backward of 32
+// rows cost 17k cycles, twice a GEMM pass.
+template <int NQ>
+__device__ __forceinline__ void rows_colsum_flush(const float (&cs)[NQ][3][8], float* red, float* const (&dst)[NQ]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
+  const int rl = wave * 4 + g;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      float* w = red + rl * (NQ * 128) + q * 128 + j16 * 8;
+      *reinterpret_cast<f32x4_t*>(w) = f32x4_t{cs[q][m][0], cs[q][m][1], cs[q][m][2], cs[q][m][3]};
+      *reinterpret_cast<f32x4_t*>(w + 4) = f32x4_t{cs[q][m][4], cs[q][m][5], cs[q][m][6], cs[q][m][7]};
+    }
+    lds_barrier();
+    if (threadIdx.x < NQ * 128) {
+      float v = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) v += red[r * (NQ * 128) + threadIdx.x];
+      float* d = dst[threadIdx.x / 128];
+      if (d) atomicAdd(d + m * 128 + (threadIdx.x & 127), v);
+    }
+  }
+  lds_barrier();
+}
+
+// LayerNorm backward of the 32 tile rows, one row per 16-lane group; rows [row0, rowEnd) are real.
+//   dy: the tile (bf16) or fp32 global rows (DY32);  x: the saved LN input, bf16 global, or the fp32 network input (X32)
+//   DROPY: dy is first multiplied by the dropout mask the forward applied to the LN output
+//   MASKX: dxm = dx * mask(dx_drop) is what stays in the tile and goes to out_dxm; dx goes to out_dx (bf16) / out32 (fp32)
+//   gradients: g_gain += sum dy xc / s, g_bias += sum dy (the column sums of dx / dxm = the bias gradient of the Linear in front
+//   are taken by the weight-gradient GEMM that streams that tensor anyway: GemmTN::a_colsum)
+template <bool DROPY, bool MASKX, bool DY32, bool X32>
+__device__ __forceinline__ void glob_ln_bwd(bf16_t* As, const float* dy32, long lddy32, const void* xsrc, const float* gain, int row0, int rowEnd,
+                                            bf16_t* out_dx, bf16_t* out_dxm, float* out32, const DropK& dy_drop, const DropK& dx_drop, float* red,
+                                            float* g_gain, float* g_bias) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
+  const int rl = wave * 4 + g, row = row0 + rl;
+  const bool on = row < rowEnd;
+  float x[3][8], dy[3][8], gn[3][8];
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int col = m * 128 + j16 * 8;
+    load8f(gain + col, gn[m]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x[m][e] = 0.f; dy[m][e] = 0.f; }
+    if (on) {
+      if constexpr (X32) load8f(reinterpret_cast<const float*>(xsrc) + (long)row * FZ_D + col, x[m]);
+      else unpack8(gld16(xsrc, (unsigned)(row * FZ_D + col) * 2u), x[m]);
+      if constexpr (DY32) load8f(dy32 + (long)row * lddy32 + col, dy[m]);
+      else unpack8(*reinterpret_cast<const u32x4_t*>(&As[rl * APITCH + col]), dy[m]);
+      if constexpr (DROPY) {
+        float sc[8];
+        drop_scales_key<8>(dy_drop.key, (unsigned long long)row * FZ_D + col, dy_drop.thr, dy_drop.inv_keep, sc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dy[m][e] *= sc[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += x[m][e];
+  }
+  const float mu = row16_sum(s) * (1.0f / 384.0f);
+  float q = 0.f, hs = 0.f, hx = 0.f;
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      x[m][e] -= mu;
+      q += x[m][e] * x[m][e];
+      const float h = dy[m][e] * gn[m][e];
+      hs += h; hx += h * x[m][e];
+    }
+  q = row16_sum(q); hs = row16_sum(hs); hx = row16_sum(hx);
+  const float stdv = sqrtf(q * (1.0f / 383.0f));
+  const float rs = 1.0f / (stdv + kLnEps), hmean = hs * (1.0f / 384.0f);
+  const float k2 = stdv > 0.f ? hx * rs * rs / (383.0f * stdv) : 0.f;
+  float cs[2][3][8];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int col = m * 128 + j16 * 8;
+    float dx[8], dm[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dx[e] = (dy[m][e] * gn[m][e] - hmean) * rs - k2 * x[m][e];
+    if constexpr (MASKX) {
+      float sc[8];
+      drop_scales_key<8>(dx_drop.key, (unsigned long long)row * FZ_D + col, dx_drop.thr, dx_drop.inv_keep, sc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dm[e] = dx[e] * sc[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dm[e] = dx[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      cs[0][m][e] = on ? dy[m][e] * x[m][e] * rs : 0.f;
+      cs[1][m][e] = on ? dy[m][e] : 0.f;
+    }
+    const u32x4_t om = on ? pack8(dm) : u32x4_t{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4_t*>(&As[rl * APITCH + col]) = om;
+    if (on) {
+      const unsigned boff = (unsigned)(row * FZ_D + col) * 2u;
+      if (out_dx) gst16(out_dx, boff, pack8(dx));
+      if constexpr (MASKX) gst16(out_dxm, boff, om);
+      if (out32) {
+        float* o32 = out32 + (long)row * FZ_D + col;
+        *reinterpret_cast<f32x4_t*>(o32) = f32x4_t{dx[0], dx[1], dx[2], dx[3]};
+        *reinterpret_cast<f32x4_t*>(o32 + 4) = f32x4_t{dx[4], dx[5], dx[6], dx[7]};
+      }
+    }
+  }
+  float* const dst[2] = {g_gain, g_bias};
+  rows_colsum_flush<2>(cs, red, dst);
+}
+
+// rows [grow0, grow0 + nvalid) of a bf16 [., ld] matrix at column col0 -> tile rows 0.. (the rest of the 32 rows: zeros)
+__device__ __forceinline__ void load_rows32(bf16_t* Ts, const bf16_t* src, long ld, int col0, int grow0, int nvalid) {
+  for (int c = threadIdx.x; c < 32 * 48; c += NTHR) {
+    const int rl = c / 48, ch = c - rl * 48;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (rl < nvalid) v = gld16(src, (unsigned)((grow0 + rl) * (int)ld + col0 + ch * 8) * 2u);
+    *reinterpret_cast<u32x4_t*>(&Ts[rl * APITCH + ch * 8]) = v;
+  }
+}
+
+// The chain of pre_attn_bwd_kernel on the 32-row tile: LN2 backward, FF2^T, GELU', FF1^T, LN1 backward (through the post-LN
+// dropout), out-proj^T.  In: the gradient wrt the layer output in As (bf16) or dy32 (fp32 rows).  Out: the gradient wrt the
+// attention output in As; dr2 / dr2m / dh1 / dr1 in global memory (the weight-gradient GEMMs read them), parameter gradients added.
+template <bool DROP, bool DY32>
+__device__ __forceinline__ void glob_chain_bwd(bf16_t* As, float* Stg, const GlobLayerBwd& L, const float* dy32, long lddy32, int row0, int rowEnd,
+                                               unsigned long long sbase) {
+  constexpr int RF = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const DropK d_postln = resolve_drop(L.d_postln, sbase), d_ff1 = resolve_drop(L.d_ff1, sbase), d_ff2 = resolve_drop(L.d_ff2, sbase);
+  f32x4_t acc[RF][3];
+  glob_ln_bwd<false, DROP, DY32, false>(As, dy32, lddy32, L.r2, L.ln2g, row0, rowEnd, L.dr2, L.dr2m, nullptr, d_ff2, d_ff2, Stg, L.g_ln2g, L.g_ln2b);
+  __syncthreads();  // the tile holds df2; dr2 (global) is read back below
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, L.w2_kn + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
+      [&](int row, int col) { return PreRes{row < rowEnd ? gld16(L.h1, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
+      [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
+        float a[8];
+        unpack8(pr.res, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+        apply_drop<DROP>(d_ff1, (unsigned long long)row * FZ_D + col, v);
+        if (row < rowEnd) {
+          gst16(L.dh1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+      }, true);
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, L.w1_kn + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
+      [&](int row, int col) { return PreRes{row < rowEnd ? gld16(L.dr2, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
+      [&](int, int, float (&v)[8], const PreRes& pr, int) {
+        float r[8];
+        unpack8(pr.res, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+      }, true);
+  glob_ln_bwd<DROP, false, false, false>(As, nullptr, 0, L.r1, L.ln1g, row0, rowEnd, L.dr1, nullptr, nullptr, d_postln, d_postln, Stg, L.g_ln1g,
+                                         L.g_ln1b);
+  __syncthreads();
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(As, L.wo_kn + wave * GSZ, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr, [&](int, int) { return PreNone{}; }, [&](int, int, float (&)[8], const PreNone&, int) {}, true);
+  __syncthreads();
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void glob_bwd_kernel(GlobBwd p) {
+  constexpr int RF = 2, BT = 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BT * APITCH * 2 + BT * SPITCH * 4];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Qs = As + BT * APITCH;
+  bf16_t* Ks = Qs + BT * APITCH;
+  bf16_t* Vs = Ks + BT * APITCH;
+  float* Stg = reinterpret_cast<float*>(smem + 4 * BT * APITCH * 2);
+  float* Sc = Stg;               // attention: probabilities [256 pairs][32 keys]
+  float* Dl = Stg + 256 * 32;    // delta [256 pairs]
+  float* Ls = Dl + 256;          // lse [256 pairs]
+  static_assert(BT * SPITCH >= 256 * 32 + 512, "staging buffer holds the attention scratch");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Cm = p.Cmax, G = 32 / Cm;
+  if ((int)blockIdx.x >= p.tiles) {
+    const bf16_t* ws[8] = {p.ctx.wqkv_kn, p.ctx.wo_kn, p.ctx.w1_kn, p.ctx.w2_kn, p.self.wqkv_kn, p.self.wo_kn, p.self.w1_kn, p.self.w2_kn};
+    l2_prefetch(ws, ((int)blockIdx.x - p.tiles) >> 3, p.warm_per_xcd);
+    return;
+  }
+  const int v0 = blockIdx.x * G, nv = (p.B - v0) < G ? (p.B - v0) : G;
+  const int row0 = v0 * Cm, nrows = nv * Cm, rowEnd = row0 + nrows;
+  unsigned long long sbase = 0;
+  if constexpr (DROP) { if (p.self.d_ff1.seed_ptr) sbase = *p.self.d_ff1.seed_ptr; }
+  const float scale = 0.14433756729740643f;
+  f32x4_t acc[RF][3];
+  const int pair = tid >> 1, half = tid & 1, pr_ = pair >> 3, ph = pair & 7, coff = ph * 48 + half * 24;
+  int tsn = 0;
+  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  stamp();
+
+  // ---- context block backward: rows = sequences (tile row r = sequence v0 + r) -------------------------------------------------
+  glob_chain_bwd<DROP, true>(As, Stg, p.ctx, p.dpooled + FZ_D, 2 * FZ_D, v0, v0 + nv, sbase);   // As: gradient wrt the attention output
+  stamp();
+  load_rows32(Qs, p.ctx.q, p.ctx.ldq, 0, v0, nv);
+  load_rows32(Ks, p.ctx.k, p.ctx.ldk, 0, row0, nrows);
+  load_rows32(Vs, p.ctx.v, p.ctx.ldv, 0, row0, nrows);
+  __syncthreads();
+  {  // one-query attention backward, thread pair = (sequence r, head h), in place: Qs -> dq, Ks -> dk, Vs -> dv
+    const DropK dk_ = resolve_drop(p.ctx.d_attn, sbase);
+    const bool on = pr_ < nv;
+    const int r = on ? pr_ : 0, kr0 = r * Cm;
+    const int nvalid = on ? (int)p.lens[v0 + r] : 0;
+    const float lse = on ? p.ctx.lse[(long)(v0 + r) * 8 + ph] : 0.f;
+    float q[24], dO[24];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      unpack8(*reinterpret_cast<const u32x4_t*>(&Qs[r * APITCH + coff + c * 8]), &q[c * 8]);
+      unpack8(*reinterpret_cast<const u32x4_t*>(&As[r * APITCH + coff + c * 8]), &dO[c * 8]);
+    }
+    const unsigned mrow = (unsigned)((v0 + r) * 8 + ph);
+    float delta = 0.f;
+    for (int j = 0; j < Cm; ++j) {
+      float kk[24], vv[24];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(&Ks[(kr0 + j) * APITCH + coff + c * 8]), &kk[c * 8]);
+        unpack8(*reinterpret_cast<const u32x4_t*>(&Vs[(kr0 + j) * APITCH + coff + c * 8]), &vv[c * 8]);
+      }
+      float sv = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < 24; ++c) { sv += q[c] * kk[c]; dp += dO[c] * vv[c]; }
+      sv += __shfl_xor(sv, 1, 64); dp += __shfl_xor(dp, 1, 64);
+      sv = j < nvalid ? sv * scale : kMaskFill;
+      const float pj = __expf(sv - lse);
+      float dr = 1.f;
+      if constexpr (DROP) dr = attn_drop_f(dk_.key, mrow, j, (unsigned)(Cm + 1) >> 1, dk_.thr, dk_.inv_keep);
+      delta += pj * dr * dp;
+      if (half == 0) { Sc[pair * 32 + j] = pj; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float dq[24];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) dq[c] = 0.f;
+    for (int j = 0; j < Cm; ++j) {
+      float kk[24], vv[24];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(&Ks[(kr0 + j) * APITCH + coff + c * 8]), &kk[c * 8]);
+        unpack8(*reinterpret_cast<const u32x4_t*>(&Vs[(kr0 + j) * APITCH + coff + c * 8]), &vv[c * 8]);
+      }
+      float dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < 24; ++c) dp += dO[c] * vv[c];
+      dp += __shfl_xor(dp, 1, 64);
+      const float pj = Sc[pair * 32 + j];
+      float dr = 1.f;
+      if constexpr (DROP) dr = attn_drop_f(dk_.key, mrow, j, (unsigned)(Cm + 1) >> 1, dk_.thr, dk_.inv_keep);
+      const float ds = j < nvalid ? pj * (dr * dp - delta) * scale : 0.f;
+      const float pd = pj * dr;
+#pragma unroll
+      for (int c = 0; c < 24; ++c) dq[c] += ds * kk[c];
+      if (on) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float t8[8], u8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { t8[e] = ds * q[c * 8 + e]; u8[e] = pd * dO[c * 8 + e]; }
+          const u32x4_t pk = pack8(t8), pv = pack8(u8);
+          *reinterpret_cast<u32x4_t*>(&Ks[(kr0 + j) * APITCH + coff + c * 8]) = pk;
+          *reinterpret_cast<u32x4_t*>(&Vs[(kr0 + j) * APITCH + coff + c * 8]) = pv;
+          gst16(p.ctx.dk, (unsigned)((row0 + kr0 + j) * (int)p.ctx.lddk + coff + c * 8) * 2u, pk);
+          gst16(p.ctx.dv, (unsigned)((row0 + kr0 + j) * (int)p.ctx.lddv + coff + c * 8) * 2u, pv);
+        }
+      }
+    }
+    if (on) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const u32x4_t pk = pack8(&dq[c * 8]);
+        *reinterpret_cast<u32x4_t*>(&Qs[r * APITCH + coff + c * 8]) = pk;
+        gst16(p.ctx.dq, (unsigned)((v0 + r) * (int)p.ctx.lddq + coff + c * 8) * 2u, pk);
+      }
+    }
+  }
+  __syncthreads();
+  stamp();
+  // ---- gradient wrt the context vectors: dhidden = dq . Wq + dr1 ------------------------------------------------------------------
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(Qs, p.ctx.wqkv_kn + (long)wave * (36L * 3 * 512), acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, v0, nullptr,
+      [&](int row, int col) { return PreRes{row < v0 + nv ? gld16(p.ctx.dr1, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
+      [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
+        float r[8];
+        unpack8(pr.res, r);
+        if (row < v0 + nv) {
+          float* o = p.dhidden + (long)row * FZ_D + col;
+          *reinterpret_cast<f32x4_t*>(o) = f32x4_t{v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
+          *reinterpret_cast<f32x4_t*>(o + 4) = f32x4_t{v[4] + r[4], v[5] + r[5], v[6] + r[6], v[7] + r[7]};
+        }
+      }, false);
+  stamp();
+  // ---- gradient wrt the encoder output: dk . Wk + dv . Wv + avg_special backward (dpooled / len on ALL Cmax rows) ---------------------
+  zero_acc<RF>(acc);
+  gemm_pass<RF, 12>(Ks, p.ctx.wqkv_kn + (long)wave * (36L * 3 * 512) + 12L * 3 * 512, acc, lane);
+  gemm_pass<RF, 12>(Vs, p.ctx.wqkv_kn + (long)wave * (36L * 3 * 512) + 24L * 3 * 512, acc, lane);
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr, [&](int, int) { return PreNone{}; },
+      [&](int row, int col, float (&v)[8], const PreNone&, int) {
+        if (row < rowEnd) {
+          const int vid = row / Cm;
+          const float inv = 1.0f / (float)p.lens[vid];
+          float g[8];
+          load8f(p.dpooled + (long)vid * (2 * FZ_D) + col, g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += g[j] * inv;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+      }, true);
+  __syncthreads();
+  stamp();
+
+  // ---- encoder layer backward: rows = tokens -------------------------------------------------------------------------------------
+  glob_chain_bwd<DROP, false>(As, Stg, p.self, nullptr, 0, row0, rowEnd, sbase);   // As: gradient wrt the attention output
+  stamp();
+  load_rows32(Qs, p.self.q, p.self.ldq, 0, row0, nrows);
+  load_rows32(Ks, p.self.k, p.self.ldk, 0, row0, nrows);
+  load_rows32(Vs, p.self.v, p.self.ldv, 0, row0, nrows);
+  __syncthreads();
+  {
+    const DropK dk_ = resolve_drop(p.self.d_attn, sbase);
+    const bool on = pr_ < nrows;
+    const int r = on ? pr_ : 0, sl = r / Cm, kr0 = sl * Cm, cpos = r - kr0;
+    const int nvalid = on ? (int)p.lens[v0 + sl] : 0;
+    // pass A, thread pair = (query row r, head h): delta, dq
+    {
+      const float lse = on ? p.self.lse[(long)(row0 + r) * 8 + ph] : 0.f;
+      float q[24], dO[24];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(&Qs[r * APITCH + coff + c * 8]), &q[c * 8]);
+        unpack8(*reinterpret_cast<const u32x4_t*>(&As[r * APITCH + coff + c * 8]), &dO[c * 8]);
+      }
+      const unsigned mrow = (unsigned)(((v0 + sl) * 8 + ph) * Cm + cpos);
+      float delta = 0.f;
+      for (int j = 0; j < Cm; ++j) {
+        float kk[24], vv[24];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          unpack8(*reinterpret_cast<const u32x4_t*>(&Ks[(kr0 + j) * APITCH + coff + c * 8]), &kk[c * 8]);
+          unpack8(*reinterpret_cast<const u32x4_t*>(&Vs[(kr0 + j) * APITCH + coff + c * 8]), &vv[c * 8]);
+        }
+        float sv = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) { sv += q[c] * kk[c]; dp += dO[c] * vv[c]; }
+        sv += __shfl_xor(sv, 1, 64); dp += __shfl_xor(dp, 1, 64);
+        sv = j < nvalid ? sv * scale : kMaskFill;
+        const float pj = __expf(sv - lse);
+        float dr = 1.f;
+        if constexpr (DROP) dr = attn_drop_f(dk_.key, mrow, j, (unsigned)(Cm + 1) >> 1, dk_.thr, dk_.inv_keep);
+        delta += pj * dr * dp;
+        if (half == 0) Sc[pair * 32 + j] = pj;
+      }
+      if (half == 0) { Dl[pair] = delta; Ls[pair] = lse; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float dq[24];
+#pragma unroll
+      for (int c = 0; c < 24; ++c) dq[c] = 0.f;
+      for (int j = 0; j < Cm; ++j) {
+        float kk[24], vv[24];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          unpack8(*reinterpret_cast<const u32x4_t*>(&Ks[(kr0 + j) * APITCH + coff + c * 8]), &kk[c * 8]);
+          unpack8(*reinterpret_cast<const u32x4_t*>(&Vs[(kr0 + j) * APITCH + coff + c * 8]), &vv[c * 8]);
+        }
+        float dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) dp += dO[c] * vv[c];
+        dp += __shfl_xor(dp, 1, 64);
+        const float pj = Sc[pair * 32 + j];
+        float dr = 1.f;
+        if constexpr (DROP) dr = attn_drop_f(dk_.key, mrow, j, (unsigned)(Cm + 1) >> 1, dk_.thr, dk_.inv_keep);
+        const float ds = j < nvalid ? pj * (dr * dp - delta) * scale : 0.f;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) dq[c] += ds * kk[c];
+      }
+      if (on) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gst16(p.self.dq, (unsigned)((row0 + r) * (int)p.self.lddq + coff + c * 8) * 2u, pack8(&dq[c * 8]));
+      }
+    }
+    lds_barrier();  // every pair's delta / lse is in LDS
+    // pass B, thread pair = (key row r, head h): dk, dv over the queries of the sequence
+    {
+      float kk[24], vv[24], dkr[24], dvr[24];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(&Ks[r * APITCH + coff + c * 8]), &kk[c * 8]);
+        unpack8(*reinterpret_cast<const u32x4_t*>(&Vs[r * APITCH + coff + c * 8]), &vv[c * 8]);
+      }
+#pragma unroll
+      for (int c = 0; c < 24; ++c) { dkr[c] = 0.f; dvr[c] = 0.f; }
+      const bool kvalid = on && cpos < nvalid;
+      for (int i = 0; i < Cm; ++i) {
+        float q[24], dO[24];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          unpack8(*reinterpret_cast<const u32x4_t*>(&Qs[(kr0 + i) * APITCH + coff + c * 8]), &q[c * 8]);
+          unpack8(*reinterpret_cast<const u32x4_t*>(&As[(kr0 + i) * APITCH + coff + c * 8]), &dO[c * 8]);
+        }
+        float sv = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) { sv += q[c] * kk[c]; dp += dO[c] * vv[c]; }
+        sv += __shfl_xor(sv, 1, 64); dp += __shfl_xor(dp, 1, 64);
+        const int qp = (kr0 + i) * 8 + ph;  // the query's pair index
+        const float pj = kvalid ? __expf(sv * scale - Ls[qp]) : 0.f;
+        float dr = 1.f;
+        if constexpr (DROP) dr = attn_drop_f(dk_.key, (unsigned)(((v0 + sl) * 8 + ph) * Cm + i), cpos, (unsigned)(Cm + 1) >> 1, dk_.thr, dk_.inv_keep);
+        const float ds = pj * (dr * dp - Dl[qp]) * scale;
+        const float pd = pj * dr;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) { dkr[c] += ds * q[c]; dvr[c] += pd * dO[c]; }
+      }
+      if (on) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          gst16(p.self.dk, (unsigned)((row0 + r) * (int)p.self.lddk + coff + c * 8) * 2u, pack8(&dkr[c * 8]));
+          gst16(p.self.dv, (unsigned)((row0 + r) * (int)p.self.lddv + coff + c * 8) * 2u, pack8(&dvr[c * 8]));
+        }
+      }
+    }
+  }
+  __syncthreads();  // dq | dk | dv (global, this workgroup's rows) are read back as the GEMM operand
+  stamp();
+  // ---- dz0 = dqkv . Wqkv + dr1, K = 1152 as three 384-wide tiles ---------------------------------------------------------------------
+  zero_acc<RF>(acc);
+  load_rows32(Qs, p.self.dq, p.self.lddq, 0, row0, nrows);  // q | k | v tiles are dead: all three operand tiles at once
+  load_rows32(Ks, p.self.dk, p.self.lddk, 0, row0, nrows);
+  load_rows32(Vs, p.self.dv, p.self.lddv, 0, row0, nrows);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    const bf16_t* Ts = c == 0 ? Qs : (c == 1 ? Ks : Vs);
+    gemm_pass<RF, 12>(Ts, p.self.wqkv_kn + (long)wave * (36L * 3 * 512) + (long)c * 12 * 3 * 512, acc, lane);
+  }
+  epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
+      [&](int row, int col) { return PreRes{row < rowEnd ? gld16(p.self.dr1, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
+      [&](int, int, float (&v)[8], const PreRes& pr, int) {
+        float r[8];
+        unpack8(pr.res, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+      }, true);
+  stamp();
+  // ---- input LayerNorm backward (the positional encoding has no gradient) -----------------------------------------------------------
+  {
+    const DropK none;
+    glob_ln_bwd<false, false, false, true>(As, nullptr, 0, p.x, p.n_gain, row0, rowEnd, nullptr, nullptr, p.dx, none, none, Stg, p.g_n_gain, p.g_n_bias);
+  }
+  stamp();
+}
+
 // ---- input FC (K = Din, streamed) + GELU + pe + QKV -----------------------------------------------------------------
 constexpr int XPITCH = 80;  // bf16 elements per row of a 64-column slab (160 B: conflict-free fragment reads)
 
@@ -1411,6 +1883,26 @@ int launch_glob_fwd(const GlobFwd& p_in, hipStream_t st) {
   else hipLaunchKernelGGL(glob_fwd_kernel<false>, dim3(grid), dim3(NTHR), 0, st, p);
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("glob_fwd");
+  return 0;
+}
+int launch_glob_bwd(const GlobBwd& p_in, hipStream_t st) {
+  COOT_REQUIRE(p_in.x && p_in.lens && p_in.n_gain && p_in.dpooled && p_in.dhidden, "glob_bwd: null pointer");
+  COOT_REQUIRE(glob_fwd_supported(p_in.Cmax), "glob_bwd: %d items per sequence (max 32)", p_in.Cmax);
+  if (p_in.B <= 0) return 0;
+  GlobBwd p = p_in;
+  const int G = 32 / p.Cmax, tiles = (p.B + G - 1) / G;
+  p.tiles = tiles;
+  p.warm_per_xcd = tiles >= 128 ? 0 : (tiles > 64 ? 8 : 16);
+  const bool drop = p.self.d_attn.thr || p.self.d_postln.thr || p.self.d_ff1.thr || p.self.d_ff2.thr;
+  if (drop) COOT_REQUIRE(p.self.d_attn.thr && p.self.d_postln.thr && p.self.d_ff1.thr && p.self.d_ff2.thr && p.ctx.d_attn.thr && p.ctx.d_postln.thr &&
+                         p.ctx.d_ff1.thr && p.ctx.d_ff2.thr && p.self.dr2m && p.ctx.dr2m, "glob_bwd: dropout on some sites only");
+  const double T = (double)p.B * p.Cmax;
+  void* ts = timing_begin(TIMING_GLOB, 2.0 * 384.0 * 384.0 * (6.0 * T + 6.0 * T + 4.0 * p.B), 0, st);
+  const int grid = tiles + 8 * p.warm_per_xcd;
+  if (drop) hipLaunchKernelGGL(glob_bwd_kernel<true>, dim3(grid), dim3(NTHR), 0, st, p);
+  else hipLaunchKernelGGL(glob_bwd_kernel<false>, dim3(grid), dim3(NTHR), 0, st, p);
+  timing_end(ts, st);
+  COOT_CHECK_LAUNCH("glob_bwd");
   return 0;
 }
 int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st) {

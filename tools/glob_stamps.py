@@ -12,6 +12,8 @@ lib = cva.lib.load()
 cfg = O.NetConfig(input_dim=384, hidden_dim=384, num_heads=8, ff_dim=384, use_input_fc=False, use_context=True, pooler="avg_special")
 net = H.make_hip_net(cfg, O.make_params(cfg, 3), dropout=0.025)
 ts = torch.zeros(64, dtype=torch.int64, device="cuda")
+bnames = ["start", "context chain", "one-query attention bwd", "dhidden (q proj dX)", "k, v proj dX + avg pool bwd", "encoder chain", "self-attention bwd",
+          "QKV dX", "input LN bwd"]
 names = ["start", "LN + pe", "q", "k", "v", "self attention", "encoder chain", "context k, v (+ avg pool)", "query tile + q", "context attention", "context chain"]
 for train in (False, True):
     net.train(train)
@@ -20,6 +22,15 @@ for train in (False, True):
         hid = torch.randn(N, 384, device="cuda")
         lens = torch.full((N,), L, dtype=torch.long, device="cuda")
         mask = torch.zeros(N, L, dtype=torch.bool, device="cuda")
+        xg = x.clone().requires_grad_(True)
+        hg = hid.clone().requires_grad_(True)
+        cva.lib.check(lib.coot_debug_timestamps(ts.data_ptr()))
+        pooled, _ = net(xg, mask, lens, hg, seed=1)
+        pooled.sum().backward()
+        torch.cuda.synchronize()
+        cva.lib.check(lib.coot_debug_timestamps(None))
+        tb = ts.cpu().numpy()[16:16 + len(bnames)]
+        print(f"train={train} N={N} L={L} BACKWARD block 0 total {tb[-1] - tb[0]} shader cycles; " + ", ".join(f"{n} {int(v)}" for n, v in zip(bnames[1:], tb[1:] - tb[:-1])))
         with torch.no_grad():
             for _ in range(3):
                 net(x, mask, lens, hid, seed=1)
