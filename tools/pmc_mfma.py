@@ -24,8 +24,12 @@ def read(path):
 
 
 def short(k):
-    m = re.search(r"(\d+)([a-z_0-9]+_kernel)", k)
-    return m.group(2) if m else k
+    m = re.search(r"(\d+)([a-z_0-9]+_kernel)(ILi(\d+)E)?", k)
+    if not m:
+        return k
+    name = m.group(2)
+    name = re.sub(r"^coot\d+", "", name)
+    return name + (f"<{m.group(4)}>" if m.group(4) else "")
 
 
 def main(busy_csv, mops_csv, out_json):
