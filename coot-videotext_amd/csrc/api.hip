@@ -587,6 +587,14 @@ int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)d
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
 extern "C" void coot_step_tn_aux(int sides);
 extern "C" void coot_step_defer_global_tn(int on);
+int coot_get_option(const char* name, int* value) {
+  if (!value) { set_error("get_option: null result"); return -1; }
+  if (!strcmp(name, "tn_dma")) { *value = get_tn_dma(); return 0; }
+  if (!strcmp(name, "xcd_order")) { *value = get_xcd_order(); return 0; }
+  if (!strcmp(name, "tn_mode")) { *value = get_tn_mode(); return 0; }
+  set_error("get_option: unknown or write-only option %s", name);
+  return -2;
+}
 int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
   if (!strcmp(name, "step_stamps")) { coot_step_stamps_enable(value); return 0; }
@@ -600,6 +608,8 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_small")) { set_gemm_small(value); return 0; }
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
   if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
+  if (!strcmp(name, "tn_dma")) { set_tn_dma(value); return 0; }
+  if (!strcmp(name, "tn_target_wgs")) { set_tn_target_wgs(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "tn_aux")) { coot_step_tn_aux(value); return 0; }
   if (!strcmp(name, "defer_global_tn")) { coot_step_defer_global_tn(value); return 0; }

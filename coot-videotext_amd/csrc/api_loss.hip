@@ -99,6 +99,25 @@ int coot_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int T, 
   t.ws = (float*)workspace; t.ws_floats = workspace_bytes / sizeof(float);
   return launch_gemm_tn(t, (hipStream_t)stream);
 }
+int coot_gemm_tn_batch(const coot_tn_problem* p, int n, void* workspace, size_t workspace_bytes, uint64_t* stamps, coot_stream_t stream) {
+  if (n < 0 || (n > 0 && !p)) { set_error("gemm_tn_batch: bad arguments"); return -1; }
+  float* old_ws; size_t old_n;
+  get_tn_default_workspace(&old_ws, &old_n);
+  set_tn_default_workspace((float*)workspace, workspace_bytes / sizeof(float));
+  tn_batch_begin();
+  int rc = 0;
+  for (int i = 0; i < n && !rc; ++i) {
+    GemmTN t; t.A = (const bf16_t*)p[i].A; t.lda = p[i].lda; t.B = (const bf16_t*)p[i].B; t.ldb = p[i].ldb; t.T = p[i].T; t.Mo = p[i].Mo; t.No = p[i].No;
+    t.C = p[i].C; t.ldc = p[i].ldc; t.a_colsum = p[i].a_colsum; t.overwrite = p[i].overwrite;
+    t.groups = p[i].groups > 0 ? p[i].groups : 1; t.zA = p[i].zA; t.zB = p[i].zB; t.zC = p[i].zC;
+    if (i == 0) t.stamps = (unsigned long long*)stamps;
+    rc = launch_gemm_tn(t, (hipStream_t)stream);
+  }
+  if (!rc) rc = tn_batch_flush((hipStream_t)stream);
+  tn_batch_end();
+  set_tn_default_workspace(old_ws, old_n);
+  return rc;
+}
 int coot_ln_fwd(const float* x, int R, int D, const float* gain, const float* bias, void* y_bf16, float* y_f32, coot_stream_t stream) {
   LnFwd l; l.x = x; l.x_f32 = 1; l.ldx = D; l.R = R; l.D = D; l.gain = gain; l.bias = bias; l.y = (bf16_t*)y_bf16; l.ldy = D; l.y32 = y_f32; l.ldy32 = D;
   return launch_ln_fwd(l, (hipStream_t)stream);

@@ -51,6 +51,9 @@ struct GemmTN {
   // groups must be 1; added with one fp32 atomic per column per split.
   float* a_colsum = nullptr;
   int overwrite = 0;  // C = alpha * (...) instead of += (saves the caller a zero fill; groups == 1)
+  // microbenchmarks: tile (0, 0) of split 0 adds its shader-clock time per phase of the k loop (wide tiles only):
+  // [0] k-steps, [1] issue of the operand loads, [2] LDS reads + MFMA, [3] wait for the loads + LDS stores, [4] barrier, [5] total
+  unsigned long long* stamps = nullptr;
 };
 
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream);
@@ -59,6 +62,7 @@ size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups);
 // recorded; flush launches all recorded problems as ONE kernel (+ one split reduction) on `stream`.  The operands must
 // stay untouched until the flush.  tn_batch_end() leaves the collecting mode.
 void tn_batch_begin();
+void get_tn_default_workspace(float** ws, size_t* floats);
 int tn_batch_flush(hipStream_t stream);
 void tn_batch_end();
 // optional second stream for early flushes (thread-local, set by the step; nullptr = off)
@@ -73,6 +77,10 @@ hipStream_t tn_deferred_stream();        // the stream the deferred flush runs o
 int tn_deferred_join(hipStream_t st);    // `st` waits for the deferred flush, if any
 // 1 (default): batched problems with Mo % 384 == 0 use the 384 x 128 output tiles; 0: always 128 x 128 (A/B switch)
 void set_tn_wide(int on);
+// 1: wide tiles fed by LDS-DMA (gemm_tn_dma_kernel); 0: register-staged (A/B switch)
+void set_tn_target_wgs(int n);
+void set_tn_dma(int on);
+int get_tn_dma();
 void set_xcd_order(int bits);  // XCD-aware workgroup -> tile order: 1 = gemm_nt, 4 = short attention (A/B switch)
 int get_xcd_order();
 // default workspace used by launch_gemm_tn when GemmTN::ws is null (set by the orchestrator for one call)

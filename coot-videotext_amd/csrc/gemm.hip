@@ -11,6 +11,7 @@
 // "store what the MFMA layout gives you" epilogue (8-byte stores in 32-byte runs) cost more than the K loop
 // at K = 384 (profiles/README.md).
 #include "gemm.h"
+#include <algorithm>
 #include "rowops.h"
 
 namespace coot {
@@ -421,7 +422,7 @@ void timing_end(void* slot, hipStream_t stream) {
   if (slot) (void)hipEventRecord(static_cast<TimingSlot*>(slot)->b, stream);
 }
 
-static int g_xcd_order = 5;  // coot_set_option("xcd_order", bits): 1 = gemm_nt tile order, 4 = short attention (sequence, head) order
+static int g_xcd_order = 7;  // coot_set_option("xcd_order", bits): 1 = gemm_nt tile order, 2 = weight-gradient tiles of one split on one XCD, 4 = short attention (sequence, head) order
 int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
   GemmNT g = g_in;
   COOT_REQUIRE(g.X && g.W && g.epi.out, "gemm_nt: null operand");
@@ -747,9 +748,14 @@ __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int b
   __syncthreads();
   const int grp = lane >> 4, p = lane & 15;
   typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const bool prof = g.stamps != nullptr && bx == 0 && by == 0 && bz == 0;
+  unsigned long long pt[4] = {0ull, 0ull, 0ull, 0ull}, tp = 0ull, tstart = 0ull;
+#define TNW_PT(k) do { if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn = __builtin_amdgcn_s_memtime(); pt[k] += tn - tp; tp = tn; } } while (0)
+  if (prof) { tstart = tp = __builtin_amdgcn_s_memtime(); }
   for (int st = 0; st < nsteps; ++st) {
     const int buf = st & 1;
     if (st + 1 < nsteps) gload(t_begin + (st + 1) * TN_BT);
+    TNW_PT(0);
     const bf16_t* ab = As + buf * ASZ;
     const bf16_t* bb = Bs + buf * BSZ;
 #pragma unroll
@@ -778,9 +784,18 @@ __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int b
         for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af, acc[a][b], 0, 0, 0);
       }
     }
+    TNW_PT(1);
     if (st + 1 < nsteps) { if (do_cs) cs_acc(); sstore(buf ^ 1); }
+    TNW_PT(2);
     __syncthreads();
+    TNW_PT(3);
   }
+  if (prof && tid == 0) {
+    g.stamps[0] = (unsigned long long)nsteps;
+    for (int k = 0; k < 4; ++k) g.stamps[1 + k] = pt[k];
+    g.stamps[5] = tp - tstart;
+  }
+#undef TNW_PT
   if (do_cs) {
     // Per-thread partial column sums -> LDS rows -> 384 threads add them up.  (The first version used LDS float atomics:
     // 24 ds_add_f32 wave-instructions that serialise per lane, ~1.5k cycles each — the workgroups carrying a bias gradient
@@ -827,6 +842,229 @@ __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int b
   }
 }
 
+// ---- wide variant fed by LDS-DMA ------------------------------------------------------------------------------------
+// Phase stamps of the register-staged wide kernel (tools/tn_probe.py, r02d): a 64-row k-step takes ~4200 shader clocks of
+// which the 48 MFMAs of a wave are 770: issuing the 8 operand loads of a thread blocks every wave for ~1100 clocks (64 KB
+// through the CU's 64 B/clk vector-memory path, nothing else scheduled meanwhile), LDS reads + MFMA 1200, wait for the loads +
+// ds_write 680, barrier 1150 — four serial phases.  Here the operands go global -> LDS by DMA (global_load_lds_dwordx4: no
+// staging registers, no ds_write pass) into a ring of five 32-row stages with four stages in flight across the barriers
+// (counted s_waitcnt vmcnt, raw s_barrier), so the loads of k-steps s+1 .. s+3 fly under the MFMAs of k-step s.  12 waves: 8
+// MFMA waves that never touch vector memory inside the k loop + 4 loader waves (one per SIMD) that do nothing else.
+//   * DMA writes LDS lane-linear (wave-uniform base + 16 B x lane), so rows cannot be padded: the stage holds unpadded rows
+//     (768 B of dY, 256 B of X) whose 32-byte granules are XOR-swizzled with (row & 7) — applied to the SOURCE address of the
+//     DMA and to the ds_read_b64_tr_b16 address; the 8 rows x 32 B of a half-wave's transposing read then cover all 64 banks.
+//   * the DMA statements are inline asm (M0 = LDS destination is compiler-reserved and must be written in the statement that
+//     uses it): hipcc does not count them, every wait on them is written by hand.  No other vector-memory operation lives in
+//     the k loop.  Rows past the split's end / columns past No come from a 16-byte zero page.
+//   * bias-gradient column sums (a_colsum) are taken by the loader waves from the landed stages.
+constexpr int TND_ROWS = 32, TND_NST = 5;  // stages in the ring: NST - 1 in flight, 5 x 32 KB = the whole LDS
+constexpr int TND_A_BYTES = TND_ROWS * TNW_BM * 2, TND_B_BYTES = TND_ROWS * TNW_BN * 2, TND_STAGE = TND_A_BYTES + TND_B_BYTES;
+__device__ __attribute__((aligned(16))) unsigned int g_tn_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void gemm_tn_dma_body(const GemmTN& g, int bx, int by, int bz, int t_per_split, float* ws, int direct) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[TND_NST * TND_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = bz % g.groups, split = bz / g.groups;
+  const int m0 = by * TNW_BM, n0 = bx * TNW_BN;
+  const int t_begin = split * t_per_split;
+  const int t_end = min(g.T, t_begin + t_per_split);
+  const int nst = t_begin < t_end ? (t_end - t_begin + TND_ROWS - 1) / TND_ROWS : 0;
+
+  if (wave >= 8) {
+    // ---- loader waves (one per SIMD): all DMA traffic of the workgroup.  A wave that issues vector-memory instructions
+    // faster than the CU's 64 B/clk path takes them stalls at the issue; with the loads on the MFMA waves (first version:
+    // 4 DMAs per wave per stage) that stall was 660 clocks of every 2100-clock k-step.  Here only these four waves stall.
+    const int pw = wave - 8;
+    const bf16_t* A = g.A + z * g.zA;
+    const bf16_t* B = g.B + z * g.zB;
+    const unsigned lds0 = (unsigned)(unsigned long)((unsigned char __attribute__((address_space(3)))*)smem);
+    // slots (1 KB of a stage each) pw + 4 i: i < 6 -> dY rows (slots 0 .. 23), i = 6, 7 -> X rows (slots 24 .. 31): the LDS
+    // destinations of a wave's eight DMAs are 4 KB apart.  Source = scalar base of the stage + a per-lane byte offset that
+    // never changes (8 VGPRs); columns past No (last column tile of a 192-wide problem) re-read column 0 of the tile: they
+    // only reach accumulator columns the epilogue does not store.
+    unsigned off[8]; int srow[8];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int o = (pw + 4 * i) * 1024 + lane * 16, r = o / (TNW_BM * 2), w = o - r * (TNW_BM * 2);
+      const int col = (((w >> 5) ^ (r & 7)) << 4) + ((w >> 4) & 1) * 8;
+      off[i] = (unsigned)(r * (int)g.lda + col) * 2u; srow[i] = r;  // Mo % 384 == 0: every column exists
+    }
+#pragma unroll
+    for (int i = 6; i < 8; ++i) {
+      const int o = (pw + 4 * (i - 6)) * 1024 + lane * 16, r = o >> 8, w = o & 255;
+      const int col = (((w >> 5) ^ (r & 7)) << 4) + ((w >> 4) & 1) * 8;
+      off[i] = (unsigned)(r * (int)g.ldb + (n0 + col < g.No ? col : 0)) * 2u; srow[i] = r;
+    }
+    const char* ap = reinterpret_cast<const char*>(A + (long)t_begin * g.lda + m0);
+    const char* bp = reinterpret_cast<const char*>(B + (long)t_begin * g.ldb + n0);
+    const long stepA = (long)TND_ROWS * g.lda * 2, stepB = (long)TND_ROWS * g.ldb * 2;
+    int ibuf = 0;
+    auto issue = [&](int s) {  // called with s = 0, 1, 2, ... in order
+      const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)ibuf * TND_STAGE + (unsigned)pw * 1024u);
+      ibuf = ibuf + 1 == TND_NST ? 0 : ibuf + 1;
+      const int t0 = t_begin + s * TND_ROWS;
+      if (t0 + TND_ROWS <= t_end) {  // every row of the stage exists: one statement, M0 stepped by 4 KB between the DMAs
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[o0], %[sa]\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[o1], %[sa]\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[o2], %[sa]\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[o3], %[sa]\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[o4], %[sa]\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[o5], %[sa]\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[o6], %[sb]\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[o7], %[sb]\n\ts_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),
+              [o6] "v"(off[6]), [o7] "v"(off[7]), [sa] "s"(ap), [sb] "s"(bp), [dst] "s"(dst0)
+            : "memory", "scc");
+      } else {  // the split's last, partial stage: rows past its end come from the zero page
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const void* p = t0 + srow[i] < t_end ? static_cast<const void*>((i < 6 ? ap : bp) + off[i]) : static_cast<const void*>(g_tn_zero16);
+          glds16(p, __builtin_amdgcn_readfirstlane(dst0 + (unsigned)i * 4096u));
+        }
+      }
+      ap += stepA; bp += stepB;
+    };
+    // bias gradient (a_colsum: column sums of the dY slab, tiles bx == 0 only): taken by the loader waves from the landed
+    // stages — lane id < 192 sums 16-byte chunk id % 48 over rows 8 (id / 48) .. + 7 of every stage, fp32 atomics at the end
+    const bool do_cs = g.a_colsum != nullptr && bx == 0;
+    const int cid = pw * 64 + lane, cc = cid % 48, crg = cid / 48;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int lbuf = 0;
+    const bool aprof = g.stamps != nullptr && bx == 0 && by == 0 && bz == 0;
+    const bool lprof = aprof && pw == 0;
+    unsigned long long lt[3] = {0ull, 0ull, 0ull}, lp = 0ull;
+#define TND_LT(k) do { if (lprof) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); lt[k] += tn - lp; lp = tn; } } while (0)
+    static_assert(TND_NST == 5, "the counted waits below are written for 4 stages in flight");
+    for (int s = 0; s < TND_NST - 1 && s < nst; ++s) issue(s);
+    if (lprof) lp = __builtin_amdgcn_s_memtime();
+    for (int s = 0; s < nst; ++s) {
+      // stage s has landed once this wave's DMAs of the (up to three) later stages are the only ones outstanding; the barrier
+      // tells the MFMA waves so, and tells this wave that they have read out stage s - 1 (the buffer stage s + 4 goes to)
+      if (s + 3 < nst) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TND_LT(0);
+      if (aprof && s == 20 && lane == 0) g.stamps[16 + 2 * wave] = __builtin_amdgcn_s_memtime();
+      asm volatile("s_barrier" ::: "memory");
+      if (aprof && s == 20 && lane == 0) g.stamps[17 + 2 * wave] = __builtin_amdgcn_s_memtime();
+      TND_LT(1);
+      if (s + TND_NST - 1 < nst) issue(s + TND_NST - 1);
+      TND_LT(2);
+      if (do_cs) {  // stage s is complete (barrier s) and stays until some wave passes barrier s + 1
+        if (cid < 192) {
+          const unsigned char* st = smem + lbuf * TND_STAGE;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = crg * 8 + k;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(st + r * (TNW_BM * 2) + (((cc >> 1) ^ (r & 7)) << 5) + (cc & 1) * 16);
+            cs[0] += bflo(v[0]); cs[1] += bfhi(v[0]); cs[2] += bflo(v[1]); cs[3] += bfhi(v[1]);
+            cs[4] += bflo(v[2]); cs[5] += bfhi(v[2]); cs[6] += bflo(v[3]); cs[7] += bfhi(v[3]);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      lbuf = lbuf + 1 == TND_NST ? 0 : lbuf + 1;
+    }
+    if (do_cs && cid < 192) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(g.a_colsum + m0 + cc * 8 + j, cs[j]);
+    }
+    if (lprof && lane == 0) for (int k = 0; k < 3; ++k) g.stamps[8 + k] = lt[k];  // loader wave 0: landing wait, barrier, DMA issue
+#undef TND_LT
+    return;
+  }
+
+  // ---- MFMA waves: 4 (m, 96 rows) x 2 (n, 64 columns) as in the register-staged kernel -----------------------------------
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4_t acc[6][4];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a stage (the same k-slot <-> token row map as the register-staged kernel, both operands)
+  const int grp = lane >> 4, p = lane & 15;
+  const int trow = 4 * grp + (p >> 2), x7 = trow & 7, tcb = (p & 3) * 8;
+  int aoff[6], boff[4];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) aoff[a] = trow * (TNW_BM * 2) + (((wm * 6 + a) ^ x7) << 5) + tcb;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) boff[b] = TND_A_BYTES + trow * (TNW_BN * 2) + (((wn * 4 + b) ^ x7) << 5) + tcb;
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
+
+  const bool aprof = g.stamps != nullptr && bx == 0 && by == 0 && bz == 0;
+  const bool prof = aprof && wave == 0;
+  unsigned long long pt[4] = {0ull, 0ull, 0ull, 0ull}, tp = 0ull, tstart = 0ull;
+#define TND_PT(k) do { if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn = __builtin_amdgcn_s_memtime(); pt[k] += tn - tp; tp = tn; } } while (0)
+  if (prof) { tstart = tp = __builtin_amdgcn_s_memtime(); }
+  int cbuf = 0;
+  for (int s = 0; s < nst; ++s) {
+    if (aprof && s == 20 && lane == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g.stamps[16 + 2 * wave] = __builtin_amdgcn_s_memtime(); }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (aprof && s == 20 && lane == 0) g.stamps[17 + 2 * wave] = __builtin_amdgcn_s_memtime();
+    TND_PT(1);
+    const unsigned char* st = smem + cbuf * TND_STAGE;
+    cbuf = cbuf + 1 == TND_NST ? 0 : cbuf + 1;
+    bf16x8_t bfr[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + boff[b]));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + boff[b] + 16 * TNW_BN * 2));
+      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      bfr[b] = __builtin_bit_cast(bf16x8_t, v);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + aoff[a]));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + aoff[a] + 16 * TNW_BM * 2));
+      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af, acc[a][b], 0, 0, 0);
+    }
+    TND_PT(3);
+  }
+  if (prof && tid == 0) {
+    g.stamps[0] = (unsigned long long)nst;
+    for (int k = 0; k < 4; ++k) g.stamps[1 + k] = pt[k];
+    g.stamps[5] = tp - tstart;
+  }
+#undef TND_PT
+  // partial tile straight from the accumulators: direct (single split) C += alpha * tile, else ws[split][z][Mo][No]
+  float* dst = direct ? g.C + z * g.zC : ws + ((long)split * g.groups + z) * g.Mo * g.No;
+  const long ldd = direct ? g.ldc : g.No;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int row = m0 + wm * 96 + a * 16 + (lane & 15);
+    if (row >= g.Mo) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = n0 + wn * 64 + b * 16 + (lane >> 4) * 4;
+      if (col >= g.No) continue;
+      f32x4_t* dp = reinterpret_cast<f32x4_t*>(dst + (long)row * ldd + col);
+      if (direct) {
+        f32x4_t o = g.overwrite ? f32x4_t{0.f, 0.f, 0.f, 0.f} : *dp;
+        o[0] += acc[a][b][0] * g.alpha; o[1] += acc[a][b][1] * g.alpha; o[2] += acc[a][b][2] * g.alpha; o[3] += acc[a][b][3] * g.alpha;
+        *dp = o;
+      } else {
+        *dp = acc[a][b];
+      }
+    }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split, int splits, float* ws, int direct) {
   gemm_tn_body<MODE>(g, blockIdx.x, blockIdx.y, blockIdx.z, t_per_split, splits, ws, direct);
@@ -858,6 +1096,48 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_batch_kernel(TnBatch b, floa
   // blocks of a slab then start together on one L2 and queue on the same channels; id = bx + gx * (...) spreads them)
   const int bx = local % it.gx, by = (local / it.gx) % it.gy, bz = local / (it.gx * it.gy);
   gemm_tn_wide_body(it.g, bx, by, bz, it.t_per_split, it.direct ? nullptr : ws_base + it.ws_off, it.direct);
+}
+
+// The same launch with an explicit workgroup -> (problem, tile) table built on the host (tn_batch_flush): the workgroups that
+// read the SAME token rows — all (m, n) tiles of one problem and one split — sit on ONE XCD (block b runs on XCD b % 8), so a
+// 384-column dY slab / 128-column X block is fetched over the fabric once per split instead of once per tile that uses it.
+// Without it the launch is bound by the fabric: FETCH_SIZE = the algorithmic re-read count (r02c: 0.99 GB of 1.15 GB per
+// video-side launch, 5.4 TB/s).
+// The table is a list of pieces (runs of consecutive tiles of one problem) ordered by XCD; kept small (~400 B of kernel
+// arguments: a 1.5 KB per-workgroup table next to the 1.8 KB problem list crashed hipGraphLaunch on replay).
+constexpr int TN_MAP_PIECES = 96;
+struct TnPiece { unsigned short first; unsigned char item, count; };
+struct TnMap { unsigned char xstart[12]; TnPiece pc[TN_MAP_PIECES]; };  // pieces [xstart[x], xstart[x + 1]) belong to XCD x
+__device__ __forceinline__ bool tn_map_lookup(const TnMap& m, int& item, int& local) {
+  const int x = blockIdx.x & 7;
+  int j = blockIdx.x >> 3;
+  for (int k = m.xstart[x]; k < m.xstart[x + 1]; ++k) {
+    const int c = m.pc[k].count;
+    if (j < c) { item = m.pc[k].item; local = m.pc[k].first + j; return true; }
+    j -= c;
+  }
+  return false;
+}
+__global__ __launch_bounds__(512) void gemm_tn_wide_mapped_kernel(TnBatch b, TnMap m, float* ws_base) {
+  int i, local;
+  if (!tn_map_lookup(m, i, local)) return;
+  const TnItem& it = b.it[i];
+  const int bx = local % it.gx, by = (local / it.gx) % it.gy, bz = local / (it.gx * it.gy);
+  gemm_tn_wide_body(it.g, bx, by, bz, it.t_per_split, it.direct ? nullptr : ws_base + it.ws_off, it.direct);
+}
+
+__global__ __launch_bounds__(768) void gemm_tn_dma_kernel(TnBatch b, TnMap m, float* ws_base, int use_map) {
+  int i, local;
+  if (use_map) {
+    if (!tn_map_lookup(m, i, local)) return;
+  } else {
+    i = 0;
+    for (int t = 1; t < b.n; ++t) if ((int)blockIdx.x >= b.it[t].blk0) i = t;
+    local = blockIdx.x - b.it[i].blk0;
+  }
+  const TnItem& it = b.it[i];
+  const int bx = local % it.gx, by = (local / it.gx) % it.gy, bz = local / (it.gx * it.gy);
+  gemm_tn_dma_body(it.g, bx, by, bz, it.t_per_split, it.direct ? nullptr : ws_base + it.ws_off, it.direct);
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_batch_reduce_kernel(TnBatch b, const float* ws_base) {
@@ -900,6 +1180,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTN g, int split
 static thread_local float* g_tn_ws = nullptr;
 static thread_local size_t g_tn_ws_floats = 0;
 void set_tn_default_workspace(float* ws, size_t floats) { g_tn_ws = ws; g_tn_ws_floats = floats; }
+void get_tn_default_workspace(float** ws, size_t* floats) { *ws = g_tn_ws; *floats = g_tn_ws_floats; }
 static int g_tn_mode = 0;
 void set_tn_mode(int mode) { g_tn_mode = mode ? 1 : 0; }
 int get_tn_mode() { return g_tn_mode; }
@@ -933,8 +1214,48 @@ void set_tn_aux_stream(hipStream_t aux) { g_tn_aux = aux; }
 
 static int g_tn_wide = 1;
 void set_tn_wide(int on) { g_tn_wide = on; }
+static int g_tn_target_wgs = 256;  // wide tiles: workgroups per launch the split count aims at (one per CU)
+void set_tn_target_wgs(int n) { g_tn_target_wgs = n > 0 ? n : 256; }
+static int g_tn_dma = 1;
+void set_tn_dma(int on) { g_tn_dma = on; }
+int get_tn_dma() { return g_tn_dma; }
 void set_xcd_order(int on) { g_xcd_order = on; }
 int get_xcd_order() { return g_xcd_order; }
+
+// Workgroup table of gemm_tn_wide_mapped_kernel / gemm_tn_dma_kernel: sharing groups (one problem, one split, one batch group:
+// gx * gy tiles, cut into pieces of <= 16) go to the least loaded XCD, largest first; slot j of XCD x is block 8 j + x.
+// Returns the grid size, 0 when the launch does not fit the table (the linear order is used).
+static int tn_xcd_map(const TnBatch& b, TnMap& map) {
+  struct Piece { int item, first, count, xcd; };
+  Piece pc[TN_MAP_PIECES];
+  int np = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const TnItem& it = b.it[i];
+    const int per = it.gx * it.gy, nb = it.g.groups * it.splits;
+    for (int bz = 0; bz < nb; ++bz)
+      for (int o = 0; o < per; o += 16) {
+        if (np == TN_MAP_PIECES || bz * per + o > 0xFFFF) return 0;
+        pc[np++] = Piece{i, bz * per + o, per - o < 16 ? per - o : 16, 0};
+      }
+  }
+  std::stable_sort(pc, pc + np, [](const Piece& a, const Piece& c) { return a.count > c.count; });
+  int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < np; ++k) {
+    int x = 0;
+    for (int q = 1; q < 8; ++q) if (load[q] < load[x]) x = q;
+    pc[k].xcd = x; load[x] += pc[k].count;
+  }
+  int n = 0, mx = 0;
+  for (int x = 0; x < 8; ++x) {
+    map.xstart[x] = (unsigned char)n;
+    for (int k = 0; k < np; ++k)
+      if (pc[k].xcd == x) map.pc[n++] = TnPiece{(unsigned short)pc[k].first, (unsigned char)pc[k].item, (unsigned char)pc[k].count};
+    if (load[x] > mx) mx = load[x];
+  }
+  map.xstart[8] = (unsigned char)n;
+  for (int k = n; k < TN_MAP_PIECES; ++k) map.pc[k] = TnPiece{0, 0, 0};
+  return 8 * mx;
+}
 
 int tn_batch_flush(hipStream_t stream) {
   const int n = g_tn_nitems;
@@ -962,7 +1283,7 @@ int tn_batch_flush(hipStream_t stream) {
     it.gy = w ? g.Mo / TNW_BM : (g.Mo + TN_BC - 1) / TN_BC;
     // wide: one 512-thread workgroup per CU -> about 256 workgroups; narrow: two per CU.  Every split >= 512 token rows.
     const long tiles = w ? tiles_w : tiles_n;
-    int splits = w ? (int)(256 / tiles) : (int)((512 + tiles - 1) / tiles);
+    int splits = w ? (int)(g_tn_target_wgs / tiles) : (int)((512 + tiles - 1) / tiles);
     const int max_splits = g.T / 512 > 0 ? g.T / 512 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits > 8) splits = 8;
@@ -989,7 +1310,12 @@ int tn_batch_flush(hipStream_t stream) {
   for (int i = 0; i < n; ++i) flops += 2.0 * g_tn_items[i].T * g_tn_items[i].Mo * g_tn_items[i].No * g_tn_items[i].groups;
   void* ts = timing_begin(TIMING_TN, flops, 0, stream);
   if (bw.n) {
-    hipLaunchKernelGGL(gemm_tn_wide_batch_kernel, dim3(blk_w), dim3(512), 0, stream, bw, ws);
+    TnMap map = {};
+    const int grid = (g_xcd_order & 2) ? tn_xcd_map(bw, map) : 0;
+    const bool dma = g_tn_dma != 0;
+    if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3(grid > 0 ? grid : blk_w), dim3(768), 0, stream, bw, map, ws, grid > 0 ? 1 : 0);
+    else if (grid > 0) hipLaunchKernelGGL(gemm_tn_wide_mapped_kernel, dim3(grid), dim3(512), 0, stream, bw, map, ws);
+    else hipLaunchKernelGGL(gemm_tn_wide_batch_kernel, dim3(blk_w), dim3(512), 0, stream, bw, ws);
     COOT_CHECK_LAUNCH("gemm_tn_wide_batch");
   }
   if (bn.n) {

@@ -19,7 +19,7 @@ EXPORTS = [
     "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights", "coot_nets_pack_weights",
     "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_pack_fwd",
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_cyclecons_fwd_bwd",
-    "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
+    "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
     "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_contrastive_fwd_bwd_dp", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
 ]
@@ -53,6 +53,13 @@ class StepConfig(C.Structure):
 class StepDims(C.Structure):
     """coot_step_dims; tok_vis / tok_txt: packed token totals (0 = padded layout)."""
     _fields_ = [(n, C.c_int) for n in ("B", "Nc", "Lv", "Lc", "Lp", "Ls", "Cmax_clip", "Cmax_sent", "tok_vis", "tok_txt")]
+
+
+class TnProblem(C.Structure):
+    """coot_tn_problem: one weight-gradient GEMM C[Mo, No] (+)= A[T, Mo]^T . B[T, No] of a batched launch."""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("T", C.c_int), ("Mo", C.c_int),
+                ("No", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int64), ("a_colsum", C.c_void_p), ("overwrite", C.c_int),
+                ("groups", C.c_int), ("zA", C.c_int64), ("zB", C.c_int64), ("zC", C.c_int64)]
 
 
 class PackedSeqs(C.Structure):
@@ -90,6 +97,7 @@ def load():
     lib.coot_last_error.argtypes = []
     lib.coot_version.restype = i32
     lib.coot_set_option.argtypes = [C.c_char_p, i32]
+    lib.coot_get_option.argtypes = [C.c_char_p, C.POINTER(i32)]
     lib.coot_debug_timestamps.argtypes = [vp]
     lib.coot_debug_step_stamps.argtypes = [C.c_char_p, i32]
     lib.coot_net_param_numel.restype = i64
@@ -119,6 +127,7 @@ def load():
     lib.coot_retrieval_ranks.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.coot_gemm_nt.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp, i64, i32, vp]
     lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, sz, vp]
+    lib.coot_gemm_tn_batch.argtypes = [C.POINTER(TnProblem), i32, vp, sz, vp, vp]
     lib.coot_gemm_tn_workspace_bytes.restype = sz
     lib.coot_gemm_tn_workspace_bytes.argtypes = [i32, i32, i32]
     lib.coot_ln_fwd.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
@@ -153,6 +162,12 @@ def load():
         if lib.coot_set_option(k.strip().encode(), int(v)) != 0:
             raise RuntimeError(f"COOT_OPTIONS: {lib.coot_last_error().decode()}")
     return lib
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(load().coot_get_option(name.encode(), C.byref(v)), "get_option")
+    return v.value
 
 
 def check(rc: int, what: str = "") -> None:

@@ -44,6 +44,8 @@ const char* coot_last_error(void);
 int coot_version(void);
 /* option switches for A/B measurements: "tn_mode" 0 = ds_read_b64_tr_b16 fragments, 1 = transposing LDS stores */
 int coot_set_option(const char* name, int value);
+/* current value of "tn_dma" / "xcd_order" / "tn_mode" (tests restore what they switch) */
+int coot_get_option(const char* name, int* value);
 /* profiling aid: device buffer (>= 64 x uint64) receiving s_memtime stamps of block 0 of the fused chain kernels (NULL = off) */
 int coot_debug_timestamps(void* dev_u64);
 /* coot_set_option("step_stamps", 1): coot_train_step records HIP events at its phase boundaries; this call synchronises
@@ -279,6 +281,22 @@ int coot_gemm_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, int M, 
 size_t coot_gemm_tn_workspace_bytes(int T, int Mo, int No);
 int coot_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int T, int Mo, int No, float* C,
                  int64_t ldc, void* workspace, size_t workspace_bytes, coot_stream_t stream);
+/* n weight-gradient problems C_i[Mo_i,No_i] (+)= A_i^T . B_i in ONE launch (+ one split reduction) — the way a network's
+ * backward pass issues them (coot_net_bwd); a_colsum (optional) += column sums of A_i (the bias gradient).  workspace: fp32
+ * partial tiles, sum_i splits_i * Mo_i * No_i * 4 bytes with splits_i <= 8 (too small: the problems run one by one).
+ * stamps (optional, 48 x uint64 on the device): phase times of tile (0,0) of problem 0 in shader clocks. */
+typedef struct coot_tn_problem {
+  const void* A; int64_t lda;   /* bf16 [T, Mo] */
+  const void* B; int64_t ldb;   /* bf16 [T, No] */
+  int T, Mo, No;
+  float* C; int64_t ldc;        /* fp32 [Mo, No] */
+  float* a_colsum;              /* fp32 [Mo] or NULL (groups == 1) */
+  int overwrite;                /* 1: C = ..., 0: C += ... */
+  int groups;                   /* >= 1: batch of problems, group z at A + z*zA, B + z*zB, C + z*zC (elements) */
+  int64_t zA, zB, zC;
+} coot_tn_problem;
+int coot_gemm_tn_batch(const coot_tn_problem* problems, int n, void* workspace, size_t workspace_bytes,
+                       uint64_t* stamps, coot_stream_t stream);
 int coot_ln_fwd(const float* x, int R, int D, const float* gain, const float* bias, void* y_bf16, float* y_f32,
                 coot_stream_t stream);
 int coot_attn_fwd(const void* qkv, int Nseq, int L, int H, int dh, const int64_t* lens, void* out, float* lse,

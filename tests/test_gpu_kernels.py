@@ -101,6 +101,57 @@ def test_gemm_tn(env, mode, use_ws, T, Mo, No):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("dma,xcd", [(0, 5), (0, 7), (1, 5), (1, 7)])
+@pytest.mark.parametrize("T", [6000, 1237, 90])
+def test_gemm_tn_batch(env, dma, xcd, T):
+    """The batched weight-gradient launch of a backward pass (coot_gemm_tn_batch): wide 384-row tiles register-staged or fed by
+    LDS-DMA, linear or XCD-grouped workgroup order, against float64 products of the bf16-rounded operands.  Problems: a wide
+    one written (overwrite), a grouped one with 192-column groups (half-empty column tile), a grouped one sharing A, a 3-slab
+    one accumulated onto C, a narrow one (128 x 128 tiles in the same flush), one with a bias-gradient column sum."""
+    torch, cva, lib = env
+    from coot_videotext_amd.lib import TnProblem
+    rs = np.random.RandomState(T + dma)
+    keep, probs, checks = [], [], []
+
+    def add(Aw, Bw, Mo, No, groups=1, zA=0, zB=0, overwrite=0, colsum=False):
+        A = rs.randn(T, Aw).astype(np.float32)
+        B = rs.randn(T, Bw).astype(np.float32)
+        Aq, Bq = from_bf16_bits(to_bf16_bits(A)).astype(np.float64), from_bf16_bits(to_bf16_bits(B)).astype(np.float64)
+        C0 = rs.randn(groups, Mo, No).astype(np.float32)
+        dA, dB, dC = _dev_bf16(torch, A), _dev_bf16(torch, B), torch.from_numpy(C0.copy()).cuda()
+        dcs = torch.zeros(Mo, device="cuda") if colsum else None
+        keep.extend([dA, dB, dC, dcs])
+        probs.append(TnProblem(dA.data_ptr(), Aw, dB.data_ptr(), Bw, T, Mo, No, dC.data_ptr(), No, dcs.data_ptr() if colsum else None,
+                               overwrite, groups, zA, zB, Mo * No))
+        ref = np.stack([Aq[:, z * zA:z * zA + Mo].T @ Bq[:, z * zB:z * zB + No] for z in range(groups)])
+        checks.append((dC, C0 * (0 if overwrite else 1), ref, dcs, Aq[:, :Mo].sum(0)))
+
+    add(384, 640, 384, 640, overwrite=1)
+    add(768, 384, 384, 192, groups=2, zA=384, zB=192)
+    add(384, 768, 384, 384, groups=2, zA=0, zB=384)
+    add(1152, 384, 1152, 384)
+    add(200, 72, 200, 72)
+    add(384, 384, 384, 384, colsum=True)
+    add(1152, 384, 1152, 384, colsum=True)
+    arr = (TnProblem * len(probs))(*probs)
+    ws = torch.empty(8 * sum(p.Mo * p.No * p.groups for p in probs), device="cuda")
+    dma0, xcd0 = cva.lib.get_option("tn_dma"), cva.lib.get_option("xcd_order")
+    cva.lib.check(lib.coot_set_option(b"tn_dma", dma))
+    cva.lib.check(lib.coot_set_option(b"xcd_order", xcd))
+    try:
+        cva.lib.check(lib.coot_gemm_tn_batch(arr, len(probs), ws.data_ptr(), ws.numel() * 4, None, _sp(torch)), "gemm_tn_batch")
+        torch.cuda.synchronize()
+    finally:
+        lib.coot_set_option(b"tn_dma", dma0)
+        lib.coot_set_option(b"xcd_order", xcd0)
+    for i, (dC, C0, ref, dcs, csref) in enumerate(checks):
+        err = rel_err(dC.cpu().numpy() - C0, ref)
+        print(f"gemm_tn_batch dma={dma} xcd={xcd} T={T} problem {i} rel_err={err:.2e}")
+        assert err < 2e-5, (i, err)
+        if dcs is not None:
+            assert rel_err(dcs.cpu().numpy(), csref) < 2e-5
+
+
 @pytest.mark.parametrize("R,D", [(37, 384), (100, 2048), (9, 1536), (5, 4096), (64, 64)])
 def test_ln_fwd(env, R, D):
     torch, cva, lib = env
