@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], help="library A/B switch name=value (coot_set_option), repeatable")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (phase calls + RCCL collectives) even with one rank")
     ap.add_argument("--step-stamps", action="store_true", help="print a HIP-event timeline of one training step to stderr")
+    ap.add_argument("--clock-monitor", action="store_true", help="after the timed loop: sample the shader clock on a side stream while more steps run (stderr)")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--padded", action="store_true", help="ragged workloads: run the reference's padded layout instead of packed (varlen) rows")
     ap.add_argument("--mode", default="native", choices=["native", "native-graph", "native-phases", "autograd", "graph"],
@@ -214,6 +215,27 @@ def main():
         sys.stderr.write("step timeline (HIP events, us since the step's first launch):\n" + buf.value.decode())
     ms_per_step = 1e3 * elapsed / args.steps
     value = clip_pairs * args.steps / elapsed
+    if args.clock_monitor and rank == 0:
+        # shader clock the device delivers under this load (outside the timed region): one wave on a side stream samples the
+        # 100 MHz real-time counter and the shader clock counter every 10 us while 8 more steps run
+        import numpy as np
+        nsamp = int(8 * ms_per_step * 100) + 200
+        mon = torch.zeros(2 * nsamp, dtype=torch.int64, device="cuda")
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            cva.lib.check(lib.coot_debug_clock_monitor(mon.data_ptr(), nsamp, 1000, side.cuda_stream), "clock_monitor")
+        time.sleep(0.0005)
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        m = mon.cpu().numpy().reshape(-1, 2).astype(np.float64)
+        ghz = np.diff(m[:, 1]) / (np.diff(m[:, 0]) * 10.0)
+        busy = ghz[20:int(8 * ms_per_step * 100) - 20]
+        sys.stderr.write(f"shader clock under load (10 us samples over 8 steps): mean {busy.mean():.2f} GHz, p10 {np.percentile(busy, 10):.2f}, "
+                         f"p90 {np.percentile(busy, 90):.2f}; idle tail {ghz[-50:].mean():.2f} GHz\n")
+        per = max(1, int(ms_per_step * 100 / 16))
+        sys.stderr.write("  per 1/16 step (GHz, first monitored step): " + " ".join(f"{ghz[20 + i * per:20 + (i + 1) * per].mean():.2f}" for i in range(16)) + "\n")
 
     roofline = None
     if rank == 0 and not args.no_roofline:

@@ -110,7 +110,7 @@ int coot_gemm_tn_batch(const coot_tn_problem* p, int n, void* workspace, size_t 
     GemmTN t; t.A = (const bf16_t*)p[i].A; t.lda = p[i].lda; t.B = (const bf16_t*)p[i].B; t.ldb = p[i].ldb; t.T = p[i].T; t.Mo = p[i].Mo; t.No = p[i].No;
     t.C = p[i].C; t.ldc = p[i].ldc; t.a_colsum = p[i].a_colsum; t.overwrite = p[i].overwrite;
     t.groups = p[i].groups > 0 ? p[i].groups : 1; t.zA = p[i].zA; t.zB = p[i].zB; t.zC = p[i].zC;
-    if (i == 0) t.stamps = (unsigned long long*)stamps;
+    t.stamps = (unsigned long long*)stamps;  // phase stamps: tile (0, 0, 0) of EVERY problem writes them (same slots: use one problem, or read them as "some problem")
     rc = launch_gemm_tn(t, (hipStream_t)stream);
   }
   if (!rc) rc = tn_batch_flush((hipStream_t)stream);
@@ -130,6 +130,25 @@ int coot_attn_fwd(const void* qkv, int Nseq, int L, int H, int dh, const int64_t
 }
 
 }  // extern "C"
+
+// Clock monitor: ONE wave samples (100 MHz real-time counter, shader clock counter) every `interval_ticks` ticks of the former,
+// n samples: the shader clock actually delivered while other streams run (power management lowers it under matrix load).
+__global__ void clock_monitor_kernel(unsigned long long* out, int n, int interval_ticks) {
+  if (threadIdx.x != 0) return;
+  unsigned long long next = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < n; ++i) {
+    unsigned long long rt;
+    do { __builtin_amdgcn_s_sleep(8); rt = __builtin_amdgcn_s_memrealtime(); } while (rt < next);
+    out[2 * i] = rt;
+    out[2 * i + 1] = __builtin_amdgcn_s_memtime();
+    next = rt + interval_ticks;
+  }
+}
+extern "C" int coot_debug_clock_monitor(uint64_t* out, int n, int interval_ticks, coot_stream_t stream) {
+  hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, n, interval_ticks);
+  COOT_CHECK_LAUNCH("clock_monitor");
+  return 0;
+}
 
 extern "C" int coot_timing_enable(int on) { gemm_timing_enable(on); return 0; }
 extern "C" int coot_timing_collect(int only_big_k, double* ms, double* flops, int* launches) {

@@ -944,24 +944,23 @@ __device__ __forceinline__ void gemm_tn_dma_body(const GemmTN& g, int bx, int by
     const bool lprof = aprof && pw == 0;
     unsigned long long lt[3] = {0ull, 0ull, 0ull}, lp = 0ull;
 #define TND_LT(k) do { if (lprof) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); lt[k] += tn - lp; lp = tn; } } while (0)
-    static_assert(TND_NST == 5, "the counted waits below are written for 4 stages in flight");
+    static_assert(TND_NST == 5, "the counted waits below are written for a ring of 5 stages");
+    // Barrier s (s = -1 .. nst - 1) certifies stage s + 1: the MFMA waves read the first fragments of a stage one barrier
+    // before they multiply them (no LDS latency in front of the first MFMA of a stage).  This wave passes barrier s with
+    // stages s + 2, s + 3 in flight and then refills the buffer of stage s - 1 (read out: every wave is past barrier s).
     for (int s = 0; s < TND_NST - 1 && s < nst; ++s) issue(s);
     if (lprof) lp = __builtin_amdgcn_s_memtime();
-    for (int s = 0; s < nst; ++s) {
-      // stage s has landed once this wave's DMAs of the (up to three) later stages are the only ones outstanding; the barrier
-      // tells the MFMA waves so, and tells this wave that they have read out stage s - 1 (the buffer stage s + 4 goes to)
-      if (s + 3 < nst) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int s = -1; s < nst; ++s) {
+      if (s + 3 < nst) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TND_LT(0);
-      if (aprof && s == 20 && lane == 0) g.stamps[16 + 2 * wave] = __builtin_amdgcn_s_memtime();
       asm volatile("s_barrier" ::: "memory");
-      if (aprof && s == 20 && lane == 0) g.stamps[17 + 2 * wave] = __builtin_amdgcn_s_memtime();
       TND_LT(1);
+      if (s < 0) continue;
       if (s + TND_NST - 1 < nst) issue(s + TND_NST - 1);
       TND_LT(2);
-      if (do_cs) {  // stage s is complete (barrier s) and stays until some wave passes barrier s + 1
+      if (do_cs) {  // stage s is complete (barrier s - 1) and stays until some wave passes barrier s + 1
         if (cid < 192) {
           const unsigned char* st = smem + lbuf * TND_STAGE;
 #pragma unroll
@@ -1006,36 +1005,66 @@ __device__ __forceinline__ void gemm_tn_dma_body(const GemmTN& g, int bx, int by
 
   const bool aprof = g.stamps != nullptr && bx == 0 && by == 0 && bz == 0;
   const bool prof = aprof && wave == 0;
+  // per-workgroup span (100 MHz real-time counter) at stamps[64 + 2 * block]: launch-wide load balance (tools/tn_probe.py)
+  if (g.stamps && tid == 0) g.stamps[64 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   unsigned long long pt[4] = {0ull, 0ull, 0ull, 0ull}, tp = 0ull, tstart = 0ull;
 #define TND_PT(k) do { if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn = __builtin_amdgcn_s_memtime(); pt[k] += tn - tp; tp = tn; } } while (0)
   if (prof) { tstart = tp = __builtin_amdgcn_s_memtime(); }
-  int cbuf = 0;
-  for (int s = 0; s < nst; ++s) {
-    if (aprof && s == 20 && lane == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g.stamps[16 + 2 * wave] = __builtin_amdgcn_s_memtime(); }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (aprof && s == 20 && lane == 0) g.stamps[17 + 2 * wave] = __builtin_amdgcn_s_memtime();
-    TND_PT(1);
-    const unsigned char* st = smem + cbuf * TND_STAGE;
-    cbuf = cbuf + 1 == TND_NST ? 0 : cbuf + 1;
-    bf16x8_t bfr[4];
+  // One stage: 24 MFMAs on fragments of `st` — the B fragments and the first two A fragments were read before the barrier in
+  // front of it (bc, ac) — and, half way, the same first reads of the next stage `stn` (certified by that barrier) into bn, an.
+  auto read_a = [&](const unsigned char* st, int a) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + aoff[a]));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + aoff[a] + 16 * TNW_BM * 2));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto read_b = [&](const unsigned char* st, int b) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + boff[b]));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + boff[b] + 16 * TNW_BN * 2));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto preload = [&](const unsigned char* st, bf16x8_t (&bn)[4], bf16x8_t (&an)[2]) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + boff[b]));
-      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + boff[b] + 16 * TNW_BN * 2));
-      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      bfr[b] = __builtin_bit_cast(bf16x8_t, v);
-    }
+    for (int b = 0; b < 4; ++b) bn[b] = read_b(st, b);
+    an[0] = read_a(st, 0); an[1] = read_a(st, 1);
+  };
+  auto stage = [&](const unsigned char* st, const unsigned char* stn, const bf16x8_t (&bc)[4], const bf16x8_t (&ac)[2],
+                   bf16x8_t (&bn)[4], bf16x8_t (&an)[2]) {
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + aoff[a]));
-      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(st + aoff[a] + 16 * TNW_BM * 2));
-      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+      const bf16x8_t af = a < 2 ? ac[a] : read_a(st, a);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af, acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[b], af, acc[a][b], 0, 0, 0);
+      if (a == 3) preload(stn, bn, an);  // (past the last stage: a buffer nobody needs — harmless)
     }
+  };
+  auto stage_ptr = [&](int k) { return smem + k * TND_STAGE; };
+  auto next = [](int k) { return k + 1 == TND_NST ? 0 : k + 1; };
+  bf16x8_t b0[4], a0[2], b1[4], a1[2];
+  asm volatile("s_barrier" ::: "memory");  // barrier -1: stage 0 has landed
+  if (nst > 0) preload(smem, b0, a0);
+  int k0 = 0;
+  int s = 0;
+  for (; s + 1 < nst; s += 2) {
+    const int k1 = next(k0), k2 = next(k1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TND_PT(1);
+    stage(stage_ptr(k0), stage_ptr(k1), b0, a0, b1, a1);
+    TND_PT(3);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TND_PT(1);
+    stage(stage_ptr(k1), stage_ptr(k2), b1, a1, b0, a0);
+    TND_PT(3);
+    k0 = k2;
+  }
+  if (s < nst) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TND_PT(1);
+    stage(stage_ptr(k0), stage_ptr(next(k0)), b0, a0, b1, a1);
     TND_PT(3);
   }
+  if (g.stamps && tid == 0) g.stamps[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   if (prof && tid == 0) {
     g.stamps[0] = (unsigned long long)nst;
     for (int k = 0; k < 4; ++k) g.stamps[1 + k] = pt[k];

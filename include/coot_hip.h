@@ -284,7 +284,7 @@ int coot_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int T, 
 /* n weight-gradient problems C_i[Mo_i,No_i] (+)= A_i^T . B_i in ONE launch (+ one split reduction) — the way a network's
  * backward pass issues them (coot_net_bwd); a_colsum (optional) += column sums of A_i (the bias gradient).  workspace: fp32
  * partial tiles, sum_i splits_i * Mo_i * No_i * 4 bytes with splits_i <= 8 (too small: the problems run one by one).
- * stamps (optional, 48 x uint64 on the device): phase times of tile (0,0) of problem 0 in shader clocks. */
+ * stamps (optional, (64 + 2 x workgroups) x uint64 on the device): phase times of tile (0,0) of problem 0 in shader clocks. */
 typedef struct coot_tn_problem {
   const void* A; int64_t lda;   /* bf16 [T, Mo] */
   const void* B; int64_t ldb;   /* bf16 [T, No] */
@@ -297,6 +297,9 @@ typedef struct coot_tn_problem {
 } coot_tn_problem;
 int coot_gemm_tn_batch(const coot_tn_problem* problems, int n, void* workspace, size_t workspace_bytes,
                        uint64_t* stamps, coot_stream_t stream);
+/* one wave writes n pairs (100 MHz real-time counter, shader clock counter), one every interval_ticks real-time ticks:
+ * run it on a side stream to see the shader clock the device delivers under the step's load (tools/clock_probe.py) */
+int coot_debug_clock_monitor(uint64_t* out, int n, int interval_ticks, coot_stream_t stream);
 int coot_ln_fwd(const float* x, int R, int D, const float* gain, const float* bias, void* y_bf16, float* y_f32,
                 coot_stream_t stream);
 int coot_attn_fwd(const void* qkv, int Nseq, int L, int H, int dh, const int64_t* lens, void* out, float* lse,

@@ -34,7 +34,7 @@ probs = [
 arr = (TnProblem * len(probs))(*probs)
 flops = sum(2.0 * T * p.Mo * p.No * p.groups for p in probs)
 ws = torch.empty(8 * sum(p.Mo * p.No * p.groups for p in probs), device=dev)
-stamps = torch.zeros(48, dtype=torch.int64, device=dev)
+stamps = torch.zeros(64 + 2 * 512, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 run = lambda s=None: cva.lib.check(lib.coot_gemm_tn_batch(arr, len(probs), ws.data_ptr(), ws.numel() * 4, s, st))
 for _ in range(3):
@@ -59,3 +59,19 @@ if s[16:40].any():
     t0 = min(int(v) for v in s[16:40] if v)
     print("  k-step 20, barrier arrival / release per wave (clocks after the first arrival; waves 8-11 load): " +
           ", ".join(f"w{w} {int(s[16 + 2 * w]) - t0}/{int(s[17 + 2 * w]) - t0}" for w in range(12)))
+sp = s[64:].reshape(-1, 2)
+sp = sp[sp[:, 0] > 0]
+if len(sp):
+    t0 = sp[:, 0].min()
+    st, en = (sp[:, 0] - t0) / 100.0, (sp[:, 1] - t0) / 100.0   # us
+    import numpy as np
+    order = np.argsort(en)
+    print(f"  {len(sp)} workgroups (MFMA wave 0, us after the first start): start max {st.max():.1f}; end min / median / max {en.min():.1f} / {np.median(en):.1f} / {en.max():.1f}")
+    blk = np.nonzero(s[64:].reshape(-1, 2)[:, 0] > 0)[0]
+    for x in range(8):
+        m = (blk % 8) == x
+        if m.any():
+            print(f"    XCD {x}: {int(m.sum())} workgroups, end median {np.median(en[m]):.1f}, max {en[m].max():.1f}")
+if len(sp) and s[5]:
+    b0 = s[64:66]
+    print(f"  workgroup 0: {int(s[5])} s_memtime clocks in {(b0[1] - b0[0]) / 100.0:.1f} us of the 100 MHz counter -> {s[5] / ((b0[1] - b0[0]) * 10.0):.2f} clocks per ns")
