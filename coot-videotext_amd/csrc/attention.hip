@@ -434,6 +434,30 @@ __device__ __forceinline__ void stage_rows(const bf16_t* src, long ld, long rowb
   }
 }
 
+// The same in two halves — loads of every operand first, LDS stores after — so that a workgroup pays ONE memory round trip for
+// its staging instead of one per loop iteration and operand (the launcher gives a workgroup 4 threads per padded row and a row
+// has DH / 8 <= 8 chunks: at most two chunks per thread).
+template <int DH>
+__device__ __forceinline__ void stage_load(const bf16_t* src, long ld, long rowbase, int L, int L16, int c0, u32x4_t (&v)[2]) {
+  constexpr int CPR = DH / 8;
+  static_assert(CPR <= 8, "two chunks per thread cover a row block only up to 8 chunks per row");
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + i * blockDim.x, r = c / CPR, cc = (c % CPR) * 8;
+    v[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if (c < L16 * CPR && r < L) v[i] = *reinterpret_cast<const u32x4_t*>(src + (rowbase + r) * ld + c0 + cc);
+  }
+}
+template <int DH>
+__device__ __forceinline__ void stage_store(bf16_t* R, int L16, const u32x4_t (&v)[2]) {
+  constexpr int RP = AttnSmem<DH>::RP, CPR = DH / 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + i * blockDim.x, r = c / CPR, cc = (c % CPR) * 8;
+    if (c < L16 * CPR) *reinterpret_cast<u32x4_t*>(&R[r * RP + cc]) = v[i];
+  }
+}
+
 template <int DH>
 __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
   constexpr int RP = AttnSmem<DH>::RP, NK = DH / 16;
@@ -452,14 +476,17 @@ __global__ __launch_bounds__(512) void attn_short_fwd_kernel(AttnArgs a) {
   const int lq = lane & 15, lg = lane >> 4;
   const int qrow = wave * 16 + lq;
   const bool qok = qrow < L;
-  stage_rows<DH>(a.k, a.ldk, base, L, L16, h * DH, Ks);
-  stage_rows<DH>(a.v, a.ldv, base, L, L16, h * DH, Vs);
+  u32x4_t kst[2], vst[2];
+  stage_load<DH>(a.k, a.ldk, base, L, L16, h * DH, kst);
+  stage_load<DH>(a.v, a.ldv, base, L, L16, h * DH, vst);
   s16x4_t qf[NK];
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
     qf[ks] = s16x4_t{0, 0, 0, 0};
     if (qok) qf[ks] = *reinterpret_cast<const s16x4_t*>(a.q + (base + qrow) * a.ldq + h * DH + ks * 16 + lg * 4);
   }
+  stage_store<DH>(Ks, L16, kst);
+  stage_store<DH>(Vs, L16, vst);
   __syncthreads();
   f32x4_t s[SH_MAXW];
   float mx = -INFINITY;
@@ -544,31 +571,40 @@ __global__ __launch_bounds__(512) void attn_short_bwd_kernel(AttnArgs a) {
   const int nvalid = sq.nvalid;
   const long base = sq.base;
   const int l15 = lane & 15, lg = lane >> 4;
-  stage_rows<DH>(a.k, a.ldk, base, L, L16, h * DH, Ks);
-  stage_rows<DH>(a.v, a.ldv, base, L, L16, h * DH, Vs);
-  stage_rows<DH>(a.q, a.ldq, base, L, L16, h * DH, Qs);
-  stage_rows<DH>(a.dout, a.lddo, base, L, L16, h * DH, dOs);
-  // ---- phase A: this wave's 16 queries: delta, dQ ------------------------------------------------------------
+  // every global load of the workgroup is issued here, before the first wait: the four staged operands, this wave's query-side
+  // fragments of q / dO / O and its lse (one memory round trip; staged one loop and one operand at a time they were nine)
   const int qrow = wave * 16 + l15;
   const bool qok = qrow < L;
-  s16x4_t qf[NK], dof[NK];
-  float dl = 0.f;
+  u32x4_t kst[2], vst[2], qst[2], dst[2];
+  stage_load<DH>(a.k, a.ldk, base, L, L16, h * DH, kst);
+  stage_load<DH>(a.v, a.ldv, base, L, L16, h * DH, vst);
+  stage_load<DH>(a.q, a.ldq, base, L, L16, h * DH, qst);
+  stage_load<DH>(a.dout, a.lddo, base, L, L16, h * DH, dst);
+  s16x4_t qf[NK], dof[NK], of[NK];
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
-    qf[ks] = s16x4_t{0, 0, 0, 0}; dof[ks] = qf[ks];
+    qf[ks] = s16x4_t{0, 0, 0, 0}; dof[ks] = qf[ks]; of[ks] = qf[ks];
     if (qok) {
       const long off = h * DH + ks * 16 + lg * 4;
       qf[ks] = *reinterpret_cast<const s16x4_t*>(a.q + (base + qrow) * a.ldq + off);
       dof[ks] = *reinterpret_cast<const s16x4_t*>(a.dout + (base + qrow) * a.lddo + off);
-      const s16x4_t of = *reinterpret_cast<const s16x4_t*>(a.o + (base + qrow) * a.ldo + off);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dl += bf2f((bf16_t)dof[ks][j]) * bf2f((bf16_t)of[j]);
+      of[ks] = *reinterpret_cast<const s16x4_t*>(a.o + (base + qrow) * a.ldo + off);
     }
   }
-  dl += __shfl_xor(dl, 16, 64);
-  dl += __shfl_xor(dl, 32, 64);
   float lse = 0.f;
   if (qok) lse = a.lse[(base + qrow) * a.H + h];
+  stage_store<DH>(Ks, L16, kst);
+  stage_store<DH>(Vs, L16, vst);
+  stage_store<DH>(Qs, L16, qst);
+  stage_store<DH>(dOs, L16, dst);
+  // ---- phase A: this wave's 16 queries: delta, dQ ------------------------------------------------------------
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dl += bf2f((bf16_t)dof[ks][j]) * bf2f((bf16_t)of[ks][j]);
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
   if (lg == 0) { lse_s[wave * 16 + l15] = lse; delta_s[wave * 16 + l15] = dl; }
   __syncthreads();
   {
