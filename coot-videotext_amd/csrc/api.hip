@@ -4,7 +4,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/coot_hip.h"
@@ -154,7 +156,7 @@ static void layout_wpack(const coot_net_config& c, Arena& A, WPack& W) {
   const size_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
   if (c.use_input_fc) {
     W.in_w = A.get<bf16_t>(D * Din); W.in_bias = A.get<float>(D);
-    if (fused_layer_ok(c) && Din % 64 == 0) W.f_in_w = A.get<bf16_t>(D * Din);
+    if (fused_layer_ok(c) && Din % 64 == 0 && Din >= 128) W.f_in_w = A.get<bf16_t>(D * Din);  // infc_qkv_fwd's K loop: two 64-column slabs deep
   }
   auto lay = [&]() {
     LayerW w;
@@ -362,6 +364,7 @@ struct PoolFuseBwd { const bf16_t *ds, *dzp, *hp, *pw2, *pw1; bf16_t* dhp; float
 static int g_use_fused_bwd = 1;  // coot_set_option("fused_bwd", 0/1)
 static int g_use_fused_infc = 1;  // coot_set_option("fused_infc", 0/1): input FC + QKV in one launch (+1.4 % on the step once its K loop was pipelined two slabs deep)
 static int g_use_fused = 1;
+static int g_pack_lazy = 1, g_pack_poison = 0;  // coot_set_option("pack_lazy" / "pack_poison"): lazily packed per-op layouts (below)
 static int g_fz_debug = 0;
 static unsigned long long* g_fz_tstamps = nullptr;
 static int g_fused_fwd_small = 1;  // coot_set_option("fused_fwd_small", 0/1): forward chain on 32-token tiles below fused_min_rows
@@ -609,6 +612,8 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
   if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
   if (!strcmp(name, "tn_dma")) { set_tn_dma(value); return 0; }
+  if (!strcmp(name, "pack_lazy")) { g_pack_lazy = value; return 0; }
+  if (!strcmp(name, "pack_poison")) { g_pack_poison = value; return 0; }
   if (!strcmp(name, "tn_target_wgs")) { set_tn_target_wgs(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "tn_aux")) { coot_step_tn_aux(value); return 0; }
@@ -647,7 +652,24 @@ size_t coot_net_wpack_bytes(const coot_net_config* cfg) {
 
 // Records the pack jobs of one network into `jobs`, offsets relative to (P0, wpack0) — a base at or below every network of the
 // launch, so one launch can carry several networks (coot_nets_pack_weights); a full job table is flushed on the way.
-static int pack_net_jobs(const coot_net_config* cfg, const float* P, void* wpack, const float* P0, void* wpack0, PackJobs& jobs, hipStream_t st) {
+// Lazy per-op layouts.  Every weight exists in up to four bf16 layouts: [n][k] and [k][n] for the per-op GEMMs, and the two
+// fragment-major P48 images of the fused kernels.  A network that runs on the fused kernels (every launch of the benchmark
+// shapes) never reads the first two, yet rebuilding them after every optimizer step was half of the pack launch (52 us at the
+// end of the video side's critical path, ~170 MB of the step's HBM traffic).  coot_set_option("pack_lazy", 1) (default): the
+// repack writes the fused images only — and the per-op ones of weights that have no fused image; the per-op layouts of the
+// pack are marked stale in a host-side table, and the first per-op GEMM that reads one (launch_gemm_nt's weight hook, armed by
+// coot_net_fwd / coot_net_bwd) packs them on its stream first.  A pack that needed them once keeps packing them eagerly.
+// coot_set_option("pack_poison", 1) (tests) fills stale per-op layouts with NaN patterns so that a reader the hook misses
+// cannot go unnoticed.
+enum { PACK_ALL = 0, PACK_FUSED = 1, PACK_PEROP_REST = 2 };
+struct PackState { bool perop_fresh = true, perop_wanted = false; };
+static std::mutex g_pack_mu;
+static std::unordered_map<const void*, PackState> g_pack_state;
+static PackState pack_state_get(const void* wpack) { std::lock_guard<std::mutex> lk(g_pack_mu); auto it = g_pack_state.find(wpack); return it == g_pack_state.end() ? PackState() : it->second; }
+static void pack_state_set(const void* wpack, PackState s) { std::lock_guard<std::mutex> lk(g_pack_mu); g_pack_state[wpack] = s; }
+
+static int pack_net_jobs(const coot_net_config* cfg, const float* P, void* wpack, const float* P0, void* wpack0, PackJobs& jobs, hipStream_t st,
+                         int mode = PACK_ALL, bool* has_lazy = nullptr) {
   coot_net_config c; RUN(norm_cfg(cfg, &c));
   const int64_t pd = P - P0;  // >= 0
   NetLayout L; build_layout(c, L);
@@ -667,22 +689,36 @@ static int pack_net_jobs(const coot_net_config* cfg, const float* P, void* wpack
     jobs.j[jobs.n - 1].p48 = 1;
     return 0;
   };
+  // per-op layouts of a weight group: always with PACK_ALL; with PACK_FUSED only when the group has no fused image; with
+  // PACK_PEROP_REST exactly the ones PACK_FUSED left out.  Fused images: PACK_ALL and PACK_FUSED.
+  bool lazy = false;
+  auto perop = [&](bool has_fused) { if (has_fused && mode == PACK_FUSED) lazy = true; return mode == PACK_ALL || (mode == PACK_FUSED ? !has_fused : has_fused); };
+  const bool fused_on = mode != PACK_PEROP_REST;
+  auto poison = [&](bf16_t* dst, size_t elems) -> int {
+    if (!g_pack_poison || mode != PACK_FUSED) return 0;
+    return check_hip(hipMemsetAsync(dst, 0xFF, elems * sizeof(bf16_t), st), "poison");
+  };
   if (c.use_input_fc) {
-    RUN(add(L.in_w, Din, D, Din, W.in_w, Din, 0, L.n_gain));  // W * gain: LN affine folded into the FC
-    if (W.f_in_w) { RUN(add(L.in_w, Din, D, Din, W.f_in_w, 0, 0, L.n_gain)); jobs.j[jobs.n - 1].p48 = 1; }
+    if (perop(W.f_in_w != nullptr)) RUN(add(L.in_w, Din, D, Din, W.in_w, Din, 0, L.n_gain));  // W * gain: LN affine folded into the FC
+    else RUN(poison(W.in_w, (size_t)D * Din));
+    if (W.f_in_w && fused_on) { RUN(add(L.in_w, Din, D, Din, W.f_in_w, 0, 0, L.n_gain)); jobs.j[jobs.n - 1].p48 = 1; }
     // folded bias b' = b + W . norm_bias: rides on the (last) pack launch of this call
-    jobs.mv.W = P + L.in_w; jobs.mv.ldw = Din; jobs.mv.N = D; jobs.mv.K = Din; jobs.mv.v = P + L.n_bias; jobs.mv.b = P + L.in_b; jobs.mv.out = W.in_bias;
+    if (fused_on) { jobs.mv.W = P + L.in_w; jobs.mv.ldw = Din; jobs.mv.N = D; jobs.mv.K = Din; jobs.mv.v = P + L.n_bias; jobs.mv.b = P + L.in_b; jobs.mv.out = W.in_bias; }
   }
   auto pack_layer = [&](const LayerP& lp, const LayerW& lw) -> int {
-    RUN(add(lp.wqkv, D, 3 * D, D, lw.wqkv_nk, D, 0, -1));
-    RUN(add(lp.wqkv, D, 3 * D, D, lw.wqkv_kn, 3 * D, 1, -1));
-    RUN(add(lp.wo, D, D, D, lw.wo_nk, D, 0, -1));
-    RUN(add(lp.wo, D, D, D, lw.wo_kn, D, 1, -1));
-    RUN(add(lp.w1, D, F, D, lw.w1_nk, D, 0, -1));
-    RUN(add(lp.w1, D, F, D, lw.w1_kn, F, 1, -1));
-    RUN(add(lp.w2, F, D, F, lw.w2_nk, F, 0, -1));
-    RUN(add(lp.w2, F, D, F, lw.w2_kn, D, 1, -1));
-    if (lw.f_wo) {
+    if (perop(lw.f_wo != nullptr)) {
+      RUN(add(lp.wqkv, D, 3 * D, D, lw.wqkv_nk, D, 0, -1));
+      RUN(add(lp.wqkv, D, 3 * D, D, lw.wqkv_kn, 3 * D, 1, -1));
+      RUN(add(lp.wo, D, D, D, lw.wo_nk, D, 0, -1));
+      RUN(add(lp.wo, D, D, D, lw.wo_kn, D, 1, -1));
+      RUN(add(lp.w1, D, F, D, lw.w1_nk, D, 0, -1));
+      RUN(add(lp.w1, D, F, D, lw.w1_kn, F, 1, -1));
+      RUN(add(lp.w2, F, D, F, lw.w2_nk, F, 0, -1));
+      RUN(add(lp.w2, F, D, F, lw.w2_kn, D, 1, -1));
+    } else {
+      RUN(poison(lw.wqkv_nk, (size_t)(6 * D * D + 4 * F * D)));  // wqkv_nk .. w2_kn are contiguous (layout_wpack)
+    }
+    if (lw.f_wo && fused_on) {
       RUN(add48(lp.wo, D, D, D, lw.f_wo, 0));
       RUN(add48(lp.w1, D, F, D, lw.f_w1, 0));
       RUN(add48(lp.w2, F, D, F, lw.f_w2, 0));
@@ -699,14 +735,18 @@ static int pack_net_jobs(const coot_net_config* cfg, const float* P, void* wpack
   for (size_t i = 0; i < L.ctx.size(); ++i) RUN(pack_layer(L.ctx[i], W.ctx[i]));
   if (c.pooler == 0) {
     const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
+    const bool pool_perop = perop(W.f_pw1 != nullptr);
+    if (!pool_perop) RUN(poison(W.pw1_nk, (size_t)(2 * PH * D + 2 * PH * dop)));  // pw1_nk .. pw2_kn are contiguous
     for (int h = 0; h < H; ++h) {
-      // W1[h]: [D, dhp].  nk: rows (h*dhp + e) = W1[h][:, e]  -> [PH, D].  kn: [D, PH] with row d = concat_h W1[h][d][:]
-      RUN(add(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.pw1_nk + (size_t)h * dhp * D, D, 1, -1));
-      RUN(add(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.pw1_kn + (size_t)h * dhp, PH, 0, -1));
-      // W2[h]: [dhp, dop].  nk (fwd): [dop, dhp] per head.  kn (dX): natural [dhp, dop] per head
-      RUN(add(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.pw2_nk + (size_t)h * dop * dhp, dhp, 1, -1));
-      RUN(add(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.pw2_kn + (size_t)h * dhp * dop, dop, 0, -1));
-      if (W.f_pw1) {  // logical [n = pool feature e][k = d] = W1[h]^T, [n = o][k = e] = W2[h]^T
+      if (pool_perop) {
+        // W1[h]: [D, dhp].  nk: rows (h*dhp + e) = W1[h][:, e]  -> [PH, D].  kn: [D, PH] with row d = concat_h W1[h][d][:]
+        RUN(add(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.pw1_nk + (size_t)h * dhp * D, D, 1, -1));
+        RUN(add(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.pw1_kn + (size_t)h * dhp, PH, 0, -1));
+        // W2[h]: [dhp, dop].  nk (fwd): [dop, dhp] per head.  kn (dX): natural [dhp, dop] per head
+        RUN(add(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.pw2_nk + (size_t)h * dop * dhp, dhp, 1, -1));
+        RUN(add(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.pw2_kn + (size_t)h * dhp * dop, dop, 0, -1));
+      }
+      if (W.f_pw1 && fused_on) {  // logical [n = pool feature e][k = d] = W1[h]^T, [n = o][k = e] = W2[h]^T
         RUN(add48(L.pw1 + (int64_t)h * D * dhp, dhp, D, dhp, W.f_pw1 + (size_t)h * dhp * D, 1));
         RUN(add48(L.pw2 + (int64_t)h * dhp * dop, dop, dhp, dop, W.f_pw2 + (size_t)h * dop * dhp, 1));
         // dX orientation: dz[d] += sum_e dhp[e] W1[h][d][e];  dhp[e] = sum_o ds[o] W2[h][e][o]  (the sources are already [n][k])
@@ -715,8 +755,45 @@ static int pack_net_jobs(const coot_net_config* cfg, const float* P, void* wpack
       }
     }
   }
+  if (has_lazy) *has_lazy = lazy;
   return 0;
 }
+
+// ---- the weight hook of the lazily packed per-op layouts ----------------------------------------------------------------------
+struct PerOpGuard { bool armed = false; coot_net_config cfg; const float* P = nullptr; void* wpack = nullptr; const char* lo[8]; const char* hi[8]; int n = 0; };
+static thread_local PerOpGuard g_guard;
+static int perop_weight_hook(const void* Wp, hipStream_t st) {
+  PerOpGuard& G = g_guard;
+  if (!G.armed) return 0;
+  bool hit = false;
+  for (int i = 0; i < G.n && !hit; ++i) hit = (const char*)Wp >= G.lo[i] && (const char*)Wp < G.hi[i];
+  if (!hit) return 0;
+  G.armed = false;
+  PackJobs jobs;
+  RUN(pack_net_jobs(&G.cfg, G.P, G.wpack, G.P, G.wpack, jobs, st, PACK_PEROP_REST));
+  RUN(launch_pack_jobs(G.P, G.wpack, jobs, st));
+  PackState ps; ps.perop_fresh = true; ps.perop_wanted = true;
+  pack_state_set(G.wpack, ps);
+  return 0;
+}
+// arms the hook for the scope of one coot_net_fwd / coot_net_bwd call when the network's per-op layouts are stale
+struct PerOpGuardScope {
+  PerOpGuardScope(const coot_net_config& c, const WPack& W, const float* P, const void* wpack) {
+    PerOpGuard& G = g_guard;
+    G.armed = false;
+    if (pack_state_get(wpack).perop_fresh) return;
+    G.cfg = c; G.P = P; G.wpack = (void*)wpack; G.n = 0;
+    const size_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
+    auto range = [&](const bf16_t* p, size_t elems) { if (p && G.n < 8) { G.lo[G.n] = (const char*)p; G.hi[G.n] = (const char*)(p + elems); ++G.n; } };
+    if (c.use_input_fc && W.f_in_w) range(W.in_w, D * Din);
+    for (const LayerW& lw : W.layers) if (lw.f_wo) range(lw.wqkv_nk, 6 * D * D + 4 * F * D);
+    for (const LayerW& lw : W.ctx) if (lw.f_wo) range(lw.wqkv_nk, 6 * D * D + 4 * F * D);
+    if (c.pooler == 0 && W.f_pw1) range(W.pw1_nk, 2 * (size_t)c.pool_hidden * D + 2 * (size_t)c.pool_hidden * (D / c.pool_heads));
+    G.armed = G.n > 0;
+    set_gemm_weight_hook(perop_weight_hook);
+  }
+  ~PerOpGuardScope() { g_guard.armed = false; }
+};
 
 int coot_nets_pack_weights(int n, const coot_net_config* const* cfgs, const float* const* Ps, void* const* wpacks, coot_stream_t stream) {
   COOT_REQUIRE(n >= 1 && cfgs && Ps && wpacks, "nets_pack_weights: bad arguments");
@@ -727,7 +804,12 @@ int coot_nets_pack_weights(int n, const coot_net_config* const* cfgs, const floa
   PackJobs jobs;
   for (int i = 0; i < n; ++i) {
     if (jobs.mv.W && cfgs[i]->use_input_fc) { RUN(launch_pack_jobs(P0, w0, jobs, (hipStream_t)stream)); jobs.n = 0; jobs.mv = PackMatvec(); }  // one rider per launch
-    RUN(pack_net_jobs(cfgs[i], Ps[i], wpacks[i], P0, w0, jobs, (hipStream_t)stream));
+    PackState ps = pack_state_get(wpacks[i]);
+    const int mode = (g_pack_lazy && !ps.perop_wanted) ? PACK_FUSED : PACK_ALL;
+    bool lazy = false;
+    RUN(pack_net_jobs(cfgs[i], Ps[i], wpacks[i], P0, w0, jobs, (hipStream_t)stream, mode, &lazy));
+    ps.perop_fresh = !lazy;
+    pack_state_set(wpacks[i], ps);
   }
   return launch_pack_jobs(P0, w0, jobs, (hipStream_t)stream);
 }
@@ -765,6 +847,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
+  PerOpGuardScope perop_guard(c, W, P, wpack);
   Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);  // sized for the padded layout (>= the packed rows)
   COOT_REQUIRE(!AS.overflow, "net_fwd: saved buffer too small (%zu < %zu)", saved_bytes, AS.off);
   if (packed_ok(c, W, sg, packed)) {
@@ -896,6 +979,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
+  PerOpGuardScope perop_guard(c, W, P, wpack);
   Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);
   COOT_REQUIRE(!AS.overflow, "net_bwd: saved buffer too small");
   Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, Ntot, sg.Tpad(), AX, X);

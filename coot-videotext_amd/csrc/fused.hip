@@ -1907,7 +1907,7 @@ int launch_glob_bwd(const GlobBwd& p_in, hipStream_t st) {
 }
 int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st) {
   COOT_REQUIRE(p.xhat && p.win && p.bin && p.pe && p.wqkv && p.bqkv && p.h0 && p.z0 && p.qkv, "infc_qkv_fwd: null pointer");
-  COOT_REQUIRE(p.Din % 64 == 0 && p.Din >= 128 && p.L1 > 0 && p.L2 > 0, "infc_qkv_fwd: Din = %d must be a multiple of 64", p.Din);
+  COOT_REQUIRE(p.Din % 64 == 0 && p.Din >= 128 && p.L1 > 0 && p.L2 > 0, "infc_qkv_fwd: Din = %d must be a multiple of 64, >= 128", p.Din);
   if (p.T <= 0) return 0;
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * (p.Din + 1152.0), 0, st);
   if (half_tiles(p.T)) hipLaunchKernelGGL(infc_qkv_fwd_kernel<4>, dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);

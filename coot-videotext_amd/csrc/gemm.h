@@ -38,6 +38,11 @@ struct GemmNT {
 };
 
 int launch_gemm_nt(const GemmNT& g, hipStream_t stream);
+// Hook called with the weight operand of every launch_gemm_nt() of this thread before the launch (nullptr: none): the owner of
+// the weight packs uses it to complete layouts it packs lazily (api.hip: per-op layouts of networks that run on the fused
+// kernels).  Non-zero return aborts the launch.
+typedef int (*gemm_weight_hook_t)(const void* W, hipStream_t stream);
+void set_gemm_weight_hook(gemm_weight_hook_t fn);
 
 struct GemmTN {
   const bf16_t* A = nullptr; long lda = 0;  // [T, Mo]

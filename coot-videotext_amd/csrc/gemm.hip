@@ -423,9 +423,12 @@ void timing_end(void* slot, hipStream_t stream) {
 }
 
 static int g_xcd_order = 7;  // coot_set_option("xcd_order", bits): 1 = gemm_nt tile order, 2 = weight-gradient tiles of one split on one XCD, 4 = short attention (sequence, head) order
+static thread_local gemm_weight_hook_t g_weight_hook = nullptr;
+void set_gemm_weight_hook(gemm_weight_hook_t fn) { g_weight_hook = fn; }
 int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
   GemmNT g = g_in;
   COOT_REQUIRE(g.X && g.W && g.epi.out, "gemm_nt: null operand");
+  if (g_weight_hook) { const int rc = g_weight_hook(g.W, stream); if (rc) return rc; }
   COOT_REQUIRE(g.K % 8 == 0 && g.ldx % 8 == 0 && g.ldw % 8 == 0 && g.zX % 8 == 0 && g.zW % 8 == 0,
                "gemm_nt: K/ldx/ldw must be multiples of 8 (K=%d ldx=%ld ldw=%ld)", g.K, g.ldx, g.ldw);
   COOT_REQUIRE(g.N % 8 == 0 && g.epi.ldc % 8 == 0 && g.zOut % 8 == 0, "gemm_nt: N/ldc must be multiples of 8 (N=%d ldc=%ld)", g.N, g.epi.ldc);

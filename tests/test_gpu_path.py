@@ -814,3 +814,39 @@ def test_native_optimizer_state_round_trip(env):
     assert d_resumed <= 2.1e-3 and d_cold > 3 * max(d_resumed, 1e-5) or d_resumed < 1e-6
     frac = np.mean([float(((a._flat - b._flat).abs() > 1e-6).float().mean()) for a, b in zip(mgr_a.model_dict.values(), mgr_b.model_dict.values())])
     assert frac < 5e-3, frac
+
+
+def test_lazy_perop_layouts(env):
+    """coot_set_option("pack_lazy", 1): after the library's optimizer steps at fused-kernel shapes only the fused weight images
+    are rebuilt — the per-op layouts are stale (here: filled with NaN patterns, "pack_poison") until a per-op GEMM asks for
+    them.  A small batch (below the fused kernels' row threshold) through the same networks must then see current weights:
+    its embeddings equal the ones computed after an eager full repack, bit for bit."""
+    torch, cva = env
+    lib = cva.lib.load()
+    dims = (256, 128, 384, 8, 384, 768)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    big = cva.synthetic.make_batch(3, 16, 4, 40, 40, 32, 16, dims[0], dims[1], ragged=False)   # 16*40 + 64*40 = 3200 rows per side
+    small = cva.synthetic.make_batch(4, 4, [1, 2, 3, 2], 12, 10, 9, 6, dims[0], dims[1], ragged=True)
+    cva.lib.check(lib.coot_set_option(b"pack_lazy", 1)); cva.lib.check(lib.coot_set_option(b"pack_poison", 1))
+    try:
+        cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg, mgr)
+        for _ in range(2):
+            tr.train_step_native(big)
+        mgr.set_all_models_eval()
+        with torch.no_grad():
+            v1, t1 = mgr.encode_visual(small), mgr.encode_text(small)
+        torch.cuda.synchronize()
+        for e in (v1.vid_emb, v1.clip_emb, t1.par_emb, t1.sent_emb):
+            assert torch.isfinite(e).all()
+        cva.lib.check(lib.coot_set_option(b"pack_lazy", 0))
+        mgr.mark_weights_dirty()   # eager repack of every layout from the same parameters
+        with torch.no_grad():
+            v2, t2 = mgr.encode_visual(small), mgr.encode_text(small)
+        torch.cuda.synchronize()
+        for a, b in ((v1.vid_emb, v2.vid_emb), (v1.clip_emb, v2.clip_emb), (t1.par_emb, t2.par_emb), (t1.sent_emb, t2.sent_emb)):
+            assert torch.equal(a, b)
+    finally:
+        lib.coot_set_option(b"pack_lazy", 1); lib.coot_set_option(b"pack_poison", 0)
