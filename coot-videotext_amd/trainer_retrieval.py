@@ -687,6 +687,20 @@ class RetrievalTrainer:
         fresh = int(all(n.pack_is_fresh() for n in st.nets))
         _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *[t.data_ptr() for t in st.emb], ws, wsn,
                                          train, int(seed), fresh, main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_forward")
+        # cycle-consistency (per video, no exchange) on the text stream, next to the gathers and the contrastive loss on the main stream
+        use_cc = st.cfg.cc_weight != 0.0
+        if use_cc:
+            stt.wait_stream(main)  # main is ordered after both sides' forward and the zero fills
+            with torch.cuda.stream(stt):
+                if cc_indices is not None:  # a given draw ([2B] int64: this rank's clip positions, then its sentence positions)
+                    st.cyc_idx.copy_(cc_indices)
+                else:
+                    _lib.check(lib.coot_sample_cycle_indices(batch.clip_num.data_ptr(), batch.sent_num.data_ptr(), B, int(seed),
+                                                             st.cyc_idx.data_ptr(), stt.cuda_stream), "coot_sample_cycle_indices")
+                _lib.check(lib.coot_cyclecons_fwd_bwd(resh_v.data_ptr(), resh_t.data_ptr(), batch.clip_num.data_ptr(), batch.sent_num.data_ptr(),
+                                                      st.cyc_idx.data_ptr(), st.cyc_idx[B:].data_ptr(), B, d.Cmax_clip, d.Cmax_sent, D,
+                                                      float(st.cfg.cc_weight), 1.0 / float(gb), st.cc_word.data_ptr(), None, None,
+                                                      d_resh_v.data_ptr(), d_resh_t.data_ptr(), stt.cuda_stream), "coot_cyclecons_fwd_bwd")
         # ---- exchange: two packed all-gathers (per-video sets, per-clip sets); the loss reads the gathered buffers in place ----
         high = torch.cat([glob_v, glob_t, local_v[:B], local_t[:B]], dim=1)      # [B, 2D | 2D | D | D]
         low = torch.cat([local_v[B:], local_t[B:]], dim=1)                        # [Nc, D | D]
@@ -702,17 +716,8 @@ class RetrievalTrainer:
         _lib.check(lib.coot_contrastive_fwd_bwd_dp(C.byref(st.cfg.contr), gb, gn, 2 * D, D, C.byref(sets), C.byref(lds), st.losses[1:2].data_ptr(),
                                                    C.byref(down), v0, B, c0, Nc, st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
                    "coot_contrastive_fwd_bwd_dp")
-        use_cc = st.cfg.cc_weight != 0.0
         if use_cc:
-            if cc_indices is not None:  # a given draw ([2B] int64: this rank's clip positions, then its sentence positions)
-                st.cyc_idx.copy_(cc_indices)
-            else:
-                _lib.check(lib.coot_sample_cycle_indices(batch.clip_num.data_ptr(), batch.sent_num.data_ptr(), B, int(seed),
-                                                         st.cyc_idx.data_ptr(), sp), "coot_sample_cycle_indices")
-            _lib.check(lib.coot_cyclecons_fwd_bwd(resh_v.data_ptr(), resh_t.data_ptr(), batch.clip_num.data_ptr(), batch.sent_num.data_ptr(),
-                                                  st.cyc_idx.data_ptr(), st.cyc_idx[B:].data_ptr(), B, d.Cmax_clip, d.Cmax_sent, D,
-                                                  float(st.cfg.cc_weight), 1.0 / float(gb), st.cc_word.data_ptr(), None, None,
-                                                  d_resh_v.data_ptr(), d_resh_t.data_ptr(), sp), "coot_cyclecons_fwd_bwd")
+            main.wait_stream(stt)  # the backward reads d_resh / the cycle-consistency word
         lib.coot_step_set_global_done_events(st.ev_glob[0].cuda_event, st.ev_glob[1].cuda_event)
         _lib.check(lib.coot_step_backward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), local_v.data_ptr(), local_t.data_ptr(),
                                           resh_v.data_ptr(), resh_t.data_ptr(), d_local_v.data_ptr(), d_local_t.data_ptr(), d_glob_v.data_ptr(),
