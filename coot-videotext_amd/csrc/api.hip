@@ -589,6 +589,7 @@ int coot_version(void) { return 1; }
 int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)dev_u64; return 0; }
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
 extern "C" void coot_step_tn_aux(int sides);
+extern "C" void coot_step_split_loss(int on);
 extern "C" void coot_step_defer_global_tn(int on);
 int coot_get_option(const char* name, int* value) {
   if (!value) { set_error("get_option: null result"); return -1; }
@@ -617,6 +618,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_target_wgs")) { set_tn_target_wgs(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "tn_aux")) { coot_step_tn_aux(value); return 0; }
+  if (!strcmp(name, "split_loss")) { coot_step_split_loss(value); return 0; }
   if (!strcmp(name, "defer_global_tn")) { coot_step_defer_global_tn(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }

@@ -46,7 +46,18 @@ int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int
                              const float* par_ctx, float* loss, float* d_vid_emb, float* d_par_emb, float* d_clip_emb,
                              float* d_sent_emb, float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes,
                              coot_stream_t stream) {
+  return coot_contrastive_fwd_bwd_part(cfg, n_high, n_low, d_high, d_low, vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx, loss, d_vid_emb,
+                                       d_par_emb, d_clip_emb, d_sent_emb, d_vid_ctx, d_par_ctx, scratch, scratch_bytes,
+                                       COOT_CONTRASTIVE_GLOBAL | COOT_CONTRASTIVE_LOCAL, stream);
+}
+
+int coot_contrastive_fwd_bwd_part(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low, const float* vid_emb,
+                                  const float* par_emb, const float* clip_emb, const float* sent_emb, const float* vid_ctx,
+                                  const float* par_ctx, float* loss, float* d_vid_emb, float* d_par_emb, float* d_clip_emb,
+                                  float* d_sent_emb, float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes, int part,
+                                  coot_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  COOT_REQUIRE((part & ~3) == 0 && part != 0, "contrastive: part = COOT_CONTRASTIVE_GLOBAL | COOT_CONTRASTIVE_LOCAL");
   COOT_REQUIRE(cfg && vid_emb && par_emb && clip_emb && sent_emb && vid_ctx && par_ctx && loss && scratch, "contrastive: null pointer");
   const bool bwd = d_vid_emb != nullptr;
   COOT_REQUIRE(!bwd || (d_par_emb && d_clip_emb && d_sent_emb && d_vid_ctx && d_par_ctx), "contrastive: gradient pointers must be all set or all null");
@@ -56,7 +67,9 @@ int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int
   const float w_pair[3] = {cfg->weight_high, cfg->weight_low, cfg->weight_context};
   const float w_self[3] = {0.5f * cfg->weight_high_internal, 0.5f * cfg->weight_low_internal,
                            cfg->weight_context_internal != 0.f ? 0.5f * cfg->weight_low_internal : 0.f};
-  return launch_contrastive_fused(vs, dvs, n_high, n_low, d_high, d_low, w_pair, w_self, cfg->margin, loss, scratch, scratch_bytes, st);
+  const int pair_mask = ((part & COOT_CONTRASTIVE_GLOBAL) ? 1 : 0) | ((part & COOT_CONTRASTIVE_LOCAL) ? 6 : 0);
+  return launch_contrastive_fused(vs, dvs, n_high, n_low, d_high, d_low, w_pair, w_self, cfg->margin, loss, scratch, scratch_bytes, st, nullptr,
+                                  nullptr, pair_mask);
 }
 
 int coot_contrastive_fwd_bwd_dp(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low, const float* const sets[6],

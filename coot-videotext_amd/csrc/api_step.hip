@@ -132,6 +132,7 @@ thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller even
 // the dependent launches, the 36-workgroup TN launch overlapped with them anyway) and the aux launch slows the local backward's
 // first kernels.  Off.
 int g_defer_global_tn = 0;
+int g_split_loss = 1;  // coot_set_option("split_loss", 0/1): local contrastive terms on the text stream ahead of the join (coot_train_step)
 int g_tn_aux_sides = 0;  // coot_set_option("tn_aux", bits): 1 = video side, 2 = text side.  Measured: 136.6k -> 133k (video) / 131k (both)
                           // clip-pairs/s — the local backward is area bound, two half batches of weight gradients are less efficient than one
 // bf16 weight packs of `count` networks in one launch
@@ -171,7 +172,7 @@ int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, 
                  int Lctx, const float* item_feat, const int64_t* item_len, int Litem, const int64_t* item_num, int Cmax,
                  const coot_step_dims& d, float* local_out, float* glob_out, float* resh, unsigned char* mask, long long* lens,
                  void* saved_l, size_t sz_l, void* saved_g, size_t sz_g, int train, uint64_t seed, hipStream_t st, bool pack = true,
-                 const coot_packed_seqs* pk = nullptr) {
+                 const coot_packed_seqs* pk = nullptr, int local_done_slot = -1) {
   const int D = c.net[0].hidden_dim;
   if (pack) {
     { const int two[2] = {li, gi}; RUN(pack_nets(c, b, two, 2, st)); }
@@ -180,6 +181,7 @@ int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, 
   RUN(coot_net_fwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
                    nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, g_step_seed_dev, st, pk));
   g_stamps.mark(li == 0 ? "video: local forward done" : "text: local forward done", st);
+  if (local_done_slot >= 0) RUN(g_hops.record(local_done_slot, st));  // the local embeddings exist: the other side may start on their loss terms
   RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
   RUN(coot_net_fwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0,
                    local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi, g_step_seed_dev, st,
@@ -223,7 +225,7 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   }
   // the cycle-consistency gradients come from the other stream; they are first needed HERE, a whole global backward after the
   // contrastive loss — waiting only now keeps the cross-stream hop off the critical path
-  if (d_resh && g_resh_wait_slot >= 0 && li == 0) RUN(g_hops.wait(g_resh_wait_slot, st));
+  if (g_resh_wait_slot >= 0 && li == 0) RUN(g_hops.wait(g_resh_wait_slot, st));
   // context grad += dhidden, item grads += unpack(global input grad) + unpack(cycle-consistency grad): one launch
   RUN(launch_pack_bwd_join(dfeat, d_resh, dhid, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, d_local, st));
   set_tn_aux_stream(((g_tn_aux_sides >> side) & 1) ? g_aux.get(side) : nullptr);
@@ -505,8 +507,10 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   }
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
+  const bool split_loss = g_split_loss != 0 && sv != st;
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
-                   W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first, &pk.v));
+                   W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first, &pk.v,
+                   split_loss ? 9 : -1));
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
                    W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st,
                    pack_first, &pk.t));
@@ -523,6 +527,19 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   RUN(g_hops.hop(2, st, sv));
   g_stamps.mark("video: text forward joined", sv);
   const bool cc = cfg->cc_weight != 0.f;
+  // The contrastive terms on the clip / sentence embeddings and on the context vectors need the LOCAL networks only: they run
+  // here on the text stream (whose forward finishes ~90 us before the video side's: the device is nearly idle while the video
+  // side's global network runs) instead of behind the video side's global forward — only the (vid, par) terms, 64 rows, stay
+  // on the critical path.  coot_set_option("split_loss", 0): the whole loss behind the join (A/B).
+  if (split_loss) {
+    RUN(g_hops.wait(9, st));  // the video side's local embeddings
+    RUN(coot_contrastive_fwd_bwd_part(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
+                                      W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
+                                      W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
+                                      W.sz_loss, COOT_CONTRASTIVE_LOCAL, side_t));
+    g_stamps.mark("text: local contrastive terms done", st);
+    if (!cc) RUN(g_hops.record(7, st));  // the video side's backward waits for these gradients (with cc: behind the cycle-consistency loss)
+  }
   if (cc) {  // cycle-consistency -> losses[2] on the text stream, next to the contrastive loss on the video stream
     RUN(g_hops.hop(6, sv, st));
     RUN(draw_cycle_indices(*x, *d, seed, W.idx, st));
@@ -533,14 +550,16 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
     g_stamps.mark("text: cycle-consistency done", st);
   }
   // contrastive loss on the video stream -> losses[1]
-  RUN(coot_contrastive_fwd_bwd(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
-                               W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
-                               W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
-                               W.sz_loss, side_v));
+  RUN(coot_contrastive_fwd_bwd_part(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
+                                    W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
+                                    W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
+                                    W.sz_loss, split_loss ? COOT_CONTRASTIVE_GLOBAL : (COOT_CONTRASTIVE_GLOBAL | COOT_CONTRASTIVE_LOCAL), side_v));
   g_stamps.mark("video: contrastive done", sv);
   RUN(g_hops.hop(3, sv, st));  // text backward needs the contrastive gradients
   const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
-  g_resh_wait_slot = cc ? 7 : -1;  // d_resh_v was recorded on the text stream (slot 7); side_backward waits where it is first read
+  // what the text stream produced for the video side's backward (cycle-consistency gradients d_resh_v, the local contrastive
+  // terms' gradients) was recorded in slot 7; side_backward waits where it is first read
+  g_resh_wait_slot = (cc || split_loss) ? 7 : -1;
   const int rc_v = side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                                  W.local_v, W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv,
                                  W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, sv, &pk.v);
@@ -648,6 +667,7 @@ int coot_step_set_device_state(void* state) {
 int coot_step_set_cycle_indices(const int64_t* idx) { g_cc_idx_inject = idx; return 0; }
 int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
 void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
+void coot_step_split_loss(int on) { g_split_loss = on; }
 void coot_step_defer_global_tn(int on) { g_defer_global_tn = on; }
 
 // text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.

@@ -32,6 +32,6 @@ size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_
 // [rows, d] arrays (data parallel: the loss is over the gathered batch, a rank keeps the rows of its own videos).
 int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
                              const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st,
-                             const long* ldv = nullptr, const int* window = nullptr);
+                             const long* ldv = nullptr, const int* window = nullptr, int pair_mask = 7);
 
 }  // namespace coot

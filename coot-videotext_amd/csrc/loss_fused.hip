@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
       for (int b = 0; b < A.loss_n[t]; ++b) s += A.loss_part[t][b];
       tot += s * A.loss_coef[t];
     }
-    *A.loss += tot;
+    atomicAdd(A.loss, tot);  // (two calls on different pairs may finish at the same time)
   }
   const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (grow >= A.rows) return;
@@ -317,7 +317,11 @@ size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_
 // weights: w_pair[p] (alignment), w_self[p] (already includes the 1/2 of compute_cluster_loss)
 int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
                              const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st,
-                             const long* ldv, const int* window) {
+                             const long* ldv, const int* window, int pair_mask) {
+  // pair_mask: bit p set = pair p (0 vid | par, 1 clip | sent, 2 vid_ctx | par_ctx) is part of this call.  The pairs own
+  // disjoint scratch buffers and gradient outputs and the loss word is added atomically, so two calls with complementary masks
+  // may run on different streams (the step computes pairs 1 and 2 as soon as the local networks are done).
+  auto active = [&](int p) { return ((pair_mask >> p) & 1) != 0; };
   {
     const bool hi_on = w_pair[0] != 0.f || w_self[0] != 0.f, lo_on = w_pair[1] != 0.f || w_self[1] != 0.f || w_pair[2] != 0.f || w_self[2] != 0.f;
     COOT_REQUIRE((!hi_on || d_high % 32 == 0) && (!lo_on || d_low % 32 == 0), "contrastive: embedding dims must be multiples of 32 (%d, %d)", d_high, d_low);
@@ -332,11 +336,13 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
     ClPair& P = na.p[p]; const PairBufs& b = L.p[p];
     P.va = v[2 * p]; P.vb = v[2 * p + 1]; P.lda = ldv ? ldv[2 * p] : ds[p]; P.ldb = ldv ? ldv[2 * p + 1] : ds[p]; P.a = b.a; P.b = b.b; P.aT = b.aT; P.bT = b.bT; P.inva = b.inva; P.invb = b.invb;
     P.dab = b.dab; P.daa = b.daa; P.dbb = b.dbb; P.N = Ns[p]; P.Np = pad16(Ns[p]); P.d = ds[p];
-    na.row0[p] = rows; rows += P.Np;
+    na.row0[p] = rows; rows += active(p) ? P.Np : 0;  // an inactive pair has no rows (cl_norm picks the LAST pair whose row0 <= row)
   }
   na.row0[3] = rows;
-  hipLaunchKernelGGL(cl_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, na);
-  COOT_CHECK_LAUNCH("cl_norm");
+  if (rows > 0) {
+    hipLaunchKernelGGL(cl_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, na);
+    COOT_CHECK_LAUNCH("cl_norm");
+  }
   ClHalfArgs ha; ha.nh = 0; ha.margin = margin; int nblk = 0, maxNp = 0;
   ClFinishArgs fa; fa.nl = 0; fa.loss = loss;
   int hidx[3][4];
@@ -345,7 +351,7 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
     const int N = Ns[p], Np = pad16(N), d = ds[p];
     for (int q = 0; q < 4; ++q) {
       hidx[p][q] = -1;
-      const bool on = q < 2 ? (w_pair[p] != 0.f) : (w_self[p] != 0.f);
+      const bool on = active(p) && (q < 2 ? (w_pair[p] != 0.f) : (w_self[p] != 0.f));
       if (!on || N <= 0) continue;
       if (q == 1 && !bwd) continue;  // the swapped half only provides the gradient wrt B (and its violation counts)
       ClHalf& H = ha.h[ha.nh];
@@ -378,11 +384,11 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
   for (int s = 0; s < 6; ++s) {
     const int p = s / 2, isb = s & 1;
     ClSet& S = fa.s[s]; const PairBufs& b = L.p[p];
-    S.v = v[s]; S.ldv = ldv ? ldv[s] : ds[p]; S.inv = isb ? b.invb : b.inva; S.dv = bwd ? dv[s] : nullptr; S.N = Ns[p]; S.d = ds[p]; S.nc = 0; S.row0 = frows;
+    S.v = v[s]; S.ldv = ldv ? ldv[s] : ds[p]; S.inv = isb ? b.invb : b.inva; S.dv = (bwd && active(p)) ? dv[s] : nullptr; S.N = Ns[p]; S.d = ds[p]; S.nc = 0; S.row0 = frows;
     S.w0 = 0; S.wn = Ns[p];
     if (window) { S.w0 = window[p == 1 ? 2 : 0]; S.wn = window[p == 1 ? 3 : 1]; }  // {high row0, high rows, low row0, low rows}
-    frows += Ns[p];
-    if (!bwd) continue;
+    frows += active(p) ? Ns[p] : 0;  // (cl_finish picks the LAST set whose row0 <= row: a set without rows is never picked)
+    if (!bwd || !active(p)) continue;
     const float n2 = (float)Ns[p] * (float)Ns[p];
     if (hidx[p][0] >= 0) {  // alignment term: this set's half + diagonal (c1 of both orientations) against the other set's rows
       ClContrib& c = S.c[S.nc++];

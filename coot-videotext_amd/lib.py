@@ -18,7 +18,7 @@ EXPORTS = [
     "coot_last_error", "coot_version", "coot_set_option", "coot_debug_timestamps", "coot_debug_step_stamps", "coot_net_param_numel", "coot_net_param_count",
     "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights", "coot_nets_pack_weights",
     "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_pack_fwd",
-    "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_cyclecons_fwd_bwd",
+    "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
     "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_contrastive_fwd_bwd_dp", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
@@ -121,6 +121,7 @@ def load():
     lib.coot_contrastive_scratch_bytes.restype = sz
     lib.coot_contrastive_scratch_bytes.argtypes = [i32, i32, i32, i32]
     lib.coot_contrastive_fwd_bwd.argtypes = [C.POINTER(ContrastiveConfig), i32, i32, i32, i32] + [vp] * 6 + [vp] + [vp] * 6 + [vp, sz, vp]
+    lib.coot_contrastive_fwd_bwd_part.argtypes = lib.coot_contrastive_fwd_bwd.argtypes[:-1] + [i32, vp]
     lib.coot_cyclecons_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp]
     lib.coot_retrieval_workspace_bytes.argtypes = [i32, i32]
     lib.coot_retrieval_workspace_bytes.restype = C.c_size_t

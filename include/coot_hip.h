@@ -131,6 +131,19 @@ int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int
                              float* d_vid_emb, float* d_par_emb, float* d_clip_emb, float* d_sent_emb,
                              float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes,
                              coot_stream_t stream);
+/* The same, restricted to a part of the seven terms: COOT_CONTRASTIVE_GLOBAL = the terms on (vid_emb, par_emb) — the outputs of
+ * the global networks (trainer_retrieval.py:168-171); COOT_CONTRASTIVE_LOCAL = the terms on (clip_emb, sent_emb) and
+ * (vid_ctx, par_ctx) (:172-182), which need the local networks only.  Two calls with the two parts on the same scratch buffer
+ * add up to the full call (disjoint scratch regions and gradient outputs, *loss added atomically) and may run on different
+ * streams: coot_train_step computes the local part on the text stream while the video side's global network still runs. */
+#define COOT_CONTRASTIVE_GLOBAL 1
+#define COOT_CONTRASTIVE_LOCAL 2
+int coot_contrastive_fwd_bwd_part(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low,
+                                  const float* vid_emb, const float* par_emb, const float* clip_emb,
+                                  const float* sent_emb, const float* vid_ctx, const float* par_ctx, float* loss,
+                                  float* d_vid_emb, float* d_par_emb, float* d_clip_emb, float* d_sent_emb,
+                                  float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes, int part,
+                                  coot_stream_t stream);
 
 /* The same loss for data-parallel training: sets[i] are the six GATHERED sets (row stride ld[i] floats: they may be column
  * slices of the all-gather buffers), the loss is the mean over the global batch; gradients are produced only for this
