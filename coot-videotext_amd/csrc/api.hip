@@ -879,7 +879,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       g.epi.out = S.z0; g.epi.ldc = D;
       RUN(launch_gemm_nt(g, st));
     }
-  } else {
+  } else if (!(glob_fused_ok(c, sg) && W.layers[0].f_wqkv && W.ctx[0].f_wqkv)) {  // (the single-launch context network normalises its input itself)
     LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T0; l.D = Din; l.gain = P + L.n_gain; l.bias = P + L.n_bias;
     l.pe = pe; l.pe_L = Lseq; l.y = S.z0; l.ldy = D;
     RUN(launch_ln_fwd(l, st));
