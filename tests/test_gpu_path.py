@@ -850,3 +850,45 @@ def test_lazy_perop_layouts(env):
             assert torch.equal(a, b)
     finally:
         lib.coot_set_option(b"pack_lazy", 1); lib.coot_set_option(b"pack_poison", 0)
+
+
+def test_contrastive_parts_add_up(env):
+    """coot_contrastive_fwd_bwd_part: the terms on the global networks' outputs and the terms that need the local networks only,
+    computed by two calls on TWO streams sharing one scratch buffer (the way coot_train_step issues them), add up to the one-call
+    loss and gradients (every gradient row is produced by exactly one of the two calls: equality is exact; the loss word is an
+    atomic sum of two partial sums)."""
+    import ctypes as C
+    torch, cva = env
+    lib = cva.lib.load()
+    rs = np.random.RandomState(11)
+    nh, nl, dh_, dl = 64, 230, 768, 384
+    names = ["vid_emb", "par_emb", "clip_emb", "sent_emb", "vid_ctx", "par_ctx"]
+    shapes = [(nh, dh_), (nh, dh_), (nl, dl), (nl, dl), (nh, dl), (nh, dl)]
+    E = []
+    for i in range(0, 6, 2):
+        shared = rs.randn(1, shapes[i][1])
+        a = shared + 0.6 * rs.randn(*shapes[i])
+        E += [a, a + 0.9 * rs.randn(*shapes[i])]  # diagonal cosines ~0.75 next to off-diagonal ~0.7: many violated margins
+    ts = [torch.from_numpy(e).float().cuda() for e in E]
+    cfg = cva.lib.ContrastiveConfig(0.2, 1.0, 1.0, 1.0, 1.0, 1.0, 0.5)
+    scratch = torch.empty(lib.coot_contrastive_scratch_bytes(nh, nl, dh_, dl), dtype=torch.uint8, device="cuda")
+
+    def run(parts):
+        loss = torch.zeros(1, device="cuda")
+        grads = [torch.zeros_like(t) for t in ts]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in parts]
+        for part, st in zip(parts, streams):
+            cva.lib.check(lib.coot_contrastive_fwd_bwd_part(C.byref(cfg), nh, nl, dh_, dl, *[t.data_ptr() for t in ts], loss.data_ptr(),
+                                                            *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(), part, st.cuda_stream),
+                          "contrastive_part")
+        torch.cuda.synchronize()
+        return float(loss), grads
+
+    l_full, g_full = run([3])
+    l_two, g_two = run([2, 1])
+    print(f"contrastive: one call {l_full:.6f}, global + local parts {l_two:.6f}")
+    assert abs(l_full - l_two) < 1e-6 * max(1.0, abs(l_full))
+    for n, a, b in zip(names, g_full, g_two):
+        assert float(a.abs().max()) > 0, n
+        assert torch.equal(a, b), n
