@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -364,6 +365,7 @@ struct PoolFuseBwd { const bf16_t *ds, *dzp, *hp, *pw2, *pw1; bf16_t* dhp; float
 static int g_use_fused_bwd = 1;  // coot_set_option("fused_bwd", 0/1)
 static int g_use_fused_infc = 1;  // coot_set_option("fused_infc", 0/1): input FC + QKV in one launch (+1.4 % on the step once its K loop was pipelined two slabs deep)
 static int g_use_fused = 1;
+static int g_grad_poison = 0;  // coot_set_option("grad_poison", 1) (tests): coot_nets_zero_grads fills the matrices it skips with NaN
 static int g_pack_lazy = 1, g_pack_poison = 0;  // coot_set_option("pack_lazy" / "pack_poison"): lazily packed per-op layouts (below)
 static int g_fz_debug = 0;
 static unsigned long long* g_fz_tstamps = nullptr;
@@ -590,6 +592,7 @@ int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)d
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
 extern "C" void coot_step_tn_aux(int sides);
 extern "C" void coot_step_split_loss(int on);
+extern "C" void coot_step_grad_write(int on);
 extern "C" void coot_step_defer_global_tn(int on);
 int coot_get_option(const char* name, int* value) {
   if (!value) { set_error("get_option: null result"); return -1; }
@@ -615,10 +618,12 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_dma")) { set_tn_dma(value); return 0; }
   if (!strcmp(name, "pack_lazy")) { g_pack_lazy = value; return 0; }
   if (!strcmp(name, "pack_poison")) { g_pack_poison = value; return 0; }
+  if (!strcmp(name, "grad_poison")) { g_grad_poison = value; return 0; }
   if (!strcmp(name, "tn_target_wgs")) { set_tn_target_wgs(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "tn_aux")) { coot_step_tn_aux(value); return 0; }
   if (!strcmp(name, "split_loss")) { coot_step_split_loss(value); return 0; }
+  if (!strcmp(name, "grad_write")) { coot_step_grad_write(value); return 0; }
   if (!strcmp(name, "defer_global_tn")) { coot_step_defer_global_tn(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
@@ -829,6 +834,64 @@ size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int Lseq, int N
   Arena A(nullptr, 0); Scratch S; layout_scratch(c, N + N2, (long)N * Lseq + (long)N2 * L2, A, S); return A.off + 256;
 }
 
+// ---- gradients written instead of accumulated ------------------------------------------------------------------------------------
+// coot_net_bwd ACCUMULATES into the gradient arena (the contract of the autograd route and of gradient accumulation), so a step
+// used to zero all 30 MB of it and every weight-gradient launch read its destination back.  Every weight MATRIX gradient is the
+// result of exactly one weight-gradient problem per pass: coot_net_grads_overwrite(1) (thread-local; coot_train_step sets it
+// around its backward) makes those problems write, and coot_nets_zero_grads(..., skip_matrices = 1) zeroes only what is still
+// accumulated (biases, LayerNorm parameters: < 1 % of the arena) — one launch instead of four fills.
+static thread_local int g_grad_overwrite = 0;
+int coot_net_grads_overwrite(int on) { g_grad_overwrite = on ? 1 : 0; return 0; }
+
+struct ZeroRanges { float* p[64]; int n[64]; int poison[64]; int count; };
+__global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges r) {
+  float* p = r.p[blockIdx.x];
+  const int n = r.n[blockIdx.x];
+  const float v = r.poison[blockIdx.x] ? __uint_as_float(0x7FC00000u) : 0.f;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) p[i] = v;
+}
+int coot_nets_zero_grads(int nnets, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices, coot_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  COOT_REQUIRE(nnets >= 1 && nnets <= 8 && cfgs && grads, "nets_zero_grads: bad arguments");
+  ZeroRanges zr; zr.count = 0;
+  auto flush = [&]() -> int {
+    if (zr.count == 0) return 0;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(zr.count, g_grad_poison ? 64 : 2), dim3(256), 0, st, zr);
+    COOT_CHECK_LAUNCH("zero_ranges");
+    zr.count = 0;
+    return 0;
+  };
+  auto add = [&](float* p, int64_t n, int poison) -> int {
+    if (n <= 0) return 0;
+    if (zr.count == 64) RUN(flush());
+    zr.p[zr.count] = p; zr.n[zr.count] = (int)n; zr.poison[zr.count] = poison; ++zr.count;
+    return 0;
+  };
+  for (int k = 0; k < nnets; ++k) {
+    coot_net_config c; RUN(norm_cfg(cfgs[k], &c));
+    NetLayout L; build_layout(c, L);
+    if (!skip_matrices) { RUN(check_hip(hipMemsetAsync(grads[k], 0, (size_t)L.total * sizeof(float), st), "memset grads")); continue; }
+    // the matrices a backward pass writes (offset, elements), ascending offsets; everything between them is zeroed
+    const int64_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
+    std::vector<std::pair<int64_t, int64_t>> mats;
+    if (c.use_input_fc) mats.push_back({L.in_w, D * Din});
+    auto layer = [&](const LayerP& lp) { mats.push_back({lp.wqkv, 3 * D * D}); mats.push_back({lp.wo, D * D}); mats.push_back({lp.w1, F * D}); mats.push_back({lp.w2, D * F}); };
+    for (const LayerP& lp : L.layers) layer(lp);
+    for (const LayerP& lp : L.ctx) layer(lp);
+    if (c.pooler == 0) { mats.push_back({L.pw1, D * (int64_t)c.pool_hidden}); mats.push_back({L.pw2, (int64_t)c.pool_hidden * (D / c.pool_heads)}); }
+    std::sort(mats.begin(), mats.end());
+    int64_t pos = 0;
+    for (const auto& m : mats) {
+      COOT_REQUIRE(m.first >= pos && m.first + m.second <= L.total, "nets_zero_grads: parameter layout");
+      RUN(add(grads[k] + pos, m.first - pos, 0));
+      if (g_grad_poison) RUN(add(grads[k] + m.first, m.second, 1));
+      pos = m.first + m.second;
+    }
+    RUN(add(grads[k] + pos, L.total - pos, 0));
+  }
+  return flush();
+}
+
 int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, const float* pe, const float* feats,
                  const int64_t* lengths, int N, int Lseq, const float* feats2, const int64_t* lengths2, int N2, int L2,
                  const float* hidden, float* pooled, float* per_token, void* saved,
@@ -993,6 +1056,8 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   // single encoder (and context) layer no operand buffer is re-used before the end of the pass; deeper networks flush
   // after every layer, whose scratch buffers the next layer overwrites.
   struct TnBatchScope { TnBatchScope() { tn_batch_begin(); } ~TnBatchScope() { tn_batch_end(); } } tnbatch;
+  // coot_net_grads_overwrite(1): every weight-matrix gradient is WRITTEN by this pass (each comes from exactly one problem)
+  struct OverwriteScope { OverwriteScope(bool on) { set_tn_force_overwrite(on); } ~OverwriteScope() { set_tn_force_overwrite(false); } } ovw(g_grad_overwrite != 0);
   // the column-sum reductions of the fused kernels (bias / LayerNorm gradients) are recorded and run as one launch at the end
   struct DeferScope { DeferScope() { colsum_defer_begin(); } ~DeferScope() { colsum_defer_end(); } } deferscope;
   const bool flush_per_layer = c.num_layers > 1 || (c.use_context && c.ctx_num_layers > 1);
@@ -1131,7 +1196,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     RUN(tn_batch_flush(st));  // all weight gradients of the pass (the parameter-gradient kernel below reads Mbuf)
     RUN(colsum_defer_flush(st));  // ... and every deferred column sum (it reads cvec)
     RUN(launch_infc_param_grads(X.Mbuf, P + L.in_w, P + L.n_gain, P + L.n_bias, X.cvec, D, Din, G + L.in_w, G + L.n_gain, G + L.n_bias,
-                                G + L.in_b /* db_in += colsum(dh0) */, st));
+                                G + L.in_b /* db_in += colsum(dh0) */, st, g_grad_overwrite));
   } else {
     LnBwd l; l.dy = dz; l.lddy = D; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.gain = P + L.n_gain; l.R = T; l.D = D;
     l.dx32 = dfeats; l.lddx32 = Din; l.dgain = G + L.n_gain; l.dbias = G + L.n_bias;

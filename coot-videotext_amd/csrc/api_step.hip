@@ -132,6 +132,7 @@ thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller even
 // the dependent launches, the 36-workgroup TN launch overlapped with them anyway) and the aux launch slows the local backward's
 // first kernels.  Off.
 int g_defer_global_tn = 0;
+int g_grad_write = 1;  // coot_set_option("grad_write", 0/1): coot_train_step writes the weight-matrix gradients and zeroes only the rest
 int g_split_loss = 1;  // coot_set_option("split_loss", 0/1): local contrastive terms on the text stream ahead of the join (coot_train_step)
 int g_tn_aux_sides = 0;  // coot_set_option("tn_aux", bits): 1 = video side, 2 = text side.  Measured: 136.6k -> 133k (video) / 131k (both)
                           // clip-pairs/s — the local backward is area bound, two half batches of weight gradients are less efficient than one
@@ -519,8 +520,11 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   // forward ~75 us earlier (HIP-event timeline), so the six fills are free there.  (At the head of the text stream they delayed
   // its start by 70 us; behind the video forward they sat on the critical path.)  Everything that accumulates into these
   // buffers is ordered after hop 2: the losses on the video stream, the text side through hop 6 / hop 3.
-  for (int i = 0; i < 4; ++i)
-    RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), st), "memset grads"));
+  // (weight-matrix gradients are written, not accumulated, by this step's backward: only the vectors are zeroed — g_grad_write)
+  {
+    const coot_net_config* cfgs[4] = {&cfg->net[0], &cfg->net[1], &cfg->net[2], &cfg->net[3]};
+    RUN(coot_nets_zero_grads(4, cfgs, b->grads, g_grad_write, side_t));
+  }
   RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, st), "memset embedding grads"));
   RUN(check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), st), "memset losses"));
   g_stamps.mark("text: gradients zeroed", st);
@@ -560,17 +564,21 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   // what the text stream produced for the video side's backward (cycle-consistency gradients d_resh_v, the local contrastive
   // terms' gradients) was recorded in slot 7; side_backward waits where it is first read
   g_resh_wait_slot = (cc || split_loss) ? 7 : -1;
+  (void)coot_net_grads_overwrite(g_grad_write);
   const int rc_v = side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                                  W.local_v, W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv,
                                  W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, sv, &pk.v);
   g_resh_wait_slot = -1;
+  if (rc_v) (void)coot_net_grads_overwrite(0);
   RUN(rc_v);
   if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
   if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
   g_stamps.mark("video: updated", sv);
-  RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, W.local_t,
-                    W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt,
-                    W.scratch_t, W.sz_st, train, seed + 1000, st, &pk.t));
+  const int rc_t = side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, W.local_t,
+                                 W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt,
+                                 W.scratch_t, W.sz_st, train, seed + 1000, st, &pk.t);
+  (void)coot_net_grads_overwrite(0);
+  RUN(rc_t);
   // total = contrastive + cycle-consistency (not needed by the backward): rides on the text side's update launch
   if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st, losses));
   else {
@@ -668,6 +676,7 @@ int coot_step_set_cycle_indices(const int64_t* idx) { g_cc_idx_inject = idx; ret
 int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
 void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
 void coot_step_split_loss(int on) { g_split_loss = on; }
+void coot_step_grad_write(int on) { g_grad_write = on ? 1 : 0; }
 void coot_step_defer_global_tn(int on) { g_defer_global_tn = on; }
 
 // text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.

@@ -1417,11 +1417,21 @@ int tn_deferred_join(hipStream_t st) {
   return check_hip(hipStreamWaitEvent(st, g_tn_ev[1], 0), "streamWait");
 }
 
-int launch_gemm_tn(const GemmTN& g, hipStream_t stream) {
+// set_tn_force_overwrite(true): every problem launched / recorded by this thread WRITES its C (coot_net_bwd inside a step whose
+// caller did not zero the weight-matrix gradients: each is produced by exactly one problem)
+static thread_local bool g_tn_force_overwrite = false;
+void set_tn_force_overwrite(bool on) { g_tn_force_overwrite = on; }
+int launch_gemm_tn(const GemmTN& g_in, hipStream_t stream) {
+  GemmTN g = g_in;
+  if (g_tn_force_overwrite) g.overwrite = 1;
   COOT_REQUIRE(g.A && g.B && g.C, "gemm_tn: null operand");
   COOT_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.Mo % 8 == 0 && g.No % 8 == 0 && g.zA % 8 == 0 && g.zB % 8 == 0,
                "gemm_tn: lda/ldb/Mo/No must be multiples of 8 (Mo=%d No=%d lda=%ld ldb=%ld)", g.Mo, g.No, g.lda, g.ldb);
-  if (g.T <= 0 || g.Mo <= 0 || g.No <= 0) return 0;
+  if (g.Mo <= 0 || g.No <= 0) return 0;
+  if (g.T <= 0) {  // an empty sum: nothing to add; "written" means zeros
+    if (g.overwrite) for (int z = 0; z < g.groups; ++z) for (int m = 0; m < g.Mo; ++m) { int rc = launch_fill_f32(g.C + z * g.zC + (long)m * g.ldc, g.No, 0.f, stream); if (rc) return rc; }
+    return 0;
+  }
   COOT_REQUIRE(!g.a_colsum || g.groups == 1, "gemm_tn: a_colsum needs groups == 1");
   if (g_tn_collect && !g.ws) {  // inside tn_batch_begin() .. tn_batch_flush(): deferred, launched together
     if (g_tn_nitems == TN_MAX_ITEMS) { int rc = tn_batch_flush(stream); if (rc) return rc; }

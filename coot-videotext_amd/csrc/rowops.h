@@ -67,7 +67,7 @@ int launch_matvec_bias(const float* W, long ldw, int N, int K, const float* v, c
 //   dW[n,k] += M[n,k]*g[k] + c[n]*b0[k];  dg[k] += sum_n W[n,k]*M[n,k];  db0[k] += sum_n c[n]*W[n,k]
 //   db_in[n] += c[n] (optional: the input-FC bias gradient, c = colsum of dh0)
 int launch_infc_param_grads(const float* M, const float* W, const float* g0, const float* b0, const float* c,
-                            int N, int K, float* dW, float* dg0, float* db0, float* db_in, hipStream_t stream);
+                            int N, int K, float* dW, float* dg0, float* db0, float* db_in, hipStream_t stream, int overwrite = 0);
 
 // ---- contention-free column reductions ---------------------------------------------------------------
 // Producers write per-workgroup partial sums into a stream-ordered scratch region instead of issuing hundreds of

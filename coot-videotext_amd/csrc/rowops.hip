@@ -502,7 +502,8 @@ int launch_matvec_bias(const float* W, long ldw, int N, int K, const float* v, c
 // serial loop was a 20 us chain of load latencies); dg0/db0 partials via atomics
 constexpr int IPG_ROWS = 8;
 __global__ __launch_bounds__(256) void infc_param_grads_kernel(const float* M, const float* W, const float* g0, const float* b0,
-                                                               const float* c, int N, int K, float* dW, float* dg0, float* db0, float* db_in) {
+                                                               const float* c, int N, int K, float* dW, float* dg0, float* db0, float* db_in,
+                                                               int overwrite) {
   if (db_in && blockIdx.x == 0 && blockIdx.y == 0)  // db_in += colsum(dh0) (was its own axpy launch)
     for (int n = threadIdx.x; n < N; n += 256) db_in[n] += c[n];
   const int k = blockIdx.x * 256 + threadIdx.x;
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void infc_param_grads_kernel(const float* M, c
   for (int i = 0; i < IPG_ROWS; ++i) {
     const bool on = n0 + i < N;
     const long o = (long)(on ? n0 + i : n0) * K + k;
-    m[i] = on ? M[o] : 0.f; w[i] = on ? W[o] : 0.f; d[i] = on ? dW[o] : 0.f;
+    m[i] = on ? M[o] : 0.f; w[i] = on ? W[o] : 0.f; d[i] = (on && !overwrite) ? dW[o] : 0.f;
   }
   float sg = 0.f, sb = 0.f;
 #pragma unroll
@@ -531,9 +532,9 @@ __global__ __launch_bounds__(256) void infc_param_grads_kernel(const float* M, c
 }
 
 int launch_infc_param_grads(const float* M, const float* W, const float* g0, const float* b0, const float* c,
-                            int N, int K, float* dW, float* dg0, float* db0, float* db_in, hipStream_t stream) {
+                            int N, int K, float* dW, float* dg0, float* db0, float* db_in, hipStream_t stream, int overwrite) {
   hipLaunchKernelGGL(infc_param_grads_kernel, dim3((K + 255) / 256, (N + IPG_ROWS - 1) / IPG_ROWS), dim3(256), 0, stream, M, W, g0, b0, c, N, K,
-                     dW, dg0, db0, db_in);
+                     dW, dg0, db0, db_in, overwrite);
   COOT_CHECK_LAUNCH("infc_param_grads");
   return 0;
 }

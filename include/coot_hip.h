@@ -109,6 +109,16 @@ int coot_net_bwd(const coot_net_config* cfg, const float* params, const void* wp
                  const uint64_t* seed_dev, coot_stream_t stream,
                  const coot_packed_seqs* packed /* the forward's */);
 
+/* coot_net_bwd accumulates into `grads`.  coot_net_grads_overwrite(1) (thread-local, until switched off): the weight MATRIX
+ * gradients (input FC, QKV / output / feed-forward projections, pooling FCs — each the result of exactly one weight-gradient
+ * problem of the pass) are WRITTEN instead; biases and LayerNorm parameters are still accumulated.  coot_nets_zero_grads zeroes
+ * the gradient arenas of n networks: all of them (skip_matrices = 0), or only what is still accumulated in that mode
+ * (skip_matrices = 1: < 1 % of the arena, one launch).  coot_train_step uses the pair: no 30 MB fill, no read-back of the
+ * destination by the weight-gradient launches. */
+int coot_net_grads_overwrite(int on);
+int coot_nets_zero_grads(int n, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices,
+                         coot_stream_t stream);
+
 /* ---- clip -> video packing: the python loop of coot/model_retrieval.py:121-136 ---------------- */
 int coot_pack_fwd(const float* emb, const int64_t* counts, int B, int Cmax, int D, float* out /*[B,Cmax,D]*/,
                   uint8_t* mask /*[B,Cmax] 1 = pad*/, int64_t* lens /*[B]*/, coot_stream_t stream);
