@@ -851,12 +851,20 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges r) {
   for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) p[i] = v;
 }
 int coot_nets_zero_grads(int nnets, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices, coot_stream_t stream) {
+  return coot_nets_zero_grads_ex(nnets, cfgs, grads, skip_matrices, nullptr, nullptr, 0, stream);
+}
+// ... plus n_extra more fp32 ranges in the same launch (the step's embedding-gradient block and loss words)
+int coot_nets_zero_grads_ex(int nnets, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices, float* const* extra,
+                            const int64_t* extra_n, int n_extra, coot_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-  COOT_REQUIRE(nnets >= 1 && nnets <= 8 && cfgs && grads, "nets_zero_grads: bad arguments");
+  COOT_REQUIRE(nnets >= 1 && nnets <= 8 && cfgs && grads && (n_extra == 0 || (extra && extra_n)), "nets_zero_grads: bad arguments");
   ZeroRanges zr; zr.count = 0;
   auto flush = [&]() -> int {
     if (zr.count == 0) return 0;
-    hipLaunchKernelGGL(zero_ranges_kernel, dim3(zr.count, g_grad_poison ? 64 : 2), dim3(256), 0, st, zr);
+    int big = 0;
+    for (int i = 0; i < zr.count; ++i) if (zr.n[i] > big) big = zr.n[i];
+    const int gy = big > (1 << 16) ? 64 : 2;  // vectors: two workgroups per range; a large block (embedding gradients, poison): 64
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(zr.count, gy), dim3(256), 0, st, zr);
     COOT_CHECK_LAUNCH("zero_ranges");
     zr.count = 0;
     return 0;
@@ -889,6 +897,8 @@ int coot_nets_zero_grads(int nnets, const coot_net_config* const* cfgs, float* c
     }
     RUN(add(grads[k] + pos, L.total - pos, 0));
   }
+  for (int e = 0; e < n_extra; ++e)
+    for (int64_t o = 0; o < extra_n[e]; o += (1 << 30)) RUN(add(extra[e] + o, extra_n[e] - o < (1 << 30) ? extra_n[e] - o : (1 << 30), 0));
   return flush();
 }
 

@@ -523,10 +523,10 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   // (weight-matrix gradients are written, not accumulated, by this step's backward: only the vectors are zeroed — g_grad_write)
   {
     const coot_net_config* cfgs[4] = {&cfg->net[0], &cfg->net[1], &cfg->net[2], &cfg->net[3]};
-    RUN(coot_nets_zero_grads(4, cfgs, b->grads, g_grad_write, side_t));
+    float* extra[2] = {W.zero_begin, losses};  // + the embedding-gradient block and the loss words: ONE launch (was six fills)
+    const int64_t extra_n[2] = {(int64_t)(W.zero_bytes / sizeof(float)), 3};
+    RUN(coot_nets_zero_grads_ex(4, cfgs, b->grads, g_grad_write, extra, extra_n, 2, side_t));
   }
-  RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, st), "memset embedding grads"));
-  RUN(check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), st), "memset losses"));
   g_stamps.mark("text: gradients zeroed", st);
   RUN(g_hops.hop(2, st, sv));
   g_stamps.mark("video: text forward joined", sv);

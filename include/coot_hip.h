@@ -118,6 +118,9 @@ int coot_net_bwd(const coot_net_config* cfg, const float* params, const void* wp
 int coot_net_grads_overwrite(int on);
 int coot_nets_zero_grads(int n, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices,
                          coot_stream_t stream);
+/* the same launch also zeroes n_extra fp32 ranges (extra[i], extra_n[i] floats) */
+int coot_nets_zero_grads_ex(int n, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices,
+                            float* const* extra, const int64_t* extra_n, int n_extra, coot_stream_t stream);
 
 /* ---- clip -> video packing: the python loop of coot/model_retrieval.py:121-136 ---------------- */
 int coot_pack_fwd(const float* emb, const int64_t* counts, int B, int Cmax, int D, float* out /*[B,Cmax,D]*/,
