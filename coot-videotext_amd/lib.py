@@ -101,6 +101,8 @@ def load():
     lib.coot_debug_timestamps.argtypes = [vp]
     lib.coot_debug_step_stamps.argtypes = [C.c_char_p, i32]
     lib.coot_net_param_numel.restype = i64
+    lib.coot_net_grads_overwrite.argtypes = [i32]
+    lib.coot_nets_zero_grads_ex.argtypes = [i32, C.POINTER(cfgp), C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(i64), i32, vp]
     lib.coot_net_param_numel.argtypes = [cfgp]
     lib.coot_net_param_count.argtypes = [cfgp]
     lib.coot_net_param_info.argtypes = [cfgp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]

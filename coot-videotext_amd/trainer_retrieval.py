@@ -681,8 +681,16 @@ class RetrievalTrainer:
         main = torch.cuda.current_stream()
         sv, stt = main, st.streams[1]  # video side on the caller's stream (no hop), text on a side stream
         sp = main.cuda_stream
-        st.gall.zero_()
-        st.zbuf.zero_()
+        # the backward WRITES the weight-matrix gradients (coot_net_grads_overwrite): only the vectors that are still accumulated (biases,
+        # LayerNorm parameters), the cycle-consistency word and the embedding-gradient block are zeroed — one launch instead of two fills
+        if getattr(st, "zero_args", None) is None or st.zero_key != (st.gall.data_ptr(), st.zbuf.data_ptr()):
+            cfgs = (C.POINTER(_lib.NetConfig) * 4)(*[C.pointer(st.cfg.net[i]) for i in range(4)])
+            grads = (C.c_void_p * 4)(*[st.bufs.grads[i] for i in range(4)])
+            extra = (C.c_void_p * 2)(st.cc_word.data_ptr(), st.zbuf.data_ptr())
+            extra_n = (C.c_int64 * 2)(st.cc_word.numel() + 3, st.zbuf.numel())   # the arena's 4 tail words (cc word + padding)
+            st.zero_args, st.zero_key = (cfgs, grads, extra, extra_n), (st.gall.data_ptr(), st.zbuf.data_ptr())
+        za = st.zero_args
+        _lib.check(lib.coot_nets_zero_grads_ex(4, za[0], za[1], 1, za[2], za[3], 2, main.cuda_stream), "coot_nets_zero_grads_ex")
         ws, wsn = st.ws.data_ptr(), st.ws.numel()
         fresh = int(all(n.pack_is_fresh() for n in st.nets))
         _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *[t.data_ptr() for t in st.emb], ws, wsn,
@@ -719,10 +727,24 @@ class RetrievalTrainer:
         if use_cc:
             main.wait_stream(stt)  # the backward reads d_resh / the cycle-consistency word
         lib.coot_step_set_global_done_events(st.ev_glob[0].cuda_event, st.ev_glob[1].cuda_event)
+        lib.coot_net_grads_overwrite(1)
+        try:
+            self._dp_backward(lib, st, x, d, local_v, local_t, resh_v, resh_t, d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t, use_cc,
+                              ws, wsn, train, seed, main, sv, stt)
+        finally:
+            lib.coot_net_grads_overwrite(0)
+        self._dp_finish(lib, dp, st, main, sv, stt, do_optimizer)
+        return st.losses[0], st.losses[1], st.losses[2]
+
+    @staticmethod
+    def _dp_backward(lib, st, x, d, local_v, local_t, resh_v, resh_t, d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t, use_cc,
+                     ws, wsn, train, seed, main, sv, stt):
         _lib.check(lib.coot_step_backward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), local_v.data_ptr(), local_t.data_ptr(),
                                           resh_v.data_ptr(), resh_t.data_ptr(), d_local_v.data_ptr(), d_local_t.data_ptr(), d_glob_v.data_ptr(),
                                           d_glob_t.data_ptr(), d_resh_v.data_ptr() if use_cc else None, d_resh_t.data_ptr() if use_cc else None,
                                           ws, wsn, train, int(seed), main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_backward")
+
+    def _dp_finish(self, lib, dp, st, main, sv, stt, do_optimizer):
         # gradient all-reduce: the global networks' half on the communication stream as soon as both global backward passes are
         # done (events recorded inside coot_step_backward: it overlaps the local backward), the local half + the cycle-consistency
         # word (a per-rank partial sum of a global mean) behind the backward on the main stream
@@ -740,7 +762,6 @@ class RetrievalTrainer:
             for n in st.nets:
                 n.mark_packed()
         self.total_step += 1
-        return st.losses[0], st.losses[1], st.losses[2]
 
     # ---- epoch loop (coot/trainer_retrieval.py:235-310 and the nntrainer/trainer_base.py hooks it calls) --------------
     def check_is_val_epoch(self) -> bool:
