@@ -669,7 +669,7 @@ size_t coot_net_wpack_bytes(const coot_net_config* cfg) {
 // coot_set_option("pack_poison", 1) (tests) fills stale per-op layouts with NaN patterns so that a reader the hook misses
 // cannot go unnoticed.
 enum { PACK_ALL = 0, PACK_FUSED = 1, PACK_PEROP_REST = 2 };
-struct PackState { bool perop_fresh = true, perop_wanted = false; };
+struct PackState { bool perop_fresh = false, perop_wanted = false; };  // a pack this table has never seen: assume nothing (first per-op use completes it)
 static std::mutex g_pack_mu;
 static std::unordered_map<const void*, PackState> g_pack_state;
 static PackState pack_state_get(const void* wpack) { std::lock_guard<std::mutex> lk(g_pack_mu); auto it = g_pack_state.find(wpack); return it == g_pack_state.end() ? PackState() : it->second; }

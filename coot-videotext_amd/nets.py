@@ -128,13 +128,15 @@ class TransformerHip(nn.Module):
 
     def pack_is_fresh(self) -> bool:
         """True when the bf16 weight pack matches the fp32 parameters (nothing touched them since the last packing)."""
-        return self._wpack is not None and not self._dirty and self._param_version() == getattr(self, "_packed_version", None)
+        return (self._wpack is not None and not self._dirty and self._param_version() == getattr(self, "_packed_version", None)
+                and self._wpack.data_ptr() == getattr(self, "_packed_ptr", None))
 
     def mark_packed(self) -> None:
         """The library updated the parameters through the flat arena AND rebuilt the pack (coot_train_step with
         COOT_STEP_REPACK): raw-pointer writes do not bump the tensors' version counters, so record the pack as current."""
         self._dirty = False
         self._packed_version = self._param_version()
+        self._packed_ptr = self._wpack.data_ptr() if self._wpack is not None else None
 
     def bind_flat_grads(self) -> torch.Tensor:
         """Pre-assign every param.grad as a view of one flat fp32 gradient arena (zeroed), so the
@@ -165,11 +167,14 @@ class TransformerHip(nn.Module):
             self._wpack = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
             self._dirty = True
         ver = self._param_version()
-        if self._dirty or ver != getattr(self, "_packed_version", None):
+        # (a pack that was COPIED — copy.deepcopy of the module — lives at a new address: the library tracks which layouts of a pack are
+        # current by its address, so such a pack is rebuilt rather than trusted)
+        if self._dirty or ver != getattr(self, "_packed_version", None) or self._wpack.data_ptr() != getattr(self, "_packed_ptr", None):
             _lib.check(lib.coot_net_pack_weights(C.byref(self.c_cfg), _lib.ptr(self._flat), _lib.ptr(self._wpack),
                                                  _lib.stream_ptr()), "coot_net_pack_weights")
             self._dirty = False
             self._packed_version = ver
+            self._packed_ptr = self._wpack.data_ptr()
         return self._wpack
 
     # ---- forward ----------------------------------------------------------------------------------------

@@ -841,6 +841,21 @@ def test_lazy_perop_layouts(env):
         torch.cuda.synchronize()
         for e in (v1.vid_emb, v1.clip_emb, t1.par_emb, t1.sent_emb):
             assert torch.isfinite(e).all()
+        # a deep copy of a network carries a COPY of the pack (new address, the library knows nothing about it) taken while its
+        # per-op layouts were stale after two more fused-only repacks: the copy must not trust them
+        for _ in range(2):
+            mgr.set_all_models_train(); tr.train_step_native(big)
+        mgr.set_all_models_eval()
+        import copy
+        net = mgr.model_dict["net_video_local"]
+        twin = copy.deepcopy(net)
+        with torch.no_grad():
+            pa, _ = net(small.clip_feat, small.clip_feat_mask, small.clip_feat_len, None, want_tokens=False)
+            pb, _ = twin(small.clip_feat, small.clip_feat_mask, small.clip_feat_len, None, want_tokens=False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(pb).all() and torch.equal(pa, pb)
+        with torch.no_grad():
+            v1, t1 = mgr.encode_visual(small), mgr.encode_text(small)
         cva.lib.check(lib.coot_set_option(b"pack_lazy", 0))
         mgr.mark_weights_dirty()   # eager repack of every layout from the same parameters
         with torch.no_grad():
