@@ -131,6 +131,9 @@ int coot_gemm_tn_batch(const coot_tn_problem* p, int n, void* workspace, size_t 
   set_tn_default_workspace(old_ws, old_n);
   return rc;
 }
+int coot_debug_tn_xcd_map(int n, const int* gx, const int* gy, const int* groups, const int* splits, int* out_item, int* out_local, int max_blocks) {
+  return tn_debug_xcd_map(n, gx, gy, groups, splits, out_item, out_local, max_blocks);
+}
 int coot_ln_fwd(const float* x, int R, int D, const float* gain, const float* bias, void* y_bf16, float* y_f32, coot_stream_t stream) {
   LnFwd l; l.x = x; l.x_f32 = 1; l.ldx = D; l.R = R; l.D = D; l.gain = gain; l.bias = bias; l.y = (bf16_t*)y_bf16; l.ldy = D; l.y32 = y_f32; l.ldy32 = D;
   return launch_ln_fwd(l, (hipStream_t)stream);

@@ -62,7 +62,8 @@ struct GemmTN {
 };
 
 int launch_gemm_tn(const GemmTN& g, hipStream_t stream);
-void set_tn_force_overwrite(bool on);  // every problem of this thread writes C instead of adding to it (gemm.hip)
+void set_tn_force_overwrite(bool on);
+int tn_debug_xcd_map(int n, const int* gx, const int* gy, const int* groups, const int* splits, int* out_item, int* out_local, int max_blocks);  // every problem of this thread writes C instead of adding to it (gemm.hip)
 size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups);
 // Batching: between tn_batch_begin() and tn_batch_flush() every launch_gemm_tn() (without an explicit workspace) is only
 // recorded; flush launches all recorded problems as ONE kernel (+ one split reduction) on `stream`.  The operands must

@@ -1140,9 +1140,9 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_batch_kernel(TnBatch b, floa
 constexpr int TN_MAP_PIECES = 96;
 struct TnPiece { unsigned short first; unsigned char item, count; };
 struct TnMap { unsigned char xstart[12]; TnPiece pc[TN_MAP_PIECES]; };  // pieces [xstart[x], xstart[x + 1]) belong to XCD x
-__device__ __forceinline__ bool tn_map_lookup(const TnMap& m, int& item, int& local) {
-  const int x = blockIdx.x & 7;
-  int j = blockIdx.x >> 3;
+__host__ __device__ __forceinline__ bool tn_map_find(const TnMap& m, int block, int& item, int& local) {
+  const int x = block & 7;
+  int j = block >> 3;
   for (int k = m.xstart[x]; k < m.xstart[x + 1]; ++k) {
     const int c = m.pc[k].count;
     if (j < c) { item = m.pc[k].item; local = m.pc[k].first + j; return true; }
@@ -1150,6 +1150,7 @@ __device__ __forceinline__ bool tn_map_lookup(const TnMap& m, int& item, int& lo
   }
   return false;
 }
+__device__ __forceinline__ bool tn_map_lookup(const TnMap& m, int& item, int& local) { return tn_map_find(m, (int)blockIdx.x, item, local); }
 __global__ __launch_bounds__(512) void gemm_tn_wide_mapped_kernel(TnBatch b, TnMap m, float* ws_base) {
   int i, local;
   if (!tn_map_lookup(m, i, local)) return;
@@ -1287,6 +1288,23 @@ static int tn_xcd_map(const TnBatch& b, TnMap& map) {
   map.xstart[8] = (unsigned char)n;
   for (int k = n; k < TN_MAP_PIECES; ++k) map.pc[k] = TnPiece{0, 0, 0};
   return 8 * mx;
+}
+
+// host-side check of the table (tests): problems given as (gx, gy, groups, splits); out_item / out_local [max_blocks] receive what
+// each block of the launch would work on (-1: an empty slot); returns the grid size, 0 = the launch does not fit the table
+int tn_debug_xcd_map(int n, const int* gx, const int* gy, const int* groups, const int* splits, int* out_item, int* out_local, int max_blocks) {
+  if (n < 1 || n > TN_MAX_ITEMS) return -1;
+  TnBatch b; b.n = n;
+  for (int i = 0; i < n; ++i) { b.it[i].gx = gx[i]; b.it[i].gy = gy[i]; b.it[i].g.groups = groups[i]; b.it[i].splits = splits[i]; }
+  TnMap map = {};
+  const int grid = tn_xcd_map(b, map);
+  if (grid > max_blocks) return -2;
+  for (int blk = 0; blk < grid; ++blk) {
+    int item = -1, local = -1;
+    if (!tn_map_find(map, blk, item, local)) { item = -1; local = -1; }
+    out_item[blk] = item; out_local[blk] = local;
+  }
+  return grid;
 }
 
 int tn_batch_flush(hipStream_t stream) {

@@ -19,7 +19,7 @@ EXPORTS = [
     "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights", "coot_nets_pack_weights",
     "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_net_grads_overwrite", "coot_nets_zero_grads", "coot_nets_zero_grads_ex", "coot_pack_fwd",
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_cyclecons_fwd_bwd",
-    "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
+    "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_tn_xcd_map", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
     "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_contrastive_fwd_bwd_dp", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
 ]
@@ -131,6 +131,8 @@ def load():
     lib.coot_gemm_nt.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp, i64, i32, vp]
     lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, sz, vp]
     lib.coot_gemm_tn_batch.argtypes = [C.POINTER(TnProblem), i32, vp, sz, vp, vp]
+    ip = C.POINTER(i32)
+    lib.coot_debug_tn_xcd_map.argtypes = [i32, ip, ip, ip, ip, ip, ip, i32]
     lib.coot_debug_clock_monitor.argtypes = [vp, i32, i32, vp]
     lib.coot_gemm_tn_workspace_bytes.restype = sz
     lib.coot_gemm_tn_workspace_bytes.argtypes = [i32, i32, i32]

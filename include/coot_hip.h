@@ -323,6 +323,11 @@ typedef struct coot_tn_problem {
 } coot_tn_problem;
 int coot_gemm_tn_batch(const coot_tn_problem* problems, int n, void* workspace, size_t workspace_bytes,
                        uint64_t* stamps, coot_stream_t stream);
+/* host-only: the workgroup -> (problem, tile) table of such a launch (tiles of one problem, split and group on one XCD: block b
+ * runs on XCD b % 8) for n problems with gx x gy tiles, `groups` groups and `splits` splits each; out_item / out_local
+ * [max_blocks] (-1 = empty slot); returns the grid size (0: the launch does not fit the table, linear order is used) */
+int coot_debug_tn_xcd_map(int n, const int* gx, const int* gy, const int* groups, const int* splits, int* out_item,
+                          int* out_local, int max_blocks);
 /* one wave writes n pairs (100 MHz real-time counter, shader clock counter), one every interval_ticks real-time ticks:
  * run it on a side stream to see the shader clock the device delivers under the step's load (tools/clock_probe.py) */
 int coot_debug_clock_monitor(uint64_t* out, int n, int interval_ticks, coot_stream_t stream);

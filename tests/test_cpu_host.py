@@ -290,3 +290,36 @@ def test_embedding_export_hdf5_branch_with_a_recording_h5py(tmp_path, monkeypatc
     d = written[fn]
     assert set(d) == {"clip_num", "sent_num", "key"} | set(names) | {n + "_before_norm" for n in names}
     assert d["key"] == ["a", "b", "c"] and np.array_equal(d["vid_emb"], emb["vid_emb"])
+
+
+def test_weight_gradient_workgroup_table(cva):
+    """The host-built workgroup -> (problem, tile) table of the batched weight-gradient launch (gemm.hip: tn_xcd_map): every tile
+    of every problem exactly once; all tiles that read the same token rows (one problem, one split, one batch group; cut into
+    pieces of <= 16) on ONE XCD (block b runs on XCD b % 8); the XCDs evenly loaded."""
+    import ctypes as C
+    lib = cva.lib.load()
+    # the video-side local backward of the ActivityNet workload: input FC 16 x 1, pooling FC 2 (2 groups of 2 x 1), pooling FC 1
+    # (2 groups of 3 x 1), W2 / W1 / Wo 3 x 1, QKV 3 x 3; five splits each
+    gx, gy, groups, splits = [16, 2, 3, 3, 3, 3, 3], [1, 1, 1, 1, 1, 1, 3], [1, 2, 2, 1, 1, 1, 1], [5] * 7
+    n = len(gx)
+    arr = lambda v: (C.c_int * len(v))(*v)
+    out_item, out_local = (C.c_int * 512)(), (C.c_int * 512)()
+    grid = lib.coot_debug_tn_xcd_map(n, arr(gx), arr(gy), arr(groups), arr(splits), out_item, out_local, 512)
+    tiles = sum(gx[i] * gy[i] * groups[i] * splits[i] for i in range(n))
+    assert grid > 0 and grid % 8 == 0 and tiles <= grid <= 288, (grid, tiles)
+    seen, xcd_of, load = set(), {}, [0] * 8
+    for b in range(grid):
+        it, lo = out_item[b], out_local[b]
+        if it < 0:
+            continue
+        assert 0 <= it < n and 0 <= lo < gx[it] * gy[it] * groups[it] * splits[it]
+        assert (it, lo) not in seen
+        seen.add((it, lo))
+        load[b % 8] += 1
+        per = gx[it] * gy[it]
+        key = (it, lo // per, (lo % per) // 16)     # problem, (split, group), piece of 16 tiles
+        assert xcd_of.setdefault(key, b % 8) == b % 8, key
+    assert len(seen) == tiles
+    assert max(load) - min(load) <= 4 and max(load) <= 32, load
+    # a launch that does not fit the table falls back to the linear order (grid 0)
+    assert lib.coot_debug_tn_xcd_map(2, arr([64, 64]), arr([3, 3]), arr([1, 1]), arr([8, 8]), out_item, out_local, 512) == 0
