@@ -100,6 +100,9 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
   const int rb = blockIdx.x - H.blk0, i0 = rb * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = H.N, Np = H.Np, d = H.d, Np32 = (Np + 31) & ~31, gp = Np32 + CL_GP;
+  // data parallel: a rank scores ITS rows [w0, w0 + wn) against the gathered batch — strips without own rows are nobody's business
+  // here (their hinge sums belong to the loss partial of the rank that owns them, which the caller adds up across ranks)
+  if (i0 + 16 <= H.w0 || i0 >= H.w0 + H.wn) return;
   if (tid < 16) c1s[tid] = 0;
   __syncthreads();
   // ---- S strip: wave w takes column blocks w, w + CL_NW, ...; X (A operand, m = row i), Y (B operand, n = column j) ----
@@ -145,8 +148,9 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
       if (i < N && j < N && i != j) {
         const float cs = A.margin + acc[r] - di[r];
         const float ci = A.margin + acc[r] - dj;
-        if (cs > 0.f) { lsum += cs; g += 1.f; c1r[r] += 1; }
-        if (ci > 0.f) { lsum += ci; g += 1.f; }
+        const bool own = i >= H.w0 && i < H.w0 + H.wn;  // (a strip at the edge of the window holds rows of the neighbouring rank)
+        if (cs > 0.f) { if (own) lsum += cs; g += 1.f; c1r[r] += 1; }
+        if (ci > 0.f) { if (own) lsum += ci; g += 1.f; }
       }
       Gs[(l4 * 4 + r) * gp + j] = f2bf(g);
     }
@@ -171,7 +175,6 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
     for (int w = 0; w < CL_NW; ++w) t += lred[w];
     H.loss_part[rb] = t;
   }
-  if (i0 + 16 <= H.w0 || i0 >= H.w0 + H.wn) return;  // nobody reads the gradient strip of another rank's rows
   // ---- dX strip [16, d] = G strip [16, Np] . Y [Np, d]: A operand = G (LDS), B operand = Y^T rows (k contiguous) ----
   const int nf = d / 16;
   for (int f0 = wave; f0 < nf; f0 += CL_NW * 3) {
@@ -363,8 +366,9 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
       H.dX = hb.dX; H.c1 = hb.c1; H.loss_part = hb.lp; H.N = N; H.Np = Np; H.d = d; H.blk0 = nblk; H.primary = (q != 1);
       H.w0 = 0; H.wn = N;
       if (window) { H.w0 = window[p == 1 ? 2 : 0]; H.wn = window[p == 1 ? 3 : 1]; }
-      if (H.primary) {
-        fa.loss_part[fa.nl] = hb.lp; fa.loss_n[fa.nl] = Np / 16; fa.loss_coef[fa.nl] = (q == 0 ? w_pair[p] : w_self[p]) / ((float)N * (float)N);
+      if (H.primary) {  // the strips that hold rows of the window (all of them on one GPU): this call's share of the term
+        const int s0 = H.w0 / 16, s1 = (H.w0 + H.wn + 15) / 16;
+        fa.loss_part[fa.nl] = hb.lp + s0; fa.loss_n[fa.nl] = H.wn > 0 ? s1 - s0 : 0; fa.loss_coef[fa.nl] = (q == 0 ? w_pair[p] : w_self[p]) / ((float)N * (float)N);
         ++fa.nl;
       }
       hidx[p][q] = ha.nh++;

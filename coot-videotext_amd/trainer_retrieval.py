@@ -671,7 +671,8 @@ class RetrievalTrainer:
                     st.g_glob = st.gall[:off]
                     off_loc = off
             st.cc_word = st.gall[off:off + 1]
-            st.g_loc = st.gall[off_loc:off + 1]  # local networks + the cycle-consistency word
+            st.cl_word = st.gall[off + 1:off + 2]  # this rank's share of the contrastive loss (its rows against the gathered batch)
+            st.g_loc = st.gall[off_loc:off + 2]  # local networks + the two loss words: per-rank partial sums, reduced with the gradients
             st.comm = torch.cuda.Stream()
             st.ev_glob = (torch.cuda.Event(), torch.cuda.Event())
             for e in st.ev_glob:
@@ -721,7 +722,7 @@ class RetrievalTrainer:
         v0, c0 = sum(vid_counts[:dp.rank]), sum(clip_counts[:dp.rank])
         down = (C.c_void_p * 6)(d_glob_v.data_ptr(), d_glob_t.data_ptr(), d_local_v[B:].data_ptr(), d_local_t[B:].data_ptr(),
                                 d_local_v.data_ptr(), d_local_t.data_ptr())
-        _lib.check(lib.coot_contrastive_fwd_bwd_dp(C.byref(st.cfg.contr), gb, gn, 2 * D, D, C.byref(sets), C.byref(lds), st.losses[1:2].data_ptr(),
+        _lib.check(lib.coot_contrastive_fwd_bwd_dp(C.byref(st.cfg.contr), gb, gn, 2 * D, D, C.byref(sets), C.byref(lds), st.cl_word.data_ptr(),
                                                    C.byref(down), v0, B, c0, Nc, st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
                    "coot_contrastive_fwd_bwd_dp")
         if use_cc:
@@ -754,6 +755,7 @@ class RetrievalTrainer:
             dp.all_reduce_sum(st.g_glob)
         dp.all_reduce_sum(st.g_loc)
         main.wait_stream(st.comm)
+        st.losses[1:2].copy_(st.cl_word)
         st.losses[2:3].copy_(st.cc_word)
         torch.add(st.losses[1:2], st.losses[2:3], out=st.losses[0:1])
         if do_optimizer:

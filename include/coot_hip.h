@@ -159,7 +159,9 @@ int coot_contrastive_fwd_bwd_part(const coot_contrastive_config* cfg, int n_high
                                   coot_stream_t stream);
 
 /* The same loss for data-parallel training: sets[i] are the six GATHERED sets (row stride ld[i] floats: they may be column
- * slices of the all-gather buffers), the loss is the mean over the global batch; gradients are produced only for this
+ * slices of the all-gather buffers), the loss is the mean over the global batch — *loss receives THIS RANK'S SHARE of it (the
+ * hinge terms of its rows against every column: the caller adds the shares of all ranks, e.g. in the gradient all-reduce;
+ * scoring only its own strips keeps the per-rank cost linear in the global batch); gradients are produced only for this
  * rank's rows — [own_high0, own_high0 + own_high) of the per-video sets (0 vid_emb, 1 par_emb, 4 vid_ctx, 5 par_ctx),
  * [own_low0, own_low0 + own_low) of the per-clip sets (2 clip_emb, 3 sent_emb) — accumulated into the compact arrays
  * d_own[i] [own rows, d]. */
