@@ -8,7 +8,8 @@ namespace coot {
 
 // ---- row load/store helpers: chunk = 4 consecutive elements ---------------------------------
 __device__ __forceinline__ f32x4_t load4(const void* base, int is_f32, long off) {
-  if (is_f32) return *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(base) + off);
+  // fp32 sources are input features, read exactly once per step: streaming loads (no reuse to keep in the caches)
+  if (is_f32) return __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(base) + off));
   u32x2_t u = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(base) + off);
   return f32x4_t{bflo(u[0]), bfhi(u[0]), bflo(u[1]), bfhi(u[1])};
 }
@@ -93,6 +94,7 @@ int launch_ln_fwd(const LnFwd& p, hipStream_t stream) {
   // bytes it must move (input once, bf16 xhat once) in the flops field
   void* ts = (p.x_f32 && !p.gain && p.y) ? timing_begin(TIMING_INLN, (double)p.R * p.D * 6.0, 0, stream) : nullptr;
   if (p.D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, stream, p);
+  else if (p.D <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, stream, p);
   else if (p.D <= 2048) hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, dim3(256), 0, stream, p);
   timing_end(ts, stream);
