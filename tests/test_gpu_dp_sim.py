@@ -35,13 +35,14 @@ def _split(total, R, rs):
     return np.diff(np.concatenate([[0], cuts, [total]])).astype(int).tolist()
 
 
-@pytest.mark.parametrize("R", [2, 4, 8])
-def test_contrastive_dp_windows_reproduce_full_batch(env, R):
+@pytest.mark.parametrize("R,nh0", [(2, 24), (4, 24), (8, 24), (4, 330), (8, 600)])
+def test_contrastive_dp_windows_reproduce_full_batch(env, R, nh0):
+    """(nh0 = 330 / 600 videos: ~1 300 / ~2 400 clips — strips as long as those of 8 ranks of the ActivityNet workload.)"""
     torch, cva = env
     lib, L = cva.lib.load(), cva.lib
-    rs = np.random.RandomState(100 + R)
+    rs = np.random.RandomState(100 + R + nh0)
     D = 64
-    nh = 24 + R
+    nh = nh0 + R
     vid_counts = _split(nh, R, rs)
     clips_per_video = rs.randint(1, 6, size=nh)
     clip_counts = [int(clips_per_video[sum(vid_counts[:r]):sum(vid_counts[:r + 1])].sum()) for r in range(R)]
