@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Timeline of the LAST training step in a rocprofv3 rocpd (.db) kernel trace: one line per kernel dispatch with its
 queue (= HIP stream), start offset and duration, plus per-queue busy time and the idle gaps on the busiest queue.
-A step is delimited by cl_norm_kernel (the first launch of the contrastive loss: exactly one per step): the window shown
-runs from one loss section to the next, i.e. backward of step n followed by forward of step n + 1.
+A step is delimited by sample_idx_kernel (the draw of the cycle-consistency positions: exactly one per step; else every second
+cl_norm_kernel): the window shown runs from one loss section to the next, i.e. backward of step n followed by forward of step n + 1.
 Usage: python tools/rocpd_timeline.py x_results.db [out.txt]"""
 import re
 import sqlite3
@@ -22,13 +22,17 @@ def main(db, out=None):
     gcols = [c for c in ("grid_size_x", "workgroup_size_x") if c in cols]
     sel = f"s.{namecol}, d.start, d.end, " + (f"d.{qcol}" if qcol else "0") + "".join(f", d.{c}" for c in gcols)
     rows = list(cur.execute(f"select {sel} from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
-    ad = [i for i, r in enumerate(rows) if "cl_norm_kernel" in r[0]]
+    # exactly one per step: the draw of the cycle-consistency positions; without that loss, the contrastive normalisation (two
+    # launches per step since the loss runs in two parts: every second one)
+    ad = [i for i, r in enumerate(rows) if "sample_idx_kernel" in r[0]]
+    if len(ad) < 3:
+        ad = [i for i, r in enumerate(rows) if "cl_norm_kernel" in r[0]][::2]
     if len(ad) < 3:
         raise SystemExit("need at least 3 steps in the trace")
     lo, hi = ad[-2] + 1, ad[-1] + 1
     step = rows[lo:hi]
     t0 = rows[ad[-2]][2]
-    lines = [f"# step: {len(step)} dispatches, {(step[-1][2] - t0) / 1e3:.1f} us from one contrastive-loss launch to the next"]
+    lines = [f"# step: {len(step)} dispatches, {(step[-1][2] - t0) / 1e3:.1f} us from one loss section to the next"]
     busy = {}
     for r in step:
         name = re.sub(r"\(.*", "", r[0]).replace("coot::", "").replace("(anonymous namespace)::", "")
