@@ -850,6 +850,25 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges r) {
   const float v = r.poison[blockIdx.x] ? __uint_as_float(0x7FC00000u) : 0.f;
   for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) p[i] = v;
 }
+// the gradient matrices a backward pass WRITES in overwrite mode, as (offset, elements) in ascending order
+static void written_matrices(const coot_net_config& c, const NetLayout& L, std::vector<std::pair<int64_t, int64_t>>& mats) {
+  const int64_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
+  if (c.use_input_fc) mats.push_back({L.in_w, D * Din});
+  auto layer = [&](const LayerP& lp) { mats.push_back({lp.wqkv, 3 * D * D}); mats.push_back({lp.wo, D * D}); mats.push_back({lp.w1, F * D}); mats.push_back({lp.w2, D * F}); };
+  for (const LayerP& lp : L.layers) layer(lp);
+  for (const LayerP& lp : L.ctx) layer(lp);
+  if (c.pooler == 0) { mats.push_back({L.pw1, D * (int64_t)c.pool_hidden}); mats.push_back({L.pw2, (int64_t)c.pool_hidden * (D / c.pool_heads)}); }
+  std::sort(mats.begin(), mats.end());
+}
+// host-only (tests): the ranges coot_nets_zero_grads(skip_matrices = 1) leaves alone; returns their number (or -1)
+int coot_debug_written_matrices(const coot_net_config* cfg, int64_t* offsets, int64_t* sizes, int max_ranges) {
+  coot_net_config c; if (norm_cfg(cfg, &c)) return -1;
+  NetLayout L; build_layout(c, L);
+  std::vector<std::pair<int64_t, int64_t>> mats; written_matrices(c, L, mats);
+  if ((int)mats.size() > max_ranges) return -1;
+  for (size_t i = 0; i < mats.size(); ++i) { offsets[i] = mats[i].first; sizes[i] = mats[i].second; }
+  return (int)mats.size();
+}
 int coot_nets_zero_grads(int nnets, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices, coot_stream_t stream) {
   return coot_nets_zero_grads_ex(nnets, cfgs, grads, skip_matrices, nullptr, nullptr, 0, stream);
 }
@@ -880,14 +899,7 @@ int coot_nets_zero_grads_ex(int nnets, const coot_net_config* const* cfgs, float
     NetLayout L; build_layout(c, L);
     if (!skip_matrices) { RUN(check_hip(hipMemsetAsync(grads[k], 0, (size_t)L.total * sizeof(float), st), "memset grads")); continue; }
     // the matrices a backward pass writes (offset, elements), ascending offsets; everything between them is zeroed
-    const int64_t D = c.hidden_dim, F = c.ff_dim, Din = c.input_dim;
-    std::vector<std::pair<int64_t, int64_t>> mats;
-    if (c.use_input_fc) mats.push_back({L.in_w, D * Din});
-    auto layer = [&](const LayerP& lp) { mats.push_back({lp.wqkv, 3 * D * D}); mats.push_back({lp.wo, D * D}); mats.push_back({lp.w1, F * D}); mats.push_back({lp.w2, D * F}); };
-    for (const LayerP& lp : L.layers) layer(lp);
-    for (const LayerP& lp : L.ctx) layer(lp);
-    if (c.pooler == 0) { mats.push_back({L.pw1, D * (int64_t)c.pool_hidden}); mats.push_back({L.pw2, (int64_t)c.pool_hidden * (D / c.pool_heads)}); }
-    std::sort(mats.begin(), mats.end());
+    std::vector<std::pair<int64_t, int64_t>> mats; written_matrices(c, L, mats);
     int64_t pos = 0;
     for (const auto& m : mats) {
       COOT_REQUIRE(m.first >= pos && m.first + m.second <= L.total, "nets_zero_grads: parameter layout");

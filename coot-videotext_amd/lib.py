@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcoot_hip.so")
 EXPORTS = [
     "coot_last_error", "coot_version", "coot_set_option", "coot_debug_timestamps", "coot_debug_step_stamps", "coot_net_param_numel", "coot_net_param_count",
     "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights", "coot_nets_pack_weights",
-    "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_net_grads_overwrite", "coot_nets_zero_grads", "coot_nets_zero_grads_ex", "coot_pack_fwd",
+    "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_net_grads_overwrite", "coot_nets_zero_grads", "coot_nets_zero_grads_ex", "coot_debug_written_matrices", "coot_pack_fwd",
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_tn_xcd_map", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
@@ -102,6 +102,7 @@ def load():
     lib.coot_debug_step_stamps.argtypes = [C.c_char_p, i32]
     lib.coot_net_param_numel.restype = i64
     lib.coot_net_grads_overwrite.argtypes = [i32]
+    lib.coot_debug_written_matrices.argtypes = [cfgp, C.POINTER(i64), C.POINTER(i64), i32]
     lib.coot_nets_zero_grads_ex.argtypes = [i32, C.POINTER(cfgp), C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(i64), i32, vp]
     lib.coot_net_param_numel.argtypes = [cfgp]
     lib.coot_net_param_count.argtypes = [cfgp]

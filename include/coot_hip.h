@@ -118,6 +118,8 @@ int coot_net_bwd(const coot_net_config* cfg, const float* params, const void* wp
 int coot_net_grads_overwrite(int on);
 int coot_nets_zero_grads(int n, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices,
                          coot_stream_t stream);
+/* host-only (tests): the (offset, elements) ranges of the arena that mode leaves to the backward; returns their number */
+int coot_debug_written_matrices(const coot_net_config* cfg, int64_t* offsets, int64_t* sizes, int max_ranges);
 /* the same launch also zeroes n_extra fp32 ranges (extra[i], extra_n[i] floats) */
 int coot_nets_zero_grads_ex(int n, const coot_net_config* const* cfgs, float* const* grads, int skip_matrices,
                             float* const* extra, const int64_t* extra_n, int n_extra, coot_stream_t stream);

@@ -323,3 +323,37 @@ def test_weight_gradient_workgroup_table(cva):
     assert max(load) - min(load) <= 4 and max(load) <= 32, load
     # a launch that does not fit the table falls back to the linear order (grid 0)
     assert lib.coot_debug_tn_xcd_map(2, arr([64, 64]), arr([3, 3]), arr([1, 1]), arr([8, 8]), out_item, out_local, 512) == 0
+
+
+def test_written_gradient_matrices_cover_every_weight_matrix(cva):
+    """coot_train_step does not zero the weight-matrix gradients: its backward WRITES them (coot_net_grads_overwrite) and only the
+    rest of the arena is zeroed (coot_nets_zero_grads, skip_matrices = 1).  The list of skipped ranges must therefore be exactly
+    the parameters a weight-gradient GEMM produces — every *.weight and the pooling weights — and nothing else: a bias or
+    LayerNorm vector in it would keep last step's gradient, a matrix missing from it would be accumulated onto garbage."""
+    import ctypes as C
+    lib = cva.lib.load()
+    for oc in H.full_cfgs(2048, 1536, 384, 8, 384, 768) + H.full_cfgs(64, 48, 64, 4, 64, 128):
+        tc = cva.TransformerConfig(H.ocfg_to_dict(oc), oc.input_dim)
+        cfg = tc.to_c()
+        total, table = cva.lib.param_table(cfg)
+        offs, sizes = (C.c_int64 * 32)(), (C.c_int64 * 32)()
+        n = lib.coot_debug_written_matrices(C.byref(cfg), offs, sizes, 32)
+        assert n > 0
+        written = sorted((int(offs[i]), int(offs[i]) + int(sizes[i])) for i in range(n))
+        assert all(a[1] <= b[0] for a, b in zip(written, written[1:])) and written[-1][1] <= total
+        is_matrix = lambda name: name.endswith(".weight") or name.endswith("genpool_w1_head") or name.endswith("genpool_w2_head")
+        assert all(is_matrix(name) or name.endswith((".bias", ".gain", "genpool_b1_head", "genpool_b2_head")) for name, _, _ in table)
+        matrices = sorted((o, o + int(np.prod(s))) for name, o, s in table if is_matrix(name))
+        vectors = [(name, o, int(np.prod(s))) for name, o, s in table if not is_matrix(name)]
+        # the per-head pooling weights are one contiguous block per parameter: merge adjacent spans before comparing
+        def merge(spans):
+            out = []
+            for a, b in spans:
+                if out and out[-1][1] == a:
+                    out[-1] = (out[-1][0], b)
+                else:
+                    out.append((a, b))
+            return out
+        assert merge(written) == merge(matrices), (written, matrices)
+        for name, o, cnt in vectors:
+            assert not any(a < o + cnt and o < b for a, b in written), name
