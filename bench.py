@@ -123,13 +123,40 @@ def cpu_baseline(w, budget_s=25.0):
                       f"{len(times)} steps, {dt:.3f} s/step, host cpu_count {os.cpu_count()}"}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, LOCAL_RANK = device
+    index, rendezvous on 127.0.0.1 at a free port) — what `python -m torch.distributed.run --nproc-per-node N` would do.  Rank 0
+    inherits stdout and prints the JSON line.  Fails loudly when fewer than N devices are visible."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise RuntimeError(f"bench.py --gpus {n}: only {have} GPU(s) visible — refusing to report a {n}-GPU number from fewer devices")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    return next((rc for rc in rcs if rc), 0)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise RuntimeError(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if torch.cuda.device_count() <= local_rank:
+        raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     import coot_videotext_amd as cva
     from coot_videotext_amd import dist as cdist
@@ -144,6 +171,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world)
         dp = cdist.DataParallelContext()
+        assert dist.get_world_size() == world
     w = cva.synthetic.WORKLOADS[args.workload]
     cfg = cva.load_named_config(*cva.synthetic.WORKLOAD_CONFIG[args.workload])
     torch.manual_seed(0)  # identical initial weights on every rank
@@ -323,7 +351,7 @@ def main():
             fwd_flops, train_flops = algorithmic_flops_per_step(w, cfg)
         out = {
             "metric": "clip-pairs/sec (COOT retrieval " + ("eval forward" if args.eval else "train step") + ", whole job)",
-            "value": round(value, 1), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "clip-pairs/s", "n_gpus": (torch.distributed.get_world_size() if dp is not None else 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{cva.synthetic.WORKLOAD_LABEL[args.workload]}: {w['B']} videos x "

@@ -588,6 +588,23 @@ extern "C" {
 
 const char* coot_last_error(void) { return coot::g_err; }
 int coot_version(void) { return 1; }
+// host-only (tests): the keep-scales (0 or 1 / keep) the kernels draw for n consecutive elements idx0 .. of an element-wise
+// dropout site, resp. for the attention probabilities (row32, k = 0 .. n - 1) — evaluated by the SAME functions (common.h) and
+// the same quantisation of p (mkdrop) as on the device
+int coot_debug_dropout_scales(uint64_t seed, unsigned site, uint64_t idx0, int64_t n, float p, float* out_host) {
+  COOT_REQUIRE(out_host && n >= 0 && p > 0.f, "debug_dropout_scales: bad arguments");
+  const DropCfg d = mkdrop(1, p, seed, site);
+  const unsigned key = drop_key(seed, site);
+  for (int64_t i = 0; i < n; ++i) out_host[i] = drop_scale_key(key, idx0 + (uint64_t)i, d.thr, d.inv_keep);
+  return 0;
+}
+int coot_debug_attn_dropout_scales(uint64_t seed, unsigned site, unsigned row32, int Lk, float p, float* out_host) {
+  COOT_REQUIRE(out_host && Lk >= 0 && p > 0.f, "debug_attn_dropout_scales: bad arguments");
+  const DropCfg d = mkdrop(1, p, seed, site);
+  const unsigned key = drop_key(seed, site);
+  for (int k = 0; k < Lk; ++k) out_host[k] = attn_drop_scale(key, row32, k, (unsigned)(Lk + 1) >> 1, d.thr, d.inv_keep);
+  return 0;
+}
 int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)dev_u64; return 0; }
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
 extern "C" void coot_step_tn_aux(int sides);

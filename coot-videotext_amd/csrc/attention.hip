@@ -11,14 +11,9 @@
 
 namespace coot {
 
-// Dropout mask of attention probability (sequence n, head h, query q, key k): 32-bit index arithmetic (it is only a hash
-// input, wrap-around is harmless): the pair (k / 2) of row r = (n H + h) Lq + q shares one hash, k & 1 picks the half.
-// The 64-bit element index of the first version cost ~8 VALU instructions per probability (v_mad_u64_u32, 64-bit shifts
-// and compares) in kernels that are VALU bound.  All attention kernels (forward and the backward passes) use this map.
+// dropout mask of one attention probability: common.h (attn_drop_scale)
 __device__ __forceinline__ float attn_drop(unsigned key, unsigned row, int k, unsigned lk_half, unsigned thr, float inv_keep) {
-  const unsigned h = drop_hash((row * lk_half + ((unsigned)k >> 1)) ^ key);
-  const unsigned u = (k & 1) ? (h >> 16) : (h & 0xFFFFu);
-  return u >= (thr >> 16) ? inv_keep : 0.0f;
+  return attn_drop_scale(key, row, k, lk_half, thr, inv_keep);
 }
 
 constexpr int KC = 64;  // rows per staged chunk

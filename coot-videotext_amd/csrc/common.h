@@ -71,7 +71,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- counter-based RNG for dropout: one 32-bit draw per (seed, site, element) ---------------
 // (cannot match torch's Philox stream; training parity is statistical)
-__device__ __forceinline__ unsigned mix32(unsigned x) {
+__host__ __device__ __forceinline__ unsigned mix32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
@@ -90,21 +90,40 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long salt, 
 // Now: key = f(seed, site) once per call site; ONE hash (drop_hash below) per PAIR of consecutive elements (2 q, 2 q + 1), 16 bits each,
 // compared with the 16-bit threshold thr >> 16 (mkdrop() quantises p to 1/65536 and derives 1/(1-p) from the quantised
 // value, so E[mask * inv_keep] = 1 exactly).  Element index < 2^33.
-__device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned site) {
+__host__ __device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned site) {
   return mix32((unsigned)seed ^ mix32((unsigned)(seed >> 32) + site * 0x9E3779B9u));
 }
 // The per-pair mixer.  mix32's two v_mul_lo_u32 run at a quarter of the VALU rate on CDNA (16 cycles per wave each): 15
 // issue slots per pair, and the mask generation was ~20 % of the fused chains in training mode.  This one uses the
 // full-rate 24 x 24 -> 32 bit multiply-add (v_mad_u32_u24): 9 slots.  Rate / correlation statistics over 4M consecutive
 // pairs (neighbours, next row, the two halves, keys one bit apart) are as good as mix32's (tools: see DESIGN.md).
-__device__ __forceinline__ unsigned drop_hash(unsigned t) {
-  t = __umul24(t, 0xD2B54Bu) + (t >> 16);
+// (host + device: coot_debug_dropout_scales evaluates the same functions on the host, which is what pins the numpy restatement
+// in oracle/dropout_masks.py to THIS source in the CPU suite)
+__host__ __device__ __forceinline__ unsigned umul24_hd(unsigned a, unsigned b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned t) {
+  t = umul24_hd(t, 0xD2B54Bu) + (t >> 16);
   t ^= t >> 13;
-  t = __umul24(t, 0x95A53Du) + (t >> 11);
+  t = umul24_hd(t, 0x95A53Du) + (t >> 11);
   t ^= t >> 16;
   return t;
 }
-__device__ __forceinline__ unsigned drop_pair(unsigned key, unsigned long long idx) { return drop_hash((unsigned)(idx >> 1) ^ key); }
+// Dropout mask of attention probability (sequence n, head h, query q, key k): 32-bit index arithmetic (it is only a hash
+// input, wrap-around is harmless): the pair (k / 2) of row r = (n H + h) Lq + q shares one hash, k & 1 picks the half.
+// The 64-bit element index of the first version cost ~8 VALU instructions per probability (v_mad_u64_u32, 64-bit shifts
+// and compares) in kernels that are VALU bound.  All attention kernels (forward and the backward passes, attention.hip and the
+// in-tile attention of fused.hip) use this map.
+__host__ __device__ __forceinline__ float attn_drop_scale(unsigned key, unsigned row, int k, unsigned lk_half, unsigned thr, float inv_keep) {
+  const unsigned h = drop_hash((row * lk_half + ((unsigned)k >> 1)) ^ key);
+  const unsigned u = (k & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return u >= (thr >> 16) ? inv_keep : 0.0f;
+}
+__host__ __device__ __forceinline__ unsigned drop_pair(unsigned key, unsigned long long idx) { return drop_hash((unsigned)(idx >> 1) ^ key); }
 // keep-scale of one element: 0 if dropped else 1/(1-p)
 __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned site, unsigned long long idx,
                                             unsigned thr, float inv_keep) {
@@ -117,7 +136,7 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned si
 __device__ __forceinline__ unsigned drop_site_key(unsigned long long salt, const unsigned long long* base, unsigned site) {
   return drop_key(eff_seed(salt, base), site);
 }
-__device__ __forceinline__ float drop_scale_key(unsigned key, unsigned long long idx, unsigned thr, float inv_keep) {
+__host__ __device__ __forceinline__ float drop_scale_key(unsigned key, unsigned long long idx, unsigned thr, float inv_keep) {
   const unsigned h = drop_pair(key, idx);
   const unsigned u = (idx & 1ull) ? (h >> 16) : (h & 0xFFFFu);
   return u >= (thr >> 16) ? inv_keep : 0.0f;

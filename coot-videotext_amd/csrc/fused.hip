@@ -281,9 +281,7 @@ __device__ __forceinline__ DropK resolve_drop(const DropCfg& d, unsigned long lo
 // dropout mask of one attention probability: the map of attention.hip (attn_drop), so that this file's in-tile attention and
 // the attention kernels draw the same masks for the same (seed, site, sequence, head, query, key)
 __device__ __forceinline__ float attn_drop_f(unsigned key, unsigned row, int k, unsigned lk_half, unsigned thr, float inv_keep) {
-  const unsigned h = drop_hash((row * lk_half + ((unsigned)k >> 1)) ^ key);
-  const unsigned u = (k & 1) ? (h >> 16) : (h & 0xFFFFu);
-  return u >= (thr >> 16) ? inv_keep : 0.0f;
+  return attn_drop_scale(key, row, k, lk_half, thr, inv_keep);
 }
 
 template <bool DROP>

@@ -33,7 +33,7 @@ class _GatherRows(torch.autograd.Function):
         pad = x.new_zeros((maxc,) + tuple(x.shape[1:]))
         pad[: x.shape[0]] = x
         out = x.new_empty((world * maxc,) + tuple(x.shape[1:]))
-        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+        _all_gather_into(out, pad.contiguous(), group)
         ctx.counts, ctx.rank, ctx.maxc = counts, rank, maxc
         if all(c == maxc for c in counts):
             return out
@@ -50,6 +50,31 @@ def gather_rows(x: torch.Tensor, counts: List[int], rank: int, group=None) -> to
     return _GatherRows.apply(x, counts, rank, group)
 
 
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """Backend "gloo" with device tensors (several ranks sharing ONE GPU in tests/test_gpu_dp_procs.py — RCCL refuses two ranks on
+    one device): the collective runs on a host copy.  With "nccl" (RCCL) tensors never leave the device."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(out: torch.Tensor, x: torch.Tensor, group=None) -> None:
+    if _host_staged(x, group):
+        xc = x.cpu()  # (synchronises the current stream: the rows are final)
+        oc = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(oc, xc, group=group)
+        out.copy_(oc)
+    else:
+        dist.all_gather_into_tensor(out, x, group=group)
+
+
+def _all_reduce(t: torch.Tensor, op, group=None) -> None:
+    if _host_staged(t, group):
+        c = t.cpu()
+        dist.all_reduce(c, op=op, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 def gather_rows_nograd(x: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
     """The collective of gather_rows without autograd (native step: gradients are sliced by the caller)."""
     world, maxc = len(counts), max(counts)
@@ -58,7 +83,7 @@ def gather_rows_nograd(x: torch.Tensor, counts: List[int], group=None) -> torch.
         pad[: x.shape[0]] = x
         x = pad
     out = x.new_empty((world * maxc,) + tuple(x.shape[1:]))
-    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    _all_gather_into(out, x.contiguous(), group)
     if all(c == maxc for c in counts):
         return out
     idx = torch.cat([torch.arange(r * maxc, r * maxc + c, device=x.device) for r, c in enumerate(counts)])
@@ -75,19 +100,19 @@ class DataParallelContext:
 
     def global_max(self, value: int, device) -> int:
         t = torch.tensor([int(value)], dtype=torch.int32, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        _all_reduce(t, dist.ReduceOp.MAX, self.group)
         return int(t.item())
 
     def global_max_pair(self, a: int, b: int, device) -> Tuple[int, int]:
         t = torch.tensor([int(a), int(b)], dtype=torch.int32, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        _all_reduce(t, dist.ReduceOp.MAX, self.group)
         v = t.tolist()
         return int(v[0]), int(v[1])
 
     def global_counts(self, n: int, device) -> List[int]:
         t = torch.tensor([int(n)], dtype=torch.int64, device=device)
         out = torch.empty(self.world, dtype=torch.int64, device=device)
-        dist.all_gather_into_tensor(out, t, group=self.group)
+        _all_gather_into(out, t, self.group)
         return [int(v) for v in out.tolist()]
 
     def gather_rows_nograd(self, x: torch.Tensor, counts: List[int]) -> torch.Tensor:
@@ -96,7 +121,7 @@ class DataParallelContext:
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
         """In-place sum over ranks on the current stream."""
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        _all_reduce(t, dist.ReduceOp.SUM, self.group)
 
     def gather_embeddings(self, vis, txt, clip_counts: Optional[List[int]] = None, vid_counts: Optional[List[int]] = None):
         """Returns the six full-batch embedding sets (vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx).
@@ -124,10 +149,10 @@ class DataParallelContext:
         (ordered after the current stream) and the current stream waits for them afterwards."""
         if side_stream is None:
             for g in flat_grads:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                _all_reduce(g, dist.ReduceOp.SUM, self.group)
             return
         side_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side_stream):
             for g in flat_grads:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                _all_reduce(g, dist.ReduceOp.SUM, self.group)
         torch.cuda.current_stream().wait_stream(side_stream)

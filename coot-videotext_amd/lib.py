@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcoot_hip.so")
 
 EXPORTS = [
-    "coot_last_error", "coot_version", "coot_set_option", "coot_debug_timestamps", "coot_debug_step_stamps", "coot_net_param_numel", "coot_net_param_count",
+    "coot_last_error", "coot_version", "coot_set_option", "coot_get_option", "coot_debug_timestamps", "coot_debug_step_stamps", "coot_debug_dropout_scales", "coot_debug_attn_dropout_scales", "coot_net_param_numel", "coot_net_param_count",
     "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights", "coot_nets_pack_weights",
     "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_net_grads_overwrite", "coot_nets_zero_grads", "coot_nets_zero_grads_ex", "coot_debug_written_matrices", "coot_pack_fwd",
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_cyclecons_fwd_bwd",

@@ -196,12 +196,26 @@ class RetrievalTrainer:
             # its step count and rectification scalars are host values: a replay would freeze them (the native step keeps them in a
             # device block instead: train_step_native(use_graph=True))
             raise NotImplementedError("train_step(use_graph=True) supports torch.optim.Adam only; use train_step_native for RAdam")
-        lr = float(self.optimizer.param_groups[0]["lr"])
-        key = self._graph_key(batch, lr)
-        graphs = self.__dict__.setdefault("_graphs", {})
+        key = self._graph_key(batch)
+        graphs = self.__dict__.get("_graphs")
+        if graphs is None:
+            import collections
+            graphs = self._graphs = collections.OrderedDict()
         g = graphs.get(key)
-        if g is None:  # one graph per (batch shapes, learning rate): ragged batches and LR schedule steps re-capture, they never re-use a stale graph
+        if g is None:
+            # one graph per batch SHAPE (tensor shapes, host-side maxima and — packed batches — the valid-token totals the
+            # captured launches carry as host scalars).  The learning rate is NOT part of the key: the captured Adam reads it
+            # from a device tensor per parameter group that is rewritten before a replay when the scheduler moved it.
             g = graphs[key] = self._capture(batch, vid_counts, clip_counts)
+            while len(graphs) > self.max_graphs:  # least recently used first; dropping the CUDAGraph frees its private pool
+                graphs.popitem(last=False)
+        else:
+            graphs.move_to_end(key)
+        for group, lr_dev, mirror in zip(self.optimizer.param_groups, g["lr_dev"], g["lr_host"]):
+            lr = float(group["lr"])  # a python float: the reference's schedulers write floats (nntrainer/lr_scheduler.py)
+            if lr != mirror[0]:
+                lr_dev.fill_(lr)
+                mirror[0] = lr
         if batch is not g["batch"]:
             for name, value in batch.__dict__.items():
                 if torch.is_tensor(value):
@@ -210,10 +224,12 @@ class RetrievalTrainer:
         self.total_step += 1
         return g["out"]
 
+    max_graphs = 8  # captured whole-step graphs kept alive (ragged batches: one per shape)
+
     @staticmethod
-    def _graph_key(batch, lr: float):
+    def _graph_key(batch):
         return (tuple((k, tuple(v.shape)) for k, v in sorted(batch.__dict__.items()) if torch.is_tensor(v)), batch.max_clip_num,
-                batch.max_sent_num, lr)
+                batch.max_sent_num, getattr(batch, "tok_vis", None), getattr(batch, "tok_txt", None))
 
     def _capture(self, batch, vid_counts, clip_counts, warmup: int = 3):
         """Whole-step capture.  The eager warm-up (allocator, RCCL, lazy optimizer state) runs on a SNAPSHOT: parameters,
@@ -258,12 +274,22 @@ class RetrievalTrainer:
             self.model_mgr.mark_weights_dirty()
 
         restore()
+        # the learning rate as a device tensor per parameter group for the capture (torch.optim.Adam(capturable=True) accepts
+        # tensors): replays read whatever train_step wrote there; the groups get their floats back for the schedulers
+        host_lrs = [float(gr["lr"]) for gr in self.optimizer.param_groups]
+        lr_dev = [torch.full((), lr, dtype=torch.float32, device=batch.vid_feat.device) for lr in host_lrs]
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self._step_impl(batch, vid_counts, clip_counts)
+        try:
+            for gr, t in zip(self.optimizer.param_groups, lr_dev):
+                gr["lr"] = t
+            with torch.cuda.graph(graph):
+                out = self._step_impl(batch, vid_counts, clip_counts)
+        finally:
+            for gr, lr in zip(self.optimizer.param_groups, host_lrs):
+                gr["lr"] = lr
         # the capture itself executed nothing, but host-side bookkeeping of _step_impl ran: put the counters back
         self.total_step = snap["total_step"]
-        return dict(graph=graph, out=out, batch=batch)
+        return dict(graph=graph, out=out, batch=batch, lr_dev=lr_dev, lr_host=[[lr] for lr in host_lrs])
 
     def _step_prepare_seed(self, batch, nets) -> None:
         self._seed_dev = torch.zeros(1, dtype=torch.int64, device=batch.vid_feat.device)
@@ -457,6 +483,10 @@ class RetrievalTrainer:
         buffers.  Same masks, same update as the eager native step (tests/test_gpu_path.py).  Falls back to the eager call
         for the first step of a shape (lazy state is created outside a capture)."""
         lib = _lib.load()
+        if getattr(batch, "cu_vis", None) is not None:
+            # packed (cu_seqlens) batches carry their token totals as host scalars of the launches and change them every batch:
+            # the captured step would replay the first batch's totals.  They run eagerly (the caller falls back on None).
+            return None
         st, x = self._native_setup(batch)
         lr = float(self.optimizer.param_groups[0]["lr"]) if self.optimizer is not None else float(st.cfg.lr)
         ptrs = tuple(int(st.bufs.params[i]) for i in range(4)) + tuple(int(st.bufs.wpack[i]) for i in range(4))
@@ -579,6 +609,8 @@ class RetrievalTrainer:
         lib = _lib.load()
         if getattr(self, "dp", None) is not None:
             return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts, cc_indices)
+        if use_graph and cc_indices is not None:
+            raise ValueError("train_step_native: injected cycle-consistency positions are not available under graph replay")
         if use_graph and do_optimizer and seed is None and self.model_mgr.is_train:
             out = self._train_step_native_graph(batch, phases=(use_graph == "phases"))
             if out is not None:

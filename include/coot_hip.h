@@ -18,6 +18,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared between this push and the pop at the end of
+ * the header leave libcoot_hip.so (tests/test_cpu_host.py checks the dynamic symbol table against this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef void* coot_stream_t; /* hipStream_t */
 
@@ -42,7 +47,11 @@ typedef struct coot_net_config {
 
 const char* coot_last_error(void);
 int coot_version(void);
-/* option switches for A/B measurements: "tn_mode" 0 = ds_read_b64_tr_b16 fragments, 1 = transposing LDS stores */
+/* Option switches for A/B measurements and tests ("fused", "packed", "tn_dma", "grad_poison", ...: the names coot_set_option
+ * accepts are listed in csrc/api.hip).  They are PROCESS-GLOBAL ints read at launch time without synchronisation: set them
+ * while no other host thread is inside the library (one host thread per process and device is the supported model, SURVEY
+ * 8b); the error string, coot_net_grads_overwrite, the step's device-state pointer and the injected cycle indices are
+ * thread-local. */
 int coot_set_option(const char* name, int value);
 /* current value of "tn_dma" / "xcd_order" / "tn_mode" (tests restore what they switch) */
 int coot_get_option(const char* name, int* value);
@@ -51,6 +60,14 @@ int coot_debug_timestamps(void* dev_u64);
 /* coot_set_option("step_stamps", 1): coot_train_step records HIP events at its phase boundaries; this call synchronises
  * the device and writes one line per boundary (microseconds since the start of the last step) into buf.  Profiling aid. */
 int coot_debug_step_stamps(char* buf, int buf_bytes);
+/* host-only (tests): the keep-scales (0 or 1 / keep-probability) the kernels draw for the n consecutive elements idx0, idx0 + 1, ...
+ * of an element-wise dropout site (idx = token row * row width + column), resp. for the Lk attention probabilities of mask row
+ * row32 = (sequence * heads + head) * Lq + query — evaluated on the host by the SAME functions (csrc/common.h) and the same
+ * quantisation of p the device code uses.  out_host: HOST memory.  Pins oracle/dropout_masks.py (the masks injected into the
+ * reference for train-mode parity; nn.Dropout sites of nntrainer/models/transformer_legacy.py:418,435,487,553,592-598 and
+ * nntrainer/models/poolers.py:139-143) to this library. */
+int coot_debug_dropout_scales(uint64_t seed, unsigned site, uint64_t idx0, int64_t n, float p, float* out_host);
+int coot_debug_attn_dropout_scales(uint64_t seed, unsigned site, unsigned row32, int Lk, float p, float* out_host);
 
 /* ---- parameter layout (flat fp32 arena per network; gradients use the same layout) -----------
  * Names and shapes are the reference state-dict names, e.g.
@@ -347,6 +364,9 @@ int coot_timing_collect(int only_big_k, double* ms, double* flops, int* launches
 /* probe of ds_read_b64_tr_b16: out[64*4] = what each lane reads from a 16x64 bf16 LDS tile holding its own index */
 int coot_probe_tr16(uint16_t* out, coot_stream_t stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,11 @@ from oracle import coot_oracle as O  # noqa: E402
 th.set_num_threads(4)
 
 
-def ref_config(dv, dt, hidden, heads, ff, pool_hidden, layers=1):
+def ref_config(dv, dt, hidden, heads, ff, pool_hidden, layers=1, dropout=None):
+    """The reference's ActivityNet config with other widths.  layers: encoder layers of the LOCAL networks (the global networks
+    copy the local section through same_as, anet_coot.yaml:111-113, so their own self-attention section is spelled out to keep
+    them at one layer: 'YouCook2-100m d=512, 2-layer local/1-layer global' in BASELINE.json).  dropout: every dropout
+    probability of the four networks (self-attention, context and pooler sections)."""
     d = utils_yaml.load_yaml_config_file(os.path.join(REF, "config/retrieval/paper2020/anet_coot.yaml"))
     d["use_cuda"] = False
     d["fp16_train"] = False
@@ -65,13 +69,21 @@ def ref_config(dv, dt, hidden, heads, ff, pool_hidden, layers=1):
     glob = d["net_video_global"]
     glob["output_dim"] = 2 * hidden
     glob["crossatn_config"].update(hidden_dim=hidden, num_heads=heads, pointwise_ff_dim=ff)
+    if layers != 1:
+        glob["selfatn_config"] = dict(loc["selfatn_config"], num_layers=1)
+    if dropout is not None:
+        loc["selfatn_config"]["dropout"] = dropout
+        loc["pooler_config"]["dropout"] = dropout
+        glob["crossatn_config"]["dropout"] = dropout
+        if "selfatn_config" in glob:
+            glob["selfatn_config"]["dropout"] = dropout
     return RetrievalConfig(d)
 
 
 def oracle_cfgs(dv, dt, hidden, heads, ff, pool_hidden, layers=1):
-    kw = dict(hidden_dim=hidden, num_heads=heads, ff_dim=ff, num_layers=layers, pool_hidden=pool_hidden)
-    loc_v = O.NetConfig(input_dim=dv, **kw)
-    loc_t = O.NetConfig(input_dim=dt, **kw)
+    kw = dict(hidden_dim=hidden, num_heads=heads, ff_dim=ff, pool_hidden=pool_hidden)
+    loc_v = O.NetConfig(input_dim=dv, num_layers=layers, **kw)
+    loc_t = O.NetConfig(input_dim=dt, num_layers=layers, **kw)
     glob = O.NetConfig(input_dim=hidden, use_input_fc=False, use_context=True, pooler="avg_special", **kw)
     return loc_v, glob, loc_t, copy.deepcopy(glob)
 
@@ -127,6 +139,96 @@ def subsample(a, step=97):
     return np.asarray(a, dtype=np.float32).reshape(-1)[::step].copy()
 
 
+# ---- train-mode parity: the library's dropout masks injected into the unmodified reference ---------------------------------
+from oracle import dropout_masks as DM  # noqa: E402
+import re  # noqa: E402
+
+_SITE_PATTERNS = [  # module path inside a TransformerLegacy -> (kind, site offset); group(1) = layer index where there is one
+    (re.compile(r"^tf\.encoder_layers\.(\d+)\.self_attention_layer\.sublayer\.dropout$"), "attn", DM.SITE_ATTN, 0),
+    (re.compile(r"^tf\.encoder_layers\.(\d+)\.dropout$"), "rows", DM.SITE_POSTLN, 0),
+    (re.compile(r"^tf\.encoder_layers\.(\d+)\.pointwise_feedforward_layer\.sublayer\.feed_forward\.1$"), "rows", DM.SITE_FF1, 0),
+    (re.compile(r"^tf\.encoder_layers\.(\d+)\.pointwise_feedforward_layer\.sublayer\.feed_forward\.4$"), "rows", DM.SITE_FF2, 0),
+    (re.compile(r"^tf_context\.encoder_layers\.(\d+)\.self_attention_layer\.sublayer\.dropout$"), "cattn", DM.SITE_ATTN, 8),
+    (re.compile(r"^tf_context\.encoder_layers\.(\d+)\.dropout$"), "crows", DM.SITE_POSTLN, 8),
+    (re.compile(r"^tf_context\.encoder_layers\.(\d+)\.pointwise_feedforward_layer\.sublayer\.feed_forward\.1$"), "crows", DM.SITE_FF1, 8),
+    (re.compile(r"^tf_context\.encoder_layers\.(\d+)\.pointwise_feedforward_layer\.sublayer\.feed_forward\.4$"), "crows", DM.SITE_FF2, 8),
+    (re.compile(r"^pooler\.pools\.0\.dropout1()$"), "pool", DM.SITE_POOL1, 15),
+    (re.compile(r"^pooler\.pools\.0\.dropout2()$"), "pool", DM.SITE_POOL2, 15),
+    (re.compile(r"^pooler\.pools\.0\.dropout3()$"), "pool3", DM.SITE_POOL3, 15),
+]
+
+
+class _InjectedDropout(th.nn.Module):
+    """Stands where an nn.Dropout stood: multiplies with the keep-scales the HIP library draws for this site and this call."""
+
+    def __init__(self, state, kind, site, p):
+        super().__init__()
+        self.state, self.kind, self.site, self.p = state, kind, site, p
+
+    def forward(self, x):
+        lay, seed, shp = self.state["layout"], self.state["seed"], tuple(x.shape)
+        if self.kind == "rows":       # [N, L, ld]
+            assert shp[:2] == (lay.N, lay.L), (shp, lay.N, lay.L)
+            m = DM.mask_rows(seed, self.site, lay, shp[2], self.p)
+        elif self.kind == "crows":    # context layer: one query row per sequence [N, 1, ld]
+            assert shp[:2] == (lay.N, 1)
+            m = DM.mask_rows(seed, self.site, DM.CallLayout(0, lay.N, 1, 0), shp[2], self.p)
+        elif self.kind == "attn":     # [N, H, L, L]
+            assert shp[0] == lay.N and shp[2] == shp[3] == lay.L
+            m = DM.mask_attention(seed, self.site, lay, shp[1], lay.L, lay.L, self.p)
+        elif self.kind == "cattn":    # [N, H, 1, L]
+            assert shp[0] == lay.N and shp[2] == 1 and shp[3] == lay.L
+            m = DM.mask_attention(seed, self.site, DM.CallLayout(0, lay.N, lay.L, 0), shp[1], 1, lay.L, self.p)
+        else:                         # GenPool: [N, heads, L, d]
+            assert shp[0] == lay.N and shp[2] == lay.L
+            m = DM.mask_heads(seed, self.site, lay, shp[1], shp[3], self.p, pool3=(self.kind == "pool3"))
+        self.state["used"].add(self.site)
+        return x * th.from_numpy(np.ascontiguousarray(m)).reshape(shp)
+
+
+def inject_dropout(net, seed, p, packed=False):
+    """Replaces every active nn.Dropout of one reference TransformerLegacy (nntrainer/models/transformer_legacy.py:418,435,487,
+    553,592-598; nntrainer/models/poolers.py:139-143) by _InjectedDropout; a forward pre-hook keeps track of which SEGMENT of
+    the library's network call the current module call is (the reference calls a local network twice per step, on the videos
+    and on the clips: coot/model_retrieval.py:104,120; the library runs both through one call).  Returns the shared state."""
+    state = dict(seed=seed, calls=0, row_next=0, tok_next=0, layout=None, used=set(), packed=packed)
+    todo = []
+    for name, mod in net.named_modules():
+        if not isinstance(mod, th.nn.Dropout):
+            continue
+        for pat, kind, off, base in _SITE_PATTERNS:
+            mt = pat.match(name)
+            if mt:
+                layer = int(mt.group(1)) if mt.group(1) else 0
+                todo.append((name, _InjectedDropout(state, kind, 16 * (base + layer) + off, p)))
+                break
+        else:
+            assert mod.p == 0, f"dropout module {name} (p = {mod.p}) has no site in the library"
+    for name, new in todo:
+        parent = net
+        parts = name.split(".")
+        for a in parts[:-1]:
+            parent = getattr(parent, a)
+        setattr(parent, parts[-1], new)
+
+    def pre_hook(_mod, args):
+        feats, _mask, lengths = args[0], args[1], args[2]
+        N, L = int(feats.shape[0]), int(feats.shape[1])
+        lens = lengths.numpy().astype(np.int64)
+        seg = state["calls"]
+        assert seg < 2
+        cu = None
+        if state["packed"]:
+            cu = state["tok_next"] + np.concatenate([[0], np.cumsum(lens)[:-1]])
+        state["layout"] = DM.CallLayout(seg, N, L, state["row_next"], lens, cu)
+        state["calls"] += 1
+        state["row_next"] += N * L
+        state["tok_next"] += int(lens.sum())
+
+    net.register_forward_pre_hook(pre_hook)
+    return state
+
+
 def gen_single_net(name, cfg_o: O.NetConfig, N, L, seed, with_ctx):
     """One TransformerLegacy: forward (pooled, per-token) + grads of sum(pooled * R)."""
     tc = dict(name="transformer", output_dim=cfg_o.hidden_dim * (2 if with_ctx else 1), dropout_input=0,
@@ -177,19 +279,29 @@ def gen_single_net(name, cfg_o: O.NetConfig, N, L, seed, with_ctx):
 
 
 def gen_full(name, dims, B, counts, Ls, seed, full_grads, ragged=True, cc_weight=None, sub_step=97, scale=0.05,
-             store_reshape=True):
-    """encode_visual + encode_text + total contrastive + cycle-consistency, fwd and bwd."""
+             store_reshape=True, layers=1, train=None):
+    """encode_visual + encode_text + total contrastive + cycle-consistency, fwd and bwd.
+
+    train = dict(p=..., step_seed=..., packed=bool): TRAIN mode with every dropout site active at probability p, the masks being
+    the ones the HIP library draws for coot_train_step(seed = step_seed) (oracle/dropout_masks.py; packed: the masks of the
+    packed token-row layout).  Otherwise eval mode (dropout off)."""
     dv, dt, hidden, heads, ff, pool_hidden = dims
     Lv, Lc, Lp, Lsent = Ls
-    cfg = ref_config(*dims)
+    cfg = ref_config(*dims, layers=layers, dropout=(train["p"] if train else None))
     if cc_weight is not None:
         cfg.train.loss_cycle_cons = cc_weight
-    ocfgs = oracle_cfgs(*dims)
+    ocfgs = oracle_cfgs(*dims, layers=layers)
     th.manual_seed(0)
     mgr = model_retrieval.RetrievalModelManager(cfg)
     for i, k in enumerate(NET_KEYS):
         load_params(mgr.model_dict[k], O.make_params(ocfgs[i], seed + 10 * i, scale=scale))
     mgr.set_all_models_eval()
+    drop_states = []
+    if train:
+        mgr.set_all_models_train()
+        for k, net_seed in zip(NET_KEYS, DM.step_net_seeds(int(train["step_seed"]))):
+            drop_states.append(inject_dropout(mgr.model_dict[k], net_seed, float(train["p"]),
+                                              packed=bool(train.get("packed")) and k.endswith("local")))
     b = O.make_batch(seed + 100, B, counts, Lv, Lc, Lp, Lsent, dv, dt, ragged=ragged, corr=0.5)
     batch = to_batch(b)
     vis = mgr.encode_visual(batch)
@@ -227,6 +339,14 @@ def gen_full(name, dims, B, counts, Ls, seed, full_grads, ragged=True, cc_weight
     out["sub_step"] = np.array(sub_step)
     out["param_scale"] = np.array(scale)
     out["counts"] = np.asarray(counts)
+    out["layers"] = np.array(layers)
+    if train:
+        for k, stt in zip(NET_KEYS, drop_states):  # every site of the library's table was hit (7 per local, 8 per global network)
+            want = 7 * layers - 3 * (layers - 1) if k.endswith("local") else 8
+            assert len(stt["used"]) == want, (k, sorted(stt["used"]))
+        out["train_p"] = np.array(float(train["p"]))
+        out["train_step_seed"] = np.array(int(train["step_seed"]), dtype=np.uint64)
+        out["train_packed"] = np.array(int(bool(train.get("packed"))))
     for k in NET_KEYS:
         for n, p in mgr.model_dict[k].named_parameters():
             if p.grad is None:
@@ -395,6 +515,17 @@ ANET_DIMS = (2048, 1536, 384, 8, 384, 768)
 anet_like_counts = O.anet_like_counts
 
 
+def gen_full_small():
+    """full path, small dims, full gradients"""
+    gen_full("full_small", (40, 24, 32, 4, 32, 64), B=4, counts=[2, 1, 3, 2], Ls=(9, 7, 8, 5), seed=21, full_grads=True)
+
+
+def gen_full_anet():
+    """full path, ActivityNet paper dims (d_model 384, 8 heads, Dv 2048, Dt 1536), sub-sampled grads"""
+    gen_full("full_anet", (2048, 1536, 384, 8, 384, 768), B=6, counts=[3, 1, 4, 2, 2, 5], Ls=(20, 16, 18, 9), seed=31,
+             full_grads=False)
+
+
 def gen_bench_anet():
     """BASELINE.json configs[1] exactly as bench.py runs it: 64 videos x 4 clips, Lv = Lc = 80, Lp = 64, Ls = 16 (fixed shape)."""
     gen_full("bench_anet", ANET_DIMS, B=64, counts=[4] * 64, Ls=(80, 80, 64, 16), seed=41, full_grads=False, ragged=False,
@@ -411,6 +542,38 @@ def gen_bench_yc2_100m():
     """synthetic.WORKLOADS['yc2_100m'] (yc2_100m_coot.yaml: Dv 512, 16 videos x 8 clips, cycle weight 0.001)."""
     gen_full("bench_yc2_100m", (512, 1536, 384, 8, 384, 768), B=16, counts=[8] * 16, Ls=(80, 20, 96, 12), seed=47,
              full_grads=False, ragged=False, cc_weight=0.001, sub_step=197, store_reshape=False)
+
+
+def gen_bench_anet_train():
+    """bench_anet in TRAIN mode — the mode bench.py times — at dropout 0.1 on every site (the shipped 0.025 would hide a
+    misplaced site under the bf16 noise), masks = the library's for step seed 20250926."""
+    gen_full("bench_anet_train", ANET_DIMS, B=64, counts=[4] * 64, Ls=(80, 80, 64, 16), seed=41, full_grads=False, ragged=False,
+             sub_step=197, store_reshape=False, train=dict(p=0.1, step_seed=20250926))
+
+
+def gen_bench_anet_ragged_train():
+    """The ragged batch in TRAIN mode, padded token rows (the reference's layout: padded positions draw masks too)."""
+    gen_full("bench_anet_ragged_train", ANET_DIMS, B=64, counts=anet_like_counts(43, 64), Ls=(80, 80, 64, 30), seed=43,
+             full_grads=False, ragged=True, sub_step=197, store_reshape=False, train=dict(p=0.1, step_seed=77001))
+
+
+def gen_bench_anet_ragged_train_packed():
+    """... and with the masks of the PACKED token-row layout (cu_seqlens: what bench.py --workload anet_ragged runs)."""
+    gen_full("bench_anet_ragged_train_packed", ANET_DIMS, B=64, counts=anet_like_counts(43, 64), Ls=(80, 80, 64, 30), seed=43,
+             full_grads=False, ragged=True, sub_step=197, store_reshape=False, train=dict(p=0.1, step_seed=77002, packed=True))
+
+
+def gen_bench_hbm_stress():
+    """BASELINE.json configs[4], per-GPU slice as synthetic.WORKLOADS['hbm_stress']: 16 videos x 64 clips x 80 frames x d = 1024
+    (Cmax = 64: the global networks on 64-row sequences)."""
+    gen_full("bench_hbm_stress", (1024, 1536, 384, 8, 384, 768), B=16, counts=[64] * 16, Ls=(80, 80, 64, 16), seed=59,
+             full_grads=False, ragged=False, sub_step=197, store_reshape=False)
+
+
+def gen_bench_yc2_100m_2layer():
+    """BASELINE.json configs[0] as it words it: YouCook2-100m, batch 16, 2-layer local / 1-layer global encoders (d_model 384)."""
+    gen_full("bench_yc2_100m_2layer", (512, 1536, 384, 8, 384, 768), B=16, counts=[8] * 16, Ls=(80, 20, 96, 12), seed=61,
+             full_grads=False, ragged=False, cc_weight=0.001, sub_step=197, store_reshape=False, layers=2)
 
 
 def gen_bench_yc2_2d3d():
@@ -540,16 +703,17 @@ def main():
     gen_single_net("net_global_small", smallg, N=4, L=5, seed=13, with_ctx=True)
     two = O.NetConfig(input_dim=40, hidden_dim=32, num_heads=4, ff_dim=48, pool_hidden=32, num_layers=2)
     gen_single_net("net_local_2layer", two, N=3, L=6, seed=17, with_ctx=False)
-    # full path, small dims, full gradients
-    gen_full("full_small", (40, 24, 32, 4, 32, 64), B=4, counts=[2, 1, 3, 2], Ls=(9, 7, 8, 5), seed=21,
-             full_grads=True)
-    # full path, ActivityNet paper dims (d_model 384, 8 heads, Dv 2048, Dt 1536), sub-sampled grads
-    gen_full("full_anet", (2048, 1536, 384, 8, 384, 768), B=6, counts=[3, 1, 4, 2, 2, 5], Ls=(20, 16, 18, 9),
-             seed=31, full_grads=False)
+    gen_full_small()
+    gen_full_anet()
     gen_bench_anet()
     gen_bench_anet_ragged()
     gen_bench_yc2_100m()
     gen_bench_yc2_2d3d()
+    gen_bench_anet_train()
+    gen_bench_anet_ragged_train()
+    gen_bench_anet_ragged_train_packed()
+    gen_bench_hbm_stress()
+    gen_bench_yc2_100m_2layer()
     gen_rk_parity()
     gen_retrieval_metrics()
     gen_radam()

@@ -69,11 +69,12 @@ def make_hip_net(cfg: O.NetConfig, P: dict, dropout=0.0, device="cuda"):
     return net.to(device)
 
 
-def full_cfgs(dv, dt, hidden, heads, ff, ph):
+def full_cfgs(dv, dt, hidden, heads, ff, ph, layers=1):
+    """layers: encoder layers of the LOCAL networks (the global ones keep one: BASELINE.json configs[0])."""
     kw = dict(hidden_dim=hidden, num_heads=heads, ff_dim=ff, pool_hidden=ph)
-    return [O.NetConfig(input_dim=dv, **kw),
+    return [O.NetConfig(input_dim=dv, num_layers=layers, **kw),
             O.NetConfig(input_dim=hidden, use_input_fc=False, use_context=True, pooler="avg_special", **kw),
-            O.NetConfig(input_dim=dt, **kw),
+            O.NetConfig(input_dim=dt, num_layers=layers, **kw),
             O.NetConfig(input_dim=hidden, use_input_fc=False, use_context=True, pooler="avg_special", **kw)]
 
 

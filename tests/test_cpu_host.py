@@ -29,6 +29,103 @@ def test_library_exports_every_declared_symbol(cva):
     assert not missing, missing
     assert set(cva.lib.EXPORTS) <= declared
     assert lib.coot_version() >= 1
+    # ... and nothing else leaves the shared object (-fvisibility=hidden + csrc/exports.map): no C++ internals, no kernel handles
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", cva.lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, (sorted(exported - declared)[:5], sorted(declared - exported)[:5])
+
+
+def _header_prototypes():
+    """name -> number of parameters, parsed from include/coot_hip.h (declarations end in ');' and contain no function pointers)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "coot_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(coot_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return protos
+
+
+def test_ctypes_argtypes_match_the_header(cva):
+    """Every function lib.py gives argtypes takes exactly as many arguments as include/coot_hip.h declares (a binding that lags a
+    signature change would shift every later argument: e.g. a stream passed where seed_dev is expected); the ctypes stub printed
+    in INTEGRATION.md is held to the same count."""
+    import re
+    lib = cva.lib.load()
+    protos = _header_prototypes()
+    assert len(protos) >= 55
+    checked = 0
+    for name, n in protos.items():
+        fn = getattr(lib, name)
+        if fn.argtypes is None:
+            continue
+        assert len(fn.argtypes) == n, (name, len(fn.argtypes), n)
+        checked += 1
+    assert checked >= 50, checked
+    # INTEGRATION.md: calls of the form lib.coot_xxx(a, b, ...) inside its python blocks
+    doc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    doc = re.sub(r"#[^\n]*", "", doc)  # python comments (they may hold commas)
+    calls = 0
+    for m in re.finditer(r"lib\.(coot_[a-z0-9_]+)\(", doc):
+        name, i, depth, nargs, seen = m.group(1), m.end(), 1, 0, False
+        while depth and i < len(doc):
+            ch = doc[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                nargs += 1
+            elif not ch.isspace() and depth >= 1:
+                seen = True
+            i += 1
+        if depth == 0 and name in protos and not doc[m.end():i - 1].strip().startswith("..."):
+            got = nargs + 1 if seen else 0
+            assert got == protos[name], ("INTEGRATION.md", name, got, protos[name])
+            calls += 1
+    assert calls >= 1
+
+
+def test_dropout_mask_restatement_matches_the_library(cva):
+    """oracle/dropout_masks.py (the masks injected into the reference for train-mode parity) against the library's own generator
+    evaluated on the host by the same functions the kernels use (coot_debug_dropout_scales / coot_debug_attn_dropout_scales):
+    hash, key derivation, pair halves, quantisation of p, 1 / keep scale — bit-exact."""
+    import ctypes as C
+    from oracle import dropout_masks as DM
+    lib = cva.lib.load()
+    lib.coot_debug_dropout_scales.argtypes = [C.c_uint64, C.c_uint, C.c_uint64, C.c_int64, C.c_float, C.c_void_p]
+    lib.coot_debug_attn_dropout_scales.argtypes = [C.c_uint64, C.c_uint, C.c_uint, C.c_int, C.c_float, C.c_void_p]
+    rs = np.random.RandomState(0)
+    for seed, site, p in ((0, 1, 0.1), (20250926, 16 * 15 + 7, 0.025), (2 ** 63 + 12345, 16 * 8 + 3, 0.5), (77001 + 1022, 4, 1e-6),
+                          ((1 << 64) - 1, 2, 0.9999)):
+        for idx0 in (0, 1, 2 ** 32 - 3, int(rs.randint(0, 2 ** 31)) * 5):
+            n = 4099
+            out = np.empty(n, dtype=np.float32)
+            cva.lib.check(lib.coot_debug_dropout_scales(seed, site, idx0, n, p, out.ctypes.data), "debug_dropout_scales")
+            want = DM.scales_from_index(DM.drop_key(seed, site), np.arange(idx0, idx0 + n, dtype=np.uint64), p)
+            assert np.array_equal(out, want), (seed, site, p, idx0)
+            if idx0 == 0 and 0.01 < p < 0.9:
+                assert abs((out == 0).mean() - p) < 0.03  # the masks drop about p of the elements, the others carry 1 / keep
+                assert np.allclose(out[out != 0], 1.0 / (1.0 - DM.quantise_p(p)[0] / 65536.0))
+        for row32, Lk in ((0, 80), (12345, 17), (2 ** 32 - 1, 64), (640 * 8 * 80 + 7, 1)):
+            out = np.empty(Lk, dtype=np.float32)
+            cva.lib.check(lib.coot_debug_attn_dropout_scales(seed, site, row32, Lk, p, out.ctypes.data), "debug_attn_dropout_scales")
+            want = DM.scales_attn(DM.drop_key(seed, site), np.full(Lk, row32, np.uint64), np.arange(Lk), (Lk + 1) >> 1, p)
+            assert np.array_equal(out, want), (seed, site, p, row32, Lk)
+    # layouts: for full-length sequences the packed and the padded layout draw the same masks (cu[n] = n L)
+    N, L, H = 3, 6, 2
+    pad = DM.CallLayout(0, N, L, 0)
+    pk = DM.CallLayout(0, N, L, 0, lens=[L] * N, cu=np.arange(N) * L)
+    assert np.array_equal(DM.mask_rows(5, 3, pad, 8, 0.3), DM.mask_rows(5, 3, pk, 8, 0.3))
+    assert np.array_equal(DM.mask_attention(5, 1, pad, H, L, L, 0.3), DM.mask_attention(5, 1, pk, H, L, L, 0.3))
+    # second segment of a call: element-wise sites continue the row count, attention / pooling weights restart under another seed
+    seg1 = DM.CallLayout(1, 2, 4, N * L)
+    both = DM.mask_rows(5, 3, DM.CallLayout(0, 1, N * L + 8, 0), 8, 0.3)[0]
+    assert np.array_equal(DM.mask_rows(5, 3, seg1, 8, 0.3).reshape(8, 8), both[N * L:])
+    assert not np.array_equal(DM.mask_attention(5, 1, seg1, H, 4, 4, 0.3), DM.mask_attention(5, 1, DM.CallLayout(0, 2, 4, 0), H, 4, 4, 0.3))
+    assert DM.step_net_seeds(100) == [100, 111, 1122, 1133]
 
 
 def test_param_layout_matches_reference_state_dict(cva, golden_dir):

@@ -9,8 +9,8 @@ Two routes to the same fixture:
   * "autograd": RetrievalModelManager.encode_visual / encode_text + trainer loss hooks + loss.backward()
   * "native":   coot_step_forward (embeddings) and coot_train_step(do_optimizer = 0) (losses + every parameter gradient),
                 the call bench.py times
-Tolerances (north_star): embedding cosine >= 1 - 1e-3 per row; losses to 1e-3 relative; parameter gradients cosine > 0.98 on
-the fixture's sub-sample and norm within 5 %.
+Tolerances (north_star): embedding cosine >= 1 - 1e-3 per row; losses to 1e-3 relative; parameter gradients cosine > 0.99 on
+the fixture's sub-sample and norm within 2 %.
 """
 import ctypes as C
 import os
@@ -23,7 +23,9 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["bench_anet", "bench_anet_ragged", "bench_yc2_100m", "bench_yc2_2d3d"]
+# bench_hbm_stress: BASELINE.json configs[4] per-GPU slice (Dv 1024, 64 clips per video: the global networks on Cmax = 64);
+# bench_yc2_100m_2layer: configs[0] as BASELINE.json words it (2-layer local encoders at d_model 384 on the fused chains)
+CASES = ["bench_anet", "bench_anet_ragged", "bench_yc2_100m", "bench_yc2_2d3d", "bench_hbm_stress", "bench_yc2_100m_2layer"]
 
 
 @pytest.fixture(scope="module")
@@ -44,7 +46,7 @@ def _case(golden_dir, name):
         _cache.clear()  # one ~0.6 GB host batch at a time
         g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
         seed, B, Lv, Lc, Lp, Ls, dv, dt, hidden, heads, ff, ph = [int(v) for v in g["meta"]]
-        cfgs = H.full_cfgs(dv, dt, hidden, heads, ff, ph)
+        cfgs = H.full_cfgs(dv, dt, hidden, heads, ff, ph, layers=int(g["layers"]) if "layers" in g else 1)
         Ps = [O.make_params(cfgs[i], seed + 10 * i, scale=float(g["param_scale"])) for i in range(4)]
         b = O.make_batch(seed + 100, B, g["counts"], Lv, Lc, Lp, Ls, dv, dt, ragged=bool(int(g["ragged"])), corr=0.5)
         _cache[name] = (g, cfgs, Ps, b)
@@ -86,11 +88,12 @@ def _check_grads(g, grads_by_net: dict, tag):
             n_checked += 1
             if c < 0.995 or abs(nr - 1) > 0.02:
                 print(f"[{tag}]   {key}: cos(sub) {c:.4f}  norm ratio {nr:.4f}  |g_ref| / max |g_ref| = {gn / gmax:.2e}")
-            if not (c > 0.98 and 0.95 < nr < 1.05):
+            if not (c > 0.99 and 0.98 < nr < 1.02):
                 bad.append((key, round(c, 4), round(nr, 4)))
     print(f"[{tag}] {n_checked} parameter gradients checked, {len(bad)} out of tolerance")
     assert not bad, bad
     assert n_checked >= 100  # 4 networks x (26 | 42) tensors, minus the zero-gradient ones
+    return n_checked
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -131,8 +134,14 @@ def test_bench_shape_autograd_route(env, golden_dir, name):
         r12, r21, _ = cva.compute_retrieval(e1, e2)
         got = np.array([r12[k] for k in ("r1", "r5", "r10")] + [r21[k] for k in ("r1", "r5", "r10")])
         ref = g[f"ret_{tag}"][[0, 1, 2, 6, 7, 8]]
-        print(f"[{name}] R@1/5/10 {tag}: {got} vs reference {ref}")
-        assert np.abs(got - ref).max() <= 0.1 + 1e-9, (tag, got, ref)
+        # R@K are FRACTIONS here; north_star's bound is +-0.1 percentage points.  With N items one rank flip moves a value by
+        # 100 / N pp (1.56 pp at N = 64), so at these batch sizes the bound is "at most one near-tie flips per direction":
+        # max(0.1 pp, 100 / N pp).  The N = 1 024 retrieval-parity set (test_gpu_rk_parity.py) holds the 0.1 pp itself.
+        n_items = e1.shape[0]
+        bound_pp = max(0.1, 100.0 / n_items)
+        diff_pp = 100.0 * np.abs(got - ref).max()
+        print(f"[{name}] R@1/5/10 {tag}: {got} vs reference {ref}  (max diff {diff_pp:.3f} pp, bound {bound_pp:.3f} pp at N = {n_items})")
+        assert diff_pp <= bound_pp + 1e-6, (tag, got, ref)
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -737,7 +737,9 @@ def test_global_network_single_launch_matches_per_op_kernels(env, N, L, train):
 def test_autograd_graph_step_is_one_update_per_call(env):
     """train_step(use_graph=True) (the autograd step captured as one HIP graph): the capture's eager warm-up runs on a snapshot, so
     every call — the first one for a shape included — applies exactly ONE optimizer update; a learning-rate change between calls
-    re-captures instead of replaying the old rate; RAdam (host-side step scalars) is refused."""
+    is applied by the SAME graph (the captured Adam reads the rate from a device tensor: a per-step schedule must not re-capture
+    every step), checked against the eager run's trajectory; packed batches with other token totals get their own graph, the cache
+    is bounded; RAdam (host-side step scalars) is refused."""
     torch, cva = env
     dims = (64, 48, 64, 4, 64, 128)
     cfgs = H.full_cfgs(*dims)
@@ -758,7 +760,12 @@ def test_autograd_graph_step_is_one_update_per_call(env):
         torch.cuda.synchronize()
         assert tr.total_step == 4
         if graph:
-            assert len(tr._graphs) == 2  # one per learning rate
+            assert len(tr._graphs) == 1  # the learning rate is not part of the key
+            k0 = tr._graph_key(batch)
+            batch.tok_vis, batch.tok_txt = 100, 50  # host scalars a captured packed step bakes into its launches
+            assert tr._graph_key(batch) != k0
+            batch.tok_vis = batch.tok_txt = None
+            assert tr.max_graphs >= 1
         res.append((losses, [n._flat.clone() for n in mgr.model_dict.values()]))
     (la, pa), (lb, pb) = res
     assert np.allclose(la, lb, rtol=2e-3, atol=2e-5), (la, lb)  # loss BEFORE each update: equal only if the update counts are

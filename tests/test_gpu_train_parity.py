@@ -1,0 +1,137 @@
+"""TRAIN-mode (dropout on) parity at the benchmark shapes — the mode bench.py times.
+
+The reference draws its masks from torch's RNG, the library from a hash of (seed, site, element); oracle/gen_golden.py
+therefore ran the UNMODIFIED reference with every nn.Dropout replaced by a module that multiplies with the library's masks
+for that site (oracle/dropout_masks.py restates csrc/common.h; sites: nntrainer/models/transformer_legacy.py:418,435,487,553,
+592-598 — attention probabilities, post-LN1, FF x2 — and nntrainer/models/poolers.py:139-143 — GenPool x3; 7 per local and
+8 per global network) at p = 0.1, and wrote embeddings, losses and all parameter gradients.  Here: coot_step_forward /
+coot_train_step(do_optimizer = 0) with train = 1 and the same step seed, default kernel dispatch.
+
+A dropout applied on the wrong side of a GELU, a missing site, a mask indexed by another row / head / segment, or a wrong
+1 / keep scale moves the embeddings by O(p): the cosine bound 1 - 1e-3 cannot be met (the control case below runs the same
+step under another seed and must FAIL that bound).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import coot_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["bench_anet_train", "bench_anet_ragged_train", "bench_anet_ragged_train_packed"]
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import coot_videotext_amd as cva
+    assert torch.cuda.is_available()
+    cva.lib.load()
+    return torch, cva
+
+
+_cache = {}
+
+
+def _case(golden_dir, name):
+    if name not in _cache:
+        _cache.clear()
+        g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+        seed, B, Lv, Lc, Lp, Ls, dv, dt, hidden, heads, ff, ph = [int(v) for v in g["meta"]]
+        cfgs = H.full_cfgs(dv, dt, hidden, heads, ff, ph, layers=int(g["layers"]))
+        Ps = [O.make_params(cfgs[i], seed + 10 * i, scale=float(g["param_scale"])) for i in range(4)]
+        b = O.make_batch(seed + 100, B, g["counts"], Lv, Lc, Lp, Ls, dv, dt, ragged=bool(int(g["ragged"])), corr=0.5)
+        _cache[name] = (g, cfgs, Ps, b)
+    return _cache[name]
+
+
+def _step_forward(torch, cva, trainer, batch, seed, train=1):
+    lib, L = cva.lib.load(), cva.lib
+    st, x = trainer._native_setup(batch)
+    B, Nc, D = st.dims.B, st.dims.Nc, 384
+    dev = batch.vid_feat.device
+    local_v, local_t = torch.empty(B + Nc, D, device=dev), torch.empty(B + Nc, D, device=dev)
+    glob_v, glob_t = torch.empty(B, 2 * D, device=dev), torch.empty(B, 2 * D, device=dev)
+    resh_v, resh_t = torch.empty(B, st.dims.Cmax_clip, D, device=dev), torch.empty(B, st.dims.Cmax_sent, D, device=dev)
+    main = torch.cuda.current_stream()
+    L.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(st.dims), local_v.data_ptr(), local_t.data_ptr(),
+                                  glob_v.data_ptr(), glob_t.data_ptr(), resh_v.data_ptr(), resh_t.data_ptr(), st.ws.data_ptr(), st.ws.numel(),
+                                  train, int(seed), 0, main.cuda_stream, main.cuda_stream, st.streams[1].cuda_stream), "coot_step_forward")
+    torch.cuda.synchronize()
+    lv, lt = local_v.cpu().numpy(), local_t.cpu().numpy()
+    return {"vid_emb": glob_v.cpu().numpy(), "par_emb": glob_t.cpu().numpy(), "vid_context": lv[:B], "clip_emb": lv[B:],
+            "par_context": lt[:B], "sent_emb": lt[B:]}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_mode_native_step_vs_reference_with_injected_masks(env, golden_dir, name):
+    torch, cva = env
+    lib = cva.lib.load()
+    g, cfgs, Ps, b = _case(golden_dir, name)
+    p, seed, packed = float(g["train_p"]), int(g["train_step_seed"]), bool(int(g["train_packed"]))
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=p, cc_weight=float(g["cc_weight"]))
+    mgr.set_all_models_train()
+    trainer = cva.RetrievalTrainer(cfg, mgr)
+    batch = cva.synthetic.batch_from_numpy(b, packed=packed)
+    idx = torch.from_numpy(np.concatenate([g["cc_idx_clip"], g["cc_idx_sent"]]).astype(np.int64)).cuda()
+
+    # ---- embeddings of the train-mode forward under the fixture's seed ----
+    emb = _step_forward(torch, cva, trainer, batch, seed)
+    worst = 1.0
+    for key, val in emb.items():
+        cos = H.cosine_rows(val, g[key]).min()
+        worst = min(worst, cos)
+        print(f"[{name}] {key}: min row cosine vs reference (same masks) {cos:.6f}")
+        assert cos > 1 - 1e-3, (key, cos)
+
+    # ---- control: another seed draws other masks; the same bound must fail, or this test proves nothing ----
+    emb2 = _step_forward(torch, cva, trainer, batch, seed + 1)
+    ctrl = min(H.cosine_rows(emb2[k], g[k]).min() for k in emb2)
+    print(f"[{name}] control (seed + 1): min row cosine {ctrl:.4f}  (same seed: {worst:.6f})")
+    assert ctrl < 0.995, ctrl
+
+    # ---- losses and every parameter gradient of coot_train_step(train = 1), the call bench.py times ----
+    lib.coot_timing_enable(1)
+    try:
+        losses = trainer.train_step_native(batch, do_optimizer=False, seed=seed, cc_indices=idx)
+        torch.cuda.synchronize()
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+        cva.lib.check(lib.coot_timing_collect(5, C.byref(ms), C.byref(fl), C.byref(n)), "timing_collect")
+    finally:
+        lib.coot_timing_enable(0)
+    assert n.value >= 8, f"the fused token-tile kernels did not run ({n.value} launches)"
+    total, contr, cc = (float(v) for v in losses)
+    rc, rcc = float(g["contr_loss"]), float(g["cc_loss"])
+    print(f"[{name}] contrastive {contr:.5f} vs {rc:.5f}; cycle-consistency {cc:.6f} vs {rcc:.6f}")
+    assert abs(contr - rc) < 2e-3 * abs(rc) and abs(cc - rcc) < 5e-3 * abs(rcc) + 1e-6 and abs(total - contr - cc) < 1e-5
+
+    step = int(g["sub_step"])
+    gmax = max(float(g[k]) for k in g if k.startswith("gnorm:"))
+    bad, checked, cmin = [], 0, 1.0
+    for k in H.NET_KEYS:
+        net = mgr.model_dict[k]
+        flat = net._grad_flat.detach().cpu().numpy()
+        for (pname, off, shape) in net.table:
+            got = flat[off:off + int(np.prod(shape))]
+            key = f"{k}:{pname}"
+            gn = float(g["gnorm:" + key])
+            if gn < 1e-6 * gmax:
+                if np.linalg.norm(got) > 1e-3 * gmax:
+                    bad.append((key, "zero-grad", float(np.linalg.norm(got))))
+                continue
+            ref = g["gsub:" + key]
+            c = H.cosine_flat(got[::(1 if ref.size == got.size else step)], ref)
+            nr = float(np.linalg.norm(got.astype(np.float64))) / gn
+            checked += 1
+            cmin = min(cmin, c)
+            if c < 0.995 or abs(nr - 1) > 0.02:
+                print(f"[{name}]   {key}: cos(sub) {c:.4f}  norm ratio {nr:.4f}  |g_ref| / max |g_ref| = {gn / gmax:.2e}")
+            if not (c > 0.99 and 0.97 < nr < 1.03):
+                bad.append((key, round(c, 4), round(nr, 4)))
+    print(f"[{name}] {checked} parameter gradients checked (min cosine {cmin:.4f}), {len(bad)} out of tolerance")
+    assert not bad, bad
+    assert checked >= 100
