@@ -150,6 +150,26 @@ def grad_report(named_got, ref: dict, cos_min=0.99, ratio_tol=0.05):
     return bad, "\n".join(rows)
 
 
+def rank_flips(e1, e2, r1, r2):
+    """Retrieval ranks (nntrainer/retrieval.py:68-98: number of items scored above the paired one) of the L2-normalised embedding
+    sets (e1, e2) against those of the reference's (r1, r2), both directions.  Returns (number of (query, item) comparisons whose
+    outcome differs, the largest REFERENCE margin |S_ij - S_ii| among them): a flip with a margin far above the embedding
+    tolerance would be a real ranking difference, flips inside it are the near-ties any two fp32 implementations disagree on."""
+    def nrm(x):
+        x = np.asarray(x, np.float64)
+        return x / np.sqrt((x * x).sum(-1, keepdims=True))
+    S, R = nrm(e1) @ nrm(e2).T, nrm(r1) @ nrm(r2).T
+    flips, worst = 0, 0.0
+    for A, B in ((S, R), (S.T, R.T)):
+        da, db = A - np.diag(A)[:, None], B - np.diag(B)[:, None]
+        diff = (da > 0) != (db > 0)
+        np.fill_diagonal(diff, False)
+        flips += int(diff.sum())
+        if diff.any():
+            worst = max(worst, float(np.abs(db[diff]).max()))
+    return flips, worst
+
+
 def import_reference(ref_root="/root/reference"):
     """The unmodified reference, imported with the shims of SURVEY 8c (removed collections aliases, absent GPUtil / h5py /
     tensorboard).  Returns a namespace of its modules, or None where the reference tree does not exist (the GPU box)."""
