@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (phase calls + RCCL collectives) even with one rank")
     ap.add_argument("--step-stamps", action="store_true", help="print a HIP-event timeline of one training step to stderr")
     ap.add_argument("--clock-monitor", action="store_true", help="after the timed loop: sample the shader clock on a side stream while more steps run (stderr)")
+    ap.add_argument("--no-defer-join", action="store_true", help="join the text stream into the main stream at the end of every step (A/B)")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--padded", action="store_true", help="ragged workloads: run the reference's padded layout instead of packed (varlen) rows")
     ap.add_argument("--mode", default="native", choices=["native", "native-graph", "native-phases", "autograd", "graph"],
@@ -209,7 +210,10 @@ def main():
 
         def step(graph=None):
             if mode in ("native", "native-graph", "native-phases") and graph is None:  # N > 1: native phases with the RCCL collectives between them
-                return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, use_graph={"native-graph": True, "native-phases": "phases"}.get(mode, False))[0]
+                # back-to-back steps: the text side's update tail overlaps the next step's forward (COOT_STEP_DEFER_TEXT_JOIN); every
+                # step is complete when the timed region ends (barrier + device synchronisation below)
+                return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, defer_join=not args.no_defer_join,
+                                                 use_graph={"native-graph": True, "native-phases": "phases"}.get(mode, False))[0]
             return trainer.train_step(batch, vid_counts, clip_counts, use_graph=(mode == "graph") if graph is None else graph)[0]
 
     def barrier():

@@ -10,7 +10,7 @@ from .config import (RetrievalConfig, RetrievalNetworksConst, TransformerConfig,
 from .loss_fn import (ContrastiveLoss, ContrastiveLossConfig, cycle_consistency_loss, sample_cycle_indices,  # noqa: F401
                       total_contrastive_loss)
 from .model_retrieval import (RetrievalDataBatchTuple, RetrievalModelManager, RetrievalTextEmbTuple,  # noqa: F401
-                              RetrievalVisualEmbTuple, attach_packed_index, packed_index)
+                              RetrievalVisualEmbTuple, RetrievalPackedBatchTuple, attach_packed_index, packed_index)
 from .nets import TransformerHip, pack_by_count  # noqa: F401
 from .retrieval import compute_retrieval, compute_retrieval_cosine  # noqa: F401
 from .trainer_retrieval import RetrievalTrainer, make_optimizer  # noqa: F401

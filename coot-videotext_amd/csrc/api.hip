@@ -611,6 +611,7 @@ extern "C" void coot_step_tn_aux(int sides);
 extern "C" void coot_step_split_loss(int on);
 extern "C" void coot_step_grad_write(int on);
 extern "C" void coot_step_defer_global_tn(int on);
+extern "C" void coot_step_glob_xcd_split(int on);
 int coot_get_option(const char* name, int* value) {
   if (!value) { set_error("get_option: null result"); return -1; }
   if (!strcmp(name, "tn_dma")) { *value = get_tn_dma(); return 0; }
@@ -642,6 +643,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "split_loss")) { coot_step_split_loss(value); return 0; }
   if (!strcmp(name, "grad_write")) { coot_step_grad_write(value); return 0; }
   if (!strcmp(name, "defer_global_tn")) { coot_step_defer_global_tn(value); return 0; }
+  if (!strcmp(name, "glob_xcd_split")) { coot_step_glob_xcd_split(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   if (!strcmp(name, "fused_fwd_small")) { g_fused_fwd_small = value; return 0; }
@@ -940,6 +942,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   struct SeedScope { SeedScope(const uint64_t* p) { g_seed_dev = (const unsigned long long*)p; } ~SeedScope() { g_seed_dev = nullptr; } } seedscope(seed_dev);
   coot_net_config c; RUN(norm_cfg(cfg, &c));
   COOT_REQUIRE(P && wpack && pe && feats && lengths && pooled && saved, "net_fwd: null pointer");
+  if (packed && packed->source != COOT_SOURCE_PADDED && N2 > 0 && !feats2) feats2 = feats;  // (one packed matrix carries both segments)
   COOT_REQUIRE(!c.use_context || hidden, "net_fwd: context network needs hidden state (transformer_legacy.py:252)");
   COOT_REQUIRE(Lseq <= 1000 && L2 <= 1000, "net_fwd: sequence length %d exceeds positional table (max_len 1000)", Lseq);
   if (N <= 0) return 0;
@@ -954,10 +957,14 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   PerOpGuardScope perop_guard(c, W, P, wpack);
   Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);  // sized for the padded layout (>= the packed rows)
   COOT_REQUIRE(!AS.overflow, "net_fwd: saved buffer too small (%zu < %zu)", saved_bytes, AS.off);
+  const int source = packed ? packed->source : COOT_SOURCE_PADDED;
+  COOT_REQUIRE(source >= COOT_SOURCE_PADDED && source <= COOT_SOURCE_PACKED_BF16, "net_fwd: packed source %d", source);
   if (packed_ok(c, W, sg, packed)) {
     COOT_REQUIRE(!per_token, "net_fwd: per-token output is not available with packed rows");
     sg.cu = packed->cu_seqlens; sg.Tp = packed->total_tokens;
   }
+  COOT_REQUIRE(source == COOT_SOURCE_PADDED || sg.cu, "net_fwd: a packed feature source needs the packed-row path (local network on the fused "
+               "kernels, >= %d tokens, sequences of <= 128 rows): there is no padded tensor to fall back to", g_fused_min_rows);
   const int D = c.hidden_dim, T = sg.T(), Din = c.input_dim, T0 = N * Lseq;
   const int out_dim = D * (c.use_context ? 2 : 1);
 
@@ -966,6 +973,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     LnFwd l; l.x = feats; l.x_f32 = 1; l.ldx = Din; l.R = T0; l.D = Din; l.y = S.xhat; l.ldy = Din;
     if (sg.n > 1) { l.x2 = feats2; l.R0 = T0; l.R = T; }  // both segments in one launch
     if (sg.cu) { l.R = T; l.cu = sg.cu; l.nseq = Ntot; l.N0 = N; l.L0 = Lseq; l.L1 = L2; l.pos_out = S.pos; }  // gathers the valid rows
+    if (source != COOT_SOURCE_PADDED) { l.src_packed = 1; l.x2 = nullptr; l.x_f32 = source == COOT_SOURCE_PACKED_F32; }  // ... or reads them in place
     RUN(launch_ln_fwd(l, st));
     if (W.f_in_w && W.layers[0].f_wqkv && g_use_fused && g_use_fused_infc && T >= g_fused_min_rows) {
       InfcQkvFwd f; f.T = T; f.Din = Din; f.xhat = S.xhat; f.win = W.f_in_w; f.bin = W.in_bias; f.pe = pe; f.T0 = T0; f.L1 = Lseq;
@@ -1073,6 +1081,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   struct SeedScope { SeedScope(const uint64_t* p) { g_seed_dev = (const unsigned long long*)p; } ~SeedScope() { g_seed_dev = nullptr; } } seedscope(seed_dev);
   coot_net_config c; RUN(norm_cfg(cfg, &c));
   COOT_REQUIRE(P && wpack && feats && lengths && dpooled && G && saved && scratch, "net_bwd: null pointer");
+  if (packed && packed->source != COOT_SOURCE_PADDED && N2 > 0 && !feats2) feats2 = feats;  // (one packed matrix carries both segments)
   COOT_REQUIRE(!(dfeats && c.use_input_fc), "net_bwd: dfeats is only available for networks without input_fc");
   if (N <= 0) return 0;
   Segs sg; sg.N[0] = N; sg.L[0] = Lseq; sg.lens[0] = (const long long*)lengths;

@@ -8,6 +8,7 @@
 #include "../../include/coot_hip.h"
 #include "common.h"
 #include "gemm.h"
+#include "fused.h"
 #include "pool.h"
 #include "rowops.h"
 
@@ -80,8 +81,8 @@ void layout_step(const coot_step_config& c, const coot_step_dims& d, Bump& A, St
 struct SidePacked { coot_packed_seqs v, t; };
 SidePacked side_packed(const coot_step_batch& x, const coot_step_dims& d) {
   SidePacked p;
-  p.v.cu_seqlens = d.tok_vis > 0 ? x.cu_vis : nullptr; p.v.total_tokens = d.tok_vis;
-  p.t.cu_seqlens = d.tok_txt > 0 ? x.cu_txt : nullptr; p.t.total_tokens = d.tok_txt;
+  p.v.cu_seqlens = d.tok_vis > 0 ? x.cu_vis : nullptr; p.v.total_tokens = d.tok_vis; p.v.source = d.source;
+  p.t.cu_seqlens = d.tok_txt > 0 ? x.cu_txt : nullptr; p.t.total_tokens = d.tok_txt; p.t.source = d.source;
   return p;
 }
 
@@ -132,6 +133,7 @@ thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller even
 // the dependent launches, the 36-workgroup TN launch overlapped with them anyway) and the aux launch slows the local backward's
 // first kernels.  Off.
 int g_defer_global_tn = 0;
+int g_glob_xcd_split = 1;  // coot_set_option("glob_xcd_split", 0/1): each side's single-launch global passes on its own half of the XCDs (fused.h: glob_xcd_set)
 int g_grad_write = 1;  // coot_set_option("grad_write", 0/1): coot_train_step writes the weight-matrix gradients and zeroes only the rest
 int g_split_loss = 1;  // coot_set_option("split_loss", 0/1): local contrastive terms on the text stream ahead of the join (coot_train_step)
 int g_tn_aux_sides = 0;  // coot_set_option("tn_aux", bits): 1 = video side, 2 = text side.  Measured: 136.6k -> 133k (video) / 131k (both)
@@ -184,9 +186,13 @@ int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, 
   g_stamps.mark(li == 0 ? "video: local forward done" : "text: local forward done", st);
   if (local_done_slot >= 0) RUN(g_hops.record(local_done_slot, st));  // the local embeddings exist: the other side may start on their loss terms
   RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
-  RUN(coot_net_fwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0,
-                   local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi, g_step_seed_dev, st,
-                   nullptr));
+  // the two sides' global passes run at the same time: each on its own half of the XCDs (its 3.5 MB of weights then own those L2s)
+  if (g_glob_xcd_split) glob_xcd_set(li == 0 ? 0 : 4, 4);
+  const int rc_gf = coot_net_fwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0,
+                                 local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi,
+                                 g_step_seed_dev, st, nullptr);
+  glob_xcd_set(0, 8);
+  RUN(rc_gf);
   g_stamps.mark(li == 0 ? "video: global forward done" : "text: global forward done", st);
   return 0;
 }
@@ -210,9 +216,11 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   const bool defer = g_defer_global_tn != 0;
   set_tn_aux_stream(defer ? g_aux.get(side) : nullptr);
   set_tn_defer(defer);
+  if (g_glob_xcd_split) glob_xcd_set(side == 0 ? 0 : 4, 4);
   const int rc_g = coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
                                 b.grads[gi], dhid, dfeat, saved_g, sz_g, (char*)scratch + sz_loc, sz_glob, train, seed + 11 * gi, g_step_seed_dev, st,
                                 nullptr);
+  glob_xcd_set(0, 8);
   set_tn_defer(false);
   set_tn_aux_stream(nullptr);
   RUN(rc_g);
@@ -588,7 +596,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
   g_stamps.mark("text: updated", st);
   RUN(g_hops.hop(4, sv, sm));
-  RUN(g_hops.hop(5, st, sm));
+  if ((do_optimizer & COOT_STEP_DEFER_TEXT_JOIN) == 0) RUN(g_hops.hop(5, st, sm));  // else: the caller (or the next step's text side) orders it
   g_stamps.mark("step done", sm);
   return 0;
 }
@@ -678,6 +686,7 @@ void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
 void coot_step_split_loss(int on) { g_split_loss = on; }
 void coot_step_grad_write(int on) { g_grad_write = on ? 1 : 0; }
 void coot_step_defer_global_tn(int on) { g_defer_global_tn = on; }
+void coot_step_glob_xcd_split(int on) { g_glob_xcd_split = on; }
 
 // text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.
 int coot_debug_step_stamps(char* buf, int buf_bytes) {

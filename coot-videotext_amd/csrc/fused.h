@@ -122,7 +122,7 @@ struct GlobFwd {
   float* pooled = nullptr;        // [B, 768] = avg_special | context block output
   float* per_token = nullptr;     // optional [B Cmax, 384] fp32 copy of the encoder output
   int train = 0;
-  int tiles = 0, warm_per_xcd = 0;  // set by launch_glob_fwd
+  int tiles = 0, warm_per_xcd = 0, xcd_first = 0, xcd_count = 8, tiles_per_xcd = 0;  // set by launch_glob_fwd (glob_xcd_set)
   unsigned long long* tstamps = nullptr;  // profiling aid: block 0 phase stamps (tools/glob_stamps.py)
 };
 int launch_glob_fwd(const GlobFwd& p, hipStream_t st);
@@ -155,10 +155,15 @@ struct GlobBwd {
   float* dx = nullptr;              // [B, Cmax, 384] fp32 (written)
   float* dhidden = nullptr;         // [B, 384] fp32 (written)
   float *g_n_gain = nullptr, *g_n_bias = nullptr;  // +=
-  int tiles = 0, warm_per_xcd = 0;  // set by launch_glob_bwd
+  int tiles = 0, warm_per_xcd = 0, xcd_first = 0, xcd_count = 8, tiles_per_xcd = 0;  // set by launch_glob_bwd (glob_xcd_set)
   unsigned long long* tstamps = nullptr;  // profiling aid: block 0 phase stamps at slots 16.. (tools/glob_stamps.py)
 };
 int launch_glob_bwd(const GlobBwd& p, hipStream_t st);
+// XCDs the single-launch global passes of the calling thread place their workgroups on (first, count; default all 8).  A pass
+// streams 3.5 MB of weights through each of its few workgroups; the video and the text network run at the same time, and with a
+// tile of EACH on every XCD the two weight sets (7 MB) compete for every 4 MB L2.  The train step gives each side half of the
+// XCDs (block b runs on XCD b % 8: an affinity used for speed only, any placement is correct).
+void glob_xcd_set(int first, int count);
 
 constexpr int FZ_BWD_NCS = 9 * FZ_D;  // floats per tile in PreAttnBwd::part
 bool half_tiles(int T);          // the chains run on 64-row tiles for this many tokens (fused.hip)

@@ -840,6 +840,22 @@ __device__ __forceinline__ void l2_prefetch(const bf16_t* const (&ws)[8], int h,
   asm volatile("" :: "v"(x));  // the loads must be issued; their values are not needed
 }
 
+// block -> tile of the single-launch global passes.  Block b is expected on XCD b % 8 and serves slot b / 8 of that XCD: the first
+// tiles_per_xcd slots of the XCDs [xcd_first, xcd_first + xcd_count) are chain workgroups (tile = slot * xcd_count + position of
+// the XCD in the set), the following warm_per_xcd slots L2 warm-up helpers of that XCD; blocks on other XCDs leave at once (their
+// L2 belongs to the other network).  Returns the tile, or -1 after doing a helper's work / nothing.
+template <typename P>
+__device__ __forceinline__ int glob_tile_or_help(const P& p, const bf16_t* const (&ws)[8]) {
+  const int b = blockIdx.x, xr = (b & 7) - p.xcd_first, slot = b >> 3;
+  if (xr < 0 || xr >= p.xcd_count) return -1;
+  if (slot < p.tiles_per_xcd) {
+    const int tile = slot * p.xcd_count + xr;
+    return tile < p.tiles ? tile : -1;
+  }
+  l2_prefetch(ws, slot - p.tiles_per_xcd, p.warm_per_xcd);
+  return -1;
+}
+
 // out-proj + residual + LN1 (+ dropout) + FF1 + GELU + FF2 + residual + LN2 on the 32-row tile in As (rows [row0, rowEnd) are
 // real; nothing is stored for the others).  The chain of post_attn_fwd_kernel with row masks and global parameter vectors.
 template <bool DROP, bool OUT32>
@@ -905,19 +921,20 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
   float* Stg = reinterpret_cast<float*>(smem + 4 * BT * APITCH * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Cm = p.Cmax, G = 32 / Cm;
-  if ((int)blockIdx.x >= p.tiles) {  // L2 warm-up workgroups (see launch_glob_fwd)
+  int tile;
+  {  // chain workgroup, L2 warm-up helper or bystander (see launch_glob_fwd)
     const bf16_t* ws[8] = {p.self.wqkv, p.self.wo, p.self.w1, p.self.w2, p.ctx.wqkv, p.ctx.wo, p.ctx.w1, p.ctx.w2};
-    l2_prefetch(ws, ((int)blockIdx.x - p.tiles) >> 3, p.warm_per_xcd);
-    return;
+    tile = glob_tile_or_help(p, ws);
+    if (tile < 0) return;
   }
-  const int v0 = blockIdx.x * G, nv = (p.B - v0) < G ? (p.B - v0) : G;
+  const int v0 = tile * G, nv = (p.B - v0) < G ? (p.B - v0) : G;
   const int row0 = v0 * Cm, nrows = nv * Cm, rowEnd = row0 + nrows;
   unsigned long long sbase = 0;
   if constexpr (DROP) { if (p.self.d_ff1.seed_ptr) sbase = *p.self.d_ff1.seed_ptr; }
   const float scale = 0.14433756729740643f;  // 1 / sqrt(48)
   f32x4_t acc[RF][3];
   int tsn = 0;
-  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  auto stamp = [&]() { if (p.tstamps && tile == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
   stamp();
 
   // ---- z0 = LayerNorm(x) + pe (transformer_legacy.py:222-241; padded items are zero rows: LN gives bias + pe there) ----
@@ -1232,12 +1249,13 @@ __global__ __launch_bounds__(512) void glob_bwd_kernel(GlobBwd p) {
   static_assert(BT * SPITCH >= 256 * 32 + 512, "staging buffer holds the attention scratch");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Cm = p.Cmax, G = 32 / Cm;
-  if ((int)blockIdx.x >= p.tiles) {
+  int tile;
+  {
     const bf16_t* ws[8] = {p.ctx.wqkv_kn, p.ctx.wo_kn, p.ctx.w1_kn, p.ctx.w2_kn, p.self.wqkv_kn, p.self.wo_kn, p.self.w1_kn, p.self.w2_kn};
-    l2_prefetch(ws, ((int)blockIdx.x - p.tiles) >> 3, p.warm_per_xcd);
-    return;
+    tile = glob_tile_or_help(p, ws);
+    if (tile < 0) return;
   }
-  const int v0 = blockIdx.x * G, nv = (p.B - v0) < G ? (p.B - v0) : G;
+  const int v0 = tile * G, nv = (p.B - v0) < G ? (p.B - v0) : G;
   const int row0 = v0 * Cm, nrows = nv * Cm, rowEnd = row0 + nrows;
   unsigned long long sbase = 0;
   if constexpr (DROP) { if (p.self.d_ff1.seed_ptr) sbase = *p.self.d_ff1.seed_ptr; }
@@ -1245,7 +1263,7 @@ __global__ __launch_bounds__(512) void glob_bwd_kernel(GlobBwd p) {
   f32x4_t acc[RF][3];
   const int pair = tid >> 1, half = tid & 1, pr_ = pair >> 3, ph = pair & 7, coff = ph * 48 + half * 24;
   int tsn = 0;
-  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  auto stamp = [&]() { if (p.tstamps && tile == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
   stamp();
 
   // ---- context block backward: rows = sequences (tile row r = sequence v0 + r) -------------------------------------------------
@@ -1861,6 +1879,21 @@ int launch_qkv_bwd(const QkvBwd& p_in, hipStream_t st) {
 }  // namespace coot
 
 namespace coot {
+static thread_local int g_glob_xcd_first = 0, g_glob_xcd_count = 8;
+void glob_xcd_set(int first, int count) {
+  if (first < 0 || count < 1 || first + count > 8) { first = 0; count = 8; }
+  g_glob_xcd_first = first; g_glob_xcd_count = count;
+}
+// grid of a single-launch global pass: slot s of XCD x is block 8 s + x (glob_tile_or_help)
+template <typename P>
+static int glob_grid(P& p, int tiles) {
+  p.tiles = tiles;
+  p.xcd_first = g_glob_xcd_first; p.xcd_count = g_glob_xcd_count;
+  p.tiles_per_xcd = (tiles + p.xcd_count - 1) / p.xcd_count;
+  // helper workgroups per XCD (0: the chains fill the chip themselves); the same number of helpers overall on fewer XCDs
+  p.warm_per_xcd = tiles >= 128 ? 0 : (tiles > 64 ? 8 : 16) * (8 / p.xcd_count);
+  return 8 * (p.tiles_per_xcd + p.warm_per_xcd);
+}
 bool glob_fwd_supported(int Cmax) { return Cmax >= 1 && Cmax <= 32; }
 int launch_glob_fwd(const GlobFwd& p_in, hipStream_t st) {
   COOT_REQUIRE(p_in.x && p_in.lens && p_in.hidden && p_in.pe && p_in.n_gain && p_in.n_bias && p_in.z0 && p_in.cq_in && p_in.pooled, "glob_fwd: null pointer");
@@ -1868,15 +1901,12 @@ int launch_glob_fwd(const GlobFwd& p_in, hipStream_t st) {
   if (p_in.B <= 0) return 0;
   GlobFwd p = p_in;
   const int G = 32 / p.Cmax, tiles = (p.B + G - 1) / G;
-  p.tiles = tiles;
-  p.warm_per_xcd = tiles >= 128 ? 0 : (tiles > 64 ? 8 : 16);  // helper workgroups per XCD (0: the chains fill the chip themselves)
+  const int grid = glob_grid(p, tiles);
   const bool drop = p.self.d_attn.thr || p.self.d_postln.thr || p.self.d_ff1.thr || p.self.d_ff2.thr;
   if (drop) COOT_REQUIRE(p.self.d_attn.thr && p.self.d_postln.thr && p.self.d_ff1.thr && p.self.d_ff2.thr && p.ctx.d_attn.thr && p.ctx.d_postln.thr &&
                          p.ctx.d_ff1.thr && p.ctx.d_ff2.thr, "glob_fwd: dropout on some sites only");
   const double T = (double)p.B * p.Cmax;
   void* ts = timing_begin(TIMING_GLOB, 2.0 * 384.0 * 384.0 * (8.0 * T + 4.0 * p.B), 0, st);
-  // grid: the chains first (block b -> XCD b % 8), then warm_per_xcd helpers for each of the 8 XCDs
-  const int grid = tiles + 8 * p.warm_per_xcd;
   if (drop) hipLaunchKernelGGL(glob_fwd_kernel<true>, dim3(grid), dim3(NTHR), 0, st, p);
   else hipLaunchKernelGGL(glob_fwd_kernel<false>, dim3(grid), dim3(NTHR), 0, st, p);
   timing_end(ts, st);
@@ -1889,14 +1919,12 @@ int launch_glob_bwd(const GlobBwd& p_in, hipStream_t st) {
   if (p_in.B <= 0) return 0;
   GlobBwd p = p_in;
   const int G = 32 / p.Cmax, tiles = (p.B + G - 1) / G;
-  p.tiles = tiles;
-  p.warm_per_xcd = tiles >= 128 ? 0 : (tiles > 64 ? 8 : 16);
+  const int grid = glob_grid(p, tiles);
   const bool drop = p.self.d_attn.thr || p.self.d_postln.thr || p.self.d_ff1.thr || p.self.d_ff2.thr;
   if (drop) COOT_REQUIRE(p.self.d_attn.thr && p.self.d_postln.thr && p.self.d_ff1.thr && p.self.d_ff2.thr && p.ctx.d_attn.thr && p.ctx.d_postln.thr &&
                          p.ctx.d_ff1.thr && p.ctx.d_ff2.thr && p.self.dr2m && p.ctx.dr2m, "glob_bwd: dropout on some sites only");
   const double T = (double)p.B * p.Cmax;
   void* ts = timing_begin(TIMING_GLOB, 2.0 * 384.0 * 384.0 * (6.0 * T + 6.0 * T + 4.0 * p.B), 0, st);
-  const int grid = tiles + 8 * p.warm_per_xcd;
   if (drop) hipLaunchKernelGGL(glob_bwd_kernel<true>, dim3(grid), dim3(NTHR), 0, st, p);
   else hipLaunchKernelGGL(glob_bwd_kernel<false>, dim3(grid), dim3(NTHR), 0, st, p);
   timing_end(ts, st);

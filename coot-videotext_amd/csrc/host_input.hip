@@ -77,3 +77,49 @@ extern "C" int coot_collate_level(const float* const* seq, const int64_t* rows, 
   for (auto& th : pool) th.join();
   return 0;
 }
+
+namespace {
+void pack_range(const float* const* seq, const int64_t* rows, const int32_t* cu, int64_t i0, int64_t i1, int64_t dim, int dst_bf16, void* dst) {
+  const size_t esz = dst_bf16 ? 2 : 4;
+  for (int64_t i = i0; i < i1; ++i) {
+    const int64_t r = rows[i];
+    if (r <= 0) continue;
+    char* d = (char*)dst + (size_t)cu[i] * dim * esz;
+    if (dst_bf16) convert_bf16_rne(seq[i], (uint16_t*)d, r * dim);
+    else std::memcpy(d, seq[i], (size_t)r * dim * 4);
+  }
+}
+}  // namespace
+
+extern "C" int coot_collate_packed(const float* const* seq, const int64_t* rows, int64_t n, int64_t dim, int dst_bf16, void* dst,
+                                   int32_t* cu_seqlens, int threads) {
+  COOT_REQUIRE(n >= 0 && dim > 0 && cu_seqlens, "coot_collate_packed: bad arguments n=%ld dim=%ld", (long)n, (long)dim);
+  COOT_REQUIRE(n == 0 || (seq && rows && dst), "coot_collate_packed: null pointer");
+  int64_t tot = 0;
+  cu_seqlens[0] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    COOT_REQUIRE(rows[i] >= 0 && (rows[i] == 0 || seq[i]), "coot_collate_packed: sequence %ld: %ld rows / null", (long)i, (long)rows[i]);
+    tot += rows[i];
+    COOT_REQUIRE(tot < (int64_t)1 << 31, "coot_collate_packed: more than 2^31 token rows");
+    cu_seqlens[i + 1] = (int32_t)tot;
+  }
+  int nt = threads < 1 ? 1 : threads;
+  if (nt > n) nt = (int)(n > 0 ? n : 1);
+  if (tot * dim * (dst_bf16 ? 2 : 4) < (1 << 20)) nt = 1;
+  if (nt == 1) { pack_range(seq, rows, cu_seqlens, 0, n, dim, dst_bf16, dst); return 0; }
+  // threads take runs of sequences with about the same number of ROWS (sequence lengths are ragged)
+  std::vector<int64_t> cut(nt + 1, n);
+  cut[0] = 0;
+  for (int t = 1; t < nt; ++t) {
+    const int64_t want = tot * t / nt;
+    int64_t i = cut[t - 1];
+    while (i < n && cu_seqlens[i] < want) ++i;
+    cut[t] = i;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(nt - 1);
+  for (int t = 1; t < nt; ++t) pool.emplace_back(pack_range, seq, rows, cu_seqlens, cut[t], cut[t + 1], dim, dst_bf16, dst);
+  pack_range(seq, rows, cu_seqlens, cut[0], cut[1], dim, dst_bf16, dst);
+  for (auto& th : pool) th.join();
+  return 0;
+}

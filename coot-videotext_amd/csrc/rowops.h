@@ -22,6 +22,7 @@ struct LnFwd {
   // source stays the padded [N, L, D] layout of the batch: sequences [0, N0) are rows n L0 + l of x, the others rows
   // (n - N0) L1 + l of x2.  pos_out[r] = position of row r within its sequence (for the positional encoding further down).
   const int* cu = nullptr; int nseq = 0, N0 = 0, L0 = 0, L1 = 0; int* pos_out = nullptr;
+  int src_packed = 0;  // with cu: the SOURCE x is packed as well ([R, D] in cu order, coot_collate_packed): row r reads row r
 };
 int launch_ln_fwd(const LnFwd& p, hipStream_t stream);
 

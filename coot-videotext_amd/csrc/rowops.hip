@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
     const int l = row - p.cu[lo];
     second = lo >= p.N0;
     xrow = second ? (long)(lo - p.N0) * p.L1 + l : (long)lo * p.L0 + l;
+    if (p.src_packed) { second = false; xrow = row; }  // packed at the source: the row is where it belongs already
     if (p.pos_out && lane == 0) p.pos_out[row] = l;
   }
   const void* xsrc = second ? p.x2 : p.x;

@@ -11,6 +11,10 @@ and lengths — built for one GPU with a lot of HBM behind a PCIe link:
   threads instead of Python slice assignments), optionally as bf16 (round-to-nearest-even — the first thing the networks do
   with a feature is LayerNorm statistics in fp32 and a bf16 MFMA operand, so bf16 staging halves the PCIe bytes; fp32 is the
   default and is bit-identical to the reference's batch);
+* ``collate_fn(..., packed=True)`` writes the batch PACKED AT THE SOURCE instead (``coot_collate_packed``): the frames of the B videos
+  and of the Nc clips back to back in one matrix, the words of the paragraphs and sentences in another, int32 row starts
+  (cu_seqlens) next to them — no padding row is written, crosses PCIe or is read from HBM (real ActivityNet clips average far
+  fewer than the 80-frame maximum).  ``unpack_batch`` rebuilds the reference's padded batch bit-exactly;
 * ``DeviceLoader`` moves each arena with ONE asynchronous copy on a copy stream, ``depth`` batches ahead of the consumer,
   into rotating device arenas; the consumer's stream only waits on the copy's event.  Host and device arenas are reused —
   nothing is allocated per batch after warm-up.
@@ -25,7 +29,7 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .model_retrieval import RetrievalDataBatchTuple
+from .model_retrieval import RetrievalDataBatchTuple, RetrievalPackedBatchTuple
 
 _ALIGN = 256
 
@@ -88,11 +92,12 @@ def _plan(segments: List[Tuple[str, Tuple[int, ...], torch.dtype]]):
 
 
 def collate_fn(data_batch: List[RetrievalDataPointTuple], arena: Optional[BatchArena] = None, bf16: bool = False,
-               threads: int = 4) -> RetrievalDataBatchTuple:
+               threads: int = 4, packed: bool = False):
     """coot/dataset_retrieval.py:335-463 with the batch written into ``arena`` (a fresh pageable one if None).  The returned
     tuple's tensors are views of the arena (``batch.arena`` / ``batch.arena_table`` describe it for DeviceLoader); padding
     lengths are the batch maxima exactly as in the reference (vid/par: longest video / paragraph, clip/sent: longest clip /
-    sentence of the batch), sentences are cut out of the paragraph features by the running pointer (:438-452)."""
+    sentence of the batch), sentences are cut out of the paragraph features by the running pointer (:438-452).
+    packed=True: a RetrievalPackedBatchTuple (no padding rows, cu_seqlens) instead of the padded RetrievalDataBatchTuple."""
     lib = _lib.load()
     B = len(data_batch)
     assert B > 0, "empty batch"
@@ -129,6 +134,33 @@ def collate_fn(data_batch: List[RetrievalDataPointTuple], arena: Optional[BatchA
     assert len(clip_len) == sum(clip_num) and len(sent_len) == sum(sent_num)
     Lv, Lp, Lc, Ls = max(vid_len), max(par_len), max(clip_len), max(sent_len)
     Nc, Ns = len(clip_len), len(sent_len)
+    if packed:
+        assert Nc == Ns, "one sentence per clip (coot/dataset_retrieval.py:404-452)"
+        tok_vis, tok_txt = sum(vid_len) + sum(clip_len), sum(par_len) + sum(sent_len)
+        table, total = _plan([
+            ("vis_tokens", (tok_vis, vid_dim), fdt), ("txt_tokens", (tok_txt, par_dim), fdt),
+            ("cu_vis", (B + Nc + 1,), torch.int32), ("cu_txt", (B + Ns + 1,), torch.int32),
+            ("vid_feat_len", (B,), torch.int64), ("par_feat_len", (B,), torch.int64), ("clip_num", (B,), torch.int64),
+            ("clip_feat_len", (Nc,), torch.int64), ("sent_num", (B,), torch.int64), ("sent_feat_len", (Ns,), torch.int64)])
+        arena.reserve(total)
+        t = {name: arena.view(off, shape, dtype) for name, (off, shape, dtype) in table.items()}
+        for name, vals in (("vid_feat_len", vid_len), ("par_feat_len", par_len), ("clip_num", clip_num), ("clip_feat_len", clip_len),
+                           ("sent_num", sent_num), ("sent_feat_len", sent_len)):
+            t[name].copy_(torch.tensor(vals, dtype=torch.int64))
+        for name, cu_name, plist, lens, dim in (("vis_tokens", "cu_vis", vid_ptr + clip_ptr, vid_len + clip_len, vid_dim),
+                                                ("txt_tokens", "cu_txt", par_ptr + sent_ptr, par_len + sent_len, par_dim)):
+            n = len(plist)
+            seq = (C.c_void_p * n)(*plist)
+            rows = (C.c_int64 * n)(*lens)
+            _lib.check(lib.coot_collate_packed(seq, rows, n, dim, int(bf16), t[name].data_ptr(), t[cu_name].data_ptr(), threads),
+                       "coot_collate_packed")
+        pb = RetrievalPackedBatchTuple(
+            [d.key for d in data_batch], [d.data_key for d in data_batch], [d.sentences for d in data_batch],
+            t["vis_tokens"], t["txt_tokens"], t["cu_vis"], t["cu_txt"], t["vid_feat_len"], t["par_feat_len"], t["clip_num"],
+            t["clip_feat_len"], t["sent_num"], t["sent_feat_len"], max_lens=(Lv, Lc, Lp, Ls), max_clip_num=max(clip_num),
+            max_sent_num=max(sent_num), tok_vis=tok_vis, tok_txt=tok_txt)
+        pb.arena, pb.arena_table = arena, table
+        return pb
     table, total = _plan([
         ("vid_feat", (B, Lv, vid_dim), fdt), ("clip_feat", (Nc, Lc, vid_dim), fdt),
         ("par_feat", (B, Lp, par_dim), fdt), ("sent_feat", (Ns, Ls, par_dim), fdt),
@@ -158,6 +190,36 @@ def collate_fn(data_batch: List[RetrievalDataPointTuple], arena: Optional[BatchA
     return batch
 
 
+PACKED_TENSOR_FIELDS = ("vis_tokens", "txt_tokens", "cu_vis", "cu_txt", "vid_feat_len", "par_feat_len", "clip_num", "clip_feat_len", "sent_num",
+                        "sent_feat_len")
+
+
+def unpack_batch(pb: RetrievalPackedBatchTuple) -> RetrievalDataBatchTuple:
+    """The reference's padded batch (coot/dataset_retrieval.py:335-463: zero-padded feature blocks, bool masks with True = padding)
+    rebuilt from a packed one, on the packed batch's device.  fp32 packed batches give the reference's tensors bit for bit."""
+    dev = pb.vis_tokens.device
+    Lv, Lc, Lp, Ls = pb.max_lens
+    B, Nc = pb.vid_feat_len.numel(), pb.clip_feat_len.numel()
+
+    def level(tokens, cu, lens, first, n, L):
+        out = torch.zeros(n, L, tokens.shape[1], dtype=torch.float32, device=dev)
+        mask = torch.ones(n, L, dtype=torch.bool, device=dev)
+        cu_h, lens_h = cu.cpu().tolist(), lens.cpu().tolist()
+        for i in range(n):
+            r0, r = cu_h[first + i], lens_h[i]
+            out[i, :r] = tokens[r0:r0 + r].float()
+            mask[i, :r] = False
+        return out, mask
+
+    vid, vid_m = level(pb.vis_tokens, pb.cu_vis, pb.vid_feat_len, 0, B, Lv)
+    clip, clip_m = level(pb.vis_tokens, pb.cu_vis, pb.clip_feat_len, B, Nc, Lc)
+    par, par_m = level(pb.txt_tokens, pb.cu_txt, pb.par_feat_len, 0, B, Lp)
+    sent, sent_m = level(pb.txt_tokens, pb.cu_txt, pb.sent_feat_len, B, Nc, Ls)
+    return RetrievalDataBatchTuple(pb.key, pb.data_key, pb.sentences, vid, vid_m, pb.vid_feat_len, par, par_m, pb.par_feat_len, pb.clip_num, clip,
+                                   clip_m, pb.clip_feat_len, pb.sent_num, sent, sent_m, pb.sent_feat_len, max_clip_num=pb.max_clip_num,
+                                   max_sent_num=pb.max_sent_num)
+
+
 TENSOR_FIELDS = ("vid_feat", "vid_feat_mask", "vid_feat_len", "par_feat", "par_feat_mask", "par_feat_len", "clip_num", "clip_feat",
                  "clip_feat_mask", "clip_feat_len", "sent_num", "sent_feat", "sent_feat_mask", "sent_feat_len")
 
@@ -168,9 +230,10 @@ class DeviceLoader:
     batch on a copy stream, the consumer's stream waits on its event only.  A device arena is rewritten only after the work
     the consumer enqueued on it (everything up to its next ``next()``) has finished; a host arena only after its copy has."""
 
-    def __init__(self, source: Iterable, depth: int = 2, device: str = "cuda", bf16: bool = False, threads: int = 8):
+    def __init__(self, source: Iterable, depth: int = 2, device: str = "cuda", bf16: bool = False, threads: int = 8, packed: bool = False):
         assert depth >= 1
         self.source, self.depth, self.device, self.bf16, self.threads = source, depth, torch.device(device), bf16, threads
+        self.packed = packed  # collate packed at the source: no padding rows in the arena; bf16 rows are consumed as they are
         self.copy_stream = torch.cuda.Stream(device=self.device)
         n = depth + 1
         self.host = [BatchArena(pin=True) for _ in range(n)]
@@ -184,7 +247,7 @@ class DeviceLoader:
     def _stage(self, item, k: int) -> RetrievalDataBatchTuple:
         if self.copied[k] is not None:
             self.copied[k].synchronize()  # the host arena is about to be rewritten
-        hb = collate_fn(item, self.host[k], self.bf16, self.threads) if isinstance(item, list) else item
+        hb = collate_fn(item, self.host[k], self.bf16, self.threads, packed=self.packed) if isinstance(item, list) else item
         nbytes = hb.arena.nbytes
         if self.dev[k].numel() < nbytes:
             # (Re)allocate ON the copy stream: the caching allocator may hand out a block the consumer's stream freed while kernels
@@ -204,10 +267,16 @@ class DeviceLoader:
             ev.record(self.copy_stream)
         self.copied[k] = ev
         fields = {}
-        for name in TENSOR_FIELDS:
+        is_packed = isinstance(hb, RetrievalPackedBatchTuple)
+        for name in (PACKED_TENSOR_FIELDS if is_packed else TENSOR_FIELDS):
             off, shape, dtype = hb.arena_table[name]
             nb = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
             fields[name] = self.dev[k][off:off + nb].view(dtype).view(*shape)
+        if is_packed:
+            db = RetrievalPackedBatchTuple(hb.key, hb.data_key, hb.sentences, **fields, max_lens=hb.max_lens, max_clip_num=hb.max_clip_num,
+                                           max_sent_num=hb.max_sent_num, tok_vis=hb.tok_vis, tok_txt=hb.tok_txt)
+            db.ready = ev
+            return db
         db = RetrievalDataBatchTuple(hb.key, hb.data_key, hb.sentences, **fields, max_clip_num=hb.max_clip_num,
                                      max_sent_num=hb.max_sent_num)
         db.ready = ev
@@ -235,7 +304,7 @@ class DeviceLoader:
         while queue:
             k, db = queue.pop(0)
             torch.cuda.current_stream(self.device).wait_event(db.ready)
-            if self.bf16:  # the kernels take fp32 features: widen on the device (HBM pass, not a PCIe one)
+            if self.bf16 and not isinstance(db, RetrievalPackedBatchTuple):  # padded batches: the kernels take fp32 features, widen on the device (HBM pass, not a PCIe one); packed bf16 rows are read as they are
                 for name in ("vid_feat", "clip_feat", "par_feat", "sent_feat"):
                     setattr(db, name, getattr(db, name).float())
             yield db

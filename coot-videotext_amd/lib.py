@@ -21,7 +21,7 @@ EXPORTS = [
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_tn_xcd_map", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
-    "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_contrastive_fwd_bwd_dp", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
+    "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_contrastive_fwd_bwd_dp", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
 ]
 
 
@@ -40,7 +40,8 @@ class ContrastiveConfig(C.Structure):
                 ("weight_context_internal", C.c_float)]
 
 
-STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH = 1, 2, 4  # coot_train_step do_optimizer bits (include/coot_hip.h)
+SOURCE_PADDED, SOURCE_PACKED_F32, SOURCE_PACKED_BF16 = 0, 1, 2  # COOT_SOURCE_* (include/coot_hip.h)
+STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH, STEP_DEFER_TEXT_JOIN = 1, 2, 4, 8  # coot_train_step do_optimizer bits (include/coot_hip.h)
 
 
 class StepConfig(C.Structure):
@@ -51,8 +52,8 @@ class StepConfig(C.Structure):
 
 
 class StepDims(C.Structure):
-    """coot_step_dims; tok_vis / tok_txt: packed token totals (0 = padded layout)."""
-    _fields_ = [(n, C.c_int) for n in ("B", "Nc", "Lv", "Lc", "Lp", "Ls", "Cmax_clip", "Cmax_sent", "tok_vis", "tok_txt")]
+    """coot_step_dims; tok_vis / tok_txt: packed token totals (0 = padded layout); source: SOURCE_* (who holds the token rows)."""
+    _fields_ = [(n, C.c_int) for n in ("B", "Nc", "Lv", "Lc", "Lp", "Ls", "Cmax_clip", "Cmax_sent", "tok_vis", "tok_txt", "source")]
 
 
 class TnProblem(C.Structure):
@@ -64,7 +65,7 @@ class TnProblem(C.Structure):
 
 class PackedSeqs(C.Structure):
     """coot_packed_seqs: device int32 row starts [nseq + 1] + their last entry on the host."""
-    _fields_ = [("cu_seqlens", C.c_void_p), ("total_tokens", C.c_int)]
+    _fields_ = [("cu_seqlens", C.c_void_p), ("total_tokens", C.c_int), ("source", C.c_int)]
 
 
 class StepBuffers(C.Structure):
@@ -154,6 +155,7 @@ def load():
     lib.coot_step_set_device_state.argtypes = [vp]
     lib.coot_train_step_phase.argtypes = [scp, sbp, sxp, sdp, vp, vp, sz, i32, u64, i64, i32, i32, vp]
     lib.coot_collate_level.argtypes = [vp, vp, i64, i64, i64, i32, vp, vp, i32]
+    lib.coot_collate_packed.argtypes = [vp, vp, i64, i64, i32, vp, vp, i32]
     lib.coot_sample_cycle_indices.argtypes = [vp, vp, i32, u64, vp, vp]
     lib.coot_step_set_cycle_indices.argtypes = [vp]
     lib.coot_contrastive_fwd_bwd_dp.argtypes = [C.POINTER(ContrastiveConfig), i32, i32, i32, i32, C.POINTER(vp * 6), C.POINTER(i64 * 6), vp,

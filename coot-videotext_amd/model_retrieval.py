@@ -57,6 +57,41 @@ class RetrievalDataBatchTuple:
                 setattr(self, name, value.cuda(non_blocking=non_blocking))
 
 
+@dataclass
+class RetrievalPackedBatchTuple:
+    """A batch PACKED AT THE SOURCE (dataset_retrieval.collate_fn(packed=True) / coot_collate_packed): the same videos,
+    clips, paragraphs and sentences as RetrievalDataBatchTuple (coot/dataset_retrieval.py:64-102) without a single padding row —
+    ``vis_tokens`` [tok_vis, vid_feat_dim] holds the frames of the B videos followed by the frames of the Nc clips, ``txt_tokens``
+    [tok_txt, text_feat_dim] the words of the B paragraphs followed by those of the Nc sentences (fp32 or bf16), ``cu_vis`` /
+    ``cu_txt`` the int32 row starts [B + Nc + 1].  Masks are implied by the lengths.  Consumed by RetrievalTrainer.train_step_native
+    (the local networks read the rows in place); ``dataset_retrieval.unpack_batch`` rebuilds the reference's padded batch."""
+    key: List[str]
+    data_key: List[str]
+    sentences: List[List[str]]
+    vis_tokens: torch.Tensor
+    txt_tokens: torch.Tensor
+    cu_vis: torch.Tensor
+    cu_txt: torch.Tensor
+    vid_feat_len: torch.Tensor
+    par_feat_len: torch.Tensor
+    clip_num: torch.Tensor
+    clip_feat_len: torch.Tensor
+    sent_num: torch.Tensor
+    sent_feat_len: torch.Tensor
+    max_lens: Tuple[int, int, int, int] = (0, 0, 0, 0)   # host: longest video, clip, paragraph, sentence (the padded layout's L)
+    max_clip_num: Optional[int] = None
+    max_sent_num: Optional[int] = None
+    tok_vis: int = 0
+    tok_txt: int = 0
+
+    @property
+    def device(self) -> torch.device:
+        return self.vis_tokens.device
+
+    def dict(self) -> Dict[str, Any]:
+        return dict(self.__dict__)
+
+
 def packed_index(len_a: torch.Tensor, len_b: torch.Tensor) -> Tuple[torch.Tensor, int]:
     """cu_seqlens of two sets of sequences through one local network (set a first): int32 [Na + Nb + 1] exclusive prefix sums of
     the lengths on the lengths' device, and the total as a host int (one device -> host read unless the lengths live on the

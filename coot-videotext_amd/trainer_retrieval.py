@@ -20,7 +20,7 @@ import ctypes as C
 from . import lib as _lib
 from . import loss_fn
 from .config import RetrievalConfig, RetrievalNetworksConst
-from .model_retrieval import (RetrievalDataBatchTuple, RetrievalModelManager, RetrievalTextEmbTuple,
+from .model_retrieval import (RetrievalDataBatchTuple, RetrievalModelManager, RetrievalPackedBatchTuple, RetrievalTextEmbTuple,
                               RetrievalVisualEmbTuple)
 from .retrieval import compute_retrieval, compute_retrieval_device  # noqa: F401
 
@@ -306,10 +306,11 @@ class RetrievalTrainer:
             return
         if batch.max_clip_num is None or batch.max_sent_num is None:
             batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
-        batch.max_clip_num, batch.max_sent_num = dp.global_max_pair(batch.max_clip_num, batch.max_sent_num, batch.vid_feat.device)
+        batch.max_clip_num, batch.max_sent_num = dp.global_max_pair(batch.max_clip_num, batch.max_sent_num, batch.clip_num.device)
         batch.global_max_synced = True
 
     def _step_impl(self, batch, vid_counts=None, clip_counts=None):
+        self.join_streams()  # (a native step with defer_join may still be updating the text networks on its side stream)
         self._sync_global_max(batch)
         nets = list(self.model_mgr.model_dict.values())
         if getattr(self, "_seed_dev", None) is None:
@@ -351,7 +352,7 @@ class RetrievalTrainer:
     def _native_setup(self, batch: RetrievalDataBatchTuple):
         lib = _lib.load()
         nets = [self.model_mgr.model_dict[k] for k in RetrievalNetworksConst.values()]
-        dev = batch.vid_feat.device
+        dev = batch.vis_tokens.device if isinstance(batch, RetrievalPackedBatchTuple) else batch.vid_feat.device
         st = getattr(self, "_native", None)
         if st is None:
             st = type("NativeState", (), {})()
@@ -404,27 +405,39 @@ class RetrievalTrainer:
             st.bufs.params[i], st.bufs.grads[i], st.bufs.wpack[i] = n._flat.data_ptr(), n._grad_flat.data_ptr(), n._wpack.data_ptr()
             st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i] = st.m[i].data_ptr(), st.v[i].data_ptr(), st.decay[i].data_ptr()
             st.bufs.pe[i] = n.embedding.pe.data_ptr()
+        src_packed = isinstance(batch, RetrievalPackedBatchTuple)  # packed at the source (dataset_retrieval.collate_fn(packed=True))
         if batch.max_clip_num is None or batch.max_sent_num is None:
             batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
         packed = getattr(batch, "cu_vis", None) is not None and getattr(batch, "cu_txt", None) is not None
         tok_vis, tok_txt = (int(batch.tok_vis), int(batch.tok_txt)) if packed else (0, 0)
-        key = (batch.vid_feat.shape, batch.clip_feat.shape, batch.par_feat.shape, batch.sent_feat.shape, batch.max_clip_num, batch.max_sent_num,
-               tok_vis, tok_txt)
-        if key != st.dims_key:
+        if src_packed:
+            B, Nc = batch.vid_feat_len.numel(), batch.clip_feat_len.numel()
+            Lv, Lc, Lp, Ls = (int(v) for v in batch.max_lens)
+            source = _lib.SOURCE_PACKED_BF16 if batch.vis_tokens.dtype == torch.bfloat16 else _lib.SOURCE_PACKED_F32
+            assert batch.txt_tokens.dtype == batch.vis_tokens.dtype and batch.sent_feat_len.numel() == Nc and batch.par_feat_len.numel() == B
+            key = ("packed", B, Nc, Lv, Lc, Lp, Ls, batch.max_clip_num, batch.max_sent_num, tok_vis, tok_txt, source)
+        else:
             B, Lv, _ = batch.vid_feat.shape
             Nc, Lc, _ = batch.clip_feat.shape
-            st.dims = _lib.StepDims(B, Nc, Lv, Lc, batch.par_feat.shape[1], batch.sent_feat.shape[1], batch.max_clip_num, batch.max_sent_num,
-                                    tok_vis, tok_txt)
+            Lp, Ls, source = batch.par_feat.shape[1], batch.sent_feat.shape[1], _lib.SOURCE_PADDED
             assert batch.sent_feat.shape[0] == Nc and batch.par_feat.shape[0] == B
+            key = (batch.vid_feat.shape, batch.clip_feat.shape, batch.par_feat.shape, batch.sent_feat.shape, batch.max_clip_num, batch.max_sent_num,
+                   tok_vis, tok_txt)
+        if key != st.dims_key:
+            st.dims = _lib.StepDims(B, Nc, Lv, Lc, Lp, Ls, batch.max_clip_num, batch.max_sent_num, tok_vis, tok_txt, source)
             need = lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims))
             if getattr(st, "ws", None) is None or st.ws.numel() < need:  # ragged batches change shape every step: grow only
                 st.ws = torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev)
             st.dims_key = key
         x = _lib.StepBatch()
-        for f in ("vid_feat", "clip_feat", "par_feat", "sent_feat"):
-            t_ = getattr(batch, f)
-            assert t_.dtype == torch.float32 and t_.is_contiguous(), f
-            setattr(x, f, t_.data_ptr())
+        if src_packed:
+            assert batch.vis_tokens.is_contiguous() and batch.txt_tokens.is_contiguous() and batch.vis_tokens.shape[0] == tok_vis
+            x.vid_feat, x.par_feat = batch.vis_tokens.data_ptr(), batch.txt_tokens.data_ptr()
+        else:
+            for f in ("vid_feat", "clip_feat", "par_feat", "sent_feat"):
+                t_ = getattr(batch, f)
+                assert t_.dtype == torch.float32 and t_.is_contiguous(), f
+                setattr(x, f, t_.data_ptr())
         for f, src in (("vid_len", "vid_feat_len"), ("clip_len", "clip_feat_len"), ("par_len", "par_feat_len"),
                        ("sent_len", "sent_feat_len"), ("clip_num", "clip_num"), ("sent_num", "sent_num")):
             t_ = getattr(batch, src)
@@ -441,6 +454,7 @@ class RetrievalTrainer:
         and, when native steps have run, the library's optimizer state — the flat first / second moment arenas of the four
         networks and the step count (coot_train_step keeps them outside torch.optim, so the torch state dict alone would
         resume with zero moments and bias-correction step 1)."""
+        self.join_streams()
         out: Dict[str, Any] = {"optimizer": self.optimizer.state_dict() if self.optimizer is not None else None, "total_step": self.total_step}
         st = getattr(self, "_native", None)
         if st is not None:
@@ -483,7 +497,7 @@ class RetrievalTrainer:
         buffers.  Same masks, same update as the eager native step (tests/test_gpu_path.py).  Falls back to the eager call
         for the first step of a shape (lazy state is created outside a capture)."""
         lib = _lib.load()
-        if getattr(batch, "cu_vis", None) is not None:
+        if getattr(batch, "cu_vis", None) is not None or isinstance(batch, RetrievalPackedBatchTuple):
             # packed (cu_seqlens) batches carry their token totals as host scalars of the launches and change them every batch:
             # the captured step would replay the first batch's totals.  They run eagerly (the caller falls back on None).
             return None
@@ -598,8 +612,18 @@ class RetrievalTrainer:
             n.mark_packed()
         return st.losses[0], st.losses[1], st.losses[2]
 
+    def join_streams(self) -> None:
+        """Orders the current stream after the native step's text stream (train_step_native(defer_join=True) leaves the text side's
+        update running there).  Call before reading the text networks' parameters, weight packs or the step's losses on the current
+        stream (validation, checkpoints, the autograd route); a torch.cuda.synchronize() does the same for the host."""
+        st = getattr(self, "_native", None)
+        if st is not None and getattr(st, "join_pending", False):
+            torch.cuda.current_stream().wait_stream(st.streams[1])
+            st.join_pending = False
+
     def train_step_native(self, batch: RetrievalDataBatchTuple, do_optimizer: bool = True, seed: Optional[int] = None,
-                          vid_counts=None, clip_counts=None, use_graph=False, cc_indices: Optional[torch.Tensor] = None):
+                          vid_counts=None, clip_counts=None, use_graph=False, cc_indices: Optional[torch.Tensor] = None,
+                          defer_join: bool = False):
         """One optimisation step as ONE call into libcoot_hip.so (coot_train_step): forward of both sides on two
         HIP streams, losses, backward, fused Adam — no Python between the kernel launches.  Returns views of the
         device loss vector (total, contrastive, cycle-consistency).  With ``self.dp`` set the step runs as native phases
@@ -630,6 +654,11 @@ class RetrievalTrainer:
             flags |= _lib.STEP_OPTIMIZER | _lib.STEP_REPACK
         if all(n.pack_is_fresh() for n in st.nets):
             flags |= _lib.STEP_PACKS_FRESH
+        if defer_join and do_optimizer:
+            flags |= _lib.STEP_DEFER_TEXT_JOIN
+            st.join_pending = True
+        else:
+            st.join_pending = False  # this call ends with the text stream joined into the current one
         if cc_indices is not None:  # a given draw of the cycle-consistency positions ([2B] int64: clips, then sentences)
             assert cc_indices.dtype == torch.int64 and cc_indices.is_cuda and cc_indices.numel() == 2 * st.dims.B
             lib.coot_step_set_cycle_indices(cc_indices.data_ptr())
@@ -654,7 +683,7 @@ class RetrievalTrainer:
         arenas, fused Adam.  Same kernels and the same C sequencing as the single-GPU native step."""
         lib = _lib.load()
         dp = self.dp  # every collective of the step goes through this object (dist.DataParallelContext)
-        dev = batch.vid_feat.device
+        dev = batch.vis_tokens.device if isinstance(batch, RetrievalPackedBatchTuple) else batch.vid_feat.device
         self._sync_global_max(batch)
         st, x = self._native_setup(batch)
         if self.optimizer is not None:
@@ -892,6 +921,7 @@ class RetrievalTrainer:
         sent_emb / vid_context / par_context the L2-normalised rows plus ``<name>_before_norm``); ``save_path`` writes it
         (``.h5`` through h5py when that is importable — the consumers' format, mart/recursive_caption_dataset.py:159-201 —
         otherwise ``.npz`` with the same keys)."""
+        self.join_streams()
         self.model_mgr.set_all_models_eval()
         keys = ["vid_emb", "par_emb", "clip_emb", "sent_emb"] + (["vid_context", "par_context"] if save_embs else [])
         coll: Dict[str, list] = {k: [] for k in keys}

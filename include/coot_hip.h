@@ -100,8 +100,16 @@ int coot_nets_pack_weights(int n, const coot_net_config* const* cfgs, const floa
  * the launches).  The input stays the reference's padded feats (+ lengths): the input LayerNorm gathers the valid rows, the
  * token-tile chains are row independent, attention / pooling / positional encoding take the sequence boundaries from cu_seqlens.
  * Pooled outputs and all gradients equal the padded computation (padded rows carry exactly zero pooling weight, poolers.py:190).
- * NULL (or a network / size the packed path does not cover): the padded layout.  Forward and backward take the same decision. */
-typedef struct coot_packed_seqs { const int32_t* cu_seqlens; int total_tokens; } coot_packed_seqs;
+ * NULL (or a network / size the packed path does not cover): the padded layout.  Forward and backward take the same decision.
+ * source: where the token rows come from.  COOT_SOURCE_PADDED (0): feats / feats2 are the reference's zero-padded fp32 tensors
+ * (coot/dataset_retrieval.py:335-463), the input LayerNorm gathers the valid rows.  COOT_SOURCE_PACKED_F32 / _BF16: `feats` IS the
+ * packed matrix [total_tokens, input_dim] (rows in cu_seqlens order, fp32 resp. bf16 bits; feats2 is ignored) as
+ * coot_collate_packed writes it — no padding ever crosses PCIe or is read from HBM.  A packed source needs the packed path (it
+ * cannot fall back to the padded layout): the call fails where packed rows are not supported. */
+#define COOT_SOURCE_PADDED 0
+#define COOT_SOURCE_PACKED_F32 1
+#define COOT_SOURCE_PACKED_BF16 2
+typedef struct coot_packed_seqs { const int32_t* cu_seqlens; int total_tokens; int source; } coot_packed_seqs;
 size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int L, int N2, int L2);
 size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int L, int N2, int L2);
 /* Optional SECOND SEGMENT (feats2 [N2, L2, input_dim], lengths2 [N2]; N2 = 0 / NULL when unused): a second set
@@ -206,6 +214,14 @@ int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* 
  * splits the sequences over that many host threads. */
 int coot_collate_level(const float* const* seq, const int64_t* rows, int64_t n, int64_t dim, int64_t max_rows, int dst_bf16,
                        void* dst, uint8_t* mask, int threads);
+/* Packed at the source ("produce packed varlen features directly in pinned memory, drop the zero padding"): the same n
+ * sequences written BACK TO BACK, dst [sum rows, dim] (fp32 copy or bf16 round-to-nearest-even), and their row starts
+ * cu_seqlens [n + 1] (int32, cu_seqlens[0] = 0) — exactly what coot_packed_seqs / coot_step_batch.cu_vis take, so one call per side
+ * (the B videos followed by the Nc clips; the B paragraphs followed by the Nc sentences) produces the side's input.  Replaces the
+ * padded blocks of RetrievalDataset.collate_fn (coot/dataset_retrieval.py:362-364, :378-380, :404-414, :438-452); the padded
+ * batch is recoverable bit-exactly (dataset_retrieval.unpack_batch, tests/test_input_pipeline.py).  Host-only. */
+int coot_collate_packed(const float* const* seq, const int64_t* rows, int64_t n, int64_t dim, int dst_bf16, void* dst,
+                        int32_t* cu_seqlens, int threads);
 
 /* ---- retrieval ranking on the device -----------------------------------------------------------
  * validate_epoch's metric tail (coot/trainer_retrieval.py:397-402, :425-436) + nntrainer/retrieval.py:31-98 for one pair
@@ -236,6 +252,9 @@ typedef struct coot_step_dims {
   int B, Nc, Lv, Lc, Lp, Ls, Cmax_clip, Cmax_sent;
   int tok_vis, tok_txt;   /* packed rows (coot_packed_seqs): valid frames of the B videos + Nc clips, valid words of the B paragraphs +
                              Nc sentences (host values; 0 = padded layout); used with coot_step_batch.cu_vis / cu_txt */
+  int source;             /* COOT_SOURCE_*: PADDED = the four padded fp32 tensors of the reference's batch; PACKED_F32 / PACKED_BF16 =
+                             coot_step_batch.vid_feat / par_feat point at the packed matrices [tok_vis, Dv] / [tok_txt, Dt] of
+                             coot_collate_packed (videos then clips, paragraphs then sentences), clip_feat / sent_feat are unused */
 } coot_step_dims;
 typedef struct coot_step_buffers {
   float* params[4]; float* grads[4]; void* wpack[4];       /* flat arenas (coot_net_param_info layout), bf16 pack */
@@ -259,6 +278,12 @@ size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_di
 #define COOT_STEP_REPACK 2      /* rebuild the bf16 weight packs right after the update (off the next step's critical path)  */
 #define COOT_STEP_PACKS_FRESH 4 /* wpack[] is current (previous step ran with REPACK and nothing else touched the parameters):
                                    skip the packing at the start of the step                                                */
+#define COOT_STEP_DEFER_TEXT_JOIN 8 /* on return main_s is ordered after the VIDEO side only: the text side's tail (its Adam update,
+                                   weight packs, losses[0] = total) is still running on side_t.  The next coot_train_step with the
+                                   same streams needs no join (its text side continues on side_t in order, its video side touches
+                                   nothing the text tail writes): back-to-back steps overlap that tail (~30 us) with the next
+                                   forward.  Before anything else reads the text networks' parameters / packs or `losses` from
+                                   another stream, the CALLER orders that stream after side_t.                              */
 int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
                     const coot_step_dims* dims, float* losses, void* workspace, size_t workspace_bytes, int train,
                     uint64_t seed, int64_t step, int do_optimizer, coot_stream_t main_stream, coot_stream_t side_v,

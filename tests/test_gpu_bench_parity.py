@@ -144,7 +144,7 @@ def test_bench_shape_autograd_route(env, golden_dir, name):
         print(f"[{name}] R@1/5/10 {tag}: {got} vs reference {ref}  (max diff {diff_pp:.3f} pp at N = {e1.shape[0]}; "
               f"{flips} of {2 * e1.shape[0] * (e1.shape[0] - 1)} comparisons differ, largest reference margin among them {margin:.2e})")
         assert margin < 1e-3, (tag, flips, margin)
-        assert flips <= 0.01 * 2 * e1.shape[0] * (e1.shape[0] - 1), (tag, flips)
+        assert flips <= 0.05 * 2 * e1.shape[0] * (e1.shape[0] - 1), (tag, flips)  # (untrained weights: a row's similarities differ in the 4th decimal)
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -918,3 +918,29 @@ def test_contrastive_parts_add_up(env):
     for n, a, b in zip(names, g_full, g_two):
         assert float(a.abs().max()) > 0, n
         assert torch.equal(a, b), n
+
+
+def test_deferred_text_join_gives_the_same_training_trajectory(env):
+    """train_step_native(defer_join=True) (COOT_STEP_DEFER_TEXT_JOIN: the text side's update tail overlaps the next step's forward)
+    is a re-ordering only: after the same steps the parameters of all four networks are bit-identical to the joined run, and
+    join_streams() makes the losses readable on the current stream."""
+    torch, cva = env
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batch = cva.synthetic.make_batch(7, 6, [1, 2, 3, 4, 2, 1], 12, 10, 9, 6, dims[0], dims[1], ragged=False)
+    res = []
+    for defer in (False, True):
+        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.1, cc_weight=0.01)
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg_x, mgr)
+        for it in range(6):
+            out = tr.train_step_native(batch, seed=100 + it, defer_join=defer)
+        tr.join_streams()
+        losses = [float(v) for v in out]
+        torch.cuda.synchronize()
+        res.append((losses, [n._flat.detach().clone() for n in mgr.model_dict.values()]))
+    (la, pa), (lb, pb) = res
+    assert la == lb, (la, lb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)

@@ -187,3 +187,102 @@ def test_collate_random_shapes_match_layout_rule():
         for f in FIELDS:
             g = getattr(got, f).numpy()
             assert g.shape == want[f].shape and np.array_equal(g, want[f]), (trial, f)
+
+
+# ---- packed at the source: coot_collate_packed / collate_fn(packed=True) / unpack_batch ---------------------------
+
+def test_packed_collation_unpacks_to_the_reference_batch(golden_dir):
+    """collate_fn(packed=True) writes no padding row; unpack_batch() of it is the batch RetrievalDataset.collate_fn itself produced
+    (tests/golden/collate.npz), bit for bit — features, masks, lengths."""
+    import torch
+    from coot_videotext_amd.dataset_retrieval import collate_fn, unpack_batch
+    g = np.load(os.path.join(golden_dir, "collate.npz"))
+    for name in ("ragged", "single"):
+        seed, B, dv, dt = (int(v) for v in g[name + "_args"])
+        pb = collate_fn(_points(seed, B, dv, dt), packed=True)
+        Nc = int(g[f"{name}_clip_num"].sum())
+        assert pb.vis_tokens.shape == (int(g[f"{name}_vid_feat_len"].sum() + g[f"{name}_clip_feat_len"].sum()), dv)
+        assert pb.txt_tokens.shape == (int(g[f"{name}_par_feat_len"].sum() + g[f"{name}_sent_feat_len"].sum()), dt)
+        assert pb.tok_vis == pb.vis_tokens.shape[0] and pb.tok_txt == pb.txt_tokens.shape[0]
+        lens_v = np.concatenate([g[f"{name}_vid_feat_len"], g[f"{name}_clip_feat_len"]])
+        assert pb.cu_vis.dtype == torch.int32 and np.array_equal(pb.cu_vis.numpy(), np.concatenate([[0], np.cumsum(lens_v)]))
+        assert pb.cu_vis.numel() == B + Nc + 1 and pb.max_lens == tuple(int(g[f"{name}_{k}"].shape[1]) for k in ("vid_feat", "clip_feat", "par_feat", "sent_feat"))
+        batch = unpack_batch(pb)
+        for f in FIELDS:
+            got, ref = getattr(batch, f).numpy(), g[f"{name}_{f}"]
+            assert got.dtype == ref.dtype and got.shape == ref.shape and np.array_equal(got, ref), (name, f)
+
+
+def test_packed_collation_threads_bf16_and_bad_arguments():
+    """The threaded path (runs of sequences with equal row counts per thread) equals the serial one; bf16 rows are torch's
+    round-to-nearest-even cast of the fp32 rows; an arena reused for a smaller batch leaves nothing behind that is read."""
+    import ctypes as C
+    import torch
+    import coot_videotext_amd as cva
+    from coot_videotext_amd.dataset_retrieval import BatchArena, collate_fn, unpack_batch
+    pts = _points(3, 16, 256, 64, max_frames=40, max_words=30)
+    a = collate_fn(pts, None, threads=1, packed=True)
+    arena = BatchArena(pin=False)
+    b = collate_fn(pts, arena, threads=5, packed=True)
+    assert a.vis_tokens.numel() * 4 > (1 << 20)
+    for f in ("vis_tokens", "txt_tokens", "cu_vis", "cu_txt", "clip_feat_len", "sent_num"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    h = collate_fn(pts, None, bf16=True, threads=3, packed=True)
+    assert h.vis_tokens.dtype == torch.bfloat16 and torch.equal(h.vis_tokens, a.vis_tokens.to(torch.bfloat16)) and torch.equal(h.txt_tokens, a.txt_tokens.to(torch.bfloat16))
+    small = _points(4, 3, 256, 64, max_frames=9, max_words=7)
+    s1, s2 = collate_fn(small, arena, packed=True), collate_fn(small, None, packed=True)
+    ub1, ub2 = unpack_batch(s1), unpack_batch(s2)
+    for f in FIELDS:
+        assert torch.equal(getattr(ub1, f), getattr(ub2, f)), f
+    lib = cva.lib.load()
+    cu = (C.c_int32 * 3)()
+    rows = (C.c_int64 * 2)(1, -1)
+    x = np.zeros((4, 8), np.float32)
+    seq = (C.c_void_p * 2)(x.ctypes.data, x.ctypes.data)
+    out = np.zeros((8, 8), np.float32)
+    assert lib.coot_collate_packed(seq, rows, 2, 8, 0, out.ctypes.data, cu, 1) != 0 and b"rows" in lib.coot_last_error()
+    assert lib.coot_collate_packed(seq, rows, 2, 8, 0, out.ctypes.data, None, 1) != 0
+
+
+@pytest.mark.gpu
+def test_packed_source_step_equals_the_padded_batch_step():
+    """coot_train_step on a batch packed at the source (COOT_SOURCE_PACKED_F32: the input LayerNorm reads the packed rows in place)
+    gives the losses and gradients of the same batch in the reference's padded layout with cu_seqlens (the gather path) — the
+    same rows, the same arithmetic: identical up to the summation order of atomics; bf16 rows (COOT_SOURCE_PACKED_BF16) within
+    the bf16 rounding of the features.  Through DeviceLoader(packed=True), as a training loop would."""
+    import torch
+    import coot_videotext_amd as cva
+    from coot_videotext_amd.dataset_retrieval import DeviceLoader, collate_fn, unpack_batch
+    from tests import helpers as H
+    dims = (256, 128, 384, 8, 384, 768)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 3 + i, scale=0.05) for i in range(4)]
+    pts = _points(9, 12, dims[0], dims[1], max_frames=80, max_words=40)   # ~2 000 valid frames: the fused packed path on the video side
+    res = {}
+    for mode in ("padded+cu", "packed f32", "packed bf16"):
+        cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.01)
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg, mgr)
+        if mode == "padded+cu":
+            batch = collate_fn(pts)
+            batch.to_cuda()
+            cva.attach_packed_index(batch)
+        else:
+            batch = next(iter(DeviceLoader([pts], depth=1, bf16=(mode == "packed bf16"), packed=True)))
+            assert isinstance(batch, cva.RetrievalPackedBatchTuple) and batch.vis_tokens.is_cuda
+        B = len(pts)
+        idx = torch.zeros(2 * B, dtype=torch.int64, device="cuda")
+        losses = [float(v) for v in tr.train_step_native(batch, do_optimizer=False, cc_indices=idx)]
+        torch.cuda.synchronize()
+        res[mode] = (losses, [n._grad_flat.detach().cpu().numpy().copy() for n in mgr.model_dict.values()])
+        if mode == "packed f32":  # the packed batch is the padded one without its padding
+            ub, hb = unpack_batch(batch), collate_fn(pts)
+            for f in FIELDS:
+                assert torch.equal(getattr(ub, f).cpu(), getattr(hb, f)), f
+    (l0, g0), (l1, g1), (l2, g2) = res["padded+cu"], res["packed f32"], res["packed bf16"]
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
+    for a, b_ in zip(g0, g1):
+        assert float(np.abs(a - b_).max()) <= 2e-4 * float(np.abs(a).max())
+    assert np.allclose(l0, l2, rtol=5e-3), (l0, l2)
+    for a, b_ in zip(g0, g2):
+        assert H.cosine_flat(a, b_) > 0.999
