@@ -86,42 +86,53 @@ def algorithmic_flops_per_step(w, cfg):
     return fwd, 3 * fwd
 
 
-def cpu_baseline(w, budget_s=25.0):
+def cpu_baseline(w, budget_s=22.0, budget_1t_s=10.0):
     """CPU baseline ("port"): oracle/coot_torch_cpu.py — the train step restated with the same PyTorch CPU ops the
     reference's modules issue (fp32, autograd backward, torch.optim.Adam), dropout on, on the FULL per-GPU batch of the
     workload (same shapes as the GPU step).  Median step time over ~budget_s seconds of CPU work (at least 2 steps after a
     warm-up step); clip-pairs/s = clips per step / median step time.  Intra-op threads are capped at 32: on a many-core host
-    more threads are SLOWER for these op sizes ("cores" = threads actually used).  The reference itself (/root/reference)
-    does not exist on the GPU box; SURVEY 8d quotes its own time in the build container (136 clip-pairs/s on 8 cores)."""
+    more threads are SLOWER for these op sizes ("cores" = threads actually used).  A second, ONE-thread figure (SURVEY 8d asks
+    for N = 1 next to N = all cores) on a bounded sample — the first quarter of the batch's videos with their clips, ~budget_1t_s
+    seconds — rides along as "value_1thread".  The reference itself (/root/reference) does not exist on the GPU box; SURVEY 8d
+    quotes its own time in the build container (136 clip-pairs/s on 8 cores, ANet shape)."""
     from oracle import coot_oracle as O
     from oracle import coot_torch_cpu as T
     from tests import helpers as H
     Bs = w["B"]
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     dims = (w["Dv"], w["Dt"], 384, 8, 384, 768)
     cfgs = H.full_cfgs(*dims)
     Ps = [T.to_torch_params(O.make_params(cfgs[i], 5 + 10 * i, dtype=np.float32)) for i in range(4)]
-    counts = w["C"] if w["C"] else O.anet_like_counts(4321, Bs)   # C = 0: the ragged workload (the CPU path pads, as the reference does)
-    b = O.make_batch(1, Bs, counts, w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=not w["C"], dtype=np.float32)
-    idx = np.zeros(Bs, dtype=np.int64)
     opt = torch.optim.Adam([v for P in Ps for k, v in P.items() if v.requires_grad], lr=1e-3, weight_decay=2e-5)
 
-    def one():
-        T.full_step(cfgs, Ps, b, idx, idx, H.ANET_W, 0.2, 0.01, p_drop=0.025, train=True)
-        opt.step()
+    def timed(nvid, threads, budget, max_steps):
+        torch.set_num_threads(threads)
+        counts = w["C"] if w["C"] else O.anet_like_counts(4321, nvid)   # C = 0: the ragged workload (the CPU path pads, as the reference does)
+        b = O.make_batch(1, nvid, counts, w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=not w["C"], dtype=np.float32)
+        idx = np.zeros(nvid, dtype=np.int64)
 
-    t_all = time.perf_counter()
-    one()  # warm-up
-    times = []
-    while len(times) < 2 or (time.perf_counter() - t_all < budget_s and len(times) < 30):
-        t0 = time.perf_counter()
-        one()
-        times.append(time.perf_counter() - t0)
-    dt = float(np.median(times))
-    return {"value": float(np.sum(b["clip_num"])) / dt, "unit": "clip-pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
+        def one():
+            T.full_step(cfgs, Ps, b, idx, idx, H.ANET_W, 0.2, 0.01, p_drop=0.025, train=True)
+            opt.step()
+
+        t_all = time.perf_counter()
+        one()  # warm-up
+        times = []
+        while len(times) < 2 or (time.perf_counter() - t_all < budget and len(times) < max_steps):
+            t0 = time.perf_counter()
+            one()
+            times.append(time.perf_counter() - t0)
+        return float(np.sum(b["clip_num"])), float(np.median(times)), len(times)
+
+    threads = max(1, min(32, os.cpu_count() or 1))
+    clips, dt, n = timed(Bs, threads, budget_s, 30)
+    nv1 = max(2, Bs // 4)
+    clips1, dt1, n1 = timed(nv1, 1, budget_1t_s, 4)
+    return {"value": clips / dt, "unit": "clip-pairs/s", "cores": threads, "kind": "port",
             "sample": f"PyTorch-CPU fp32 restatement (oracle/coot_torch_cpu.py: same ATen ops as the reference modules, autograd, "
-                      f"Adam, dropout on), the full per-GPU batch: {Bs} videos, {int(np.sum(b['clip_num']))} clips of the same shapes, median of "
-                      f"{len(times)} steps, {dt:.3f} s/step, host cpu_count {os.cpu_count()}"}
+                      f"Adam, dropout on), the full per-GPU batch: {Bs} videos, {int(clips)} clips of the same shapes, median of "
+                      f"{n} steps, {dt:.3f} s/step, host cpu_count {os.cpu_count()}",
+            "value_1thread": clips1 / dt1, "sample_1thread": f"the same step with torch.set_num_threads(1) on the first {nv1} videos "
+                      f"({int(clips1)} clips), median of {n1} steps, {dt1:.3f} s/step"}
 
 
 def spawn_ranks(n: int) -> int:

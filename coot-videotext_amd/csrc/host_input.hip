@@ -5,9 +5,13 @@
 // padded block (fp32, or bf16 with round-to-nearest-even: half the PCIe bytes) and its mask straight into the caller's
 // arena — normally ONE pinned allocation holding all four levels, lengths and masks, moved with ONE hipMemcpyAsync on a copy
 // stream (dataset_retrieval.py: BatchArena / DeviceLoader).  Pure host code: no kernel, no stream.
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/coot_hip.h"
@@ -31,6 +35,76 @@ COOT_HOST_CLONES void convert_bf16_rne(const float* __restrict__ s, uint16_t* __
     o[k] = (u & 0x7fffffffu) > 0x7f800000u ? (uint16_t)0x7fc0 : (uint16_t)r;
   }
 }
+
+// Persistent host workers.  A batch is ~1-2 ms of copy / conversion work per level; starting 16 std::threads per call cost as much as
+// the work they did (tools/bench_input.py: 32 and 64 threads were SLOWER than 16).  The pool is created on first use, grows to the
+// largest thread count asked for, and lives until the library is unloaded; run() hands out [0, n) job indices, the caller works too.
+class HostPool {
+ public:
+  ~HostPool() {
+    if (pid_ != getpid()) return;  // a forked child: the workers never existed here
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : *workers_) t.join();
+  }
+  void run(int njobs, const std::function<void(int)>& job) {
+    if (njobs <= 1) { if (njobs == 1) job(0); return; }
+    std::unique_lock<std::mutex> call(call_mu_);  // one parallel region at a time (collation calls come from one loader thread)
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (pid_ != getpid()) {  // first use after a fork (DataLoader worker processes): threads do not survive it — start over
+        workers_ = new std::vector<std::thread>();  // (the parent's std::thread objects are left alone: not joinable from here)
+        pid_ = getpid();
+      }
+      while ((int)workers_->size() < njobs - 1) workers_->emplace_back([this] { loop(); });
+      job_ = &job; next_ = 0; njobs_ = njobs; pending_ = njobs; ++epoch_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      int i;
+      const std::function<void(int)>* j;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!job_ || next_ >= njobs_) return;
+        i = next_++; j = job_;
+      }
+      (*j)(i);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && job_ && next_ < njobs_); });
+        if (stop_) return;
+        seen = epoch_;
+      }
+      work();
+    }
+  }
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread>* workers_ = new std::vector<std::thread>();
+  pid_t pid_ = getpid();
+  const std::function<void(int)>* job_ = nullptr;
+  int next_ = 0, njobs_ = 0, pending_ = 0;
+  unsigned long epoch_ = 0;
+  bool stop_ = false;
+};
+HostPool& host_pool() { static HostPool p; return p; }
 
 void collate_range(const float* const* seq, const int64_t* rows, int64_t i0, int64_t i1, int64_t dim, int64_t max_rows, int dst_bf16,
                    void* dst, uint8_t* mask) {
@@ -69,12 +143,7 @@ extern "C" int coot_collate_level(const float* const* seq, const int64_t* rows, 
     collate_range(seq, rows, 0, n, dim, max_rows, dst_bf16, dst, mask);
     return 0;
   }
-  std::vector<std::thread> pool;
-  pool.reserve(nt - 1);
-  for (int t = 1; t < nt; ++t)
-    pool.emplace_back(collate_range, seq, rows, n * t / nt, n * (t + 1) / nt, dim, max_rows, dst_bf16, dst, mask);
-  collate_range(seq, rows, 0, n / nt, dim, max_rows, dst_bf16, dst, mask);
-  for (auto& th : pool) th.join();
+  host_pool().run(nt, [&](int t) { collate_range(seq, rows, n * t / nt, n * (t + 1) / nt, dim, max_rows, dst_bf16, dst, mask); });
   return 0;
 }
 
@@ -116,10 +185,6 @@ extern "C" int coot_collate_packed(const float* const* seq, const int64_t* rows,
     while (i < n && cu_seqlens[i] < want) ++i;
     cut[t] = i;
   }
-  std::vector<std::thread> pool;
-  pool.reserve(nt - 1);
-  for (int t = 1; t < nt; ++t) pool.emplace_back(pack_range, seq, rows, cu_seqlens, cut[t], cut[t + 1], dim, dst_bf16, dst);
-  pack_range(seq, rows, cu_seqlens, cut[0], cut[1], dim, dst_bf16, dst);
-  for (auto& th : pool) th.join();
+  host_pool().run(nt, [&](int t) { pack_range(seq, rows, cu_seqlens, cut[t], cut[t + 1], dim, dst_bf16, dst); });
   return 0;
 }

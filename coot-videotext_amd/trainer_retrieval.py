@@ -406,6 +406,12 @@ class RetrievalTrainer:
             st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i] = st.m[i].data_ptr(), st.v[i].data_ptr(), st.decay[i].data_ptr()
             st.bufs.pe[i] = n.embedding.pe.data_ptr()
         src_packed = isinstance(batch, RetrievalPackedBatchTuple)  # packed at the source (dataset_retrieval.collate_fn(packed=True))
+        if src_packed and (max(batch.max_lens) > 128 or min(batch.tok_vis, batch.tok_txt) < 1024):
+            # the packed-row kernels cover sequences of <= 128 rows and launches of >= 1 024 tokens (csrc/api.hip: packed_ok); a
+            # packed matrix has no padded tensor to fall back to, so such a batch is unpacked on the device first
+            from .dataset_retrieval import unpack_batch
+            batch = unpack_batch(batch)
+            src_packed = False
         if batch.max_clip_num is None or batch.max_sent_num is None:
             batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
         packed = getattr(batch, "cu_vis", None) is not None and getattr(batch, "cu_txt", None) is not None

@@ -42,6 +42,8 @@ def make_points_ragged(seed, B=64, L=80, Ls=30, dv=2048, dt=1536):
         Cn = int(counts[b])
         clips = [rs.standard_normal((int(rs.integers(L // 8, L + 1)), dv), dtype=np.float32) for _ in range(Cn)]
         sl = [int(rs.integers(4, Ls + 1)) for _ in range(Cn)]
+        while sum(sl) > 128:  # paragraphs of <= 128 words (the packed-row attention kernels' limit; ANet paragraphs average ~50)
+            sl = [max(3, n - 1) for n in sl]
         par = rs.standard_normal((sum(sl), dt), dtype=np.float32)
         sents, ptr = [], 0
         for n in sl:
