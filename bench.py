@@ -181,7 +181,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL prints its version banner to STDOUT when the first communicator is created: keep it off the JSON line's channel
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+            dist.barrier()  # creates the communicator now, inside the redirection
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         dp = cdist.DataParallelContext()
         assert dist.get_world_size() == world
     w = cva.synthetic.WORKLOADS[args.workload]
