@@ -93,10 +93,11 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long salt, 
 __host__ __device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned site) {
   return mix32((unsigned)seed ^ mix32((unsigned)(seed >> 32) + site * 0x9E3779B9u));
 }
-// The per-pair mixer.  mix32's two v_mul_lo_u32 run at a quarter of the VALU rate on CDNA (16 cycles per wave each): 15
-// issue slots per pair, and the mask generation was ~20 % of the fused chains in training mode.  This one uses the
-// full-rate 24 x 24 -> 32 bit multiply-add (v_mad_u32_u24): 9 slots.  Rate / correlation statistics over 4M consecutive
-// pairs (neighbours, next row, the two halves, keys one bit apart) are as good as mix32's (tools: see DESIGN.md).
+// The per-pair mixer: two 24 x 24 -> 32 bit multiply-adds (v_mad_u32_u24) and xor-shifts, 9 issue slots per pair against 15 for
+// mix32.  (Measured on gfx950, tools/micro/valu_rate.hip: v_mad_u32_u24 and v_mul_lo_u32 both issue at HALF rate, 4.85 cycles per
+// wave-instruction per SIMD against 2.6 for shifts / xors / v_fma_f32 — the gain over mix32 is the instruction count, not the
+// multiplier.)  Rate / correlation statistics over 4M consecutive pairs (neighbours, next row, the two halves, keys one bit
+// apart) are as good as mix32's (tools: see DESIGN.md).
 // (host + device: coot_debug_dropout_scales evaluates the same functions on the host, which is what pins the numpy restatement
 // in oracle/dropout_masks.py to THIS source in the CPU suite)
 __host__ __device__ __forceinline__ unsigned umul24_hd(unsigned a, unsigned b) {
