@@ -922,10 +922,11 @@ def test_contrastive_parts_add_up(env):
 
 def test_deferred_text_join_gives_the_same_training_trajectory(env):
     """train_step_native(defer_join=True) (COOT_STEP_DEFER_TEXT_JOIN: the text side's update tail overlaps the next step's forward)
-    is a re-ordering only: after the same steps the parameters of all four networks equal the joined run's up to what the summation
-    order of the few float atomics does under Adam (an update is +-lr per element whatever the gradient's size, so a sign flip of a
-    near-zero gradient moves that element by 2 lr: the bound is the one of the graph-replay test — a lost or doubled update would move
-    EVERY element by ~lr), and join_streams() makes the losses readable on the current stream."""
+    is a re-ordering only: after the same steps the parameters of all four networks equal the joined run's, and join_streams() makes
+    the losses readable on the current stream.  (Adam with eps = 1e-3: with the shipped 1e-8 an update is +-lr per element whatever
+    the gradient's size, so the last-bit noise of the few float atomics flips the sign of near-zero gradients and two runs of the SAME
+    code end on one of a few discrete trajectories — tools/defer_check.py; a lost, doubled or stale update moves every element by
+    ~lr either way.)"""
     torch, cva = env
     dims = (64, 48, 64, 4, 64, 128)
     cfgs = H.full_cfgs(*dims)
@@ -934,6 +935,7 @@ def test_deferred_text_join_gives_the_same_training_trajectory(env):
     res = []
     for defer in (False, True):
         cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.1, cc_weight=0.01)
+        cfg_x.optimizer.adam_eps = 1e-3
         mgr.set_all_models_train()
         tr = cva.RetrievalTrainer(cfg_x, mgr)
         for it in range(6):
@@ -943,7 +945,7 @@ def test_deferred_text_join_gives_the_same_training_trajectory(env):
         torch.cuda.synchronize()
         res.append((losses, [n._flat.detach().clone() for n in mgr.model_dict.values()]))
     (la, pa), (lb, pb) = res
-    assert np.allclose(la, lb, rtol=2e-3, atol=2e-5), (la, lb)
+    assert np.allclose(la, lb, rtol=1e-4, atol=1e-6), (la, lb)
     for a, b in zip(pa, pb):
         d = (a - b).abs()
-        assert float((d > 1e-6).float().mean()) < 2e-2 and float(d.max()) <= 2.5e-3 * 1.5, (float((d > 1e-6).float().mean()), float(d.max()))
+        assert float((d > 1e-5).float().mean()) < 1e-3 and float(d.max()) <= 2e-4, (float((d > 1e-5).float().mean()), float(d.max()))
