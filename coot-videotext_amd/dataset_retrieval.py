@@ -230,10 +230,15 @@ class DeviceLoader:
     batch on a copy stream, the consumer's stream waits on its event only.  A device arena is rewritten only after the work
     the consumer enqueued on it (everything up to its next ``next()``) has finished; a host arena only after its copy has."""
 
-    def __init__(self, source: Iterable, depth: int = 2, device: str = "cuda", bf16: bool = False, threads: int = 8, packed: bool = False):
+    def __init__(self, source: Iterable, depth: int = 2, device: str = "cuda", bf16: bool = False, threads: int = 8, packed: bool = False,
+                 background: bool = False):
         assert depth >= 1
         self.source, self.depth, self.device, self.bf16, self.threads = source, depth, torch.device(device), bf16, threads
         self.packed = packed  # collate packed at the source: no padding rows in the arena; bf16 rows are consumed as they are
+        # background: collation + the H2D enqueue run on a loader thread (the C collation releases the GIL), so the consumer's thread
+        # only issues its training step: per batch the host then costs max(collation, step issue) instead of their sum
+        self.background = background
+        self._consumer_stream = None
         self.copy_stream = torch.cuda.Stream(device=self.device)
         n = depth + 1
         self.host = [BatchArena(pin=True) for _ in range(n)]
@@ -254,7 +259,7 @@ class DeviceLoader:
             # reading it are still queued there; a block allocated under the copy stream is only re-used in that stream's order,
             # and record_stream tells the allocator that the consumer's stream reads it too.  The copy stream first waits for
             # everything the consumer has enqueued so far (the old arena of this slot may still be in use until then).
-            consumer = torch.cuda.current_stream(self.device)
+            consumer = self._consumer_stream if self._consumer_stream is not None else torch.cuda.current_stream(self.device)
             self.copy_stream.wait_stream(consumer)
             with torch.cuda.stream(self.copy_stream):
                 self.dev[k] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=self.device)
@@ -282,7 +287,64 @@ class DeviceLoader:
         db.ready = ev
         return db
 
+    def _finish(self, db):
+        torch.cuda.current_stream(self.device).wait_event(db.ready)
+        if self.bf16 and not isinstance(db, RetrievalPackedBatchTuple):  # padded batches: the kernels take fp32 features, widen on the device (HBM pass, not a PCIe one); packed bf16 rows are read as they are
+            for name in ("vid_feat", "clip_feat", "par_feat", "sent_feat"):
+                setattr(db, name, getattr(db, name).float())
+        return db
+
+    def _iter_background(self) -> Iterator[RetrievalDataBatchTuple]:
+        """Producer thread: takes a free slot, collates into its host arena, enqueues the copy; consumer: waits for the copy's event,
+        yields, records how far its stream has got on that slot and hands the slot back."""
+        import queue
+        import threading
+        n = self.depth + 1
+        free: "queue.Queue[int]" = queue.Queue()
+        ready: "queue.Queue" = queue.Queue()
+        for k in range(n):
+            free.put(k)
+        self._consumer_stream = torch.cuda.current_stream(self.device)
+        stop = threading.Event()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+        def produce():
+            try:
+                torch.cuda.set_device(dev_index)
+                for item in self.source:
+                    k = free.get()
+                    if stop.is_set():
+                        return
+                    ready.put((k, self._stage(item, k)))
+                ready.put(None)
+            except BaseException as e:  # surfaces in the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        try:
+            while True:
+                got = ready.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                k, db = got
+                yield self._finish(db)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.consumed[k] = ev
+                free.put(k)
+        finally:
+            stop.set()
+            free.put(0)  # wakes a producer that waits for a slot
+            th.join(timeout=10)
+            self._consumer_stream = None
+
     def __iter__(self) -> Iterator[RetrievalDataBatchTuple]:
+        if self.background:
+            yield from self._iter_background()
+            return
         n = self.depth + 1
         it = iter(self.source)
         queue: List[Tuple[int, RetrievalDataBatchTuple]] = []
@@ -303,11 +365,7 @@ class DeviceLoader:
         fill()
         while queue:
             k, db = queue.pop(0)
-            torch.cuda.current_stream(self.device).wait_event(db.ready)
-            if self.bf16 and not isinstance(db, RetrievalPackedBatchTuple):  # padded batches: the kernels take fp32 features, widen on the device (HBM pass, not a PCIe one); packed bf16 rows are read as they are
-                for name in ("vid_feat", "clip_feat", "par_feat", "sent_feat"):
-                    setattr(db, name, getattr(db, name).float())
-            yield db
+            yield self._finish(db)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.consumed[k] = ev

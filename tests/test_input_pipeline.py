@@ -124,6 +124,16 @@ def test_device_loader_stages_batches_and_feeds_training():
         assert db.key == hb.key and db.max_clip_num == hb.max_clip_num
         seen += 1
     assert seen == 7
+    # the same with collation + copy enqueue on a loader thread, padded and packed at the source
+    for packed in (False, True):
+        got = 0
+        for i, db in enumerate(DeviceLoader(lists, depth=2, background=True, packed=packed)):
+            hb = collate_fn(lists[i], packed=packed)
+            for f in (("vis_tokens", "txt_tokens", "cu_vis", "clip_feat_len") if packed else FIELDS):
+                assert getattr(db, f).is_cuda and torch.equal(getattr(db, f).cpu(), getattr(hb, f)), (packed, i, f)
+            assert db.key == hb.key
+            got += 1
+        assert got == 7
     for i, db in enumerate(DeviceLoader(lists[:3], depth=1, bf16=True)):
         hb = collate_fn(lists[i])
         assert db.clip_feat.dtype == torch.float32

@@ -58,6 +58,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--packed", type=int, nargs="+", default=[0])
+    ap.add_argument("--background", type=int, nargs="+", default=[0], help="1: collation + H2D enqueue on a loader thread")
     ap.add_argument("--batches", type=int, default=24)
     ap.add_argument("--threads", type=int, nargs="+", default=[4, 16])
     ap.add_argument("--bf16", type=int, nargs="+", default=[0, 1])
@@ -92,11 +93,12 @@ def main():
         dt = (time.perf_counter() - t0) / 6
         print(json.dumps({"stage": "collate only", "packed_at_source": bool(pk), "threads": th, "ms_per_batch": round(dt * 1e3, 2),
                           "arena_MB": round(ar.nbytes / 1e6, 1), "GB_per_s": round(ar.nbytes / dt / 1e9, 2)}))
-    for pk in a.packed:
+    for bg in a.background:
+     for pk in a.packed:
       for bf16 in a.bf16:
         for th in a.threads:
             src = [distinct[i % 2] for i in range(a.batches + 4)]
-            loader = DeviceLoader(src, depth=2, bf16=bool(bf16), threads=th, packed=bool(pk))
+            loader = DeviceLoader(src, depth=2, bf16=bool(bf16), threads=th, packed=bool(pk), background=bool(bg))
             t0 = None
             for i, batch in enumerate(loader):
                 if i == 4:
@@ -104,7 +106,7 @@ def main():
                 tr.train_step_native(batch)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.batches
-            print(json.dumps({"stage": "collate + H2D + train step", "packed_at_source": bool(pk), "bf16_staging": bool(bf16), "threads": th, "ms_per_step": round(dt * 1e3, 3),
+            print(json.dumps({"stage": "collate + H2D + train step", "loader_thread": bool(bg), "packed_at_source": bool(pk), "bf16_staging": bool(bf16), "threads": th, "ms_per_step": round(dt * 1e3, 3),
                               "clip_pairs_per_s": round(pairs / dt, 1), "arena_MB": round(loader.host[0].nbytes / 1e6, 1)}))
 
 
