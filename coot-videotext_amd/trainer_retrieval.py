@@ -455,6 +455,14 @@ class RetrievalTrainer:
         return st, x
 
     # ---- optimizer state of either path, for optimizer_<epoch>.pth (nntrainer/trainer_base.py:685-707) ------------------------
+    def get_opt_state(self) -> Dict[str, Any]:
+        """The reference's name for it (nntrainer/trainer_base.py:251-261)."""
+        return self.optimizer_state_dict()
+
+    def set_opt_state(self, opt_state: Dict[str, Any]) -> None:
+        """nntrainer/trainer_base.py:263-271; also takes a reference-written optimizer_<epoch>.pth ({"optimizer", "lr_scheduler"})."""
+        self.load_optimizer_state_dict(opt_state)
+
     def optimizer_state_dict(self) -> Dict[str, Any]:
         """What a checkpoint must hold to resume training: ``self.optimizer.state_dict()`` (the autograd path's torch optimizer)
         and, when native steps have run, the library's optimizer state — the flat first / second moment arenas of the four
@@ -462,6 +470,8 @@ class RetrievalTrainer:
         resume with zero moments and bias-correction step 1)."""
         self.join_streams()
         out: Dict[str, Any] = {"optimizer": self.optimizer.state_dict() if self.optimizer is not None else None, "total_step": self.total_step}
+        if self.lr_scheduler is not None:  # the reference's second key (nntrainer/trainer_base.py:251-261: get_opt_state)
+            out["lr_scheduler"] = self.lr_scheduler.state_dict()
         st = getattr(self, "_native", None)
         if st is not None:
             out["native"] = {"step": int(st.step), "m": [t.detach().cpu().clone() for t in st.m], "v": [t.detach().cpu().clone() for t in st.v]}
@@ -472,6 +482,8 @@ class RetrievalTrainer:
         yet the loaded moments are kept and installed by _native_setup."""
         if state.get("optimizer") is not None and self.optimizer is not None:
             self.optimizer.load_state_dict(state["optimizer"])
+        if state.get("lr_scheduler") is not None and self.lr_scheduler is not None:  # (a plain reference opt_state has exactly these two keys)
+            self.lr_scheduler.load_state_dict(state["lr_scheduler"])
         self.total_step = int(state.get("total_step", self.total_step))
         nat = state.get("native")
         if nat is None:

@@ -799,7 +799,13 @@ def test_native_optimizer_state_round_trip(env):
         ta.train_step_native(batch)
     torch.cuda.synchronize()
     ckpt_model = {k: {n: v.detach().cpu().clone() for n, v in sd.items()} for k, sd in mgr_a.get_model_state().items()}
-    ckpt_opt = ta.optimizer_state_dict()
+    # with a scheduler attached the checkpoint carries the reference's two keys (nntrainer/trainer_base.py:251-261) next to the native state
+    sc = cva.lr_scheduler.SchedulerConfig(dict(name="reduce_opw", warmup_type="epoch", warmup_epochs=1, rop_factor=0.1, rop_patience=2,
+                                               rop_cooldown=3, rop_min_lr_factor=0))
+    ta.lr_scheduler = cva.lr_scheduler.make_lr_scheduler(ta.optimizer, sc, 1e-3, 10, 4)
+    ta.lr_scheduler.step(); ta.lr_scheduler.step()
+    ckpt_opt = ta.get_opt_state()
+    assert set(ckpt_opt) >= {"optimizer", "lr_scheduler", "native"} and ckpt_opt["lr_scheduler"]["current_global_step"] == 2
     assert ckpt_opt["native"]["step"] == 2 and float(ckpt_opt["native"]["v"][0].abs().max()) > 0
     ta.train_step_native(batch)
     # resumed run
@@ -808,7 +814,11 @@ def test_native_optimizer_state_round_trip(env):
     mgr_b.cuda()
     mgr_b.set_all_models_train()
     tb = cva.RetrievalTrainer(cfg_b, mgr_b)
-    tb.load_optimizer_state_dict(ckpt_opt)       # before the first native step: installed when the native state is created
+    tb.lr_scheduler = cva.lr_scheduler.make_lr_scheduler(tb.optimizer, sc, 1e-3, 10, 4)
+    tb.set_opt_state(ckpt_opt)       # before the first native step: installed when the native state is created
+    assert tb.lr_scheduler.current_global_step == 2
+    tb.set_opt_state({"optimizer": ckpt_opt["optimizer"], "lr_scheduler": ckpt_opt["lr_scheduler"]})   # a reference-written state: two keys
+    tb.set_opt_state(ckpt_opt)
     tb.train_step_native(batch)
     # cold restart for contrast: same parameters, no optimizer state
     cfg_c, mgr_c = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
