@@ -805,7 +805,7 @@ def test_native_optimizer_state_round_trip(env):
     ta.lr_scheduler = cva.lr_scheduler.make_lr_scheduler(ta.optimizer, sc, 1e-3, 10, 4)
     ta.lr_scheduler.step(); ta.lr_scheduler.step()
     ckpt_opt = ta.get_opt_state()
-    assert set(ckpt_opt) >= {"optimizer", "lr_scheduler", "native"} and ckpt_opt["lr_scheduler"]["current_global_step"] == 1
+    assert set(ckpt_opt) >= {"optimizer", "lr_scheduler", "native"} and ckpt_opt["lr_scheduler"]["current_global_step"] == 2
     assert ckpt_opt["native"]["step"] == 2 and float(ckpt_opt["native"]["v"][0].abs().max()) > 0
     ta.train_step_native(batch)
     # resumed run
@@ -816,7 +816,7 @@ def test_native_optimizer_state_round_trip(env):
     tb = cva.RetrievalTrainer(cfg_b, mgr_b)
     tb.lr_scheduler = cva.lr_scheduler.make_lr_scheduler(tb.optimizer, sc, 1e-3, 10, 4)
     tb.set_opt_state(ckpt_opt)       # before the first native step: installed when the native state is created
-    assert tb.lr_scheduler.current_global_step == 1
+    assert tb.lr_scheduler.current_global_step == 2
     tb.set_opt_state({"optimizer": ckpt_opt["optimizer"], "lr_scheduler": ckpt_opt["lr_scheduler"]})   # a reference-written state: two keys
     tb.set_opt_state(ckpt_opt)
     tb.train_step_native(batch)
