@@ -351,6 +351,12 @@ def main():
                     "algorithmic_bytes_per_launch": by[dom].get("algorithmic_bytes_per_launch"),
                     "launches_per_step": by[dom]["launches_per_step"],
                     "avg_launch_us": by[dom]["avg_launch_us"], "ms_per_step": by[dom]["ms_per_step"],
+                    # the same launches against the OTHER roofline: their algorithmic bytes over the same durations (the chains save
+                    # 8.4 KB per token for the backward pass; with every CU busy their store phases run at the chip's write bandwidth,
+                    # profiles/README.md "Round 3") — two streams share the chip, so neither fraction can approach 1 on its own
+                    "hbm_view": ({"achieved": round(by[dom]["algorithmic_bytes_per_launch"] / by[dom]["avg_launch_us"] / 1e3, 1), "peak": 8000.0,
+                                  "unit": "GB/s", "frac": round(by[dom]["algorithmic_bytes_per_launch"] / by[dom]["avg_launch_us"] / 1e3 / 8000.0, 4)}
+                                 if by[dom].get("algorithmic_bytes_per_launch") and by[dom]["avg_launch_us"] else None),
                     "note": "algorithmic 2*M*N*K per launch / HIP-event duration on the launch stream, measured while both "
                             "sides (two streams) run concurrently; 'by_kernel' lists every MFMA kernel family the same way",
                     "all_mfma_kernels": allk, "input_fc_instances": infc, "by_kernel": by,
