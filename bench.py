@@ -190,6 +190,7 @@ def main():
             dist.barrier()  # creates the communicator now, inside the redirection
             torch.cuda.synchronize()
         finally:
+            C.CDLL(None).fflush(None)  # RCCL writes through C stdio: its buffer must be drained while fd 1 still is stderr
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
