@@ -570,6 +570,20 @@ def gen_bench_hbm_stress():
              full_grads=False, ragged=False, sub_step=197, store_reshape=False)
 
 
+def gen_bench_hbm_stress_train():
+    """bench_hbm_stress in TRAIN mode: 64 clips per video put the global networks on their per-op kernels (the single-launch passes
+    take <= 32 items per sequence), so this pins the dropout sites of THAT path (GEMM epilogues, LayerNorm, attention kernels)."""
+    gen_full("bench_hbm_stress_train", (1024, 1536, 384, 8, 384, 768), B=16, counts=[64] * 16, Ls=(80, 80, 64, 16), seed=59,
+             full_grads=False, ragged=False, sub_step=197, store_reshape=False, train=dict(p=0.1, step_seed=424242))
+
+
+def gen_bench_yc2_100m_2layer_train():
+    """The 2-layer local encoders in TRAIN mode: the second layer's sites (site base 16) on the fused chains."""
+    gen_full("bench_yc2_100m_2layer_train", (512, 1536, 384, 8, 384, 768), B=16, counts=[8] * 16, Ls=(80, 20, 96, 12), seed=61,
+             full_grads=False, ragged=False, cc_weight=0.001, sub_step=197, store_reshape=False, layers=2,
+             train=dict(p=0.1, step_seed=31337))
+
+
 def gen_bench_yc2_100m_2layer():
     """BASELINE.json configs[0] as it words it: YouCook2-100m, batch 16, 2-layer local / 1-layer global encoders (d_model 384)."""
     gen_full("bench_yc2_100m_2layer", (512, 1536, 384, 8, 384, 768), B=16, counts=[8] * 16, Ls=(80, 20, 96, 12), seed=61,
@@ -714,6 +728,8 @@ def main():
     gen_bench_anet_ragged_train_packed()
     gen_bench_hbm_stress()
     gen_bench_yc2_100m_2layer()
+    gen_bench_hbm_stress_train()
+    gen_bench_yc2_100m_2layer_train()
     gen_rk_parity()
     gen_retrieval_metrics()
     gen_radam()

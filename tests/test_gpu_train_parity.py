@@ -22,7 +22,8 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["bench_anet_train", "bench_anet_ragged_train", "bench_anet_ragged_train_packed"]
+# ..._hbm_stress_train: 64 clips per video, the global networks on their per-op kernels; ..._2layer_train: two encoder layers per local network
+CASES = ["bench_anet_train", "bench_anet_ragged_train", "bench_anet_ragged_train_packed", "bench_hbm_stress_train", "bench_yc2_100m_2layer_train"]
 
 
 @pytest.fixture(scope="module")
