@@ -1889,6 +1889,7 @@ template <typename P>
 static int glob_grid(P& p, int tiles) {
   p.tiles = tiles;
   p.xcd_first = g_glob_xcd_first; p.xcd_count = g_glob_xcd_count;
+  if (tiles > 8 * p.xcd_count) { p.xcd_first = 0; p.xcd_count = 8; }  // a pass with many tiles needs the CUs of every XCD, not L2 room
   p.tiles_per_xcd = (tiles + p.xcd_count - 1) / p.xcd_count;
   // helper workgroups per XCD (0: the chains fill the chip themselves); the same number of helpers overall on fewer XCDs
   p.warm_per_xcd = tiles >= 128 ? 0 : (tiles > 64 ? 8 : 16) * (8 / p.xcd_count);
