@@ -644,6 +644,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "grad_write")) { coot_step_grad_write(value); return 0; }
   if (!strcmp(name, "defer_global_tn")) { coot_step_defer_global_tn(value); return 0; }
   if (!strcmp(name, "glob_xcd_split")) { coot_step_glob_xcd_split(value); return 0; }
+  if (!strcmp(name, "cl_col_split")) { set_cl_col_split(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   if (!strcmp(name, "fused_fwd_small")) { g_fused_fwd_small = value; return 0; }

@@ -22,57 +22,78 @@ namespace coot {
 struct ClPair { const float* va; const float* vb; long lda, ldb; bf16_t *a, *b, *aT, *bT; float *inva, *invb; float *dab, *daa, *dbb; int N, Np, d; };
 struct ClNormArgs { ClPair p[3]; int row0[4]; };
 
-__global__ __launch_bounds__(256) void cl_norm_kernel(ClNormArgs A) {
-  const int lane = threadIdx.x & 63;
-  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (grow >= A.row0[3]) return;
+constexpr int CL_TP = 8;  // pitch padding of the transposition tile (elements)
+__global__ __launch_bounds__(1024) void cl_norm_kernel(ClNormArgs A) {
+  // one workgroup = 16 rows of one pair (the pairs are padded to multiples of 16 rows), one wave per row.  The transposed
+  // copies a^T / b^T go through an LDS tile so that a thread stores the 16 rows of one feature as 32 contiguous bytes (every
+  // wave scattering its own row's 2-byte elements at a stride of Np took 24 us for the 5 600 gathered rows of an 8-rank job).
+  extern __shared__ __attribute__((aligned(16))) bf16_t Ts[];  // [2][16][d + CL_TP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grow = blockIdx.x * 16 + wave;
   const int pi = grow >= A.row0[2] ? 2 : (grow >= A.row0[1] ? 1 : 0);
   const ClPair& P = A.p[pi];
-  const int row = grow - A.row0[pi], d = P.d;
+  const int row = grow - A.row0[pi], d = P.d, tp = d + CL_TP;
+  bf16_t* Ta = Ts + wave * tp;
+  bf16_t* Tb = Ts + (16 + wave) * tp;
   if (row >= P.N) {  // zero padding rows / columns (the MFMA strips read them)
     for (int c = lane; c < d; c += 64) {
       P.a[(long)row * d + c] = 0; P.b[(long)row * d + c] = 0;
-      P.aT[(long)c * P.Np + row] = 0; P.bT[(long)c * P.Np + row] = 0;
+      Ta[c] = 0; Tb[c] = 0;
     }
-    return;
-  }
-  // the two rows in registers (d % 32 == 0, d <= 1024: up to four 4-element chunks per lane): one pass of 16-byte loads
-  constexpr int MAXC = 4;
-  f32x4_t xa[MAXC], xb[MAXC];
-  const int nch = d / 4;
-  float sa = 0.f, sb = 0.f;
+  } else {
+    // the two rows in registers (d % 32 == 0, d <= 1024: up to four 4-element chunks per lane): one pass of 16-byte loads
+    constexpr int MAXC = 4;
+    f32x4_t xa[MAXC], xb[MAXC];
+    const int nch = d / 4;
+    float sa = 0.f, sb = 0.f;
 #pragma unroll
-  for (int q = 0; q < MAXC; ++q) {
-    const int ch = lane + 64 * q;
-    xa[q] = f32x4_t{0.f, 0.f, 0.f, 0.f}; xb[q] = xa[q];
-    if (ch < nch) {
-      xa[q] = *reinterpret_cast<const f32x4_t*>(P.va + (long)row * P.lda + ch * 4);
-      xb[q] = *reinterpret_cast<const f32x4_t*>(P.vb + (long)row * P.ldb + ch * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { sa += xa[q][j] * xa[q][j]; sb += xb[q][j] * xb[q][j]; }
-  }
-  sa = wave_sum(sa); sb = wave_sum(sb);
-  const float ia = 1.0f / fmaxf(sqrtf(sa), 1e-12f), ib = 1.0f / fmaxf(sqrtf(sb), 1e-12f);
-  float dab = 0.f, daa = 0.f, dbb = 0.f;
-#pragma unroll
-  for (int q = 0; q < MAXC; ++q) {
-    const int ch = lane + 64 * q;
-    if (ch < nch) {
-      bf16_t ha[4], hb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ha[j] = f2bf(xa[q][j] * ia); hb[j] = f2bf(xb[q][j] * ib);
-        const float fa = bf2f(ha[j]), fb = bf2f(hb[j]);
-        dab += fa * fb; daa += fa * fa; dbb += fb * fb;
-        P.aT[(long)(ch * 4 + j) * P.Np + row] = ha[j]; P.bT[(long)(ch * 4 + j) * P.Np + row] = hb[j];
+    for (int q = 0; q < MAXC; ++q) {
+      const int ch = lane + 64 * q;
+      xa[q] = f32x4_t{0.f, 0.f, 0.f, 0.f}; xb[q] = xa[q];
+      if (ch < nch) {
+        xa[q] = *reinterpret_cast<const f32x4_t*>(P.va + (long)row * P.lda + ch * 4);
+        xb[q] = *reinterpret_cast<const f32x4_t*>(P.vb + (long)row * P.ldb + ch * 4);
       }
-      *reinterpret_cast<u32x2_t*>(P.a + (long)row * d + ch * 4) = u32x2_t{(unsigned)ha[0] | ((unsigned)ha[1] << 16), (unsigned)ha[2] | ((unsigned)ha[3] << 16)};
-      *reinterpret_cast<u32x2_t*>(P.b + (long)row * d + ch * 4) = u32x2_t{(unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sa += xa[q][j] * xa[q][j]; sb += xb[q][j] * xb[q][j]; }
     }
+    sa = wave_sum(sa); sb = wave_sum(sb);
+    const float ia = 1.0f / fmaxf(sqrtf(sa), 1e-12f), ib = 1.0f / fmaxf(sqrtf(sb), 1e-12f);
+    float dab = 0.f, daa = 0.f, dbb = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+      const int ch = lane + 64 * q;
+      if (ch < nch) {
+        bf16_t ha[4], hb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ha[j] = f2bf(xa[q][j] * ia); hb[j] = f2bf(xb[q][j] * ib);
+          const float fa = bf2f(ha[j]), fb = bf2f(hb[j]);
+          dab += fa * fb; daa += fa * fa; dbb += fb * fb;
+        }
+        const u32x2_t pa = {(unsigned)ha[0] | ((unsigned)ha[1] << 16), (unsigned)ha[2] | ((unsigned)ha[3] << 16)};
+        const u32x2_t pb = {(unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16)};
+        *reinterpret_cast<u32x2_t*>(P.a + (long)row * d + ch * 4) = pa;
+        *reinterpret_cast<u32x2_t*>(P.b + (long)row * d + ch * 4) = pb;
+        *reinterpret_cast<u32x2_t*>(Ta + ch * 4) = pa;
+        *reinterpret_cast<u32x2_t*>(Tb + ch * 4) = pb;
+      }
+    }
+    dab = wave_sum(dab); daa = wave_sum(daa); dbb = wave_sum(dbb);
+    if (lane == 0) { P.inva[row] = ia; P.invb[row] = ib; P.dab[row] = dab; P.daa[row] = daa; P.dbb[row] = dbb; }
   }
-  dab = wave_sum(dab); daa = wave_sum(daa); dbb = wave_sum(dbb);
-  if (lane == 0) { P.inva[row] = ia; P.invb[row] = ib; P.dab[row] = dab; P.daa[row] = daa; P.dbb[row] = dbb; }
+  __syncthreads();
+  const int r0 = row - wave;  // first row of this workgroup within the pair
+  for (int c = tid; c < 2 * d; c += 1024) {
+    const int second = c >= d, cc = c - second * d;
+    const bf16_t* T = Ts + second * 16 * tp + cc;
+    unsigned w[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[r] = (unsigned)T[(2 * r) * tp] | ((unsigned)T[(2 * r + 1) * tp] << 16);
+    bf16_t* o = (second ? P.bT : P.aT) + (long)cc * P.Np + r0;
+    *reinterpret_cast<u32x4_t*>(o) = u32x4_t{w[0], w[1], w[2], w[3]};
+    *reinterpret_cast<u32x4_t*>(o + 8) = u32x4_t{w[4], w[5], w[6], w[7]};
+  }
 }
 
 constexpr int CL_MAX_HALF = 12;
@@ -84,59 +105,65 @@ struct ClHalf {
   float* loss_part;                                    // [nblk]   sum of hinge values of the strip (only if primary)
   int N, Np, d, blk0, primary;
   int w0, wn;                                          // rows whose dX strip is needed (data parallel: this rank's rows)
-};
+  int cs, cols;                                        // column splits of a strip and columns per split (a multiple of 32): dX, c1 and
+};                                                     // loss_part are per-split partials ([cs][Np, d], [cs][Np], [strip][cs]) cl_finish sums
 struct ClHalfArgs { ClHalf h[CL_MAX_HALF]; int nh; int nblk; float margin; };
 
 constexpr int CL_GP = 8;  // G strip pitch padding (elements)
 
 constexpr int CL_NW = 8;  // waves per strip workgroup: the strip is a chain of L2 round trips, more waves = fewer trips each
 __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t Gs[];  // [16][Np32 + CL_GP]
+  extern __shared__ __attribute__((aligned(16))) bf16_t Gs[];  // [16][cols + CL_GP]: the G strip over this workgroup's columns
   __shared__ int c1s[16];  // violation counts: integer LDS atomics (ds_add_u32), not float ones
   __shared__ float lred[CL_NW];
   int hi = 0;
   for (int t = 1; t < A.nh; ++t) if ((int)blockIdx.x >= A.h[t].blk0) hi = t;
   const ClHalf& H = A.h[hi];
-  const int rb = blockIdx.x - H.blk0, i0 = rb * 16;
+  // a strip of 16 rows x Np columns is a chain of dependent L2 round trips (S column blocks, then G . Y over k): with the gathered
+  // batch of a data-parallel job (Np = 2048 clips at 8 ranks, own rows = 16 strips per half-term) a strip per workgroup left the
+  // chip at ~100 workgroups of 50 round trips each.  The columns are therefore split over cs workgroups (adjacent block indices:
+  // they share the strip's X rows in L2); each writes partial dX / c1 / loss sums, added in a fixed order by cl_finish.
+  const int rb = (blockIdx.x - H.blk0) / H.cs, sp = (blockIdx.x - H.blk0) % H.cs, i0 = rb * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = H.N, Np = H.Np, d = H.d, Np32 = (Np + 31) & ~31, gp = Np32 + CL_GP;
+  const int N = H.N, Np = H.Np, d = H.d, gp = H.cols + CL_GP;
+  const int c0 = sp * H.cols, c1e = min(Np, c0 + H.cols);  // this workgroup's columns [c0, c1e)
   // data parallel: a rank scores ITS rows [w0, w0 + wn) against the gathered batch — strips without own rows are nobody's business
   // here (their hinge sums belong to the loss partial of the rank that owns them, which the caller adds up across ranks)
   if (i0 + 16 <= H.w0 || i0 >= H.w0 + H.wn) return;
+  // the strip's own rows (MFMA A operand of every column block) live in LDS: holding them as register fragments (up to 128 VGPRs)
+  // left one workgroup per CU — with the strip split over columns the launch has hundreds of short workgroups that should overlap
+  bf16_t* Xs = Gs + 16 * gp;  // [16][d + CL_GP]
+  const int xp = d + CL_GP;
+  for (int c = tid; c < 16 * (d / 8); c += 64 * CL_NW) {
+    const int r = c / (d / 8), cc = c % (d / 8);
+    *reinterpret_cast<bf16x8_t*>(&Xs[r * xp + cc * 8]) = *reinterpret_cast<const bf16x8_t*>(H.X + (long)(i0 + r) * d + cc * 8);
+  }
   if (tid < 16) c1s[tid] = 0;
   __syncthreads();
   // ---- S strip: wave w takes column blocks w, w + CL_NW, ...; X (A operand, m = row i), Y (B operand, n = column j) ----
   const int kbs = d / 32;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const bf16_t* xrow = H.X + (long)(i0 + l15) * d + l4 * 8;
+  const bf16_t* xfrag = Xs + l15 * xp + l4 * 8;
   float di[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { const int i = i0 + l4 * 4 + r; di[r] = i < N ? H.diag[i] : 0.f; }
   float lsum = 0.f;
   int c1r[4] = {0, 0, 0, 0};
-  // the strip's own rows (MFMA A operand) are the same for every column block: read once (d <= 1024: up to 32 fragments)
-  constexpr int CL_MAXKB = 32;
-  bf16x8_t xfr[CL_MAXKB];
-#pragma unroll
-  for (int kb = 0; kb < CL_MAXKB; ++kb) xfr[kb] = *reinterpret_cast<const bf16x8_t*>(xrow + min(kb, kbs - 1) * 32);
-  for (int cb = wave; cb * 16 < Np; cb += CL_NW) {
+  for (int cb = c0 / 16 + wave; cb * 16 < c1e; cb += CL_NW) {
     const bf16_t* yrow = H.Y + (long)(cb * 16 + l15) * d + l4 * 8;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    // eight k-blocks of Y per round trip: the loads of a group first, then its MFMAs.  (One predicated load + MFMA per
-    // k-block compiled to load, s_waitcnt vmcnt(0), mfma — 12 to 24 serial L2 round trips per column block, 33 us per launch.)
+    // twelve k-blocks of Y per round trip (d = 384: the whole row): the loads of a group first, then its MFMAs.  (One predicated
+    // load + MFMA per k-block compiled to load, s_waitcnt vmcnt(0), mfma — 12 to 24 serial L2 round trips per column block.)
+    for (int k0 = 0; k0 < kbs; k0 += 12) {
+      bf16x8_t yf[12];
 #pragma unroll
-    for (int k0 = 0; k0 < CL_MAXKB; k0 += 8) {
-      if (k0 < kbs) {
-        bf16x8_t yf[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int kb = min(k0 + j, kbs - 1);  // clamp instead of branching: every load of the group issues unconditionally
-          yf[j] = *reinterpret_cast<const bf16x8_t*>(yrow + kb * 32);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (k0 + j < kbs) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfr[k0 + j], yf[j], acc, 0, 0, 0);
+      for (int j = 0; j < 12; ++j) {
+        const int kb = min(k0 + j, kbs - 1);  // clamp instead of branching: every load of the group issues unconditionally
+        yf[j] = *reinterpret_cast<const bf16x8_t*>(yrow + kb * 32);
       }
+#pragma unroll
+      for (int j = 0; j < 12; ++j)
+        if (k0 + j < kbs) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xfrag + (k0 + j) * 32), yf[j], acc, 0, 0, 0);
     }
     // acc[r] = S[i0 + l4*4 + r][cb*16 + l15]
     const int j = cb * 16 + l15;
@@ -152,11 +179,12 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
         if (cs > 0.f) { if (own) lsum += cs; g += 1.f; c1r[r] += 1; }
         if (ci > 0.f) { if (own) lsum += ci; g += 1.f; }
       }
-      Gs[(l4 * 4 + r) * gp + j] = f2bf(g);
+      Gs[(l4 * 4 + r) * gp + j - c0] = f2bf(g);
     }
   }
-  // zero the K padding of the strip (columns Np .. Np32)
-  for (int c = Np + tid; c < Np32; c += 64 * CL_NW)
+  // zero the K padding of the strip (columns c1e .. the next multiple of 32)
+  const int kw = (c1e - c0 + 31) & ~31;
+  for (int c = c1e - c0 + tid; c < kw; c += 64 * CL_NW)
 #pragma unroll
     for (int r = 0; r < 16; ++r) Gs[r * gp + c] = 0;
 #pragma unroll
@@ -168,29 +196,30 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
   lsum = wave_sum(lsum);
   if (lane == 0) lred[wave] = lsum;
   __syncthreads();
-  if (tid < 16 && i0 + tid < N) H.c1[i0 + tid] = (float)c1s[tid];
+  if (tid < 16 && i0 + tid < N) H.c1[(long)sp * Np + i0 + tid] = (float)c1s[tid];
   if (tid == 0 && H.primary) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < CL_NW; ++w) t += lred[w];
-    H.loss_part[rb] = t;
+    H.loss_part[rb * H.cs + sp] = t;
   }
-  // ---- dX strip [16, d] = G strip [16, Np] . Y [Np, d]: A operand = G (LDS), B operand = Y^T rows (k contiguous) ----
+  // ---- dX strip [16, d] = G strip [16, cols] . Y [cols, d]: A operand = G (LDS), B operand = Y^T rows (k contiguous) ----
   const int nf = d / 16;
+  float* dXs = H.dX + (long)sp * Np * d;
   for (int f0 = wave; f0 < nf; f0 += CL_NW * 3) {
     f32x4_t acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // four k-blocks x three feature fragments of Y^T per round trip (loads first, clamped addresses instead of branches:
     // the padded columns of G are zero, so what a clamped load brings in does not matter)
-    const int nkb = Np32 / 32;
+    const int nkb = kw / 32;
     for (int k0 = 0; k0 < nkb; k0 += 4) {
       bf16x8_t yf[4][3], gf[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kk = min(k0 + j, nkb - 1) * 32 + l4 * 8;
         gf[j] = *reinterpret_cast<const bf16x8_t*>(&Gs[l15 * gp + kk]);
-        const int kc = min(kk, Np - 8);
+        const int kc = min(c0 + kk, Np - 8);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           const int f = min(f0 + CL_NW * q, nf - 1);
@@ -211,7 +240,7 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = i0 + l4 * 4 + r;
-          if (i < N) H.dX[(long)i * d + f * 16 + l15] = acc[q][r];
+          if (i < N) dXs[(long)i * d + f * 16 + l15] = acc[q][r];
         }
       }
     }
@@ -219,7 +248,7 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
 }
 
 // per set: up to 3 contributions  coef * dX_h[i] + dcoef * (c1_p[i] + c1_q[i]) * other[i]   (other = bf16 normalised rows)
-struct ClContrib { const float* dX; float coef; const float* c1p; const float* c1q; float dcoef; const bf16_t* other; };
+struct ClContrib { const float* dX; float coef; const float* c1p; const float* c1q; float dcoef; const bf16_t* other; int cs; long dxs, c1s; };  // cs partials, strides dxs / c1s
 struct ClSet { const float* v; long ldv; const float* inv; float* dv; int N, d, nc, row0, w0, wn; ClContrib c[3]; };  // dv: rows [w0, w0 + wn) only, compact
 struct ClFinishArgs { ClSet s[6]; int rows; const float* loss_part[CL_MAX_HALF]; int loss_n[CL_MAX_HALF]; float loss_coef[CL_MAX_HALF]; int nl; float* loss; };
 
@@ -245,7 +274,11 @@ __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
   if (row < S.w0 || row >= S.w0 + S.wn) return;  // data-parallel: a rank keeps the gradient rows of its own videos / clips
   const float inv = S.inv[row];
   float gdc[3];
-  for (int t = 0; t < S.nc; ++t) gdc[t] = -S.c[t].dcoef * (S.c[t].c1p[row] + S.c[t].c1q[row]);
+  for (int t = 0; t < S.nc; ++t) {
+    float c1 = 0.f;  // (counts: exact in fp32, any order)
+    if (lane < S.c[t].cs) c1 = S.c[t].c1p[lane * S.c[t].c1s + row] + S.c[t].c1q[lane * S.c[t].c1s + row];
+    gdc[t] = -S.c[t].dcoef * wave_sum(c1);
+  }
   // a lane owns the 4-element chunks lane, lane + 64, ... of the row (d % 32 == 0, d <= 1024): the gradient is formed ONCE,
   // kept in registers across the dot-product reduction (the first version recomputed it element by element in a second
   // pass: two serial chains of dependent 4-byte loads, 30 us for a few hundred rows)
@@ -260,7 +293,14 @@ __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
     if (ch < nch) {
       const long o = (long)row * d + ch * 4;
       for (int t = 0; t < S.nc; ++t) {
-        const f32x4_t dx = *reinterpret_cast<const f32x4_t*>(S.c[t].dX + o);
+        f32x4_t dx = *reinterpret_cast<const f32x4_t*>(S.c[t].dX + o);
+        if (S.c[t].cs > 1) {  // column-split partials: all loads first (one round trip), then the sum in a fixed order
+          f32x4_t part[7];
+#pragma unroll
+          for (int u = 1; u < 8; ++u) part[u - 1] = *reinterpret_cast<const f32x4_t*>(S.c[t].dX + min(u, S.c[t].cs - 1) * S.c[t].dxs + o);
+#pragma unroll
+          for (int u = 1; u < 8; ++u) if (u < S.c[t].cs) dx += part[u - 1];
+        }
         const u32x2_t ob = *reinterpret_cast<const u32x2_t*>(S.c[t].other + o);
         const f32x4_t of = {bflo(ob[0]), bfhi(ob[0]), bflo(ob[1]), bfhi(ob[1])};
         g[q] += S.c[t].coef * dx + gdc[t] * of;
@@ -283,6 +323,17 @@ __global__ __launch_bounds__(256) void cl_finish_kernel(ClFinishArgs A) {
 // ---- host side -------------------------------------------------------------------------------------------------------
 namespace {
 inline int pad16(int n) { return (n + 15) & ~15; }
+int g_cl_col_split = 0;  // coot_set_option("cl_col_split", k): 0 = by size, k >= 1 = k column splits per strip (tests)
+// column splits of a 16-row strip over Np columns and the columns per split (multiple of 32); every split has columns
+inline void col_split(int Np, int& cs, int& cols) {
+  const int Np32 = (Np + 31) & ~31;
+  cs = g_cl_col_split > 0 ? g_cl_col_split : Np32 / 256;
+  cs = cs < 1 ? 1 : (cs > 8 ? 8 : cs);
+  for (;; --cs) {
+    cols = ((Np32 + cs - 1) / cs + 31) & ~31;
+    if (cs == 1 || (cs - 1) * cols < Np) break;
+  }
+}
 struct FBump {
   char* base; size_t cap; size_t off = 0; bool overflow = false;
   FBump(void* b, size_t c) : base((char*)b), cap(c) {}
@@ -307,11 +358,14 @@ void layout_fused(int n_high, int n_low, int d_high, int d_low, FBump& A, FusedL
     L.p[p].dbb = A.get<float>(Np);
     for (int q = 0; q < 4; ++q) {
       HalfBufs& h = L.h[4 * p + q];
-      h.dX = A.get<float>(Np * d); h.c1 = A.get<float>(Np); h.lp = A.get<float>(Np / 16 + 1);
+      int cs, cols; col_split((int)Np, cs, cols);
+      h.dX = A.get<float>(cs * Np * d); h.c1 = A.get<float>(cs * Np); h.lp = A.get<float>(cs * (Np / 16 + 1));
     }
   }
 }
 }  // namespace
+
+void set_cl_col_split(int k) { g_cl_col_split = k; }
 
 size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_low) {
   FBump A(nullptr, 0); FusedLayout L; layout_fused(n_high, n_low, d_high, d_low, A, L); return A.off + 256;
@@ -343,10 +397,12 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
   }
   na.row0[3] = rows;
   if (rows > 0) {
-    hipLaunchKernelGGL(cl_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, na);
+    int dmax = 0;
+    for (int p = 0; p < 3; ++p) if (active(p) && ds[p] > dmax) dmax = ds[p];
+    hipLaunchKernelGGL(cl_norm_kernel, dim3(rows / 16), dim3(1024), (size_t)32 * (dmax + CL_TP) * sizeof(bf16_t), st, na);  // (rows: multiples of 16 per pair)
     COOT_CHECK_LAUNCH("cl_norm");
   }
-  ClHalfArgs ha; ha.nh = 0; ha.margin = margin; int nblk = 0, maxNp = 0;
+  ClHalfArgs ha; ha.nh = 0; ha.margin = margin; int nblk = 0, maxcols = 0, maxd = 0;
   ClFinishArgs fa; fa.nl = 0; fa.loss = loss;
   int hidx[3][4];
   for (int p = 0; p < 3; ++p) {
@@ -365,21 +421,23 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
       H.diag = q < 2 ? b.dab : (q == 2 ? b.daa : b.dbb);
       H.dX = hb.dX; H.c1 = hb.c1; H.loss_part = hb.lp; H.N = N; H.Np = Np; H.d = d; H.blk0 = nblk; H.primary = (q != 1);
       H.w0 = 0; H.wn = N;
+      col_split(Np, H.cs, H.cols);
       if (window) { H.w0 = window[p == 1 ? 2 : 0]; H.wn = window[p == 1 ? 3 : 1]; }
       if (H.primary) {  // the strips that hold rows of the window (all of them on one GPU): this call's share of the term
         const int s0 = H.w0 / 16, s1 = (H.w0 + H.wn + 15) / 16;
-        fa.loss_part[fa.nl] = hb.lp + s0; fa.loss_n[fa.nl] = H.wn > 0 ? s1 - s0 : 0; fa.loss_coef[fa.nl] = (q == 0 ? w_pair[p] : w_self[p]) / ((float)N * (float)N);
+        fa.loss_part[fa.nl] = hb.lp + s0 * H.cs; fa.loss_n[fa.nl] = H.wn > 0 ? (s1 - s0) * H.cs : 0; fa.loss_coef[fa.nl] = (q == 0 ? w_pair[p] : w_self[p]) / ((float)N * (float)N);
         ++fa.nl;
       }
       hidx[p][q] = ha.nh++;
-      nblk += Np / 16;
-      if (Np > maxNp) maxNp = Np;
+      nblk += (Np / 16) * H.cs;
+      if (H.cols > maxcols) maxcols = H.cols;
+      if (d > maxd) maxd = d;
     }
   }
   ha.nblk = nblk;
   if (nblk > 0) {
-    const size_t smem = (size_t)16 * (((maxNp + 31) & ~31) + CL_GP) * sizeof(bf16_t);
-    COOT_REQUIRE(smem <= 150 * 1024, "contrastive: batch of %d rows exceeds the LDS strip (max ~4600)", maxNp);
+    const size_t smem = (size_t)16 * (maxcols + CL_GP + maxd + CL_GP) * sizeof(bf16_t);  // G strip + the strip's own rows
+    COOT_REQUIRE(smem <= 150 * 1024, "contrastive: %d columns per strip workgroup exceed the LDS strip (max ~4600)", maxcols);
     hipLaunchKernelGGL(cl_half_kernel, dim3(nblk), dim3(64 * CL_NW), smem, st, ha);
     COOT_CHECK_LAUNCH("cl_half");
   }
@@ -394,15 +452,18 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
     frows += active(p) ? Ns[p] : 0;  // (cl_finish picks the LAST set whose row0 <= row: a set without rows is never picked)
     if (!bwd || !active(p)) continue;
     const float n2 = (float)Ns[p] * (float)Ns[p];
+    int cs, cols; col_split(pad16(Ns[p]), cs, cols);
+    const long c1s = pad16(Ns[p]), dxs = c1s * ds[p];
     if (hidx[p][0] >= 0) {  // alignment term: this set's half + diagonal (c1 of both orientations) against the other set's rows
       ClContrib& c = S.c[S.nc++];
       c.dX = L.h[4 * p + (isb ? 1 : 0)].dX; c.coef = w_pair[p] / n2; c.c1p = L.h[4 * p].c1; c.c1q = L.h[4 * p + 1].c1;
-      c.dcoef = w_pair[p] / n2; c.other = isb ? b.a : b.b;
+      c.dcoef = w_pair[p] / n2; c.other = isb ? b.a : b.b; c.cs = cs; c.dxs = dxs; c.c1s = c1s;
     }
     if (hidx[p][2 + isb] >= 0) {  // cluster term L(A, A): gradient = 2 * (G . A) with diagonal -2 c1
       ClContrib& c = S.c[S.nc++];
       c.dX = L.h[4 * p + 2 + isb].dX; c.coef = 2.f * w_self[p] / n2; c.c1p = L.h[4 * p + 2 + isb].c1; c.c1q = c.c1p;
       c.dcoef = 2.f * w_self[p] / n2; c.other = isb ? b.b : b.a;  // diagonal of G + G^T: -2 c1 each
+      c.cs = cs; c.dxs = dxs; c.c1s = c1s;
     }
   }
   fa.rows = frows;

@@ -10,7 +10,10 @@ lib, L = cva.lib.load(), cva.lib
 D, B, Nc = 384, 64, 256
 cfg = cva.ContrastiveLossConfig(0.2, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0).to_c()
 sp = torch.cuda.current_stream().cuda_stream
-for R in (1, 2, 4, 8):
+if os.environ.get("CL_COL_SPLIT"):   # forced column splits per strip (0 / unset: by batch size)
+    lib.coot_set_option(b"cl_col_split", int(os.environ["CL_COL_SPLIT"]))
+RS = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]   # python tools/dp_loss_probe.py 8   (one shape, e.g. under rocprofv3 --kernel-trace --stats)
+for R in RS:
     nh, nl = R * B, R * Nc
     base_h, base_l = torch.randn(1, 6 * D, device="cuda"), torch.randn(1, 2 * D, device="cuda")
     high = (base_h + 0.8 * torch.randn(nh, 6 * D, device="cuda")).contiguous()   # [n, vid 2D | par 2D | vid_ctx D | par_ctx D]
