@@ -87,6 +87,39 @@ int coot_contrastive_fwd_bwd_dp(const coot_contrastive_config* cfg, int n_high, 
                                   (hipStream_t)stream, ldv, window);
 }
 
+int coot_contrastive_fwd_bwd_dp_blocks(const coot_contrastive_config* cfg, int world, int rank, const int64_t* counts_high,
+                                       const int64_t* counts_low, int d_high, int d_low, const float* blocks, const int64_t* set_base,
+                                       const int64_t ld[6], float* loss, float* const d_own[6], void* scratch, size_t scratch_bytes,
+                                       coot_stream_t stream) {
+  COOT_REQUIRE(cfg && counts_high && counts_low && blocks && set_base && ld && loss && d_own && scratch, "contrastive_dp_blocks: null pointer");
+  COOT_REQUIRE(world >= 1 && world <= CL_MAX_RANKS && rank >= 0 && rank < world, "contrastive_dp_blocks: %d ranks (1 .. %d), rank %d", world,
+               CL_MAX_RANKS, rank);
+  const float w_pair[3] = {cfg->weight_high, cfg->weight_low, cfg->weight_context};
+  const float w_self[3] = {0.5f * cfg->weight_high_internal, 0.5f * cfg->weight_low_internal,
+                           cfg->weight_context_internal != 0.f ? 0.5f * cfg->weight_low_internal : 0.f};
+  ClBlocks B; B.blocks = blocks; B.world = world;
+  long n[2] = {0, 0};
+  for (int r = 0; r < world; ++r) {
+    COOT_REQUIRE(counts_high[r] >= 0 && counts_low[r] >= 0, "contrastive_dp_blocks: negative row count of rank %d", r);
+    B.row0[0][r] = (int)n[0]; B.row0[1][r] = (int)n[1];
+    n[0] += counts_high[r]; n[1] += counts_low[r];
+    for (int s = 0; s < 6; ++s) { COOT_REQUIRE(set_base[s * world + r] % 4 == 0, "contrastive_dp_blocks: set %d of rank %d is not 16-byte aligned", s, r); B.base[s][r] = (long)set_base[s * world + r]; }
+  }
+  COOT_REQUIRE(n[0] < (1l << 30) && n[1] < (1l << 30), "contrastive_dp_blocks: batch too large");
+  B.row0[0][world] = (int)n[0]; B.row0[1][world] = (int)n[1];
+  long ldv[6];
+  const float* vs[6];
+  const int window[4] = {B.row0[0][rank], (int)counts_high[rank], B.row0[1][rank], (int)counts_low[rank]};
+  for (int s = 0; s < 6; ++s) {
+    COOT_REQUIRE(d_own[s] && ld[s] % 4 == 0, "contrastive_dp_blocks: set %d", s);
+    ldv[s] = (long)ld[s];
+    // the window's rows (the only ones read through v[s]: F.normalize backward of this rank's rows) live in this rank's block
+    vs[s] = blocks + B.base[s][rank] - (long)window[(s == 2 || s == 3) ? 2 : 0] * ldv[s];
+  }
+  return launch_contrastive_fused(vs, d_own, (int)n[0], (int)n[1], d_high, d_low, w_pair, w_self, cfg->margin, loss, scratch, scratch_bytes,
+                                  (hipStream_t)stream, ldv, window, 7, &B);
+}
+
 int coot_cyclecons_fwd_bwd(const float* clip, const float* sent, const int64_t* clip_lens, const int64_t* sent_lens,
                            const int64_t* idx_clip, const int64_t* idx_sent, int B, int Cc, int Cs, int D, float weight,
                            float inv_batch, float* loss, float* rows_clip, float* rows_sent, float* dclip, float* dsent,

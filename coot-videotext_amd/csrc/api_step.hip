@@ -466,7 +466,7 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* b, 
 
 // optimizer update of the four networks (video side on side_v, text side on side_t, one launch each) + optional repack of the
 // bf16 weight packs; main is ordered after both
-int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* b, int64_t step, int repack, coot_stream_t main_s,
+int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* b, int64_t step, int repack, float* losses, coot_stream_t main_s,
                      coot_stream_t side_v, coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
   COOT_REQUIRE(step >= 1, "step_update: step counts from 1");
@@ -476,7 +476,7 @@ int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* b, in
   const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
   RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
   if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
-  RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
+  RUN(adam_nets(*cfg, *b, tnets, 2, step, st, losses));
   if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
   RUN(g_hops.hop(4, sv, sm));
   RUN(g_hops.hop(5, st, sm));

@@ -31,8 +31,13 @@ void set_cl_col_split(int k);  // 0: column splits of a strip by batch size; k >
 // ldv (optional): row strides of the six input sets (default dense).  window (optional) = {high row0, high rows, low row0, low
 // rows}: only these rows of the per-video sets (0, 1, 4, 5) / per-clip sets (2, 3) receive gradients, dv[] are compact
 // [rows, d] arrays (data parallel: the loss is over the gathered batch, a rank keeps the rows of its own videos).
+// blk (optional): the input rows live in the BLOCKS of an all-gather (one block per rank): row i of set s belongs to the rank r
+// with row0[level][r] <= i < row0[level][r + 1] (level 0: per-video sets, 1: per-clip sets) and starts at
+// blocks + base[s][r] + (i - row0[level][r]) * ldv[s]; v[s] then only serves the window's rows (this rank's own block).
+constexpr int CL_MAX_RANKS = 16;
+struct ClBlocks { const float* blocks; int world; int row0[2][CL_MAX_RANKS + 1]; long base[6][CL_MAX_RANKS]; };
 int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
                              const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st,
-                             const long* ldv = nullptr, const int* window = nullptr, int pair_mask = 7);
+                             const long* ldv = nullptr, const int* window = nullptr, int pair_mask = 7, const ClBlocks* blk = nullptr);
 
 }  // namespace coot

@@ -20,7 +20,7 @@
 namespace coot {
 
 struct ClPair { const float* va; const float* vb; long lda, ldb; bf16_t *a, *b, *aT, *bT; float *inva, *invb; float *dab, *daa, *dbb; int N, Np, d; };
-struct ClNormArgs { ClPair p[3]; int row0[4]; };
+struct ClNormArgs { ClPair p[3]; int row0[4]; ClBlocks blk; };  // blk.world == 0: dense / strided sets
 
 constexpr int CL_TP = 8;  // pitch padding of the transposition tile (elements)
 __global__ __launch_bounds__(1024) void cl_norm_kernel(ClNormArgs A) {
@@ -46,13 +46,23 @@ __global__ __launch_bounds__(1024) void cl_norm_kernel(ClNormArgs A) {
     f32x4_t xa[MAXC], xb[MAXC];
     const int nch = d / 4;
     float sa = 0.f, sb = 0.f;
+    const float* ra = P.va + (long)row * P.lda;
+    const float* rb = P.vb + (long)row * P.ldb;
+    if (A.blk.world > 0) {  // rows of an all-gather: find the rank's block (row is wave-uniform: scalar code)
+      const int lvl = pi == 1 ? 1 : 0;
+      int r = 0;
+      for (int t = 1; t < A.blk.world; ++t) if (row >= A.blk.row0[lvl][t]) r = t;
+      const long i = row - A.blk.row0[lvl][r];
+      ra = A.blk.blocks + A.blk.base[2 * pi][r] + i * P.lda;
+      rb = A.blk.blocks + A.blk.base[2 * pi + 1][r] + i * P.ldb;
+    }
 #pragma unroll
     for (int q = 0; q < MAXC; ++q) {
       const int ch = lane + 64 * q;
       xa[q] = f32x4_t{0.f, 0.f, 0.f, 0.f}; xb[q] = xa[q];
       if (ch < nch) {
-        xa[q] = *reinterpret_cast<const f32x4_t*>(P.va + (long)row * P.lda + ch * 4);
-        xb[q] = *reinterpret_cast<const f32x4_t*>(P.vb + (long)row * P.ldb + ch * 4);
+        xa[q] = *reinterpret_cast<const f32x4_t*>(ra + ch * 4);
+        xb[q] = *reinterpret_cast<const f32x4_t*>(rb + ch * 4);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { sa += xa[q][j] * xa[q][j]; sb += xb[q][j] * xb[q][j]; }
@@ -374,7 +384,7 @@ size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_
 // weights: w_pair[p] (alignment), w_self[p] (already includes the 1/2 of compute_cluster_loss)
 int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
                              const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st,
-                             const long* ldv, const int* window, int pair_mask) {
+                             const long* ldv, const int* window, int pair_mask, const ClBlocks* blk) {
   // pair_mask: bit p set = pair p (0 vid | par, 1 clip | sent, 2 vid_ctx | par_ctx) is part of this call.  The pairs own
   // disjoint scratch buffers and gradient outputs and the loss word is added atomically, so two calls with complementary masks
   // may run on different streams (the step computes pairs 1 and 2 as soon as the local networks are done).
@@ -396,6 +406,8 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
     na.row0[p] = rows; rows += active(p) ? P.Np : 0;  // an inactive pair has no rows (cl_norm picks the LAST pair whose row0 <= row)
   }
   na.row0[3] = rows;
+  na.blk.world = 0;
+  if (blk) na.blk = *blk;
   if (rows > 0) {
     int dmax = 0;
     for (int p = 0; p < 3; ++p) if (active(p) && ds[p] > dmax) dmax = ds[p];

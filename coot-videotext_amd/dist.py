@@ -98,6 +98,28 @@ class DataParallelContext:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
+    def host_group(self):
+        """A gloo group over the same ranks for the few integers a step exchanges about its batch: a collective on HOST tensors
+        does not touch the device queue, so the host keeps running ahead of the GPU (the same integers through RCCL cost a
+        device round trip + a stream synchronisation per step: the pipeline drains).  Created collectively on first use."""
+        g = getattr(self, "_host_group", None)
+        if g is None:
+            if dist.get_backend(self.group) == "gloo":
+                g = self.group if self.group is not None else dist.group.WORLD
+            else:
+                ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
+                g = dist.new_group(ranks=ranks, backend="gloo")
+            self._host_group = g
+        return g
+
+    def exchange_shapes(self, values: List[int]) -> List[List[int]]:
+        """All-gather of a short list of host integers (this rank's batch shape: videos, clips, max clips / sentences per
+        video): result[r] = rank r's list.  ONE host collective per batch instead of three device ones."""
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        out = torch.empty(self.world * t.numel(), dtype=torch.int64)
+        dist.all_gather_into_tensor(out, t, group=self.host_group())
+        return out.view(self.world, t.numel()).tolist()
+
     def global_max(self, value: int, device) -> int:
         t = torch.tensor([int(value)], dtype=torch.int32, device=device)
         _all_reduce(t, dist.ReduceOp.MAX, self.group)
@@ -118,6 +140,11 @@ class DataParallelContext:
     def gather_rows_nograd(self, x: torch.Tensor, counts: List[int]) -> torch.Tensor:
         """All-gather of row blocks (counts[r] rows from rank r), no autograd: the native step slices gradients itself."""
         return gather_rows_nograd(x, counts, self.group)
+
+    def gather_block(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        """ONE all-gather of equally sized blocks: recv [world * n] <- every rank's send [n] in rank order (the native step lays
+        its six embedding sets out in one block and the loss reads the gathered blocks in place)."""
+        _all_gather_into(recv, send, self.group)
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
         """In-place sum over ranks on the current stream."""

@@ -309,9 +309,33 @@ class RetrievalTrainer:
         batch.max_clip_num, batch.max_sent_num = dp.global_max_pair(batch.max_clip_num, batch.max_sent_num, batch.clip_num.device)
         batch.global_max_synced = True
 
+    def _dp_batch_shapes(self, batch, vid_counts=None, clip_counts=None):
+        """Data parallel: what every rank must know about the GLOBAL batch before it can size its step — videos and clips per rank
+        (the gathered embedding blocks) and the global max clips / sentences per video (_sync_global_max) — in ONE collective on
+        host integers (dist.DataParallelContext.exchange_shapes): nothing here waits for the device.  Callers with fixed shapes
+        pass the counts and set batch.global_max_synced: no collective at all."""
+        dp = self.dp
+        synced = getattr(batch, "global_max_synced", False)
+        if vid_counts is not None and clip_counts is not None and synced:
+            return list(vid_counts), list(clip_counts)
+        if not hasattr(dp, "exchange_shapes"):  # (a context that only implements the device collectives)
+            self._sync_global_max(batch)
+            dev = batch.clip_num.device
+            return (vid_counts if vid_counts is not None else dp.global_counts(int(batch.clip_num.shape[0]), dev),
+                    clip_counts if clip_counts is not None else dp.global_counts(int(batch.clip_feat_len.shape[0]), dev))
+        if batch.max_clip_num is None or batch.max_sent_num is None:  # (collate_fn sets them on the host; a hand-made batch pays a device sync)
+            batch.max_clip_num, batch.max_sent_num = int(batch.clip_num.max()), int(batch.sent_num.max())
+        rows = dp.exchange_shapes([int(batch.clip_num.shape[0]), int(batch.clip_feat_len.shape[0]), batch.max_clip_num, batch.max_sent_num])
+        if not synced:
+            batch.max_clip_num, batch.max_sent_num = max(r[2] for r in rows), max(r[3] for r in rows)
+            batch.global_max_synced = True
+        return (list(vid_counts) if vid_counts is not None else [r[0] for r in rows],
+                list(clip_counts) if clip_counts is not None else [r[1] for r in rows])
+
     def _step_impl(self, batch, vid_counts=None, clip_counts=None):
         self.join_streams()  # (a native step with defer_join may still be updating the text networks on its side stream)
-        self._sync_global_max(batch)
+        if getattr(self, "dp", None) is not None:
+            vid_counts, clip_counts = self._dp_batch_shapes(batch, vid_counts, clip_counts)
         nets = list(self.model_mgr.model_dict.values())
         if getattr(self, "_seed_dev", None) is None:
             self._step_prepare_seed(batch, nets)
@@ -702,7 +726,7 @@ class RetrievalTrainer:
         lib = _lib.load()
         dp = self.dp  # every collective of the step goes through this object (dist.DataParallelContext)
         dev = batch.vis_tokens.device if isinstance(batch, RetrievalPackedBatchTuple) else batch.vid_feat.device
-        self._sync_global_max(batch)
+        vid_counts, clip_counts = self._dp_batch_shapes(batch, vid_counts, clip_counts)
         st, x = self._native_setup(batch)
         if self.optimizer is not None:
             st.cfg.lr = float(self.optimizer.param_groups[0]["lr"])
@@ -713,32 +737,54 @@ class RetrievalTrainer:
         train = 1 if self.model_mgr.is_train else 0
         d = st.dims
         B, Nc, D = d.B, d.Nc, st.cfg.net[0].hidden_dim
-        if vid_counts is None:
-            vid_counts = dp.global_counts(B, dev)
-        if clip_counts is None:
-            clip_counts = dp.global_counts(Nc, dev)
+        assert vid_counts[dp.rank] == B and clip_counts[dp.rank] == Nc, (vid_counts, clip_counts, dp.rank, B, Nc)
         key = (st.dims_key, tuple(vid_counts), tuple(clip_counts))
         gb, gn = sum(vid_counts), sum(clip_counts)
         if getattr(st, "dp_key", None) != key:
             f32 = dict(dtype=torch.float32, device=dev)
-            st.emb = [torch.empty(B + Nc, D, **f32), torch.empty(B + Nc, D, **f32), torch.empty(B, 2 * D, **f32), torch.empty(B, 2 * D, **f32),
+            # The four embedding outputs of the forward live in ONE block [glob_v | glob_t | local_v | local_t] laid out at the MAX
+            # row counts over the ranks, so that a single all-gather of equally sized blocks is the whole exchange and the loss
+            # reads the gathered blocks in place (coot_contrastive_fwd_bwd_dp_blocks: per-rank base offsets of the six sets).
+            # More ranks than the loss addresses (lib.DP_MAX_RANKS), or a context without gather_block: two packed row gathers.
+            W = len(vid_counts)
+            mB, mN = max(vid_counts), max(clip_counts)
+            off_gv, off_gt, off_lv = 0, mB * 2 * D, 2 * mB * 2 * D
+            off_lt = off_lv + (mB + mN) * D
+            blk = (off_lt + (mB + mN) * D + 63) // 64 * 64
+            st.blocks_on = hasattr(dp, "gather_block") and W <= _lib.DP_MAX_RANKS
+            st.sendbuf = torch.zeros(blk, **f32)
+            st.recvbuf = torch.empty(W * blk, **f32) if st.blocks_on else None
+            cut = lambda o, r, c: st.sendbuf[o:o + r * c].view(r, c)
+            st.emb = [cut(off_lv, B + Nc, D), cut(off_lt, B + Nc, D), cut(off_gv, B, 2 * D), cut(off_gt, B, 2 * D),
                       torch.empty(B, d.Cmax_clip, D, **f32), torch.empty(B, d.Cmax_sent, D, **f32)]
-            # every buffer the step zeroes, in ONE allocation (one fill per step instead of thirteen): the gradients wrt this rank's
-            # embeddings (same shapes as st.emb) and the three loss words
-            sizes = [t.numel() for t in st.emb] + [4]
+            base = []  # [6][W]: vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx (rank r's clips sit behind ITS context rows)
+            for s_ in range(6):
+                for r in range(W):
+                    o = (off_gv, off_gt, off_lv + vid_counts[r] * D, off_lt + vid_counts[r] * D, off_lv, off_lt)[s_]
+                    base.append(r * blk + o)
+            st.blk_args = ((C.c_int64 * W)(*vid_counts), (C.c_int64 * W)(*clip_counts), (C.c_int64 * (6 * W))(*base),
+                           (C.c_int64 * 6)(2 * D, 2 * D, D, D, D, D))
+            # every buffer the step zeroes, in ONE allocation (one fill per step instead of six): the gradients wrt this rank's
+            # embeddings (same shapes as st.emb)
+            sizes = [t.numel() for t in st.emb]
             st.zbuf = torch.zeros(sum(sizes), **f32)
             views, off = [], 0
-            for t_, n_ in zip(st.emb + [None], sizes):
-                views.append(st.zbuf[off:off + n_].view(t_.shape) if t_ is not None else st.zbuf[off:off + n_])
+            for t_, n_ in zip(st.emb, sizes):
+                views.append(st.zbuf[off:off + n_].view(t_.shape))
                 off += n_
-            st.demb, st.losses = views[:6], views[6][:3]
+            st.demb = views
+            d_local_v, d_local_t, d_glob_v, d_glob_t = views[:4]
+            st.down = (C.c_void_p * 6)(d_glob_v.data_ptr(), d_glob_t.data_ptr(), d_local_v[B:].data_ptr(), d_local_t[B:].data_ptr(),
+                                       d_local_v.data_ptr(), d_local_t.data_ptr())
+            st.emb_ptrs = [t.data_ptr() for t in st.emb]
             st.loss_scratch = torch.empty(lib.coot_contrastive_scratch_bytes(gb, gn, 2 * D, D), dtype=torch.uint8, device=dev)
             st.cyc_idx = torch.empty(2 * B, dtype=torch.int64, device=dev)
             st.dp_key = key
         if getattr(st, "gall", None) is None or st.gall.device != dev:
-            # ONE gradient arena for the four networks + the cycle-consistency loss word: one fill and ONE all-reduce per step
-            # layout: [video global | text global | video local | text local | cc word] — the global networks' gradients are
-            # final after the global backward and are reduced on a communication stream under the local backward
+            # ONE gradient arena for the four networks + the loss words: one fill and ONE all-reduce per step
+            # layout: [video global | text global | video local | text local | total, contrastive, cycle-consistency, pad] — the
+            # global networks' gradients are final after the global backward and are reduced on a communication stream under the
+            # local backward; the loss words are per-rank partial sums of global means and ride on the local half's all-reduce
             st.gall = torch.zeros(sum(n.numel for n in st.nets) + 4, **dict(dtype=torch.float32, device=dev))
             off = 0
             for i in (1, 3, 0, 2):
@@ -749,9 +795,10 @@ class RetrievalTrainer:
                 if i == 3:
                     st.g_glob = st.gall[:off]
                     off_loc = off
-            st.cc_word = st.gall[off:off + 1]
+            st.losses = st.gall[off:off + 3]       # (total, contrastive, cycle-consistency): the layout coot_step_update completes
             st.cl_word = st.gall[off + 1:off + 2]  # this rank's share of the contrastive loss (its rows against the gathered batch)
-            st.g_loc = st.gall[off_loc:off + 2]  # local networks + the two loss words: per-rank partial sums, reduced with the gradients
+            st.cc_word = st.gall[off + 2:off + 3]
+            st.g_loc = st.gall[off_loc:off + 3]    # local networks + the loss words: per-rank partial sums, reduced with the gradients
             st.comm = torch.cuda.Stream()
             st.ev_glob = (torch.cuda.Event(), torch.cuda.Event())
             for e in st.ev_glob:
@@ -766,14 +813,14 @@ class RetrievalTrainer:
         if getattr(st, "zero_args", None) is None or st.zero_key != (st.gall.data_ptr(), st.zbuf.data_ptr()):
             cfgs = (C.POINTER(_lib.NetConfig) * 4)(*[C.pointer(st.cfg.net[i]) for i in range(4)])
             grads = (C.c_void_p * 4)(*[st.bufs.grads[i] for i in range(4)])
-            extra = (C.c_void_p * 2)(st.cc_word.data_ptr(), st.zbuf.data_ptr())
-            extra_n = (C.c_int64 * 2)(st.cc_word.numel() + 3, st.zbuf.numel())   # the arena's 4 tail words (cc word + padding)
+            extra = (C.c_void_p * 2)(st.losses.data_ptr(), st.zbuf.data_ptr())
+            extra_n = (C.c_int64 * 2)(4, st.zbuf.numel())   # the arena's 4 tail words (loss words + padding)
             st.zero_args, st.zero_key = (cfgs, grads, extra, extra_n), (st.gall.data_ptr(), st.zbuf.data_ptr())
         za = st.zero_args
         _lib.check(lib.coot_nets_zero_grads_ex(4, za[0], za[1], 1, za[2], za[3], 2, main.cuda_stream), "coot_nets_zero_grads_ex")
         ws, wsn = st.ws.data_ptr(), st.ws.numel()
         fresh = int(all(n.pack_is_fresh() for n in st.nets))
-        _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *[t.data_ptr() for t in st.emb], ws, wsn,
+        _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *st.emb_ptrs, ws, wsn,
                                          train, int(seed), fresh, main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_forward")
         # cycle-consistency (per video, no exchange) on the text stream, next to the gathers and the contrastive loss on the main stream
         use_cc = st.cfg.cc_weight != 0.0
@@ -789,21 +836,27 @@ class RetrievalTrainer:
                                                       st.cyc_idx.data_ptr(), st.cyc_idx[B:].data_ptr(), B, d.Cmax_clip, d.Cmax_sent, D,
                                                       float(st.cfg.cc_weight), 1.0 / float(gb), st.cc_word.data_ptr(), None, None,
                                                       d_resh_v.data_ptr(), d_resh_t.data_ptr(), stt.cuda_stream), "coot_cyclecons_fwd_bwd")
-        # ---- exchange: two packed all-gathers (per-video sets, per-clip sets); the loss reads the gathered buffers in place ----
-        high = torch.cat([glob_v, glob_t, local_v[:B], local_t[:B]], dim=1)      # [B, 2D | 2D | D | D]
-        low = torch.cat([local_v[B:], local_t[B:]], dim=1)                        # [Nc, D | D]
-        high_all = dp.gather_rows_nograd(high, vid_counts)
-        low_all = dp.gather_rows_nograd(low, clip_counts)
-        wh, wl, e4 = 6 * D, 2 * D, 4
-        hp, lp = high_all.data_ptr(), low_all.data_ptr()
-        sets = (C.c_void_p * 6)(hp, hp + 2 * D * e4, lp, lp + D * e4, hp + 4 * D * e4, hp + 5 * D * e4)  # vid, par, clip, sent, vid_ctx, par_ctx
-        lds = (C.c_int64 * 6)(wh, wh, wl, wl, wh, wh)
-        v0, c0 = sum(vid_counts[:dp.rank]), sum(clip_counts[:dp.rank])
-        down = (C.c_void_p * 6)(d_glob_v.data_ptr(), d_glob_t.data_ptr(), d_local_v[B:].data_ptr(), d_local_t[B:].data_ptr(),
-                                d_local_v.data_ptr(), d_local_t.data_ptr())
-        _lib.check(lib.coot_contrastive_fwd_bwd_dp(C.byref(st.cfg.contr), gb, gn, 2 * D, D, C.byref(sets), C.byref(lds), st.cl_word.data_ptr(),
-                                                   C.byref(down), v0, B, c0, Nc, st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
-                   "coot_contrastive_fwd_bwd_dp")
+        # ---- exchange + contrastive loss on the gathered batch (this rank's rows against every column) ----
+        if st.blocks_on:  # ONE all-gather of the embedding block; the loss reads the gathered blocks in place
+            dp.gather_block(st.sendbuf, st.recvbuf)
+            ba = st.blk_args
+            _lib.check(lib.coot_contrastive_fwd_bwd_dp_blocks(C.byref(st.cfg.contr), len(vid_counts), dp.rank, ba[0], ba[1], 2 * D, D,
+                                                              st.recvbuf.data_ptr(), ba[2], C.byref(ba[3]), st.cl_word.data_ptr(), C.byref(st.down),
+                                                              st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
+                       "coot_contrastive_fwd_bwd_dp_blocks")
+        else:  # two packed row gathers (per-video sets, per-clip sets)
+            high = torch.cat([glob_v, glob_t, local_v[:B], local_t[:B]], dim=1)      # [B, 2D | 2D | D | D]
+            low = torch.cat([local_v[B:], local_t[B:]], dim=1)                        # [Nc, D | D]
+            high_all = dp.gather_rows_nograd(high, vid_counts)
+            low_all = dp.gather_rows_nograd(low, clip_counts)
+            wh, wl, e4 = 6 * D, 2 * D, 4
+            hp, lp = high_all.data_ptr(), low_all.data_ptr()
+            sets = (C.c_void_p * 6)(hp, hp + 2 * D * e4, lp, lp + D * e4, hp + 4 * D * e4, hp + 5 * D * e4)  # vid, par, clip, sent, vid_ctx, par_ctx
+            lds = (C.c_int64 * 6)(wh, wh, wl, wl, wh, wh)
+            v0, c0 = sum(vid_counts[:dp.rank]), sum(clip_counts[:dp.rank])
+            _lib.check(lib.coot_contrastive_fwd_bwd_dp(C.byref(st.cfg.contr), gb, gn, 2 * D, D, C.byref(sets), C.byref(lds), st.cl_word.data_ptr(),
+                                                       C.byref(st.down), v0, B, c0, Nc, st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
+                       "coot_contrastive_fwd_bwd_dp")
         if use_cc:
             main.wait_stream(stt)  # the backward reads d_resh / the cycle-consistency word
         lib.coot_step_set_global_done_events(st.ev_glob[0].cuda_event, st.ev_glob[1].cuda_event)
@@ -834,14 +887,13 @@ class RetrievalTrainer:
             dp.all_reduce_sum(st.g_glob)
         dp.all_reduce_sum(st.g_loc)
         main.wait_stream(st.comm)
-        st.losses[1:2].copy_(st.cl_word)
-        st.losses[2:3].copy_(st.cc_word)
-        torch.add(st.losses[1:2], st.losses[2:3], out=st.losses[0:1])
-        if do_optimizer:
-            _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), 1, main.cuda_stream, sv.cuda_stream,
-                                            stt.cuda_stream), "coot_step_update")
+        if do_optimizer:  # (the text side's update launch also writes total = contrastive + cycle-consistency)
+            _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), 1, st.losses.data_ptr(), main.cuda_stream,
+                                            sv.cuda_stream, stt.cuda_stream), "coot_step_update")
             for n in st.nets:
                 n.mark_packed()
+        else:
+            torch.add(st.cl_word, st.cc_word, out=st.losses[0:1])
         self.total_step += 1
 
     # ---- epoch loop (coot/trainer_retrieval.py:235-310 and the nntrainer/trainer_base.py hooks it calls) --------------

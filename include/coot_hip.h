@@ -197,6 +197,18 @@ int coot_contrastive_fwd_bwd_dp(const coot_contrastive_config* cfg, int n_high, 
                                 int own_high0, int own_high, int own_low0, int own_low, void* scratch,
                                 size_t scratch_bytes, coot_stream_t stream);
 
+/* The same, reading the rows straight from the BLOCKS of ONE all-gather (no repacking between the collective and the loss): every
+ * rank contributes one block holding its six sets; set s of rank r has counts_high[r] (sets 0, 1, 4, 5) or counts_low[r]
+ * (sets 2, 3) rows of stride ld[s] floats and starts at blocks + set_base[s * world + r] (floats, multiples of 4).  The global
+ * batch is the concatenation of the ranks' rows in rank order; gradients for rank `rank`'s rows into d_own[s] [own rows, d];
+ * *loss receives this rank's share.  world <= COOT_DP_MAX_RANKS (the block table travels in the kernel arguments).
+ * counts_* / set_base / ld are host arrays.  Replaces the gather + concatenation of nn.DataParallel (nntrainer/trainer_base.py:126-129). */
+#define COOT_DP_MAX_RANKS 16
+int coot_contrastive_fwd_bwd_dp_blocks(const coot_contrastive_config* cfg, int world, int rank, const int64_t* counts_high,
+                                       const int64_t* counts_low, int d_high, int d_low, const float* blocks,
+                                       const int64_t* set_base, const int64_t ld[6], float* loss, float* const d_own[6],
+                                       void* scratch, size_t scratch_bytes, coot_stream_t stream);
+
 /* CycleConsistencyLoss.forward + get_total_loss(num_samples=1) (coot/loss_fn.py:143-319).
  * idx_* are the th.multinomial draws (one valid position per video).  loss += weight *
  * inv_batch * sum_b (l_clip[b, idx_clip[b]] + l_sent[b, idx_sent[b]]); rows_* optional [B, C]. */
@@ -324,8 +336,10 @@ int coot_step_set_device_state(void* state);
  * stays set until changed. */
 int coot_step_set_global_done_events(void* ev_video, void* ev_text);
 /* Optimizer update of the four networks after the gradient all-reduce (cfg->optimizer; `step` 1-based): one launch per side on
- * side_v / side_t, then (repack != 0) the bf16 weight packs are rebuilt so that the next coot_step_forward may skip the packing. */
-int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* bufs, int64_t step, int repack,
+ * side_v / side_t, then (repack != 0) the bf16 weight packs are rebuilt so that the next coot_step_forward may skip the packing.
+ * losses (may be NULL): the three loss words { total, contrastive, cycle-consistency } of the step; the text side's update launch
+ * writes total = contrastive + cycle-consistency (a data-parallel caller keeps the two all-reduced words there: no extra launch). */
+int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* bufs, int64_t step, int repack, float* losses,
                      coot_stream_t main_stream, coot_stream_t side_v, coot_stream_t side_t);
 /* One valid clip / sentence position per video for the cycle-consistency loss (th.multinomial(mask, 1), coot/loss_fn.py:306-314),
  * drawn on the device: idx[0 .. B) from clip_num, idx[B .. 2B) from sent_num. */

@@ -196,8 +196,25 @@ class _FakeDP:
         pass
 
 
-@pytest.mark.parametrize("R,cc_weight", [(2, 0.01), (4, 0.0), (3, 0.01)])
-def test_native_dp_step_simulated_ranks_match_union_batch(env, R, cc_weight):
+class _FakeDPBlocks(_FakeDP):
+    """+ the one-block exchange (dist.DataParallelContext.gather_block): the step then reads the gathered blocks in place through
+    coot_contrastive_fwd_bwd_dp_blocks instead of two packed row gathers."""
+
+    def gather_block(self, send, recv):
+        i = self.calls
+        self.calls += 1
+        self.board.rows[(i, self.rank)] = send.detach().clone()
+        n = send.numel()
+        for r in range(self.world):
+            t = self.board.rows.get((i, r))
+            if t is None:
+                recv[r * n:(r + 1) * n].zero_()
+            else:
+                recv[r * n:(r + 1) * n].copy_(t)
+
+
+@pytest.mark.parametrize("R,cc_weight,blocks", [(2, 0.01, True), (4, 0.0, True), (3, 0.01, True), (3, 0.01, False)])
+def test_native_dp_step_simulated_ranks_match_union_batch(env, R, cc_weight, blocks):
     torch, cva = env
     dims = (64, 48, 64, 4, 64, 128)
     cfgs = H.full_cfgs(*dims)
@@ -228,7 +245,7 @@ def test_native_dp_step_simulated_ranks_match_union_batch(env, R, cc_weight):
     g_sum, loss_contr, loss_cc = None, [], 0.0
     for pass_ in range(2):  # pass 0 fills the blackboard (every rank's forward is deterministic), pass 1 is the step proper
         for r in range(R):
-            tb.dp = _FakeDP(r, board)
+            tb.dp = (_FakeDPBlocks if blocks else _FakeDP)(r, board)
             sh = shards[r]
             sh.global_max_synced = False
             cc_idx = torch.cat([idx_c[bounds[r]:bounds[r + 1]], idx_s[bounds[r]:bounds[r + 1]]]).cuda()
@@ -237,6 +254,7 @@ def test_native_dp_step_simulated_ranks_match_union_batch(env, R, cc_weight):
             assert (sh.max_clip_num, sh.max_sent_num) == board.global_max  # padded to the GLOBAL Cmax (avg_special parity)
             if pass_ == 1:
                 st = tb._native
+                assert st.blocks_on == blocks
                 g = [n._grad_flat.detach().clone() for n in mgr_b.model_dict.values()]
                 g_sum = g if g_sum is None else [a + b for a, b in zip(g_sum, g)]
                 loss_contr.append(float(out[1]))
