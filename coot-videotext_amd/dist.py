@@ -107,8 +107,12 @@ class DataParallelContext:
             if dist.get_backend(self.group) == "gloo":
                 g = self.group if self.group is not None else dist.group.WORLD
             else:
-                ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
-                g = dist.new_group(ranks=ranks, backend="gloo")
+                try:
+                    ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
+                    g = dist.new_group(ranks=ranks, backend="gloo")
+                except Exception as e:  # (e.g. no resolvable host name for gloo's TCP transport: the same on every rank of a node)
+                    print(f"coot dist: no gloo side group ({e}); batch shapes go through the device collectives (one stream sync per step)")
+                    g = False
             self._host_group = g
         return g
 
@@ -117,7 +121,14 @@ class DataParallelContext:
         video): result[r] = rank r's list.  ONE host collective per batch instead of three device ones."""
         t = torch.tensor([int(v) for v in values], dtype=torch.int64)
         out = torch.empty(self.world * t.numel(), dtype=torch.int64)
-        dist.all_gather_into_tensor(out, t, group=self.host_group())
+        g = self.host_group()
+        if g is False:  # device collective of the main group
+            dev = torch.device("cuda", torch.cuda.current_device())
+            od = out.to(dev)
+            dist.all_gather_into_tensor(od, t.to(dev), group=self.group)
+            out = od.cpu()
+        else:
+            dist.all_gather_into_tensor(out, t, group=g)
         return out.view(self.world, t.numel()).tolist()
 
     def global_max(self, value: int, device) -> int:

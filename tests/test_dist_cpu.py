@@ -64,6 +64,12 @@ def _worker(rank, world, port, counts_v, counts_c, out):
     assert dp.global_max(3 + rank, "cpu") == 3 + world - 1
     assert dp.global_counts(counts_c[rank], "cpu") == list(counts_c)
     assert dp.global_max_pair(3 + rank, 10 - rank, "cpu") == (3 + world - 1, 10)
+    # the batch-shape exchange of the native step: ONE host collective, every rank sees every rank's integers in rank order
+    assert dp.exchange_shapes([5 + rank, 20 - rank, 7]) == [[5 + r, 20 - r, 7] for r in range(world)]
+    blk = torch.full((6,), float(rank))
+    got = torch.empty(world * 6)
+    dp.gather_block(blk, got)   # the one-block embedding exchange
+    assert got.view(world, 6).eq(torch.arange(world, dtype=torch.float32)[:, None]).all()
     # the collective of the native data-parallel step (no autograd): ragged row blocks arrive in rank order
     rows = torch.arange(counts_c[rank] * 2, dtype=torch.float32).view(-1, 2) + 100 * rank
     allrows = cdist.gather_rows_nograd(rows, list(counts_c))
