@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (phase calls + RCCL collectives) even with one rank")
     ap.add_argument("--step-stamps", action="store_true", help="print a HIP-event timeline of one training step to stderr")
     ap.add_argument("--clock-monitor", action="store_true", help="after the timed loop: sample the shader clock on a side stream while more steps run (stderr)")
+    ap.add_argument("--no-lookahead", action="store_true", help="do not announce the next batch to the step: its input LayerNorm runs at the head of its own step instead of next to the previous step's global networks (A/B)")
     ap.add_argument("--no-defer-join", action="store_true", help="join the text stream into the main stream at the end of every step (A/B)")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--padded", action="store_true", help="ragged workloads: run the reference's padded layout instead of packed (varlen) rows")
@@ -230,13 +231,17 @@ def main():
 
         mode = args.mode if (world == 1 or args.mode != "graph") else "autograd"
         batch.global_max_synced = True  # fixed shapes: every rank has the same Cmax, no MAX all-reduce needed
+        lookahead = mode == "native" and dp is None and not args.no_lookahead
 
         def step(graph=None):
             if mode in ("native", "native-graph", "native-phases") and graph is None:  # N > 1: native phases with the RCCL collectives between them
                 # back-to-back steps: the text side's update tail overlaps the next step's forward (COOT_STEP_DEFER_TEXT_JOIN); every
                 # step is complete when the timed region ends (barrier + device synchronisation below)
+                # the data loader's lookahead: the next batch (synthetic data: the same tensors) is announced to the step, which runs that
+                # batch's parameter-free input LayerNorm next to its global networks — every step still executes one per side
                 return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, defer_join=not args.no_defer_join,
-                                                 use_graph={"native-graph": True, "native-phases": "phases"}.get(mode, False))[0]
+                                                 use_graph={"native-graph": True, "native-phases": "phases"}.get(mode, False),
+                                                 next_batch=batch if lookahead else None)[0]
             return trainer.train_step(batch, vid_counts, clip_counts, use_graph=(mode == "graph") if graph is None else graph)[0]
 
     def barrier():
@@ -393,6 +398,8 @@ def main():
                        "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
                        "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",
                        "launch": "eval" if args.eval else mode,
+                       **({"input_lookahead": "each step also runs the NEXT batch's input LayerNorm (one per side per step, as without it), next to its global networks"}
+                          if (not args.eval and lookahead) else {}),
                        **({"token_layout": "padded to the batch maxima (the reference's layout)" if args.padded else "packed (cu_seqlens): valid tokens only",
                            "valid_tokens": [int(batch.vid_feat_len.sum() + batch.clip_feat_len.sum()), int(batch.par_feat_len.sum() + batch.sent_feat_len.sum())],
                            "padded_tokens": [batch.vid_feat.shape[0] * batch.vid_feat.shape[1] + batch.clip_feat.shape[0] * batch.clip_feat.shape[1],

@@ -366,6 +366,9 @@ static int g_use_fused_bwd = 1;  // coot_set_option("fused_bwd", 0/1)
 static int g_use_fused_infc = 1;  // coot_set_option("fused_infc", 0/1): input FC + QKV in one launch (+1.4 % on the step once its K loop was pipelined two slabs deep)
 static int g_use_fused = 1;
 static int g_grad_poison = 0;  // coot_set_option("grad_poison", 1) (tests): coot_nets_zero_grads fills the matrices it skips with NaN
+static int g_ln_wgs = 512;  // coot_set_option("ln_prefetch_wgs", n): workgroup cap of the prefetched input LayerNorm (0: one per four rows).  Measured
+                             // (profiles/README.md, round 3): no cap 1.227, 1024: 1.235, 512: 1.217, 256: 1.213-1.228, 128: 1.259 ms per step (1.238 without the prefetch)
+static int g_ln_nt = 1;  // coot_set_option("ln_prefetch_nt", 0/1): the prefetched input LayerNorm (input stages) with streaming loads / stores
 static int g_pack_lazy = 1, g_pack_poison = 0;  // coot_set_option("pack_lazy" / "pack_poison"): lazily packed per-op layouts (below)
 static int g_fz_debug = 0;
 static unsigned long long* g_fz_tstamps = nullptr;
@@ -645,6 +648,8 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "defer_global_tn")) { coot_step_defer_global_tn(value); return 0; }
   if (!strcmp(name, "glob_xcd_split")) { coot_step_glob_xcd_split(value); return 0; }
   if (!strcmp(name, "cl_col_split")) { set_cl_col_split(value); return 0; }
+  if (!strcmp(name, "ln_prefetch_nt")) { g_ln_nt = value; return 0; }
+  if (!strcmp(name, "ln_prefetch_wgs")) { g_ln_wgs = value; return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   if (!strcmp(name, "fused_fwd_small")) { g_fused_fwd_small = value; return 0; }
@@ -934,6 +939,16 @@ int coot_nets_zero_grads_ex(int nnets, const coot_net_config* const* cfgs, float
   return flush();
 }
 
+// Input stage of a local network (api_step.hip: software-pipelined input LayerNorm).  With a stage set, the parameter-free x^ of the
+// input LayerNorm (its gain / bias live in the packed input-FC weights) and the packed rows' position table live in the caller's
+// stage instead of the saved arena.  mode 1: coot_net_fwd ONLY normalises (writes the stage) and returns; mode 2: the stage already
+// holds this batch's x^ — the LayerNorm launch is skipped; mode 0: normalise into the stage and go on.  coot_net_bwd reads x^ there.
+struct InputStage { bf16_t* xhat = nullptr; int* pos = nullptr; int mode = 0; };
+thread_local InputStage g_input_stage;
+void coot_internal_set_input_stage(void* xhat, void* pos, int mode) {
+  g_input_stage.xhat = (bf16_t*)xhat; g_input_stage.pos = (int*)pos; g_input_stage.mode = mode;
+}
+
 int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, const float* pe, const float* feats,
                  const int64_t* lengths, int N, int Lseq, const float* feats2, const int64_t* lengths2, int N2, int L2,
                  const float* hidden, float* pooled, float* per_token, void* saved,
@@ -958,6 +973,9 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   PerOpGuardScope perop_guard(c, W, P, wpack);
   Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);  // sized for the padded layout (>= the packed rows)
   COOT_REQUIRE(!AS.overflow, "net_fwd: saved buffer too small (%zu < %zu)", saved_bytes, AS.off);
+  const bool staged = c.use_input_fc && g_input_stage.xhat != nullptr;
+  const int stage_mode = staged ? g_input_stage.mode : 0;
+  if (staged) { S.xhat = g_input_stage.xhat; S.pos = g_input_stage.pos; }
   const int source = packed ? packed->source : COOT_SOURCE_PADDED;
   COOT_REQUIRE(source >= COOT_SOURCE_PADDED && source <= COOT_SOURCE_PACKED_BF16, "net_fwd: packed source %d", source);
   if (packed_ok(c, W, sg, packed)) {
@@ -975,7 +993,10 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     if (sg.n > 1) { l.x2 = feats2; l.R0 = T0; l.R = T; }  // both segments in one launch
     if (sg.cu) { l.R = T; l.cu = sg.cu; l.nseq = Ntot; l.N0 = N; l.L0 = Lseq; l.L1 = L2; l.pos_out = S.pos; }  // gathers the valid rows
     if (source != COOT_SOURCE_PADDED) { l.src_packed = 1; l.x2 = nullptr; l.x_f32 = source == COOT_SOURCE_PACKED_F32; }  // ... or reads them in place
-    RUN(launch_ln_fwd(l, st));
+    l.nt = stage_mode == 1 && g_ln_nt;
+    l.max_wgs = stage_mode == 1 ? g_ln_wgs : 0;
+    if (stage_mode != 2) RUN(launch_ln_fwd(l, st));
+    if (stage_mode == 1) return 0;
     if (W.f_in_w && W.layers[0].f_wqkv && g_use_fused && g_use_fused_infc && T >= g_fused_min_rows) {
       InfcQkvFwd f; f.T = T; f.Din = Din; f.xhat = S.xhat; f.win = W.f_in_w; f.bin = W.in_bias; f.pe = pe; f.T0 = T0; f.L1 = Lseq;
       f.pos = sg.cu ? S.pos : nullptr;
@@ -1096,6 +1117,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   PerOpGuardScope perop_guard(c, W, P, wpack);
   Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);
   COOT_REQUIRE(!AS.overflow, "net_bwd: saved buffer too small");
+  if (c.use_input_fc && g_input_stage.xhat) { S.xhat = g_input_stage.xhat; S.pos = g_input_stage.pos; }  // (the forward's input stage)
   Arena AX(scratch, scratch_bytes); Scratch X; layout_scratch(c, Ntot, sg.Tpad(), AX, X);
   if (packed_ok(c, W, sg, packed)) { sg.cu = packed->cu_seqlens; sg.Tp = packed->total_tokens; }  // the forward's decision
   COOT_REQUIRE(!AX.overflow, "net_bwd: scratch buffer too small (%zu < %zu)", scratch_bytes, AX.off);

@@ -102,7 +102,7 @@ int check_cfg(const coot_step_config& c) {
 // streams vanish), the losses run on the video stream, and every hop left on the critical path waits for the text side,
 // which has slack.
 struct Hops {
-  static constexpr int N = 10;
+  static constexpr int N = 12;
   hipEvent_t ev[N]; bool made = false;
   int init() {
     if (made) return 0;
@@ -169,6 +169,38 @@ struct StepStamps {
   }
 };
 StepStamps g_stamps;
+
+// ---- software-pipelined input LayerNorm (coot_step_set_input_stages / coot_step_set_next_batch, COOT_STEP_INPUT_STAGES) ----------
+// The input LayerNorm of the local networks has no parameters of its own (gain / bias are folded into the packed input-FC weights),
+// so x^ of batch t + 1 depends on nothing step t computes.  It is the one HBM-bound kernel at the head of the step's critical path
+// (2 launches, 390 MB, ~60 us on the video stream) while a quarter of the step — the global networks and the loss between them — runs
+// on 8-16 CUs with the memory system idle.  With two caller-owned stages, step t normalises batch t + 1 into the stage it does not
+// use, on its own stream behind both sides' local forward passes; step t + 1 finds its x^ ready and starts with the input FC.
+extern "C" void coot_internal_set_input_stage(void* xhat, void* pos, int mode);  // api.hip
+struct StageLayout { char *xv, *xt, *pv, *pt; size_t bytes; };
+StageLayout stage_layout(const coot_step_config& c, const coot_step_dims& d, void* base) {
+  auto pad = [](size_t t) { return (t + 127) & ~(size_t)127; };  // whole 128-row tiles, as the saved arena (api.hip: layout_saved)
+  const size_t Tv = pad((size_t)d.B * d.Lv + (size_t)d.Nc * d.Lc), Tt = pad((size_t)d.B * d.Lp + (size_t)d.Nc * d.Ls);
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t o = off; off = (off + n + 255) & ~(size_t)255; return o; };
+  const size_t oxv = take(Tv * c.net[0].input_dim * 2), oxt = take(Tt * c.net[2].input_dim * 2), opv = take(Tv * 4), opt = take(Tt * 4);
+  StageLayout L; char* b = (char*)base;
+  L.xv = b ? b + oxv : nullptr; L.xt = b ? b + oxt : nullptr; L.pv = b ? b + opv : nullptr; L.pt = b ? b + opt : nullptr; L.bytes = off;
+  return L;
+}
+struct InputPipe {
+  void* stage[2] = {nullptr, nullptr}; size_t bytes = 0;
+  bool next_valid = false; coot_step_batch next_x; coot_step_dims next_d;  // the batch of the NEXT step (one-shot: consumed by a step)
+  bool ready = false; int idx = 0; coot_step_batch have_x; coot_step_dims have_d;  // stage[idx] holds x^ of (have_x, have_d)
+  hipEvent_t done = nullptr; hipStream_t stream = nullptr;
+  int init() {
+    if (stream) return 0;
+    RUN(check_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate"));
+    return check_hip(hipEventCreateWithFlags(&done, hipEventDisableTiming), "hipEventCreate");
+  }
+};
+thread_local InputPipe g_pipe;
+struct StageScope { ~StageScope() { coot_internal_set_input_stage(nullptr, nullptr, 0); } };  // no exit path leaves a stage set
 
 // one side (video or text): local(ctx segment + item segment) -> pack -> global
 int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, int gi, const float* ctx_feat, const int64_t* ctx_len,
@@ -517,12 +549,52 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   const bool split_loss = g_split_loss != 0 && sv != st;
+  // input stages: this batch's x^ in stage[cur] (already there if the previous step normalised it: `hit`), the next batch's into the other
+  const bool piped = (do_optimizer & COOT_STEP_INPUT_STAGES) != 0;
+  StageScope stage_scope;
+  StageLayout SL{}; int cur = 0; bool hit = false;
+  if (piped) {
+    COOT_REQUIRE(g_pipe.stage[0] && g_pipe.stage[1], "train_step: COOT_STEP_INPUT_STAGES without coot_step_set_input_stages");
+    COOT_REQUIRE(!g_state_dev, "train_step: input stages are not available in a replayable (captured) step");
+    hit = g_pipe.ready && !memcmp(&g_pipe.have_x, x, sizeof(*x)) && !memcmp(&g_pipe.have_d, d, sizeof(*d));
+    cur = hit ? g_pipe.idx : (g_pipe.ready ? g_pipe.idx ^ 1 : 0);
+    SL = stage_layout(*cfg, *d, g_pipe.stage[cur]);
+    COOT_REQUIRE(SL.bytes <= g_pipe.bytes, "train_step: input stages too small (%zu < %zu)", g_pipe.bytes, SL.bytes);
+    if (hit) {
+      RUN(check_hip(hipStreamWaitEvent(sv, g_pipe.done, 0), "streamWait"));
+      RUN(check_hip(hipStreamWaitEvent(st, g_pipe.done, 0), "streamWait"));
+    }
+    g_pipe.ready = false;
+  }
+  const bool prefetch = piped && g_pipe.next_valid;
+  if (piped) coot_internal_set_input_stage(SL.xv, SL.pv, hit ? 2 : 0);
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                    W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first, &pk.v,
-                   split_loss ? 9 : -1));
+                   (split_loss || prefetch) ? 9 : -1));
+  if (piped) coot_internal_set_input_stage(SL.xt, SL.pt, hit ? 2 : 0);
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
                    W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st,
-                   pack_first, &pk.t));
+                   pack_first, &pk.t, prefetch ? 10 : -1));
+  coot_internal_set_input_stage(nullptr, nullptr, 0);
+  if (prefetch) {  // x^ of the next batch, behind both local forward passes (the chip's memory system is idle from there to the local backward)
+    RUN(g_pipe.init());
+    const coot_step_batch& nx = g_pipe.next_x; const coot_step_dims& nd = g_pipe.next_d;
+    const StageLayout NL = stage_layout(*cfg, nd, g_pipe.stage[cur ^ 1]);
+    COOT_REQUIRE(NL.bytes <= g_pipe.bytes, "train_step: input stages too small for the next batch (%zu < %zu)", g_pipe.bytes, NL.bytes);
+    const SidePacked npk = side_packed(nx, nd);
+    RUN(g_hops.wait(9, g_pipe.stream));
+    RUN(g_hops.wait(10, g_pipe.stream));
+    g_pipe.next_valid = false;
+    coot_internal_set_input_stage(NL.xv, NL.pv, 1);  // mode 1: coot_net_fwd normalises into the stage and returns
+    RUN(coot_net_fwd(&cfg->net[0], b->params[0], b->wpack[0], b->pe[0], nx.vid_feat, nx.vid_len, nd.B, nd.Lv, nx.clip_feat, nx.clip_len, nd.Nc, nd.Lc,
+                     nullptr, W.local_v, nullptr, W.saved_lv, (size_t)-1, nullptr, 0, train, seed, nullptr, g_pipe.stream, &npk.v));
+    coot_internal_set_input_stage(NL.xt, NL.pt, 1);
+    RUN(coot_net_fwd(&cfg->net[2], b->params[2], b->wpack[2], b->pe[2], nx.par_feat, nx.par_len, nd.B, nd.Lp, nx.sent_feat, nx.sent_len, nd.Nc, nd.Ls,
+                     nullptr, W.local_t, nullptr, W.saved_lt, (size_t)-1, nullptr, 0, train, seed, nullptr, g_pipe.stream, &npk.t));
+    coot_internal_set_input_stage(nullptr, nullptr, 0);
+    RUN(check_hip(hipEventRecord(g_pipe.done, g_pipe.stream), "eventRecord"));
+    g_pipe.ready = true; g_pipe.idx = cur ^ 1; g_pipe.have_x = nx; g_pipe.have_d = nd;
+  }
   // Zero the parameter gradients (4 arenas), the embedding gradients (one block) and the loss words at the END of the text
   // forward: the text side shares the chip with the three times larger video side and, started at the same time, finishes its
   // forward ~75 us earlier (HIP-event timeline), so the six fills are free there.  (At the head of the text stream they delayed
@@ -573,6 +645,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   // terms' gradients) was recorded in slot 7; side_backward waits where it is first read
   g_resh_wait_slot = (cc || split_loss) ? 7 : -1;
   (void)coot_net_grads_overwrite(g_grad_write);
+  if (piped) coot_internal_set_input_stage(SL.xv, SL.pv, 0);  // the weight gradient of the input FC reads x^ there
   const int rc_v = side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                                  W.local_v, W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv,
                                  W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, sv, &pk.v);
@@ -582,10 +655,12 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
   if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
   g_stamps.mark("video: updated", sv);
+  if (piped) coot_internal_set_input_stage(SL.xt, SL.pt, 0);
   const int rc_t = side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, W.local_t,
                                  W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt,
                                  W.scratch_t, W.sz_st, train, seed + 1000, st, &pk.t);
   (void)coot_net_grads_overwrite(0);
+  coot_internal_set_input_stage(nullptr, nullptr, 0);
   RUN(rc_t);
   // total = contrastive + cycle-consistency (not needed by the backward): rides on the text side's update launch
   if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st, losses));
@@ -681,6 +756,22 @@ int coot_step_set_device_state(void* state) {
   return 0;
 }
 int coot_step_set_cycle_indices(const int64_t* idx) { g_cc_idx_inject = idx; return 0; }
+size_t coot_step_input_stage_bytes(const coot_step_config* cfg, const coot_step_dims* dims) {
+  if (!cfg || !dims) return 0;
+  return stage_layout(*cfg, *dims, nullptr).bytes;
+}
+int coot_step_set_input_stages(void* stage0, void* stage1, size_t bytes_each) {
+  COOT_REQUIRE((!stage0 && !stage1) || (stage0 && stage1 && stage0 != stage1), "set_input_stages: two distinct buffers, or both NULL");
+  if (stage0 == g_pipe.stage[0] && stage1 == g_pipe.stage[1] && bytes_each == g_pipe.bytes) return 0;  // unchanged: what a stage holds stays valid
+  g_pipe.stage[0] = stage0; g_pipe.stage[1] = stage1; g_pipe.bytes = bytes_each; g_pipe.ready = false; g_pipe.next_valid = false;
+  return 0;
+}
+int coot_step_set_next_batch(const coot_step_batch* next, const coot_step_dims* next_dims) {
+  COOT_REQUIRE((next == nullptr) == (next_dims == nullptr), "set_next_batch: batch and dims, or both NULL");
+  g_pipe.next_valid = next != nullptr;
+  if (next) { g_pipe.next_x = *next; g_pipe.next_d = *next_dims; }
+  return 0;
+}
 int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
 void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
 void coot_step_split_loss(int on) { g_split_loss = on; }

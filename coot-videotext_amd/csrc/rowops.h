@@ -23,6 +23,9 @@ struct LnFwd {
   // (n - N0) L1 + l of x2.  pos_out[r] = position of row r within its sequence (for the positional encoding further down).
   const int* cu = nullptr; int nseq = 0, N0 = 0, L0 = 0, L1 = 0; int* pos_out = nullptr;
   int src_packed = 0;  // with cu: the SOURCE x is packed as well ([R, D] in cu order, coot_collate_packed): row r reads row r
+  int max_wgs = 0;     // > 0: at most this many workgroups walk the rows (a launch that should trickle next to latency-bound kernels)
+  int nt = 0;          // streaming (non-temporal) loads of an fp32 source and stores of the bf16 output: the launch runs NEXT TO kernels
+                       // that live on L2-resident weights (the next batch's input LayerNorm beside the global networks) and must not evict them
 };
 int launch_ln_fwd(const LnFwd& p, hipStream_t stream);
 

@@ -86,15 +86,95 @@ __global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
   }
 }
 
+// The prefetched input LayerNorm (p.nt / p.max_wgs: api_step.hip, input stages): the same row code with non-temporal loads of an fp32
+// source and stores of the bf16 output, on a capped grid that walks the rows.  A kernel of its own: the plain variant's 64-VGPR budget
+// does not survive a row loop around its body (58 VGPRs spilled even for a loop of one trip, 1 800 with the body in a function).
+template <int NV>
+__global__ __launch_bounds__(256, 4) void ln_fwd_stream_kernel(LnFwd p) {
+  const unsigned dkey = p.drop.thr ? drop_site_key(p.drop.seed, p.drop.seed_ptr, p.drop.site) : 0u;
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < p.R; row += gridDim.x * 4) {
+  const int D = p.D, nch = D >> 2;
+  bool second = p.x2 && row >= p.R0;
+  long xrow = second ? row - p.R0 : row;
+  if (p.cu) {  // packed rows: find the sequence (largest n with cu[n] <= row), gather from the padded source
+    int lo = 0, hi = p.nseq;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.cu[mid] <= row) lo = mid; else hi = mid; }
+    const int l = row - p.cu[lo];
+    second = lo >= p.N0;
+    xrow = second ? (long)(lo - p.N0) * p.L1 + l : (long)lo * p.L0 + l;
+    if (p.src_packed) { second = false; xrow = row; }  // packed at the source: the row is where it belongs already
+    if (p.pos_out && lane == 0) p.pos_out[row] = l;
+  }
+  const void* xsrc = second ? p.x2 : p.x;
+  f32x4_t v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + 64 * i;
+    v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (c < nch) {
+      if (p.nt && p.x_f32) v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>((const float*)xsrc + xrow * p.ldx + c * 4));
+      else v[i] = load4(xsrc, p.x_f32, xrow * p.ldx + c * 4);
+    }
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; v[i][j] = d; q += d * d; }
+    }
+  }
+  const float stdv = sqrtf(wave_sum(q) / (float)(D - 1));
+  const float rs = 1.0f / (stdv + kLnEps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + 64 * i;
+    if (c >= nch) continue;
+    const int col = c * 4;
+    f32x4_t y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = v[i][j] * rs;
+      if (p.gain) t = t * p.gain[col + j] + p.bias[col + j];
+      if (p.pe) t += p.pe[(long)(row % p.pe_L) * D + col + j];
+      y[j] = t;
+    }
+    if (p.drop.thr) {
+      float sc[4];
+      drop_scales_key<4>(dkey, (unsigned long long)row * D + col, p.drop.thr, p.drop.inv_keep, sc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] *= sc[j];
+    }
+    if (p.y && p.nt) {
+      const u32x2_t pk = {(unsigned)f2bf(y[0]) | ((unsigned)f2bf(y[1]) << 16), (unsigned)f2bf(y[2]) | ((unsigned)f2bf(y[3]) << 16)};
+      __builtin_nontemporal_store(pk, reinterpret_cast<u32x2_t*>(p.y + (long)row * p.ldy + col));
+    } else if (p.y) store4_bf(p.y + (long)row * p.ldy + col, y);
+    if (p.y32) *reinterpret_cast<f32x4_t*>(p.y32 + (long)row * p.ldy32 + col) = y;
+  }
+  }
+}
+
+
 int launch_ln_fwd(const LnFwd& p, hipStream_t stream) {
   COOT_REQUIRE(p.x && (p.y || p.y32), "ln_fwd: null pointer");
   COOT_REQUIRE(p.D % 4 == 0 && p.D <= 4096 && p.D >= 8 && p.ldx % 4 == 0, "ln_fwd: D=%d unsupported (need D%%4==0, 8<=D<=4096)", p.D);
   if (p.R <= 0) return 0;
   dim3 grid((p.R + 3) / 4);
+  const bool stream_variant = p.nt || p.max_wgs > 0;
+  if (p.max_wgs > 0 && (int)grid.x > p.max_wgs) grid.x = p.max_wgs;
   // the input LayerNorm of a local network (the one kernel that reads the feature stream): HIP events around it, with the
   // bytes it must move (input once, bf16 xhat once) in the flops field
   void* ts = (p.x_f32 && !p.gain && p.y) ? timing_begin(TIMING_INLN, (double)p.R * p.D * 6.0, 0, stream) : nullptr;
-  if (p.D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, stream, p);
+  if (stream_variant) {
+    if (p.D <= 1024) hipLaunchKernelGGL(ln_fwd_stream_kernel<4>, grid, dim3(256), 0, stream, p);
+    else if (p.D <= 2048) hipLaunchKernelGGL(ln_fwd_stream_kernel<8>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ln_fwd_stream_kernel<16>, grid, dim3(256), 0, stream, p);
+  } else if (p.D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, stream, p);
   else if (p.D <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, stream, p);
   else if (p.D <= 2048) hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, dim3(256), 0, stream, p);

@@ -21,7 +21,7 @@ EXPORTS = [
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_tn_xcd_map", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
-    "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_contrastive_fwd_bwd_dp", "coot_contrastive_fwd_bwd_dp_blocks", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
+    "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_step_input_stage_bytes", "coot_step_set_input_stages", "coot_step_set_next_batch", "coot_contrastive_fwd_bwd_dp", "coot_contrastive_fwd_bwd_dp_blocks", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
 ]
 
 
@@ -41,7 +41,7 @@ class ContrastiveConfig(C.Structure):
 
 
 SOURCE_PADDED, SOURCE_PACKED_F32, SOURCE_PACKED_BF16 = 0, 1, 2  # COOT_SOURCE_* (include/coot_hip.h)
-STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH, STEP_DEFER_TEXT_JOIN = 1, 2, 4, 8  # coot_train_step do_optimizer bits (include/coot_hip.h)
+STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH, STEP_DEFER_TEXT_JOIN, STEP_INPUT_STAGES = 1, 2, 4, 8, 16  # coot_train_step do_optimizer bits (include/coot_hip.h)
 DP_MAX_RANKS = 16  # COOT_DP_MAX_RANKS: ranks whose gathered blocks coot_contrastive_fwd_bwd_dp_blocks addresses in place
 
 
@@ -159,6 +159,10 @@ def load():
     lib.coot_collate_packed.argtypes = [vp, vp, i64, i64, i32, vp, vp, i32]
     lib.coot_sample_cycle_indices.argtypes = [vp, vp, i32, u64, vp, vp]
     lib.coot_step_set_cycle_indices.argtypes = [vp]
+    lib.coot_step_input_stage_bytes.argtypes = [scp, sdp]
+    lib.coot_step_input_stage_bytes.restype = sz
+    lib.coot_step_set_input_stages.argtypes = [vp, vp, sz]
+    lib.coot_step_set_next_batch.argtypes = [sxp, sdp]
     lib.coot_contrastive_fwd_bwd_dp.argtypes = [C.POINTER(ContrastiveConfig), i32, i32, i32, i32, C.POINTER(vp * 6), C.POINTER(i64 * 6), vp,
                                                 C.POINTER(vp * 6), i32, i32, i32, i32, vp, sz, vp]
     lib.coot_contrastive_fwd_bwd_dp_blocks.argtypes = [C.POINTER(ContrastiveConfig), i32, i32, vp, vp, i32, i32, vp, vp, C.POINTER(i64 * 6), vp,

@@ -429,6 +429,22 @@ class RetrievalTrainer:
             st.bufs.params[i], st.bufs.grads[i], st.bufs.wpack[i] = n._flat.data_ptr(), n._grad_flat.data_ptr(), n._wpack.data_ptr()
             st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i] = st.m[i].data_ptr(), st.v[i].data_ptr(), st.decay[i].data_ptr()
             st.bufs.pe[i] = n.embedding.pe.data_ptr()
+        key, dims_args, x, _ = self._native_describe(batch)
+        if key != st.dims_key:
+            st.dims = _lib.StepDims(*dims_args)
+            need = lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims))
+            if getattr(st, "ws", None) is None or st.ws.numel() < need:  # ragged batches change shape every step: grow only
+                st.ws = torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev)
+            st.dims_key = key
+        return st, x
+
+    def _native_describe(self, batch):
+        """(shape key, coot_step_dims arguments, coot_step_batch, the batch object whose tensors the pointers refer to) of a batch.
+        The description of the batch announced as `next_batch` of the previous native step is kept (same object -> same pointers:
+        what coot_train_step compares to know that the batch's input LayerNorm already ran)."""
+        kept = getattr(self, "_next_desc", None)
+        if kept is not None and kept[0] is batch:
+            return kept[1]
         src_packed = isinstance(batch, RetrievalPackedBatchTuple)  # packed at the source (dataset_retrieval.collate_fn(packed=True))
         if src_packed and (max(batch.max_lens) > 128 or min(batch.tok_vis, batch.tok_txt) < 1024):
             # the packed-row kernels cover sequences of <= 128 rows and launches of >= 1 024 tokens (csrc/api.hip: packed_ok); a
@@ -453,12 +469,7 @@ class RetrievalTrainer:
             assert batch.sent_feat.shape[0] == Nc and batch.par_feat.shape[0] == B
             key = (batch.vid_feat.shape, batch.clip_feat.shape, batch.par_feat.shape, batch.sent_feat.shape, batch.max_clip_num, batch.max_sent_num,
                    tok_vis, tok_txt)
-        if key != st.dims_key:
-            st.dims = _lib.StepDims(B, Nc, Lv, Lc, Lp, Ls, batch.max_clip_num, batch.max_sent_num, tok_vis, tok_txt, source)
-            need = lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims))
-            if getattr(st, "ws", None) is None or st.ws.numel() < need:  # ragged batches change shape every step: grow only
-                st.ws = torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev)
-            st.dims_key = key
+        dims_args = (B, Nc, Lv, Lc, Lp, Ls, batch.max_clip_num, batch.max_sent_num, tok_vis, tok_txt, source)
         x = _lib.StepBatch()
         if src_packed:
             assert batch.vis_tokens.is_contiguous() and batch.txt_tokens.is_contiguous() and batch.vis_tokens.shape[0] == tok_vis
@@ -474,9 +485,34 @@ class RetrievalTrainer:
             assert t_.dtype == torch.int64 and t_.is_contiguous(), src
             setattr(x, f, t_.data_ptr())
         if packed:  # valid tokens only through the local networks (coot_packed_seqs)
-            assert batch.cu_vis.dtype == torch.int32 and batch.cu_vis.numel() == st.dims.B + st.dims.Nc + 1 and batch.cu_vis.is_cuda
+            assert batch.cu_vis.dtype == torch.int32 and batch.cu_vis.numel() == B + Nc + 1 and batch.cu_vis.is_cuda
             x.cu_vis, x.cu_txt = batch.cu_vis.data_ptr(), batch.cu_txt.data_ptr()
-        return st, x
+        return key, dims_args, x, batch
+
+    def _announce_next_batch(self, lib, st, batch, next_batch) -> bool:
+        """Input stages of the native step (include/coot_hip.h: COOT_STEP_INPUT_STAGES): two device buffers for the normalised input
+        features; this step normalises `next_batch` (the data loader's lookahead) into the one it does not use, behind its local forward
+        passes.  Returns whether the step runs with the stages (False: nothing to announce and no stages yet)."""
+        if next_batch is None and getattr(st, "stages", None) is None:
+            return False
+        need = lib.coot_step_input_stage_bytes(C.byref(st.cfg), C.byref(st.dims))
+        nd = None
+        if next_batch is not None:
+            desc = self._native_describe(next_batch)
+            self._next_desc = (next_batch, desc)  # (keeps the object, its description and a possibly unpacked copy alive until its own step)
+            nd = _lib.StepDims(*desc[1])
+            need = max(need, lib.coot_step_input_stage_bytes(C.byref(st.cfg), C.byref(nd)))
+        else:
+            self._next_desc = None
+        if getattr(st, "stages", None) is None or st.stages[0].numel() < need:  # (a change of buffers resets what the stages hold)
+            dev = st.ws.device
+            st.stages = (torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev), torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev))
+        _lib.check(lib.coot_step_set_input_stages(st.stages[0].data_ptr(), st.stages[1].data_ptr(), st.stages[0].numel()), "coot_step_set_input_stages")
+        if next_batch is not None:
+            _lib.check(lib.coot_step_set_next_batch(C.byref(desc[2]), C.byref(nd)), "coot_step_set_next_batch")
+        else:
+            _lib.check(lib.coot_step_set_next_batch(None, None), "coot_step_set_next_batch")
+        return True
 
     # ---- optimizer state of either path, for optimizer_<epoch>.pth (nntrainer/trainer_base.py:685-707) ------------------------
     def get_opt_state(self) -> Dict[str, Any]:
@@ -665,13 +701,16 @@ class RetrievalTrainer:
 
     def train_step_native(self, batch: RetrievalDataBatchTuple, do_optimizer: bool = True, seed: Optional[int] = None,
                           vid_counts=None, clip_counts=None, use_graph=False, cc_indices: Optional[torch.Tensor] = None,
-                          defer_join: bool = False):
+                          defer_join: bool = False, next_batch=None):
         """One optimisation step as ONE call into libcoot_hip.so (coot_train_step): forward of both sides on two
         HIP streams, losses, backward, fused Adam — no Python between the kernel launches.  Returns views of the
         device loss vector (total, contrastive, cycle-consistency).  With ``self.dp`` set the step runs as native phases
         with the RCCL collectives between them (_train_step_native_dp).  Adam state is the library's
         (flat moment arenas), the learning rate is read from self.optimizer's first param group on every call so the
-        reference's LR schedulers keep working."""
+        reference's LR schedulers keep working.
+        next_batch: the batch of the FOLLOWING step, if the data loader already has it on the device (lookahead of one): its
+        parameter-free input LayerNorm runs inside this step, next to the global networks, instead of at the head of the next one
+        (COOT_STEP_INPUT_STAGES; same results).  Pass the same object to the next call."""
         lib = _lib.load()
         if getattr(self, "dp", None) is not None:
             return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts, cc_indices)
@@ -696,6 +735,8 @@ class RetrievalTrainer:
             flags |= _lib.STEP_OPTIMIZER | _lib.STEP_REPACK
         if all(n.pack_is_fresh() for n in st.nets):
             flags |= _lib.STEP_PACKS_FRESH
+        if self._announce_next_batch(lib, st, batch, next_batch):
+            flags |= _lib.STEP_INPUT_STAGES
         if defer_join and do_optimizer:
             flags |= _lib.STEP_DEFER_TEXT_JOIN
             st.join_pending = True

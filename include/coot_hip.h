@@ -290,6 +290,7 @@ size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_di
 #define COOT_STEP_REPACK 2      /* rebuild the bf16 weight packs right after the update (off the next step's critical path)  */
 #define COOT_STEP_PACKS_FRESH 4 /* wpack[] is current (previous step ran with REPACK and nothing else touched the parameters):
                                    skip the packing at the start of the step                                                */
+#define COOT_STEP_INPUT_STAGES 16 /* x^ of the input LayerNorm lives in the caller's input stages (coot_step_set_input_stages below)      */
 #define COOT_STEP_DEFER_TEXT_JOIN 8 /* on return main_s is ordered after the VIDEO side only: the text side's tail (its Adam update,
                                    weight packs, losses[0] = total) is still running on side_t.  The next coot_train_step with the
                                    same streams needs no join (its text side continues on side_t in order, its video side touches
@@ -349,6 +350,21 @@ int coot_sample_cycle_indices(const int64_t* clip_num, const int64_t* sent_num, 
  * coot_train_step / phase 4 until reset with NULL).  For reproducing a given th.multinomial sequence of the reference
  * (coot/loss_fn.py:306-314 consumes the global torch RNG, which no device kernel can replay).  Thread-local. */
 int coot_step_set_cycle_indices(const int64_t* idx);
+/* Software-pipelined input LayerNorm (COOT_STEP_INPUT_STAGES).  The input LayerNorm of the local networks
+ * (nntrainer/models/transformer_legacy.py:224-239, norm_input) has no parameters of its own here — its gain / bias are folded into the
+ * packed input-FC weights — so the normalised features x^ of batch t + 1 depend on nothing step t computes.  With two caller-owned
+ * device buffers ("stages", each >= coot_step_input_stage_bytes() of the largest batch) a coot_train_step that carries the flag
+ *   - keeps this batch's x^ in one stage (normalising it first unless the previous step already did), and
+ *   - if a next batch was announced (coot_step_set_next_batch, one-shot: consumed by that step), normalises THAT batch into the
+ *     other stage on an internal stream behind both sides' local forward passes — where the step runs its global networks and losses
+ *     on a handful of CUs and the memory system is idle; the next coot_train_step on that batch (same pointers and dims) finds x^
+ *     ready and starts with the input FC.
+ * Every step still executes exactly one input LayerNorm per side (for the following batch); what a data loader's lookahead buys is
+ * that it runs off the critical path.  Results are bit-identical to a step without stages.  The state (which stage holds what) is
+ * thread-local and reset when the stage pointers change; steps without the flag never touch it.  Not available under graph capture. */
+size_t coot_step_input_stage_bytes(const coot_step_config* cfg, const coot_step_dims* dims);
+int coot_step_set_input_stages(void* stage0, void* stage1, size_t bytes_each);
+int coot_step_set_next_batch(const coot_step_batch* next, const coot_step_dims* next_dims);
 int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream);
 /* RAdam of nntrainer/optimization.py:79-181 on one flat arena: decoupled decay weight_decay * decay_mask,

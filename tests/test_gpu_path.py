@@ -959,3 +959,52 @@ def test_deferred_text_join_gives_the_same_training_trajectory(env):
     for a, b in zip(pa, pb):
         d = (a - b).abs()
         assert float((d > 1e-5).float().mean()) < 1e-3 and float(d.max()) <= 2e-4, (float((d > 1e-5).float().mean()), float(d.max()))
+
+
+@pytest.mark.parametrize("kind", ["fused_fixed", "small_fixed", "packed_ragged"])
+def test_input_stages_lookahead_gives_the_same_training_trajectory(env, kind):
+    """train_step_native(next_batch = the following batch) (COOT_STEP_INPUT_STAGES): step t normalises batch t + 1 into the input stage it
+    does not use, behind its local forward passes; step t + 1 skips its own input LayerNorm.  Same losses at EVERY step and the same
+    parameters at the end as plain steps on the same sequence of batches — also when the announced batch is not the one that follows (the
+    stage is ignored), when nothing is announced, and when consecutive batches have different shapes (ragged, packed rows).
+    (Adam eps = 1e-3: see test_deferred_text_join_gives_the_same_training_trajectory.)"""
+    torch, cva = env
+    if kind == "small_fixed":   # per-op kernels (below the fused kernels' row threshold)
+        dims = (64, 48, 64, 4, 64, 128)
+        mk = lambda s: cva.synthetic.make_batch(s, 6, [1, 2, 3, 4, 2, 1], 12, 10, 9, 6, dims[0], dims[1], ragged=False)
+    elif kind == "fused_fixed":  # token-tile chains: > 1 024 rows per local network call
+        dims = (256, 192, 384, 8, 384, 768)
+        mk = lambda s: cva.synthetic.make_batch(s, 12, 4, 40, 40, 32, 16, dims[0], dims[1], ragged=False)
+    else:                        # ragged batches, packed rows, another shape every step
+        dims = (256, 192, 384, 8, 384, 768)
+        mk = lambda s: cva.synthetic.make_batch(s, 12, cva.synthetic.anet_like_counts(50 + s, 12), 40, 40, 32, 16, dims[0], dims[1], ragged=True,
+                                                packed=True)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batches = [mk(20 + i) for i in range(5)]
+    decoy = mk(99)
+    # what is announced at step i: the true next batch, a batch that does NOT follow (step 1), nothing (step 3 and the last step)
+    announce = [batches[1], decoy, batches[3], None, None]
+    res = []
+    for lookahead in (False, True):
+        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.1, cc_weight=0.01)
+        cfg_x.optimizer.adam_eps = 1e-3
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg_x, mgr)
+        losses = []
+        for it, b in enumerate(batches):
+            out = tr.train_step_native(b, seed=100 + it, next_batch=announce[it] if lookahead else None)
+            losses.append([float(v) for v in out])
+        torch.cuda.synchronize()
+        res.append((losses, [n._flat.detach().clone() for n in mgr.model_dict.values()]))
+        if lookahead:
+            assert tr._native.stages is not None
+    (la, pa), (lb, pb) = res
+    # a wrong or stale x^ (e.g. the decoy's) moves that step's loss by O(0.1).  Two plain runs of the ragged sequence themselves differ by
+    # 5e-5 (step 3) to 2e-4 (step 4) — fp32 atomics order amplified by five updates, tools/lookahead_check.py — so its later steps get 5e-4.
+    assert np.allclose(la[:3], lb[:3], rtol=1e-5, atol=1e-7), (la, lb)
+    assert np.allclose(la, lb, rtol=5e-4 if kind == "packed_ragged" else 1e-4, atol=1e-6), (la, lb)
+    if kind != "packed_ragged":
+        for a, b in zip(pa, pb):
+            d = (a - b).abs()
+            assert float((d > 1e-5).float().mean()) < 1e-3 and float(d.max()) <= 2e-4, (float((d > 1e-5).float().mean()), float(d.max()))
