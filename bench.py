@@ -231,17 +231,34 @@ def main():
 
         mode = args.mode if (world == 1 or args.mode != "graph") else "autograd"
         batch.global_max_synced = True  # fixed shapes: every rank has the same Cmax, no MAX all-reduce needed
-        lookahead = mode == "native" and dp is None and not args.no_lookahead
+        two_batches = mode == "native" and dp is None
+        lookahead = two_batches and not args.no_lookahead
+        if two_batches:
+            # Two DIFFERENT synthetic batches of the workload's shape, used in turn (with and without the lookahead): a step never sees the
+            # data of the step before it (a single resident batch would partly live in the 256 MB MALL from step to step), and the batch a
+            # step announces as "next" — whose input LayerNorm it runs next to its global networks — is other data than the one it trains
+            # on: nothing a step computes for itself is ever reused, every step executes one input LayerNorm per side
+            if ragged:
+                other = cva.synthetic.make_batch(9234 + rank, w["B"], all_counts[rank], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=True,
+                                                 packed=not args.padded)
+                other.max_clip_num = other.max_sent_num = batch.max_clip_num
+            else:
+                other = cva.synthetic.make_batch(9234 + rank, w["B"], w["C"], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=False)
+            other.global_max_synced = True
+            pair, turn = (batch, other), [0]
 
         def step(graph=None):
             if mode in ("native", "native-graph", "native-phases") and graph is None:  # N > 1: native phases with the RCCL collectives between them
                 # back-to-back steps: the text side's update tail overlaps the next step's forward (COOT_STEP_DEFER_TEXT_JOIN); every
                 # step is complete when the timed region ends (barrier + device synchronisation below)
-                # the data loader's lookahead: the next batch (synthetic data: the same tensors) is announced to the step, which runs that
-                # batch's parameter-free input LayerNorm next to its global networks — every step still executes one per side
+                # the data loader's lookahead: the next batch is announced to the step, which runs that batch's parameter-free input
+                # LayerNorm next to its global networks — every step still executes one per side
+                if two_batches:
+                    cur, nxt = pair[turn[0] & 1], pair[(turn[0] + 1) & 1]
+                    turn[0] += 1
+                    return trainer.train_step_native(cur, defer_join=not args.no_defer_join, next_batch=nxt if lookahead else None)[0]
                 return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, defer_join=not args.no_defer_join,
-                                                 use_graph={"native-graph": True, "native-phases": "phases"}.get(mode, False),
-                                                 next_batch=batch if lookahead else None)[0]
+                                                 use_graph={"native-graph": True, "native-phases": "phases"}.get(mode, False))[0]
             return trainer.train_step(batch, vid_counts, clip_counts, use_graph=(mode == "graph") if graph is None else graph)[0]
 
     def barrier():
@@ -398,7 +415,8 @@ def main():
                        "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
                        "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",
                        "launch": "eval" if args.eval else mode,
-                       **({"input_lookahead": "each step also runs the NEXT batch's input LayerNorm (one per side per step, as without it), next to its global networks"}
+                       **({"batches": "two different synthetic batches in turn"} if (not args.eval and two_batches) else {}),
+                       **({"input_lookahead": "each step runs the NEXT batch's input LayerNorm (one per side per step, as without it) next to its global networks"}
                           if (not args.eval and lookahead) else {}),
                        **({"token_layout": "padded to the batch maxima (the reference's layout)" if args.padded else "packed (cu_seqlens): valid tokens only",
                            "valid_tokens": [int(batch.vid_feat_len.sum() + batch.clip_feat_len.sum()), int(batch.par_feat_len.sum() + batch.sent_feat_len.sum())],

@@ -228,11 +228,14 @@ class DeviceLoader:
     """Iterates ``source`` (lists of RetrievalDataPointTuple — collated here — or batches that collate_fn already wrote into
     their own BatchArena) and yields device-resident batches, ``depth`` arenas ahead of the consumer: one async H2D copy per
     batch on a copy stream, the consumer's stream waits on its event only.  A device arena is rewritten only after the work
-    the consumer enqueued on it (everything up to its next ``next()``) has finished; a host arena only after its copy has."""
+    the consumer enqueued on it (everything up to its next ``next()``) has finished; a host arena only after its copy has.
+    ``lookahead``: the consumer asks for batch t + 1 BEFORE it works on batch t (RetrievalTrainer.train_model: the step on batch t also
+    normalises batch t + 1, train_step_native(next_batch=)); a batch's arena is then released ``lookahead`` requests later."""
 
     def __init__(self, source: Iterable, depth: int = 2, device: str = "cuda", bf16: bool = False, threads: int = 8, packed: bool = False,
-                 background: bool = False):
-        assert depth >= 1
+                 background: bool = False, lookahead: int = 0):
+        assert depth >= 1 and lookahead >= 0
+        self.lookahead = lookahead
         self.source, self.depth, self.device, self.bf16, self.threads = source, depth, torch.device(device), bf16, threads
         self.packed = packed  # collate packed at the source: no padding rows in the arena; bf16 rows are consumed as they are
         # background: collation + the H2D enqueue run on a loader thread (the C collation releases the GIL), so the consumer's thread
@@ -240,7 +243,7 @@ class DeviceLoader:
         self.background = background
         self._consumer_stream = None
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        n = depth + 1
+        n = depth + 1 + lookahead
         self.host = [BatchArena(pin=True) for _ in range(n)]
         self.dev = [torch.empty(0, dtype=torch.uint8, device=self.device) for _ in range(n)]
         self.copied = [None] * n    # event: H2D copy of slot k finished (host arena k reusable, device arena k readable)
@@ -299,7 +302,8 @@ class DeviceLoader:
         yields, records how far its stream has got on that slot and hands the slot back."""
         import queue
         import threading
-        n = self.depth + 1
+        n = self.depth + 1 + self.lookahead
+        held: List[int] = []  # slots the consumer may still be working on (lookahead)
         free: "queue.Queue[int]" = queue.Queue()
         ready: "queue.Queue" = queue.Queue()
         for k in range(n):
@@ -331,10 +335,13 @@ class DeviceLoader:
                     raise got
                 k, db = got
                 yield self._finish(db)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                self.consumed[k] = ev
-                free.put(k)
+                held.append(k)
+                while len(held) > self.lookahead:  # everything enqueued so far covers the work on the batch yielded `lookahead` requests ago
+                    kk = held.pop(0)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    self.consumed[kk] = ev
+                    free.put(kk)
         finally:
             stop.set()
             free.put(0)  # wakes a producer that waits for a slot
@@ -345,9 +352,10 @@ class DeviceLoader:
         if self.background:
             yield from self._iter_background()
             return
-        n = self.depth + 1
+        n = self.depth + 1 + self.lookahead
         it = iter(self.source)
         queue: List[Tuple[int, RetrievalDataBatchTuple]] = []
+        held: List[int] = []
         slot = 0
         exhausted = False
 
@@ -366,7 +374,9 @@ class DeviceLoader:
         while queue:
             k, db = queue.pop(0)
             yield self._finish(db)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self.consumed[k] = ev
+            held.append(k)
+            while len(held) > self.lookahead:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.consumed[held.pop(0)] = ev
             fill()

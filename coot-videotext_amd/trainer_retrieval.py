@@ -105,6 +105,19 @@ def make_optimizer(cfg_opt, params, capturable: bool = False) -> torch.optim.Opt
     raise NotImplementedError(f"Unknown optimizer {name}")  # as nntrainer/optimization.py:62
 
 
+def _with_next(iterable):
+    """(item, the item after it or None) for every item: a lookahead of one."""
+    it = iter(iterable)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 class RetrievalTrainer:
     def __init__(self, cfg: RetrievalConfig, model_mgr: RetrievalModelManager, is_test: bool = False,
                  world_size: int = 1):
@@ -998,8 +1011,14 @@ class RetrievalTrainer:
                 break
             self.model_mgr.set_all_models_train()
             loss_sum = None
-            for batch in train_loader:
-                out = self.train_step_native(batch) if native else self.train_step(batch)
+            # native single-GPU steps: a lookahead of one batch (the loader has it on the device while the step runs: DeviceLoader) lets
+            # the step run the next batch's input LayerNorm off its critical path (train_step_native(next_batch=))
+            # (only with a loader that keeps a batch's tensors alive while the NEXT one is requested: a list of device batches, or
+            # DeviceLoader(lookahead=1))
+            lookahead = (native and getattr(self, "dp", None) is None
+                         and (isinstance(train_loader, (list, tuple)) or int(getattr(train_loader, "lookahead", 0)) >= 1))
+            for batch, nxt in (_with_next(train_loader) if lookahead else ((b, None) for b in train_loader)):
+                out = self.train_step_native(batch, next_batch=nxt) if native else self.train_step(batch)
                 loss = out[0].detach()
                 loss_sum = loss.clone() if loss_sum is None else loss_sum + loss  # device-side: no sync per step
                 self.lr_scheduler.step()

@@ -153,6 +153,50 @@ def test_device_loader_stages_batches_and_feeds_training():
     assert len(hist["epoch"]) == 2 and all(np.isfinite(hist["train_loss"])) and hist["val"][1]["val_score_at_1"] >= 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("background", [False, True])
+def test_device_loader_lookahead_keeps_the_previous_batch(background):
+    """DeviceLoader(lookahead = 1): the consumer requests batch t + 1 BEFORE it works on batch t (train_model's lookahead: the step on
+    batch t also normalises batch t + 1).  Batch t's arena must then survive one more request: device work enqueued on batch t AFTER
+    batch t + 1 was requested still reads the right data, with more batches than slots; and train_model through such a loader (native
+    steps with next_batch) gives the losses of the plain loader."""
+    import torch
+    import coot_videotext_amd as cva
+    from coot_videotext_amd.dataset_retrieval import DeviceLoader, collate_fn
+    from coot_videotext_amd.trainer_retrieval import _with_next
+    from tests import helpers as H
+    dims = (64, 48, 64, 4, 64, 128)
+    lists = [_points(150 + i, 6, dims[0], dims[1], max_frames=12, max_words=9) for i in range(9)]
+    sums = []
+    for cur, nxt in _with_next(DeviceLoader(lists, depth=1, lookahead=1, background=background)):
+        # (nxt has been requested: a loader without lookahead would have released cur's arena before this line)
+        sums.append((cur.vid_feat.double().sum() + cur.clip_feat.double().sum() + cur.sent_feat.double().sum()).clone())
+    torch.cuda.synchronize()
+    assert len(sums) == 9
+    for i, s_ in enumerate(sums):
+        hb = collate_fn(lists[i])
+        want = float(hb.vid_feat.double().sum() + hb.clip_feat.double().sum() + hb.sent_feat.double().sum())
+        assert abs(float(s_) - want) <= 1e-9 * max(1.0, abs(want)), i
+    # train_model: one epoch over 5 batches, lookahead loader against the plain one
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    hist = []
+    for la in (0, 1):
+        cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+        cfg.optimizer.adam_eps = 1e-3
+        cfg.raw["lr_scheduler"] = dict(name="none", warmup_type="none", warmup_epochs=0)
+        cfg.train.num_epochs = 1
+        for k, v in dict(val_freq=1, val_start=0, val_clips=False, val_clips_freq=1, det_best_field="val_score_at_1",
+                         det_best_compare_mode="max", det_best_threshold_mode="rel", det_best_threshold_value=1e-4,
+                         det_best_terminate_after=16).items():
+            setattr(cfg.val, k, v)
+        tr = cva.RetrievalTrainer(cfg, mgr)
+        h = tr.train_model(DeviceLoader(lists[:5], depth=1, lookahead=la, background=background), DeviceLoader(lists[5:7], depth=1))
+        assert (getattr(tr._native, "stages", None) is not None) == bool(la)
+        hist.append(h["train_loss"][0])
+    assert abs(hist[0] - hist[1]) <= 1e-4 * abs(hist[0]), hist
+
+
 def _collate_numpy(pts):
     """Plain restatement of RetrievalDataset.collate_fn (coot/dataset_retrieval.py:335-463) with numpy loops: the checker for
     the randomised shapes below (the reference-generated fixture pins two batches; this pins the layout rule for many)."""
