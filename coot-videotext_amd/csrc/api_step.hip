@@ -201,6 +201,48 @@ struct InputPipe {
 };
 thread_local InputPipe g_pipe;
 struct StageScope { ~StageScope() { coot_internal_set_input_stage(nullptr, nullptr, 0); } };  // no exit path leaves a stage set
+// what a step (coot_train_step, or coot_step_forward ... coot_step_backward) knows about its stages
+struct PipeStep { bool piped = false, hit = false, prefetch = false; int cur = 0; StageLayout SL{}; };
+thread_local PipeStep g_phase_pipe;  // of the phase calls: set by coot_step_forward, read and cleared by coot_step_backward
+// this batch's x^ in stage[cur] (already there if the previous step normalised it: `hit`), the next batch's into the other
+int pipe_begin(const coot_step_config& cfg, const coot_step_batch& x, const coot_step_dims& d, hipStream_t sv, hipStream_t st, PipeStep& ps) {
+  ps = PipeStep{}; ps.piped = true;
+  COOT_REQUIRE(g_pipe.stage[0] && g_pipe.stage[1], "step: input stages requested without coot_step_set_input_stages");
+  ps.hit = g_pipe.ready && !memcmp(&g_pipe.have_x, &x, sizeof(x)) && !memcmp(&g_pipe.have_d, &d, sizeof(d));
+  ps.cur = ps.hit ? g_pipe.idx : (g_pipe.ready ? g_pipe.idx ^ 1 : 0);
+  ps.SL = stage_layout(cfg, d, g_pipe.stage[ps.cur]);
+  COOT_REQUIRE(ps.SL.bytes <= g_pipe.bytes, "step: input stages too small (%zu < %zu)", g_pipe.bytes, ps.SL.bytes);
+  if (ps.hit) {
+    RUN(check_hip(hipStreamWaitEvent(sv, g_pipe.done, 0), "streamWait"));
+    RUN(check_hip(hipStreamWaitEvent(st, g_pipe.done, 0), "streamWait"));
+  }
+  g_pipe.ready = false;
+  ps.prefetch = g_pipe.next_valid;
+  return 0;
+}
+// x^ of the next batch, behind both local forward passes (hop slots 9 / 10: recorded by side_forward)
+int pipe_prefetch(const coot_step_config& cfg, const coot_step_buffers& b, const PipeStep& ps, float* dummy_v, float* dummy_t, void* saved_lv,
+                  void* saved_lt, int train, uint64_t seed) {
+  RUN(g_pipe.init());
+  const coot_step_batch& nx = g_pipe.next_x; const coot_step_dims& nd = g_pipe.next_d;
+  const StageLayout NL = stage_layout(cfg, nd, g_pipe.stage[ps.cur ^ 1]);
+  COOT_REQUIRE(NL.bytes <= g_pipe.bytes, "step: input stages too small for the next batch (%zu < %zu)", g_pipe.bytes, NL.bytes);
+  const SidePacked npk = side_packed(nx, nd);
+  RUN(g_hops.wait(9, g_pipe.stream));
+  RUN(g_hops.wait(10, g_pipe.stream));
+  g_pipe.next_valid = false;
+  StageScope scope;
+  coot_internal_set_input_stage(NL.xv, NL.pv, 1);  // mode 1: coot_net_fwd normalises into the stage and returns
+  RUN(coot_net_fwd(&cfg.net[0], b.params[0], b.wpack[0], b.pe[0], nx.vid_feat, nx.vid_len, nd.B, nd.Lv, nx.clip_feat, nx.clip_len, nd.Nc, nd.Lc,
+                   nullptr, dummy_v, nullptr, saved_lv, (size_t)-1, nullptr, 0, train, seed, nullptr, g_pipe.stream, &npk.v));
+  coot_internal_set_input_stage(NL.xt, NL.pt, 1);
+  RUN(coot_net_fwd(&cfg.net[2], b.params[2], b.wpack[2], b.pe[2], nx.par_feat, nx.par_len, nd.B, nd.Lp, nx.sent_feat, nx.sent_len, nd.Nc, nd.Ls,
+                   nullptr, dummy_t, nullptr, saved_lt, (size_t)-1, nullptr, 0, train, seed, nullptr, g_pipe.stream, &npk.t));
+  coot_internal_set_input_stage(nullptr, nullptr, 0);
+  RUN(check_hip(hipEventRecord(g_pipe.done, g_pipe.stream), "eventRecord"));
+  g_pipe.ready = true; g_pipe.idx = ps.cur ^ 1; g_pipe.have_x = nx; g_pipe.have_d = nd;
+  return 0;
+}
 
 // one side (video or text): local(ctx segment + item segment) -> pack -> global
 int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, int gi, const float* ctx_feat, const int64_t* ctx_len,
@@ -464,10 +506,22 @@ int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, c
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
+  const bool fresh = (packs_fresh & COOT_FWD_PACKS_FRESH) != 0;
+  StageScope stage_scope;
+  PipeStep ps;
+  g_phase_pipe = PipeStep{};
+  if (packs_fresh & COOT_FWD_INPUT_STAGES) RUN(pipe_begin(*cfg, *x, *d, sv, st, ps));
+  if (ps.piped) coot_internal_set_input_stage(ps.SL.xv, ps.SL.pv, ps.hit ? 2 : 0);
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
-                   local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, !packs_fresh, &pk.v));
+                   local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, !fresh, &pk.v,
+                   ps.prefetch ? 9 : -1));
+  if (ps.piped) coot_internal_set_input_stage(ps.SL.xt, ps.SL.pt, ps.hit ? 2 : 0);
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
-                   local_t, glob_t, resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st, !packs_fresh, &pk.t));
+                   local_t, glob_t, resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st, !fresh, &pk.t,
+                   ps.prefetch ? 10 : -1));
+  coot_internal_set_input_stage(nullptr, nullptr, 0);
+  if (ps.prefetch) RUN(pipe_prefetch(*cfg, *b, ps, local_v, local_t, W.saved_lv, W.saved_lt, train, seed));
+  g_phase_pipe = ps;  // coot_step_backward reads x^ of this batch in the same stage
   RUN(g_hops.hop(2, sv, sm));
   RUN(g_hops.hop(3, st, sm));
   return 0;
@@ -485,9 +539,14 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* b, 
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
+  StageScope stage_scope;
+  const PipeStep ps = g_phase_pipe;  // the stage coot_step_forward kept this batch's x^ in (if any)
+  g_phase_pipe = PipeStep{};
+  if (ps.piped) coot_internal_set_input_stage(ps.SL.xv, ps.SL.pv, 0);
   RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d, local_v,
                     resh_v, d_local_v, d_glob_v, d_resh_v, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, W.scratch_v,
                     W.sz_sv, train, seed, sv, &pk.v));
+  if (ps.piped) coot_internal_set_input_stage(ps.SL.xt, ps.SL.pt, 0);
   RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, local_t,
                     resh_t, d_local_t, d_glob_t, d_resh_t, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, W.scratch_t,
                     W.sz_st, train, seed + 1000, st, &pk.t));
@@ -549,24 +608,13 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   const bool split_loss = g_split_loss != 0 && sv != st;
-  // input stages: this batch's x^ in stage[cur] (already there if the previous step normalised it: `hit`), the next batch's into the other
   const bool piped = (do_optimizer & COOT_STEP_INPUT_STAGES) != 0;
   StageScope stage_scope;
-  StageLayout SL{}; int cur = 0; bool hit = false;
-  if (piped) {
-    COOT_REQUIRE(g_pipe.stage[0] && g_pipe.stage[1], "train_step: COOT_STEP_INPUT_STAGES without coot_step_set_input_stages");
-    COOT_REQUIRE(!g_state_dev, "train_step: input stages are not available in a replayable (captured) step");
-    hit = g_pipe.ready && !memcmp(&g_pipe.have_x, x, sizeof(*x)) && !memcmp(&g_pipe.have_d, d, sizeof(*d));
-    cur = hit ? g_pipe.idx : (g_pipe.ready ? g_pipe.idx ^ 1 : 0);
-    SL = stage_layout(*cfg, *d, g_pipe.stage[cur]);
-    COOT_REQUIRE(SL.bytes <= g_pipe.bytes, "train_step: input stages too small (%zu < %zu)", g_pipe.bytes, SL.bytes);
-    if (hit) {
-      RUN(check_hip(hipStreamWaitEvent(sv, g_pipe.done, 0), "streamWait"));
-      RUN(check_hip(hipStreamWaitEvent(st, g_pipe.done, 0), "streamWait"));
-    }
-    g_pipe.ready = false;
-  }
-  const bool prefetch = piped && g_pipe.next_valid;
+  PipeStep ps;
+  COOT_REQUIRE(!(piped && g_state_dev), "train_step: input stages are not available in a replayable (captured) step");
+  if (piped) RUN(pipe_begin(*cfg, *x, *d, sv, st, ps));
+  const StageLayout& SL = ps.SL; const bool hit = ps.hit;
+  const bool prefetch = ps.prefetch;
   if (piped) coot_internal_set_input_stage(SL.xv, SL.pv, hit ? 2 : 0);
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                    W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first, &pk.v,
@@ -576,25 +624,8 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
                    W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st,
                    pack_first, &pk.t, prefetch ? 10 : -1));
   coot_internal_set_input_stage(nullptr, nullptr, 0);
-  if (prefetch) {  // x^ of the next batch, behind both local forward passes (the chip's memory system is idle from there to the local backward)
-    RUN(g_pipe.init());
-    const coot_step_batch& nx = g_pipe.next_x; const coot_step_dims& nd = g_pipe.next_d;
-    const StageLayout NL = stage_layout(*cfg, nd, g_pipe.stage[cur ^ 1]);
-    COOT_REQUIRE(NL.bytes <= g_pipe.bytes, "train_step: input stages too small for the next batch (%zu < %zu)", g_pipe.bytes, NL.bytes);
-    const SidePacked npk = side_packed(nx, nd);
-    RUN(g_hops.wait(9, g_pipe.stream));
-    RUN(g_hops.wait(10, g_pipe.stream));
-    g_pipe.next_valid = false;
-    coot_internal_set_input_stage(NL.xv, NL.pv, 1);  // mode 1: coot_net_fwd normalises into the stage and returns
-    RUN(coot_net_fwd(&cfg->net[0], b->params[0], b->wpack[0], b->pe[0], nx.vid_feat, nx.vid_len, nd.B, nd.Lv, nx.clip_feat, nx.clip_len, nd.Nc, nd.Lc,
-                     nullptr, W.local_v, nullptr, W.saved_lv, (size_t)-1, nullptr, 0, train, seed, nullptr, g_pipe.stream, &npk.v));
-    coot_internal_set_input_stage(NL.xt, NL.pt, 1);
-    RUN(coot_net_fwd(&cfg->net[2], b->params[2], b->wpack[2], b->pe[2], nx.par_feat, nx.par_len, nd.B, nd.Lp, nx.sent_feat, nx.sent_len, nd.Nc, nd.Ls,
-                     nullptr, W.local_t, nullptr, W.saved_lt, (size_t)-1, nullptr, 0, train, seed, nullptr, g_pipe.stream, &npk.t));
-    coot_internal_set_input_stage(nullptr, nullptr, 0);
-    RUN(check_hip(hipEventRecord(g_pipe.done, g_pipe.stream), "eventRecord"));
-    g_pipe.ready = true; g_pipe.idx = cur ^ 1; g_pipe.have_x = nx; g_pipe.have_d = nd;
-  }
+  // x^ of the next batch, behind both local forward passes (the chip's memory system is idle from there to the local backward)
+  if (prefetch) RUN(pipe_prefetch(*cfg, *b, ps, W.local_v, W.local_t, W.saved_lv, W.saved_lt, train, seed));
   // Zero the parameter gradients (4 arenas), the embedding gradients (one block) and the loss words at the END of the text
   // forward: the text side shares the chip with the three times larger video side and, started at the same time, finishes its
   // forward ~75 us earlier (HIP-event timeline), so the six fills are free there.  (At the head of the text stream they delayed

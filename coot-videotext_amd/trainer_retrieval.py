@@ -726,7 +726,7 @@ class RetrievalTrainer:
         (COOT_STEP_INPUT_STAGES; same results).  Pass the same object to the next call."""
         lib = _lib.load()
         if getattr(self, "dp", None) is not None:
-            return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts, cc_indices)
+            return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts, cc_indices, next_batch)
         if use_graph and cc_indices is not None:
             raise ValueError("train_step_native: injected cycle-consistency positions are not available under graph replay")
         if use_graph and do_optimizer and seed is None and self.model_mgr.is_train:
@@ -771,7 +771,7 @@ class RetrievalTrainer:
         self.total_step += 1
         return st.losses[0], st.losses[1], st.losses[2]
 
-    def _train_step_native_dp(self, batch, do_optimizer=True, seed=None, vid_counts=None, clip_counts=None, cc_indices=None):
+    def _train_step_native_dp(self, batch, do_optimizer=True, seed=None, vid_counts=None, clip_counts=None, cc_indices=None, next_batch=None):
         """Data-parallel native step: this rank's videos through coot_step_forward (C, two streams), ONE
         packed all-gather per embedding level over RCCL, the contrastive loss on the full gathered batch (every rank
         keeps the gradient rows of its own videos — no collective for embedding gradients), the per-video
@@ -873,7 +873,11 @@ class RetrievalTrainer:
         za = st.zero_args
         _lib.check(lib.coot_nets_zero_grads_ex(4, za[0], za[1], 1, za[2], za[3], 2, main.cuda_stream), "coot_nets_zero_grads_ex")
         ws, wsn = st.ws.data_ptr(), st.ws.numel()
-        fresh = int(all(n.pack_is_fresh() for n in st.nets))
+        fresh = _lib.FWD_PACKS_FRESH if all(n.pack_is_fresh() for n in st.nets) else 0
+        if next_batch is not None and not getattr(next_batch, "global_max_synced", False):
+            next_batch = None  # (its padded shapes are not final before ITS batch-shape exchange: no lookahead for it)
+        if self._announce_next_batch(lib, st, batch, next_batch):  # the next batch's input LayerNorm runs under the exchange and the loss
+            fresh |= _lib.FWD_INPUT_STAGES
         _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *st.emb_ptrs, ws, wsn,
                                          train, int(seed), fresh, main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_forward")
         # cycle-consistency (per video, no exchange) on the text stream, next to the gathers and the contrastive loss on the main stream

@@ -304,10 +304,14 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* bufs, 
 /* The same step split in phases, for data parallel training where torch.distributed collectives (all-gather of the
  * embeddings, all-reduce of the gradients) sit between them.  local_* = [B + Nc, D] (context rows first, then
  * clip / sentence embeddings), glob_* = [B, 2D], resh_* = [B, Cmax, D] (packed + zero padded). */
+#define COOT_FWD_PACKS_FRESH 1
+#define COOT_FWD_INPUT_STAGES 2
 int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
                       const coot_step_dims* dims, float* local_v, float* local_t, float* glob_v, float* glob_t,
                       float* resh_v, float* resh_t, void* workspace, size_t workspace_bytes, int train, uint64_t seed,
-                      int packs_fresh /* the bf16 weight packs are current (coot_step_update repacked them): skip the packing */,
+                      int packs_fresh /* bit mask: COOT_FWD_PACKS_FRESH = the bf16 weight packs are current (coot_step_update repacked
+                                         them): skip the packing; COOT_FWD_INPUT_STAGES = as COOT_STEP_INPUT_STAGES of coot_train_step (the
+                                         following coot_step_backward of this thread reads x^ in the same stage) */,
                       coot_stream_t main_stream, coot_stream_t side_v, coot_stream_t side_t);
 int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
                        const coot_step_dims* dims, const float* local_v, const float* local_t, const float* resh_v,
