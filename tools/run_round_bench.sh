@@ -8,6 +8,8 @@ for w in yc2_2d3d yc2_2d3d_2816 hbm_stress anet_ragged; do $B --workload $w --no
 $B --workload anet_ragged --padded --no-cpu-baseline > gpurun_out/r03/bench_anet_ragged_padded.json 2> /dev/null
 $B --eval --no-cpu-baseline > gpurun_out/r03/bench_eval_anet.json 2> /dev/null
 $B --force-dp --no-cpu-baseline > gpurun_out/r03/bench_train_anet_dp1.json 2> gpurun_out/r03/bench_dp1.err
+$B --no-lookahead --no-cpu-baseline > gpurun_out/r03/bench_train_anet_no_lookahead.json 2> /dev/null
+python tools/dp_loss_probe.py > gpurun_out/r03/dp_loss_probe.txt 2>&1
 $B --no-cpu-baseline --no-roofline --step-stamps --clock-monitor > /dev/null 2> gpurun_out/r03/step_timeline.txt
 bash tools/profile_round.sh r03 > gpurun_out/r03/profile.log 2>&1
 for f in gpurun_out/r03/bench_*.json; do python -c "
