@@ -419,7 +419,7 @@ def main():
                        "launch": "eval" if args.eval else mode,
                        **({"batches": "two different synthetic batches in turn"} if (not args.eval and two_batches) else {}),
                        **({"input_lookahead": "each step runs the NEXT batch's input LayerNorm (one per side per step, as without it) next to its global networks"}
-                          if (not args.eval and lookahead) else {}),
+                          if (not args.eval and lookahead and getattr(getattr(trainer, "_native", None), "stages", None) is not None) else {}),
                        **({"token_layout": "padded to the batch maxima (the reference's layout)" if args.padded else "packed (cu_seqlens): valid tokens only",
                            "valid_tokens": [int(batch.vid_feat_len.sum() + batch.clip_feat_len.sum()), int(batch.par_feat_len.sum() + batch.sent_feat_len.sum())],
                            "padded_tokens": [batch.vid_feat.shape[0] * batch.vid_feat.shape[1] + batch.clip_feat.shape[0] * batch.clip_feat.shape[1],

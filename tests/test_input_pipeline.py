@@ -191,6 +191,7 @@ def test_device_loader_lookahead_keeps_the_previous_batch(background):
                          det_best_terminate_after=16).items():
             setattr(cfg.val, k, v)
         tr = cva.RetrievalTrainer(cfg, mgr)
+        tr.lookahead_min_stage_bytes = 0  # (the trainer skips the lookahead for inputs as small as these)
         h = tr.train_model(DeviceLoader(lists[:5], depth=1, lookahead=la, background=background), DeviceLoader(lists[5:7], depth=1))
         assert (getattr(tr._native, "stages", None) is not None) == bool(la)
         hist.append(h["train_loss"][0])

@@ -21,6 +21,7 @@ for name, look in (("plain", False), ("plain again", False), ("lookahead", True)
     cfg_x.optimizer.adam_eps = eps
     mgr.set_all_models_train()
     tr = cva.RetrievalTrainer(cfg_x, mgr)
+    tr.lookahead_min_stage_bytes = 0
     ls = []
     for it, b in enumerate(batches):
         out = tr.train_step_native(b, seed=100 + it, next_batch=announce[it] if look else None)
