@@ -68,16 +68,29 @@ def total_contrastive_loss(cfg: ContrastiveLossConfig, vid_emb, par_emb, clip_em
 
 
 class ContrastiveLoss(torch.nn.Module):
-    """ContrastiveLoss(margin)(im, s) for L2-normalised inputs (coot/loss_fn.py:51-100,
-    max_violation=False, norm=True)."""
+    """ContrastiveLoss(margin)(im, s) (coot/loss_fn.py:51-100).  The reference's training setting — max_violation=False,
+    norm=True, the only one its trainer constructs (coot/trainer_retrieval.py:84-86) — runs on the fused HIP loss; the two
+    constructor flags no configuration reaches (hardest negative only, un-normalised sum) are a few tensor ops on the
+    embeddings' device, differentiated by autograd."""
 
     def __init__(self, margin: float, max_violation: bool = False, norm: bool = True, use_cuda: bool = True):
         super().__init__()
-        if max_violation or not norm:
-            raise NotImplementedError("only max_violation=False, norm=True (the reference's training setting)")
-        self.margin = margin
+        self.margin, self.max_violation, self.norm = margin, bool(max_violation), bool(norm)
+
+    def _general(self, im: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+        scores = im @ s.t()   # cosine_sim (coot/loss_fn.py:19-30): the inputs are L2-normalised by the caller
+        diag = scores.diag()
+        off = ~torch.eye(scores.shape[0], dtype=torch.bool, device=scores.device)
+        cost_s = (self.margin + scores - diag[:, None]).clamp(min=0) * off     # caption retrieval: against the row's own pair
+        cost_im = (self.margin + scores - diag[None, :]).clamp(min=0) * off    # image retrieval: against the column's own pair
+        if self.max_violation:                                                 # the hardest negative of every query only
+            cost_s, cost_im = cost_s.max(1)[0], cost_im.max(0)[0]
+        total = cost_s.sum() + cost_im.sum()
+        return total / (im.shape[0] * s.shape[0]) if self.norm else total
 
     def forward(self, im: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+        if self.max_violation or not self.norm:
+            return self._general(im, s)
         # one alignment term; inputs are (already) normalised, re-normalising is the identity
         cfg = ContrastiveLossConfig(self.margin, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0)
         dummy = im.new_zeros((8, 8))

@@ -108,3 +108,27 @@ def test_own_manager_loads_legacy_list_checkpoints():
     for net in state:
         for k, v in mgr.model_dict[net].state_dict().items():
             assert torch.equal(v, state[net][k] * 0.5), (net, k)
+
+
+@pytest.mark.parametrize("max_violation,norm", [(True, True), (False, False), (True, False)])
+def test_contrastive_loss_constructor_flags_match_the_reference_module(max_violation, norm):
+    """ContrastiveLoss(margin, max_violation, norm) (coot/loss_fn.py:51-100): the two constructor flags no configuration reaches — the
+    hardest negative per query only, the un-normalised sum — against the reference's module on the same normalised embeddings: loss and
+    gradients wrt both inputs.  (The default flags are the fused HIP loss, pinned on the GPU by test_losses_vs_oracle and the fixtures.)"""
+    import torch
+    import coot_videotext_amd as cva
+    from coot import loss_fn as ref_loss
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(1, 48, generator=g)
+    im = torch.nn.functional.normalize(base + 0.7 * torch.randn(20, 48, generator=g), dim=-1)
+    s = torch.nn.functional.normalize(im + 0.4 * torch.randn(20, 48, generator=g), dim=-1)
+    outs = []
+    for mod in (ref_loss.ContrastiveLoss(0.2, max_violation=max_violation, norm=norm, use_cuda=False),
+                cva.ContrastiveLoss(0.2, max_violation=max_violation, norm=norm, use_cuda=False)):
+        a, b = im.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        loss = mod(a, b)
+        loss.backward()
+        outs.append((float(loss), a.grad.clone(), b.grad.clone()))
+    (lr, gar, gbr), (lo, gao, gbo) = outs
+    assert lr > 0 and abs(lr - lo) <= 1e-6 * abs(lr)
+    assert torch.allclose(gar, gao, rtol=1e-5, atol=1e-7) and torch.allclose(gbr, gbo, rtol=1e-5, atol=1e-7)
