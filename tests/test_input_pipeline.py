@@ -195,7 +195,7 @@ def test_device_loader_lookahead_keeps_the_previous_batch(background):
         h = tr.train_model(DeviceLoader(lists[:5], depth=1, lookahead=la, background=background), DeviceLoader(lists[5:7], depth=1))
         assert (getattr(tr._native, "stages", None) is not None) == bool(la)
         hist.append(h["train_loss"][0])
-    assert abs(hist[0] - hist[1]) <= 1e-4 * abs(hist[0]), hist
+    assert abs(hist[0] - hist[1]) <= 1e-3 * abs(hist[0]), hist  # (run-to-run drift of five updates: fp32 atomics order; a stale batch moves it by O(0.1))
 
 
 def _collate_numpy(pts):
