@@ -449,6 +449,8 @@ class RetrievalTrainer:
             st.dims = _lib.StepDims(*dims_args)
             need = lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims))
             if getattr(st, "ws", None) is None or st.ws.numel() < need:  # ragged batches change shape every step: grow only
+                if getattr(st, "ws", None) is not None:
+                    torch.cuda.synchronize()  # (the text stream may still work on the old workspace; the allocator only tracks the current stream)
                 st.ws = torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev)
             st.dims_key = key
         return st, x
@@ -525,6 +527,10 @@ class RetrievalTrainer:
         else:
             self._next_desc = None
         if getattr(st, "stages", None) is None or st.stages[0].numel() < need:  # (a change of buffers resets what the stages hold)
+            if getattr(st, "stages", None) is not None:
+                # the library's prefetch stream may still be writing the old stages, and the caching allocator does not know that stream:
+                # drain the device before the old buffers go back to it (rare: the stages only grow, with 10 % slack)
+                torch.cuda.synchronize()
             dev = st.ws.device
             st.stages = (torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev), torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev))
         _lib.check(lib.coot_step_set_input_stages(st.stages[0].data_ptr(), st.stages[1].data_ptr(), st.stages[0].numel()), "coot_step_set_input_stages")
