@@ -454,3 +454,39 @@ def test_written_gradient_matrices_cover_every_weight_matrix(cva):
         assert merge(written) == merge(matrices), (written, matrices)
         for name, o, cnt in vectors:
             assert not any(a < o + cnt and o < b for a, b in written), name
+
+
+def test_input_stage_layout_and_argument_checks(cva):
+    """Host side of the input stages (include/coot_hip.h: COOT_STEP_INPUT_STAGES) and of the block-gather loss: the stage size is the
+    normalised features of both sides in whole 128-row tiles + the packed rows' position tables (what csrc/api.hip: layout_saved
+    reserves for x^), and bad arguments are refused before anything touches a device."""
+    import ctypes as C
+    L = cva.lib
+    lib = L.load()
+    cfgs = H.full_cfgs(2048, 1536, 384, 8, 384, 768)
+    sc = L.StepConfig()
+    for i, oc in enumerate(cfgs):
+        sc.net[i] = cva.TransformerConfig(H.ocfg_to_dict(oc), oc.input_dim).to_c()
+    pad = lambda n, a: (n + a - 1) // a * a
+    for (B, Nc, Lv, Lc, Lp, Ls) in [(64, 256, 80, 80, 64, 16), (7, 19, 33, 21, 50, 9)]:
+        d = L.StepDims(B, Nc, Lv, Lc, Lp, Ls, 5, 5, 0, 0, L.SOURCE_PADDED)
+        Tv, Tt = pad(B * Lv + Nc * Lc, 128), pad(B * Lp + Nc * Ls, 128)
+        want = pad(Tv * 2048 * 2, 256) + pad(Tt * 1536 * 2, 256) + pad(Tv * 4, 256) + pad(Tt * 4, 256)
+        assert lib.coot_step_input_stage_bytes(C.byref(sc), C.byref(d)) == want
+    assert lib.coot_step_input_stage_bytes(None, None) == 0
+    # two distinct buffers or none
+    assert lib.coot_step_set_input_stages(C.c_void_p(4096), C.c_void_p(4096), 1024) != 0 and b"distinct" in lib.coot_last_error()
+    assert lib.coot_step_set_input_stages(C.c_void_p(4096), None, 1024) != 0
+    assert lib.coot_step_set_input_stages(None, None, 0) == 0
+    d = L.StepDims(4, 8, 8, 8, 8, 8, 2, 2, 0, 0, L.SOURCE_PADDED)
+    assert lib.coot_step_set_next_batch(None, C.byref(d)) != 0
+    assert lib.coot_step_set_next_batch(None, None) == 0
+    # the block table of coot_contrastive_fwd_bwd_dp_blocks travels in the kernel arguments: at most DP_MAX_RANKS ranks
+    cc = cva.ContrastiveLossConfig(0.2, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0).to_c()
+    W = L.DP_MAX_RANKS + 1
+    counts, base, ld, down = (C.c_int64 * W)(*([4] * W)), (C.c_int64 * (6 * W))(), (C.c_int64 * 6)(8, 8, 8, 8, 8, 8), (C.c_void_p * 6)()
+    dummy = C.c_void_p(4096)
+    rc = lib.coot_contrastive_fwd_bwd_dp_blocks(C.byref(cc), W, 0, counts, counts, 64, 32, dummy, base, C.byref(ld), dummy, C.byref(down), dummy, 1 << 20, None)
+    assert rc != 0 and b"ranks" in lib.coot_last_error()
+    rc = lib.coot_contrastive_fwd_bwd_dp_blocks(C.byref(cc), 2, 2, counts, counts, 64, 32, dummy, base, C.byref(ld), dummy, C.byref(down), dummy, 1 << 20, None)
+    assert rc != 0
