@@ -96,11 +96,11 @@ int check_cfg(const coot_step_config& c) {
   return 0;
 }
 
-// Cross-stream ordering.  A hop (event record + stream wait) costs ~30 us of latency on this stack (measured with the
-// step stamps below: 4 hops on the critical path of a 2.1 ms step), so the step is laid out to keep the heavier video
-// side on ONE stream from its first launch to its Adam update: the caller may pass side_v == main (hops between equal
-// streams vanish), the losses run on the video stream, and every hop left on the critical path waits for the text side,
-// which has slack.
+// Cross-stream ordering.  A hop (event record + stream wait) whose event is already complete costs nothing on the waiting stream
+// (tools/micro/hopgap.hip: 1.0 us between its kernels, as without the wait; round 1 read ~30 us per hop off the step stamps, which was
+// the cost of the stamps' own event records).  What a hop does cost is the wait itself, so the step is laid out to keep the heavier
+// video side on ONE stream from its first launch to its Adam update: the caller may pass side_v == main (hops between equal streams
+// vanish), the losses run on the video stream, and waits sit where the data is first read.
 struct Hops {
   static constexpr int N = 12;
   hipEvent_t ev[N]; bool made = false;
