@@ -70,6 +70,17 @@ def _worker(rank, world, port, counts_v, counts_c, out):
     got = torch.empty(world * 6)
     dp.gather_block(blk, got)   # the one-block embedding exchange
     assert got.view(world, 6).eq(torch.arange(world, dtype=torch.float32)[:, None]).all()
+    # RetrievalTrainer._dp_batch_shapes: what a rank learns about the global batch before it sizes its step — every rank's videos / clips
+    # and the GLOBAL max clips / sentences per video (padding to it keeps avg_special pooling reference-exact) — from host integers only
+    import types
+    from coot_videotext_amd.trainer_retrieval import RetrievalTrainer
+    stub = types.SimpleNamespace(dp=dp)
+    batch = types.SimpleNamespace(clip_num=torch.zeros(counts_v[rank], dtype=torch.int64), clip_feat_len=torch.zeros(counts_c[rank], dtype=torch.int64),
+                                  max_clip_num=3 + rank, max_sent_num=9 - 2 * rank)
+    vc, cc_ = RetrievalTrainer._dp_batch_shapes(stub, batch)
+    assert vc == list(counts_v) and cc_ == list(counts_c)
+    assert (batch.max_clip_num, batch.max_sent_num) == (3 + world - 1, 9) and batch.global_max_synced
+    assert RetrievalTrainer._dp_batch_shapes(stub, batch, [1, 2], [3, 4]) == ([1, 2], [3, 4])   # fixed shapes given + synced: no collective
     # the collective of the native data-parallel step (no autograd): ragged row blocks arrive in rank order
     rows = torch.arange(counts_c[rank] * 2, dtype=torch.float32).view(-1, 2) + 100 * rank
     allrows = cdist.gather_rows_nograd(rows, list(counts_c))
