@@ -615,11 +615,13 @@ extern "C" void coot_step_split_loss(int on);
 extern "C" void coot_step_grad_write(int on);
 extern "C" void coot_step_defer_global_tn(int on);
 extern "C" void coot_step_glob_xcd_split(int on);
+extern "C" int coot_internal_stage_hits(void);
 int coot_get_option(const char* name, int* value) {
   if (!value) { set_error("get_option: null result"); return -1; }
   if (!strcmp(name, "tn_dma")) { *value = get_tn_dma(); return 0; }
   if (!strcmp(name, "xcd_order")) { *value = get_xcd_order(); return 0; }
   if (!strcmp(name, "tn_mode")) { *value = get_tn_mode(); return 0; }
+  if (!strcmp(name, "stage_hits")) { *value = coot_internal_stage_hits(); return 0; }  // steps of this thread that used a prepared input stage
   set_error("get_option: unknown or write-only option %s", name);
   return -2;
 }

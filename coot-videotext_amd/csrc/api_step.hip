@@ -193,6 +193,7 @@ struct InputPipe {
   bool next_valid = false; coot_step_batch next_x; coot_step_dims next_d;  // the batch of the NEXT step (one-shot: consumed by a step)
   bool ready = false; int idx = 0; coot_step_batch have_x; coot_step_dims have_d;  // stage[idx] holds x^ of (have_x, have_d)
   hipEvent_t done = nullptr; hipStream_t stream = nullptr;
+  int hits = 0;  // steps of this thread that found their x^ prepared (coot_get_option("stage_hits"): tests assert the timed mode ran)
   int init() {
     if (stream) return 0;
     RUN(check_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate"));
@@ -205,14 +206,20 @@ struct StageScope { ~StageScope() { coot_internal_set_input_stage(nullptr, nullp
 struct PipeStep { bool piped = false, hit = false, prefetch = false; int cur = 0; StageLayout SL{}; };
 thread_local PipeStep g_phase_pipe;  // of the phase calls: set by coot_step_forward, read and cleared by coot_step_backward
 // this batch's x^ in stage[cur] (already there if the previous step normalised it: `hit`), the next batch's into the other
-int pipe_begin(const coot_step_config& cfg, const coot_step_batch& x, const coot_step_dims& d, hipStream_t sv, hipStream_t st, PipeStep& ps) {
+// `announced`: the caller vouches that (x, d) is the batch it passed to coot_step_set_next_batch, unchanged (COOT_STEP_STAGE_ANNOUNCED).
+// Pointer and shape equality alone is not an identity: a loader's fixed-shape arena slot is refilled in place.
+int pipe_begin(const coot_step_config& cfg, const coot_step_batch& x, const coot_step_dims& d, hipStream_t sv, hipStream_t st, PipeStep& ps,
+               bool announced) {
   ps = PipeStep{}; ps.piped = true;
   COOT_REQUIRE(g_pipe.stage[0] && g_pipe.stage[1], "step: input stages requested without coot_step_set_input_stages");
-  ps.hit = g_pipe.ready && !memcmp(&g_pipe.have_x, &x, sizeof(x)) && !memcmp(&g_pipe.have_d, &d, sizeof(d));
+  ps.hit = announced && g_pipe.ready && !memcmp(&g_pipe.have_x, &x, sizeof(x)) && !memcmp(&g_pipe.have_d, &d, sizeof(d));
   ps.cur = ps.hit ? g_pipe.idx : (g_pipe.ready ? g_pipe.idx ^ 1 : 0);
   ps.SL = stage_layout(cfg, d, g_pipe.stage[ps.cur]);
   COOT_REQUIRE(ps.SL.bytes <= g_pipe.bytes, "step: input stages too small (%zu < %zu)", g_pipe.bytes, ps.SL.bytes);
-  if (ps.hit) {
+  if (ps.hit) ++g_pipe.hits;
+  if (g_pipe.ready) {
+    // hit: x^ must have landed.  Miss: the prepared stage is dropped, but the internal stream may still be READING the batch it was
+    // given — order this step (and with it whatever the caller enqueues behind it, e.g. a refill of that arena slot) after it
     RUN(check_hip(hipStreamWaitEvent(sv, g_pipe.done, 0), "streamWait"));
     RUN(check_hip(hipStreamWaitEvent(st, g_pipe.done, 0), "streamWait"));
   }
@@ -510,7 +517,7 @@ int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, c
   StageScope stage_scope;
   PipeStep ps;
   g_phase_pipe = PipeStep{};
-  if (packs_fresh & COOT_FWD_INPUT_STAGES) RUN(pipe_begin(*cfg, *x, *d, sv, st, ps));
+  if (packs_fresh & COOT_FWD_INPUT_STAGES) RUN(pipe_begin(*cfg, *x, *d, sv, st, ps, (packs_fresh & COOT_FWD_STAGE_ANNOUNCED) != 0));
   if (ps.piped) coot_internal_set_input_stage(ps.SL.xv, ps.SL.pv, ps.hit ? 2 : 0);
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                    local_v, glob_v, resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, !fresh, &pk.v,
@@ -612,7 +619,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   StageScope stage_scope;
   PipeStep ps;
   COOT_REQUIRE(!(piped && g_state_dev), "train_step: input stages are not available in a replayable (captured) step");
-  if (piped) RUN(pipe_begin(*cfg, *x, *d, sv, st, ps));
+  if (piped) RUN(pipe_begin(*cfg, *x, *d, sv, st, ps, (do_optimizer & COOT_STEP_STAGE_ANNOUNCED) != 0));
   const StageLayout& SL = ps.SL; const bool hit = ps.hit;
   const bool prefetch = ps.prefetch;
   if (piped) coot_internal_set_input_stage(SL.xv, SL.pv, hit ? 2 : 0);
@@ -683,7 +690,14 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   g_resh_wait_slot = -1;
   if (rc_v) (void)coot_net_grads_overwrite(0);
   RUN(rc_v);
-  if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
+  // total = contrastive + cycle-consistency rides on the VIDEO side's update launch: both words are final on this stream (its backward
+  // waited for the text stream's loss terms, slot 7), and with COOT_STEP_DEFER_TEXT_JOIN the caller's stream is ordered after the video
+  // side only — all three loss words are readable there on return (on the text side's launch, losses[0] raced with a deferred join)
+  if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv, losses));
+  else {
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, sv, losses);
+    COOT_CHECK_LAUNCH("loss_total");
+  }
   if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
   g_stamps.mark("video: updated", sv);
   if (piped) coot_internal_set_input_stage(SL.xt, SL.pt, 0);
@@ -693,12 +707,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   (void)coot_net_grads_overwrite(0);
   coot_internal_set_input_stage(nullptr, nullptr, 0);
   RUN(rc_t);
-  // total = contrastive + cycle-consistency (not needed by the backward): rides on the text side's update launch
-  if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st, losses));
-  else {
-    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses);
-    COOT_CHECK_LAUNCH("loss_total");
-  }
+  if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
   if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
   g_stamps.mark("text: updated", st);
   RUN(g_hops.hop(4, sv, sm));
@@ -780,6 +789,7 @@ int coot_train_step_phase(const coot_step_config* cfg, const coot_step_buffers* 
 }
 
 void coot_step_stamps_enable(int on) { g_stamps.on = on != 0; }
+int coot_internal_stage_hits(void) { return g_pipe.hits; }
 size_t coot_step_device_state_bytes(void) { return sizeof(StepState); }
 int coot_step_set_device_state(void* state) {
   g_state_dev = (StepState*)state;

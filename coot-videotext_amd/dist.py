@@ -107,11 +107,22 @@ class DataParallelContext:
             if dist.get_backend(self.group) == "gloo":
                 g = self.group if self.group is not None else dist.group.WORLD
             else:
+                err = None
                 try:
                     ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
                     g = dist.new_group(ranks=ranks, backend="gloo")
-                except Exception as e:  # (e.g. no resolvable host name for gloo's TCP transport: the same on every rank of a node)
-                    print(f"coot dist: no gloo side group ({e}); batch shapes go through the device collectives (one stream sync per step)")
+                except Exception as e:  # (e.g. no resolvable host name for gloo's TCP transport)
+                    err, g = e, False
+                # The outcome is agreed COLLECTIVELY over the main group: a rank that fell back on its own would enter the device
+                # all-gather of exchange_shapes while the others enter the gloo one — a deadlock instead of an error.  The side group
+                # is used only if it exists on every rank.
+                ok = torch.tensor([0 if g is False else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                if int(ok.item()) == 0:
+                    if g is not False:
+                        dist.destroy_process_group(g)
+                    print(f"coot dist: no gloo side group on every rank ({err}); batch shapes go through the device collectives "
+                          "(one stream sync per step)")
                     g = False
             self._host_group = g
         return g

@@ -41,8 +41,8 @@ class ContrastiveConfig(C.Structure):
 
 
 SOURCE_PADDED, SOURCE_PACKED_F32, SOURCE_PACKED_BF16 = 0, 1, 2  # COOT_SOURCE_* (include/coot_hip.h)
-STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH, STEP_DEFER_TEXT_JOIN, STEP_INPUT_STAGES = 1, 2, 4, 8, 16  # coot_train_step do_optimizer bits (include/coot_hip.h)
-FWD_PACKS_FRESH, FWD_INPUT_STAGES = 1, 2  # coot_step_forward packs_fresh bits
+STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH, STEP_DEFER_TEXT_JOIN, STEP_INPUT_STAGES, STEP_STAGE_ANNOUNCED = 1, 2, 4, 8, 16, 32  # coot_train_step do_optimizer bits (include/coot_hip.h)
+FWD_PACKS_FRESH, FWD_INPUT_STAGES, FWD_STAGE_ANNOUNCED = 1, 2, 4  # coot_step_forward packs_fresh bits
 DP_MAX_RANKS = 16  # COOT_DP_MAX_RANKS: ranks whose gathered blocks coot_contrastive_fwd_bwd_dp_blocks addresses in place
 
 

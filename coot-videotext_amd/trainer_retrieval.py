@@ -440,11 +440,22 @@ class RetrievalTrainer:
                     dst.copy_(src)
                 for dst, src in zip(st.v, pending["v"]):
                     dst.copy_(src)
+            elif self.__dict__.pop("_native_seed_from_torch", False):
+                self._seed_native_from_torch_optimizer(st)
         for i, n in enumerate(nets):  # arenas move when a module is re-flattened (.cuda()/load): refresh every call
             st.bufs.params[i], st.bufs.grads[i], st.bufs.wpack[i] = n._flat.data_ptr(), n._grad_flat.data_ptr(), n._wpack.data_ptr()
             st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i] = st.m[i].data_ptr(), st.v[i].data_ptr(), st.decay[i].data_ptr()
             st.bufs.pe[i] = n.embedding.pe.data_ptr()
-        key, dims_args, x, _ = self._native_describe(batch)
+        kept = getattr(self, "_next_desc", None)
+        # this very object was announced as `next_batch` by the previous native step (COOT_STEP_STAGE_ANNOUNCED: only then may the step
+        # use the x^ that step prepared — equal pointers and shapes do not identify a batch, arena slots are refilled in place)
+        st.batch_announced = kept is not None and kept[0] is batch
+        key, dims_args, x, held = self._native_describe(batch)
+        # `x` is raw device pointers.  For a packed-source batch outside the packed-row kernels' domain they point into the padded copy
+        # _native_describe made (its 4th return value): that copy — or the caller's batch — stays referenced from here until the NEXT step's
+        # setup, i.e. past this step's launches on every stream (the main stream of the next step is ordered behind this step's forward on
+        # both sides), so the caching allocator cannot hand its blocks to an allocation that runs ahead of the launch.
+        st.batch_ref = held
         if key != st.dims_key:
             st.dims = _lib.StepDims(*dims_args)
             need = lib.coot_step_workspace_bytes(C.byref(st.cfg), C.byref(st.dims))
@@ -521,7 +532,9 @@ class RetrievalTrainer:
         nd = None
         if next_batch is not None:
             desc = self._native_describe(next_batch)
-            self._next_desc = (next_batch, desc)  # (keeps the object, its description and a possibly unpacked copy alive until its own step)
+            # keeps the object, its description and a possibly unpacked copy alive until its own step (the CURRENT batch's copy, if it came
+            # out of the previous announcement, is held by st.batch_ref: replacing _next_desc here does not free it)
+            self._next_desc = (next_batch, desc)
             nd = _lib.StepDims(*desc[1])
             need = max(need, lib.coot_step_input_stage_bytes(C.byref(st.cfg), C.byref(nd)))
         else:
@@ -573,6 +586,16 @@ class RetrievalTrainer:
         self.total_step = int(state.get("total_step", self.total_step))
         nat = state.get("native")
         if nat is None:
+            # a state the REFERENCE wrote (optimizer_<epoch>.pth = {"optimizer", "lr_scheduler"}, nntrainer/trainer_base.py:251-261) or one
+            # of this trainer's autograd route: the native step keeps its moments outside torch.optim, so they are seeded from the torch
+            # optimizer's exp_avg / exp_avg_sq / step through the flat parameter layout — a native run resumed from such a state
+            # continues Adam's moments and bias correction instead of silently restarting them next to a continuing LR schedule
+            if state.get("optimizer") is not None and self.optimizer is not None:
+                st = getattr(self, "_native", None)
+                if st is None:
+                    self._native_seed_from_torch = True
+                else:
+                    self._seed_native_from_torch_optimizer(st)
             return
         st = getattr(self, "_native", None)
         if st is None:
@@ -583,6 +606,29 @@ class RetrievalTrainer:
             dst.copy_(src)
         for dst, src in zip(st.v, nat["v"]):
             dst.copy_(src)
+
+    def _seed_native_from_torch_optimizer(self, st) -> int:
+        """Copies exp_avg / exp_avg_sq / step of self.optimizer's per-parameter state into the native step's flat moment arenas (the
+        parameters are views of each network's flat arena at the offsets of net.table).  Returns the number of parameters seeded;
+        parameters the torch optimizer holds no state for keep zero moments."""
+        if self.optimizer is None:
+            return 0
+        seeded, steps = 0, []
+        for i, net in enumerate(st.nets):
+            for (_name, off, shape), p in zip(net.table, net._params):
+                ps = self.optimizer.state.get(p)
+                if not ps or "exp_avg" not in ps or "exp_avg_sq" not in ps:
+                    continue
+                n = int(np.prod(shape))
+                st.m[i][off:off + n].copy_(ps["exp_avg"].reshape(-1))
+                st.v[i][off:off + n].copy_(ps["exp_avg_sq"].reshape(-1))
+                steps.append(int(ps["step"]) if "step" in ps else 0)
+                seeded += 1
+        if seeded:
+            if len(set(steps)) > 1:
+                raise ValueError(f"optimizer state: parameters at different step counts {sorted(set(steps))}; the native step keeps one")
+            st.step = steps[0]
+        return seeded
 
     # ---- the native step as a replayed hipGraph ----------------------------------------------------------------------
     _GRAPH_FEATS = ("vid_feat", "clip_feat", "par_feat", "sent_feat")
@@ -718,8 +764,9 @@ class RetrievalTrainer:
 
     def join_streams(self) -> None:
         """Orders the current stream after the native step's text stream (train_step_native(defer_join=True) leaves the text side's
-        update running there).  Call before reading the text networks' parameters, weight packs or the step's losses on the current
-        stream (validation, checkpoints, the autograd route); a torch.cuda.synchronize() does the same for the host."""
+        update running there).  Call before reading the text networks' parameters or weight packs on the current stream (validation,
+        checkpoints, the autograd route); a torch.cuda.synchronize() does the same for the host.  The step's three loss words are written
+        on the caller's stream (they ride on the video side's update launch) and need no join."""
         st = getattr(self, "_native", None)
         if st is not None and getattr(st, "join_pending", False):
             torch.cuda.current_stream().wait_stream(st.streams[1])
@@ -762,7 +809,7 @@ class RetrievalTrainer:
         if all(n.pack_is_fresh() for n in st.nets):
             flags |= _lib.STEP_PACKS_FRESH
         if self._announce_next_batch(lib, st, batch, next_batch):
-            flags |= _lib.STEP_INPUT_STAGES
+            flags |= _lib.STEP_INPUT_STAGES | (_lib.STEP_STAGE_ANNOUNCED if st.batch_announced else 0)
         if defer_join and do_optimizer:
             flags |= _lib.STEP_DEFER_TEXT_JOIN
             st.join_pending = True
@@ -890,7 +937,7 @@ class RetrievalTrainer:
         if next_batch is not None and not getattr(next_batch, "global_max_synced", False):
             next_batch = None  # (its padded shapes are not final before ITS batch-shape exchange: no lookahead for it)
         if self._announce_next_batch(lib, st, batch, next_batch):  # the next batch's input LayerNorm runs under the exchange and the loss
-            fresh |= _lib.FWD_INPUT_STAGES
+            fresh |= _lib.FWD_INPUT_STAGES | (_lib.FWD_STAGE_ANNOUNCED if st.batch_announced else 0)
         _lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(d), *st.emb_ptrs, ws, wsn,
                                          train, int(seed), fresh, main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_forward")
         # cycle-consistency (per video, no exchange) on the text stream, next to the gathers and the contrastive loss on the main stream

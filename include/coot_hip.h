@@ -291,12 +291,16 @@ size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_di
 #define COOT_STEP_PACKS_FRESH 4 /* wpack[] is current (previous step ran with REPACK and nothing else touched the parameters):
                                    skip the packing at the start of the step                                                */
 #define COOT_STEP_INPUT_STAGES 16 /* x^ of the input LayerNorm lives in the caller's input stages (coot_step_set_input_stages below)      */
+#define COOT_STEP_STAGE_ANNOUNCED 32 /* the caller asserts that `batch` IS the batch it announced with coot_step_set_next_batch and that its
+                                   contents have not changed since: only then may the step use the x^ a previous step prepared.  Without the
+                                   bit a prepared stage is never used, whatever the pointers say (a loader that refills a fixed-shape arena
+                                   in place presents the SAME pointers and dims with other data)                              */
 #define COOT_STEP_DEFER_TEXT_JOIN 8 /* on return main_s is ordered after the VIDEO side only: the text side's tail (its Adam update,
-                                   weight packs, losses[0] = total) is still running on side_t.  The next coot_train_step with the
+                                   weight packs) is still running on side_t; the three loss words are final on main_s.  The next coot_train_step with the
                                    same streams needs no join (its text side continues on side_t in order, its video side touches
                                    nothing the text tail writes): back-to-back steps overlap that tail (~30 us) with the next
-                                   forward.  Before anything else reads the text networks' parameters / packs or `losses` from
-                                   another stream, the CALLER orders that stream after side_t.                              */
+                                   forward.  Before anything else reads the text networks' parameters / packs from another
+                                   stream, the CALLER orders that stream after side_t.                                      */
 int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
                     const coot_step_dims* dims, float* losses, void* workspace, size_t workspace_bytes, int train,
                     uint64_t seed, int64_t step, int do_optimizer, coot_stream_t main_stream, coot_stream_t side_v,
@@ -306,6 +310,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* bufs, 
  * clip / sentence embeddings), glob_* = [B, 2D], resh_* = [B, Cmax, D] (packed + zero padded). */
 #define COOT_FWD_PACKS_FRESH 1
 #define COOT_FWD_INPUT_STAGES 2
+#define COOT_FWD_STAGE_ANNOUNCED 4   /* as COOT_STEP_STAGE_ANNOUNCED */
 int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
                       const coot_step_dims* dims, float* local_v, float* local_t, float* glob_v, float* glob_t,
                       float* resh_v, float* resh_t, void* workspace, size_t workspace_bytes, int train, uint64_t seed,
@@ -362,7 +367,9 @@ int coot_step_set_cycle_indices(const int64_t* idx);
  *   - if a next batch was announced (coot_step_set_next_batch, one-shot: consumed by that step), normalises THAT batch into the
  *     other stage on an internal stream behind both sides' local forward passes — where the step runs its global networks and losses
  *     on a handful of CUs and the memory system is idle; the next coot_train_step on that batch (same pointers and dims) finds x^
- *     ready and starts with the input FC.
+ *     ready and starts with the input FC — provided the caller says so (COOT_STEP_STAGE_ANNOUNCED): equal pointers and dims alone do
+ *     not identify a batch (arena slots are refilled in place), so without the bit the step normalises itself, after waiting for the
+ *     internal stream's last launch (whose reads of the announced batch are then ordered before anything the caller enqueues next).
  * Every step still executes exactly one input LayerNorm per side (for the following batch); what a data loader's lookahead buys is
  * that it runs off the critical path.  Results are bit-identical to a step without stages.  The state (which stage holds what) is
  * thread-local and reset when the stage pointers change; steps without the flag never touch it.  Not available under graph capture. */

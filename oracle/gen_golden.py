@@ -596,6 +596,15 @@ def gen_bench_yc2_2d3d():
              full_grads=False, ragged=False, cc_weight=0.001, sub_step=197, store_reshape=False)
 
 
+def gen_bench_yc2_2d3d_2816():
+    """BASELINE.json configs[3] AS IT WORDS IT: the concatenated 2D + 3D YouCook2 features at d = 2816 (the shipped YAML says 4096;
+    synthetic.WORKLOADS['yc2_2d3d_2816'], `bench.py --workload yc2_2d3d_2816`), 64 videos x 8 clips.  TRAIN mode with the library's masks
+    (p = 0.1): the fixture pins the timed configuration — dropout on — and with it the K = 2816 input FC (44 slabs of 64 columns:
+    not a multiple of the 128-column double slab) and the 11-chunk-per-lane input LayerNorm."""
+    gen_full("bench_yc2_2d3d_2816_train", (2816, 1536, 384, 8, 384, 768), B=64, counts=[8] * 64, Ls=(80, 20, 96, 12), seed=67,
+             full_grads=False, ragged=False, cc_weight=0.001, sub_step=197, store_reshape=False, train=dict(p=0.1, step_seed=2816001))
+
+
 RK_DIMS = (2048, 1536, 384, 8, 384, 768)
 RK_N, RK_BATCH, RK_LS = 1024, 64, (40, 40, 32, 12)   # validation videos, batch, (Lv, Lc, Lp, Ls)
 RK_EVAL = (4.0, 32, 0.3)    # validation set: feature noise, latent clusters, individual spread (make_latent_batch) — hard enough
@@ -730,6 +739,7 @@ def main():
     gen_bench_yc2_100m_2layer()
     gen_bench_hbm_stress_train()
     gen_bench_yc2_100m_2layer_train()
+    gen_bench_yc2_2d3d_2816()
     gen_rk_parity()
     gen_retrieval_metrics()
     gen_radam()

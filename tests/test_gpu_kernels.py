@@ -152,7 +152,7 @@ def test_gemm_tn_batch(env, dma, xcd, T):
             assert rel_err(dcs.cpu().numpy(), csref) < 2e-5
 
 
-@pytest.mark.parametrize("R,D", [(37, 384), (100, 2048), (9, 1536), (5, 4096), (64, 64)])
+@pytest.mark.parametrize("R,D", [(37, 384), (100, 2048), (9, 1536), (5, 4096), (64, 64), (7, 2816)])
 def test_ln_fwd(env, R, D):
     torch, cva, lib = env
     from oracle.coot_oracle import ln_coot

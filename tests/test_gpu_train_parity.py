@@ -23,7 +23,9 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 # ..._hbm_stress_train: 64 clips per video, the global networks on their per-op kernels; ..._2layer_train: two encoder layers per local network
-CASES = ["bench_anet_train", "bench_anet_ragged_train", "bench_anet_ragged_train_packed", "bench_hbm_stress_train", "bench_yc2_100m_2layer_train"]
+# ..._2816_train: BASELINE.json configs[3] as worded (Dv = 2816: K of the input FC not a multiple of 128, 11 LayerNorm chunks per lane)
+CASES = ["bench_anet_train", "bench_anet_ragged_train", "bench_anet_ragged_train_packed", "bench_hbm_stress_train", "bench_yc2_100m_2layer_train",
+         "bench_yc2_2d3d_2816_train"]
 
 
 @pytest.fixture(scope="module")
@@ -134,5 +136,148 @@ def test_train_mode_native_step_vs_reference_with_injected_masks(env, golden_dir
             if not (c > 0.99 and 0.97 < nr < 1.03):
                 bad.append((key, round(c, 4), round(nr, 4)))
     print(f"[{name}] {checked} parameter gradients checked (min cosine {cmin:.4f}), {len(bad)} out of tolerance")
+    assert not bad, bad
+    assert checked >= 100
+
+
+@pytest.mark.parametrize("name", ["bench_anet_train", "bench_anet_ragged_train_packed"])
+def test_timed_mode_lookahead_and_deferred_join_vs_reference(env, golden_dir, name):
+    """The exact mode bench.py times — optimizer steps back to back with the text side's join deferred (COOT_STEP_DEFER_TEXT_JOIN) and the
+    input LayerNorm of a batch executed by the step BEFORE it (COOT_STEP_INPUT_STAGES) — against the reference fixture, not against itself.
+    Step 0 runs on a decoy batch and announces the fixture's batch; step 1 runs on the fixture's batch with the fixture's seed and cycle
+    positions, finds its x^ prepared (asserted: the library's stage-hit counter moves) and must reproduce the reference's train-mode
+    losses and all parameter gradients.  Both steps are full optimizer steps with learning rate and weight decay 0: Adam then leaves
+    the parameters where the fixture has them (p -= 0 * finite) while everything else of the timed step — update launches, weight
+    repacks, the deferred join — runs.  And x^ in the stage is bit-identical to coot_ln_fwd of the same rows (LayerNorm has no atomics)."""
+    torch, cva = env
+    lib = cva.lib.load()
+    g, cfgs, Ps, b = _case(golden_dir, name)
+    p, seed, packed = float(g["train_p"]), int(g["train_step_seed"]), bool(int(g["train_packed"]))
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=p, cc_weight=float(g["cc_weight"]))
+    cfg.optimizer.lr, cfg.optimizer.weight_decay = 0.0, 0.0
+    mgr.set_all_models_train()
+    trainer = cva.RetrievalTrainer(cfg, mgr)
+    for gr in trainer.optimizer.param_groups:
+        gr["lr"], gr["weight_decay"] = 0.0, 0.0
+    trainer.lookahead_min_stage_bytes = 0
+    before = [n._flat.detach().clone() for n in mgr.model_dict.values()]
+    batch = cva.synthetic.batch_from_numpy(b, packed=packed)
+    meta = [int(v) for v in g["meta"]]
+    decoy_np = O.make_batch(meta[0] + 4242, meta[1], g["counts"], *meta[2:8], ragged=bool(int(g["ragged"])), corr=0.5)
+    decoy = cva.synthetic.batch_from_numpy(decoy_np, packed=packed)
+    idx = torch.from_numpy(np.concatenate([g["cc_idx_clip"], g["cc_idx_sent"]]).astype(np.int64)).cuda()
+    hits0 = cva.lib.get_option("stage_hits")
+    trainer.train_step_native(decoy, seed=seed + 17, defer_join=True, next_batch=batch)
+    # ---- the staged x^ of the fixture batch, bit for bit (padded layout: rows = videos' frames, then clips' frames) ----
+    torch.cuda.synchronize()
+    if not packed:
+        D = batch.vid_feat.shape[2]
+        rows = torch.cat([batch.vid_feat.reshape(-1, D), batch.clip_feat.reshape(-1, D)]).contiguous()
+        want = torch.empty(rows.shape, dtype=torch.bfloat16, device="cuda")
+        cva.lib.check(lib.coot_ln_fwd(rows.data_ptr(), rows.shape[0], D, None, None, want.data_ptr(), None,
+                                      torch.cuda.current_stream().cuda_stream), "ln_fwd")
+        torch.cuda.synchronize()
+        stages = trainer._native.stages
+        same = [torch.equal(s_[:want.numel() * 2].view(torch.bfloat16).view(rows.shape), want) for s_ in stages]
+        assert sum(same) == 1, same  # (the other stage holds the decoy's x^)
+    losses = trainer.train_step_native(batch, seed=seed, cc_indices=idx, defer_join=True)
+    total, contr, cc = (float(v) for v in losses)  # (the loss words are written on the caller's stream: readable without join_streams)
+    trainer.join_streams()
+    torch.cuda.synchronize()
+    assert cva.lib.get_option("stage_hits") == hits0 + 1, "step 1 did not use the x^ step 0 prepared"
+    for a, n in zip(before, mgr.model_dict.values()):
+        assert torch.equal(a, n._flat), "lr = 0 must leave the parameters untouched"
+    rc, rcc = float(g["contr_loss"]), float(g["cc_loss"])
+    print(f"[{name}] timed mode: contrastive {contr:.5f} vs {rc:.5f}; cycle-consistency {cc:.6f} vs {rcc:.6f}")
+    assert abs(contr - rc) < 2e-3 * abs(rc) and abs(cc - rcc) < 5e-3 * abs(rcc) + 1e-6 and abs(total - contr - cc) < 1e-5
+    step = int(g["sub_step"])
+    gmax = max(float(g[k]) for k in g if k.startswith("gnorm:"))
+    bad, checked = [], 0
+    for k in H.NET_KEYS:
+        net = mgr.model_dict[k]
+        flat = net._grad_flat.detach().cpu().numpy()
+        for (pname, off, shape) in net.table:
+            got = flat[off:off + int(np.prod(shape))]
+            key = f"{k}:{pname}"
+            gn = float(g["gnorm:" + key])
+            if gn < 1e-6 * gmax:
+                if np.linalg.norm(got) > 1e-3 * gmax:
+                    bad.append((key, "zero-grad", float(np.linalg.norm(got))))
+                continue
+            ref = g["gsub:" + key]
+            c = H.cosine_flat(got[::(1 if ref.size == got.size else step)], ref)
+            nr = float(np.linalg.norm(got.astype(np.float64))) / gn
+            checked += 1
+            if not (c > 0.99 and 0.97 < nr < 1.03):
+                bad.append((key, round(c, 4), round(nr, 4)))
+    print(f"[{name}] timed mode: {checked} parameter gradients checked, {len(bad)} out of tolerance")
+    assert not bad, bad
+    assert checked >= 100
+
+
+class _OneRankDP:
+    """dist.DataParallelContext of a one-rank job without torch.distributed: the block all-gather is a copy, the all-reduces are no-ops.
+    Everything else of RetrievalTrainer._train_step_native_dp is the production path — coot_step_forward into the embedding block,
+    coot_contrastive_fwd_bwd_dp_blocks on the "gathered" block, coot_step_backward into the shared gradient arena, the two-half reduce."""
+    rank, world, group = 0, 1, None
+
+    def gather_block(self, send, recv):
+        recv[:send.numel()].copy_(send)
+
+    def all_reduce_sum(self, t):
+        pass
+
+
+@pytest.mark.parametrize("name", ["bench_anet_train", "bench_anet_ragged_train_packed"])
+def test_dp_phase_calls_at_bench_shapes_vs_reference(env, golden_dir, name):
+    """The data-parallel PHASE path (what `bench.py --gpus N` times: coot_step_forward / coot_contrastive_fwd_bwd_dp_blocks /
+    coot_step_backward; nntrainer/trainer_base.py:126-129 semantics — encoders per shard, loss on the gathered batch) at d = 384 on the
+    fused chains, against the reference's train-mode fixture: losses and every parameter gradient, as for the single call."""
+    torch, cva = env
+    lib = cva.lib.load()
+    g, cfgs, Ps, b = _case(golden_dir, name)
+    p, seed, packed = float(g["train_p"]), int(g["train_step_seed"]), bool(int(g["train_packed"]))
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=p, cc_weight=float(g["cc_weight"]))
+    mgr.set_all_models_train()
+    trainer = cva.RetrievalTrainer(cfg, mgr)
+    trainer.dp = _OneRankDP()
+    batch = cva.synthetic.batch_from_numpy(b, packed=packed)
+    batch.global_max_synced = True
+    B, Nc = int(batch.clip_num.shape[0]), int(batch.clip_feat_len.shape[0])
+    idx = torch.from_numpy(np.concatenate([g["cc_idx_clip"], g["cc_idx_sent"]]).astype(np.int64)).cuda()
+    lib.coot_timing_enable(1)
+    try:
+        losses = trainer.train_step_native(batch, do_optimizer=False, seed=seed, vid_counts=[B], clip_counts=[Nc], cc_indices=idx)
+        torch.cuda.synchronize()
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+        cva.lib.check(lib.coot_timing_collect(5, C.byref(ms), C.byref(fl), C.byref(n)), "timing_collect")
+    finally:
+        lib.coot_timing_enable(0)
+    assert trainer._native.blocks_on and n.value >= 8, f"block exchange {trainer._native.blocks_on}, fused chain launches {n.value}"
+    total, contr, cc = (float(v) for v in losses)
+    rc, rcc = float(g["contr_loss"]), float(g["cc_loss"])
+    print(f"[{name}] DP phases: contrastive {contr:.5f} vs {rc:.5f}; cycle-consistency {cc:.6f} vs {rcc:.6f}")
+    assert abs(contr - rc) < 2e-3 * abs(rc) and abs(cc - rcc) < 5e-3 * abs(rcc) + 1e-6 and abs(total - contr - cc) < 1e-5
+    step = int(g["sub_step"])
+    gmax = max(float(g[k]) for k in g if k.startswith("gnorm:"))
+    bad, checked = [], 0
+    for k in H.NET_KEYS:
+        net = mgr.model_dict[k]
+        flat = net._grad_flat.detach().cpu().numpy()
+        for (pname, off, shape) in net.table:
+            got = flat[off:off + int(np.prod(shape))]
+            key = f"{k}:{pname}"
+            gn = float(g["gnorm:" + key])
+            if gn < 1e-6 * gmax:
+                if np.linalg.norm(got) > 1e-3 * gmax:
+                    bad.append((key, "zero-grad", float(np.linalg.norm(got))))
+                continue
+            ref = g["gsub:" + key]
+            c = H.cosine_flat(got[::(1 if ref.size == got.size else step)], ref)
+            nr = float(np.linalg.norm(got.astype(np.float64))) / gn
+            checked += 1
+            if not (c > 0.99 and 0.97 < nr < 1.03):
+                bad.append((key, round(c, 4), round(nr, 4)))
+    print(f"[{name}] DP phases: {checked} parameter gradients checked, {len(bad)} out of tolerance")
     assert not bad, bad
     assert checked >= 100

@@ -341,3 +341,43 @@ def test_packed_source_step_equals_the_padded_batch_step():
     assert np.allclose(l0, l2, rtol=5e-3), (l0, l2)
     for a, b_ in zip(g0, g2):
         assert H.cosine_flat(a, b_) > 0.999
+
+
+@pytest.mark.gpu
+def test_packed_source_fallback_copy_outlives_the_launch_with_lookahead():
+    """A packed-source batch outside the packed-row kernels' domain (here: fewer than 1 024 tokens) is unpacked on the device by the
+    trainer, and the step's raw pointers refer to that temporary padded copy.  The copy must stay referenced until the step has been
+    enqueued: with a lookahead, unpacking the NEXT batch allocates tensors of the same sizes in between, and a copy released too
+    early is overwritten by them before the launch (the step then trains on the next batch's features with this batch's lengths —
+    a loss off by O(0.1)).  Steps on packed batches with next_batch == steps on explicitly unpacked, explicitly held batches."""
+    import torch
+    import coot_videotext_amd as cva
+    from coot_videotext_amd.dataset_retrieval import DeviceLoader, unpack_batch
+    from tests import helpers as H
+    dims = (64, 48, 64, 4, 64, 128)
+    lists = [_points(250 + i, 6, dims[0], dims[1], max_frames=12, max_words=9) for i in range(5)]
+    packed = list(DeviceLoader(lists, depth=5, packed=True))
+    assert all(isinstance(b, cva.model_retrieval.RetrievalPackedBatchTuple) and min(b.tok_vis, b.tok_txt) < 1024 for b in packed)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    res = []
+    for mode in ("packed+lookahead", "unpacked"):
+        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.1, cc_weight=0.01)
+        cfg_x.optimizer.adam_eps = 1e-3  # (see tests/test_gpu_path.py::test_deferred_text_join_gives_the_same_training_trajectory)
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg_x, mgr)
+        tr.lookahead_min_stage_bytes = 0
+        held = [unpack_batch(b) for b in packed] if mode == "unpacked" else None
+        losses = []
+        for it in range(5):
+            if held is None:
+                nxt = packed[it + 1] if it + 1 < 5 else None
+                out = tr.train_step_native(packed[it], seed=300 + it, next_batch=nxt)
+            else:
+                out = tr.train_step_native(held[it], seed=300 + it)
+            losses.append([float(v) for v in out])
+        torch.cuda.synchronize()
+        res.append(losses)
+    la, lb = res
+    assert np.allclose(la[:2], lb[:2], rtol=1e-4, atol=1e-7), (la, lb)
+    assert np.allclose(la, lb, rtol=1e-3, atol=1e-6), (la, lb)
