@@ -57,22 +57,59 @@ __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RF][3]) {
     for (int b = 0; b < 3; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
-// acc[a][b] += tile rows [16 a, 16 a + 16) x (48 columns of weight group wg), K = 32 KB
-template <int RF, int KB>
-__device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f32x4_t (&acc)[RF][3], int lane) {
+// ---- one 384-wide GEMM pass: acc[a][b] += tile rows [16 a, 16 a + 16) x (48 columns of weight group wg), K = 32 KB -------------
+// The weight fragments of a pass go through a register ring of NB = PD + 1 k-blocks, PD of them in flight.  The ring is CARRIED from
+// pass to pass: the last PD iterations of a pass load the first PD k-blocks of the pass that FOLLOWS it (`next`), so those fly during
+// the epilogue / LayerNorm / attention phase between the two passes and a pass starts on data that has landed — a chain kernel is a
+// sequence of 6-12 passes separated by such phases, and each used to start with an exposed L2 round trip (the global networks' single-
+// launch passes are latency chains: there it was ~1.6 us per pass, a fifth of the kernel).  hipcc did some of this hoisting on its own
+// as long as every pass's addresses were kernel-wide values — the same values it then spilled; with per-pass addresses (the launders
+// that keep the kernels out of scratch) it cannot, so the schedule is explicit.
+//   PD: small tiles (the global networks, RF <= 2) do almost no MFMA work per k-block, a pass is the latency of streaming 295 KB of
+//   weights: 5 k-blocks (15 KB per wave) in flight.  Full tiles: a pass is at the MFMA time of 2 waves/SIMD, PD = 2 (3 / 4: no faster).
+//   NB must divide every pass's KB (12, 6): a pass then starts at ring slot 0 whatever preceded it.
+#ifndef FZ_PD_FULL
+#define FZ_PD_FULL 2
+#endif
+#ifndef FZ_CARRY
+#define FZ_CARRY 1   // 0: every pass loads its own first k-blocks (A/B)
+#endif
+//   CARRY: 128-row tiles do not carry (the PD x 12 ring registers live across an epilogue that already holds 96 accumulators + its
+//   chunk registers: 104-148 B of scratch per lane); their passes start with their own first k-blocks.  A ring type's CARRY decides
+//   for every pass run on it.
+#ifndef FZ_CARRY_MAX_RF
+#define FZ_CARRY_MAX_RF 4
+#endif
+template <int PD_, bool CARRY_>
+struct WRing { static constexpr int PD = PD_, NB = PD_ + 1; static constexpr bool CARRY = CARRY_; bf16x8_t w[PD_ + 1][3]; };
+template <int RF> using TileRing = WRing<(RF <= 2 ? 5 : FZ_PD_FULL), (FZ_CARRY != 0 && RF <= FZ_CARRY_MAX_RF)>;
+
+// the first PD k-blocks of weight group wg -> ring slots 0 .. PD - 1 (the first pass of a kernel; later passes inherit theirs)
+template <typename Ring>
+__device__ __forceinline__ void gemm_load_first(Ring& R, const bf16_t* wg, int lane) {
+  const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(wg) + lane;
+#pragma unroll
+  for (int s = 0; s < Ring::PD; ++s)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) R.w[s][b] = wp[(s * 3 + b) * 64];
+  // pin the loads where they are written: hipcc otherwise sinks them next to their first use
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <typename Ring>
+__device__ __forceinline__ void gemm_issue(Ring& R, const bf16_t* wg, int lane) {
+  if constexpr (Ring::CARRY) gemm_load_first(R, wg, lane);
+}
+
+// the pass proper; the ring holds k-blocks 0 .. PD - 1 of wg.  NEXT: the last PD iterations load k-blocks 0 .. PD - 1 of `next`.
+template <int RF, int KB, bool NEXT, typename Ring>
+__device__ __forceinline__ void gemm_run(Ring& R, const bf16_t* As, const bf16_t* wg, const bf16_t* next, f32x4_t (&acc)[RF][3], int lane) {
+  constexpr int PD = Ring::PD, NB = Ring::NB;
+  static_assert(KB % NB == 0 && KB >= PD, "the ring must wrap at the end of a pass");
+  asm volatile("" : "+v"(lane));  // this pass's fragment addresses are its own (not shared with — and kept live for — the other passes)
+  if constexpr (!Ring::CARRY) gemm_load_first(R, wg, lane);  // nothing is carried: the pass starts with its own L2 round trip
   const bf16_t* arow = As + (lane & 15) * APITCH + (lane >> 4) * 8;
   const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(wg) + lane;
-  // prefetch distance (k-blocks) and register ring size.  Small tiles (the global networks: RF <= 2) do almost no MFMA
-  // work per k-block, the pass is the latency of streaming 295 KB of weights: keep 6 k-blocks (18 KB per wave) in flight.
-  // Full tiles: a pass is at the MFMA time of 2 waves/SIMD; PD = 3 / 4 measured no faster and cost 60 / 140 B/lane of spills.
-  constexpr int PD = RF <= 2 ? 6 : 2, NB = PD + 1;
-  bf16x8_t w[NB][3];
-#pragma unroll
-  for (int s = 0; s < PD; ++s)
-    if (s < KB) {
-#pragma unroll
-      for (int b = 0; b < 3; ++b) w[s][b] = wp[(s * 3 + b) * 64];
-    }
+  const bf16x8_t* np = reinterpret_cast<const bf16x8_t*>(next) + lane;
   // token fragments: ONE register set, refreshed row fragment by row fragment — xf[a] of the next k-block is read right
   // after the three MFMAs that consume the current xf[a] (its next use is 21 MFMAs away, several LDS latencies).  A
   // second full set (double buffering) costs 4 RF registers the epilogues then spill.
@@ -83,7 +120,10 @@ __device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f3
   for (int kb = 0; kb < KB; ++kb) {
     if (kb + PD < KB) {
 #pragma unroll
-      for (int b = 0; b < 3; ++b) w[(kb + PD) % NB][b] = wp[((kb + PD) * 3 + b) * 64];
+      for (int b = 0; b < 3; ++b) R.w[(kb + PD) % NB][b] = wp[((kb + PD) * 3 + b) * 64];
+    } else if constexpr (NEXT && Ring::CARRY) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) R.w[(kb + PD) % NB][b] = np[((kb + PD - KB) * 3 + b) * 64];
     }
     // pin the prefetches where they are written: without this hipcc sinks the weight loads next to their first use
     // (vmcnt(0) in front of every k-block: one full L2 round trip per 24 MFMAs)
@@ -91,7 +131,7 @@ __device__ __forceinline__ void gemm_pass(const bf16_t* As, const bf16_t* wg, f3
 #pragma unroll
     for (int a = 0; a < RF; ++a) {
 #pragma unroll
-      for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kb % NB][b], xf[a], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R.w[kb % NB][b], xf[a], acc[a][b], 0, 0, 0);
       if (kb + 1 < KB) xf[a] = *reinterpret_cast<const bf16x8_t*>(arow + a * 16 * APITCH + (kb + 1) * 32);
     }
   }
@@ -150,7 +190,11 @@ __device__ __forceinline__ void epilogue(f32x4_t (&acc)[RF * NCG / 8][3], float*
   constexpr int RR = RF >= 2 ? 32 : 16, FR = RR / 16, RPR = (NCG == 8 ? RR : 2 * RR), ROUNDS = 16 * RF / RPR, CH = RR * 48, IT = CH / NTHR;
   static_assert(CH % NTHR == 0 && IT == 3 && ROUNDS <= 4 && (NCG == 8 || (NCG == 4 && ((ROUNDS == 2 && RF == 8) || (ROUNDS == 1 && RF == 4)))),
                 "tile pass geometry");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // launder the thread index: the per-thread row / column offsets below are a handful of VALU instructions; shared (CSE'd) between the
+  // ten epilogues of a chain kernel they stay live from the first to the last one — in scratch, across the GEMM passes
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   const int cg = wave % NCG, rh = wave / NCG;
   int rl[IT], col[IT];
 #pragma unroll
@@ -373,7 +417,13 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       if (threadIdx.x < FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm + k * FZ_D)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(vecs[k])[threadIdx.x];
   }
   int tsn = 0;
-  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  // (the pointer is re-read from its SGPR pair at every stamp: as a VGPR address hoisted to the kernel's entry it was the last spill)
+  auto stamp = [&]() {
+    unsigned long long* ts = p.tstamps;
+    asm volatile("" : "+s"(ts));
+    if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[tsn] = __builtin_amdgcn_s_memtime();
+    ++tsn;
+  };
   unsigned long long sbase = 0;
   if constexpr (DROP) { if (p.d_ff1.seed_ptr) sbase = *p.d_ff1.seed_ptr; }
   const DropK d_postln = resolve_drop(p.d_postln, sbase), d_ff1 = resolve_drop(p.d_ff1, sbase), d_ff2 = resolve_drop(p.d_ff2, sbase),
@@ -381,11 +431,13 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   stamp();
 
   // ---- attention output projection + residual -> r1 ------------------------------------------------------------
+  TileRing<RF> R;  // weight ring, carried from pass to pass (gemm_run)
+  gemm_issue(R, p.wo + wave * GSZ, lane);  // (flies during the tile load)
   load_tile<RF>(As, p.ctx, FZ_D, 0, row0);
   __syncthreads();
   stamp();
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, p.wo + wave * GSZ, p.w1 + wave * GSZ, acc, lane);
   stamp();
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 0 * FZ_D,
       [&](int row, int col) { return PreRes{gld16(p.xres, (unsigned)(row * FZ_D + col) * 2u)}; },
@@ -403,7 +455,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   stamp();
   // ---- FF1: Linear -> Dropout -> GELU ------------------------------------------------------------------------------
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, p.w1 + wave * GSZ, p.w2 + wave * GSZ, acc, lane);
   stamp();
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 1 * FZ_D, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&, int) {
@@ -420,7 +472,10 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   stamp();
   // ---- FF2: Linear -> Dropout, + residual z1 -> r2 -----------------------------------------------------------------
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
+  {  // what follows FF2: the first pooling pass (or nothing: the ring then re-loads this pass's own first k-blocks, harmlessly)
+    const bf16_t* nx = (RF >= 4 && p.do_pool) ? p.pw1 + wave * GSZ : p.w2 + wave * GSZ;
+    gemm_run<RF, 12, true>(R, As, p.w2 + wave * GSZ, nx, acc, lane);
+  }
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm + 2 * FZ_D,
       [&](int row, int col) { return PreRes{gld16(p.z1, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
@@ -454,7 +509,8 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
         __syncthreads();
       }
       zero_acc<RF>(acc);
-      gemm_pass<RF, 12>(As, p.pw1 + (h * 8 + wave) * GSZ, acc, lane);
+      const bf16_t* w2h = p.pw2 + (h * 4 + (wave & 3)) * GSZ;
+      gemm_run<RF, 12, true>(R, As, p.pw1 + (h * 8 + wave) * GSZ, w2h, acc, lane);
       epilogue<RF, 8>(acc, Stg, As, row0, Bsm + h * FZ_D, [&](int, int) { return PreNone{}; },
           [&](int row, int col, float (&v)[8], const PreNone&, int) {
             apply_drop<DROP>(d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
@@ -466,7 +522,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       // FC2 of head h: 192 output columns = 4 column groups x 2 row halves
       f32x4_t acc2[RF / 2][3];
       zero_acc<RF / 2>(acc2);
-      gemm_pass<RF / 2, 12>(As + (wave >> 2) * (BT / 2) * APITCH, p.pw2 + (h * 4 + (wave & 3)) * GSZ, acc2, lane);
+      gemm_run<RF / 2, 12, true>(R, As + (wave >> 2) * (BT / 2) * APITCH, w2h, h == 0 ? p.pw1 + (8 + wave) * GSZ : w2h, acc2, lane);
       epilogue<RF, 4>(acc2, Stg, As, row0, Bsm + 2 * FZ_D + h * (FZ_D / 2), [&](int, int) { return PreNone{}; },
           [&](int row, int col, float (&v)[8], const PreNone&, int) {
             apply_drop<DROP>(d_pool2, (unsigned long long)row * FZ_D + h * (FZ_D / 2) + col, v);
@@ -492,7 +548,9 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
   static_assert(RF == 8 || RF == 4, "2 RF rows per wave, 4 per pass");
   constexpr int NIT = RF / 2, RW = 2 * RF;
   asm volatile("" : "+s"(row0));  // keep this call's per-thread offsets out of the other LayerNorm's live range (they were spilled across the chain)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j16 = lane & 15, g = lane >> 4;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // ... and everything derived from the thread index (see epilogue())
+  const int lane = tid & 63, wave = tid >> 6, j16 = lane & 15, g = lane >> 4;
   u32x4_t xs[NIT][3];  // the saved LN input of this lane's rows, kept packed (all loads in flight together)
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
@@ -521,10 +579,16 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
       unpack8(*reinterpret_cast<const u32x4_t*>(ar + m * 128), dy);
       load8f(gain_lds + m * 128 + j16 * 8, gn);
       if constexpr (DROPY) {
+        // the masked gradient goes back into the tile (this lane's own chunk, bf16 like every gradient of the chain) and pass B reads
+        // it from there: drawing the mask a second time in pass B cost 12 hash evaluations per lane and the registers that pushed
+        // the row statistics into scratch
         float sc[8];
         drop_scales_key<8>(dy_drop.key, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dy_drop.thr, dy_drop.inv_keep, sc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dy[e] *= sc[e];
+        const u32x4_t md = pack8(dy);
+        *reinterpret_cast<u32x4_t*>(ar + m * 128) = md;
+        unpack8(md, dy);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -553,13 +617,7 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
       bf16_t* ar = As + rl * APITCH + j16 * 8 + m * 128;
       float x[8], dy[8], dx[8], dm[8];
       unpack8(xs[it][m], x);
-      unpack8(*reinterpret_cast<const u32x4_t*>(ar), dy);
-      if constexpr (DROPY) {  // the same mask as in pass A (recomputed: cheaper than keeping 96 masked values live)
-        float sc[8];
-        drop_scales_key<8>(dy_drop.key, (unsigned long long)row * FZ_D + m * 128 + j16 * 8, dy_drop.thr, dy_drop.inv_keep, sc);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dy[e] *= sc[e];
-      }
+      unpack8(*reinterpret_cast<const u32x4_t*>(ar), dy);  // (DROPY: masked in pass A)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         x[e] -= mean[it];
@@ -596,11 +654,11 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
       *reinterpret_cast<f32x4_t*>(rw + 256 + 4) = f32x4_t{csx[4], csx[5], csx[6], csx[7]};
     }
     lds_barrier();
-    if (threadIdx.x < 3 * 128) {
+    if (tid < 3 * 128) {
       float v = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) v += red[r * (3 * 128) + threadIdx.x];
-      const int q = threadIdx.x / 128, c = threadIdx.x % 128;  // quantity (dgain, dbias, colsum dx), column within the chunk
+      for (int r = 0; r < 32; ++r) v += red[r * (3 * 128) + tid];
+      const int q = tid / 128, c = tid % 128;  // quantity (dgain, dbias, colsum dx), column within the chunk
       part_dst[q * FZ_D + m * 128 + c] = v;
     }
     lds_barrier();
@@ -612,7 +670,9 @@ __device__ __forceinline__ void ln_bwd_tile(bf16_t* As, const float* gain_lds, c
 // For chunk index i the threads t = ch + 48 k (k < 11) share column chunk (ch + 32 i) % 48: they park their sums in
 // red[k][384] and 384 threads add the (up to) 11 rows.  `red` = the staging buffer (free between epilogues).
 __device__ __forceinline__ void colsum_flush(const float (&cs)[3][8], float* red, float* dst) {
-  const int tid = threadIdx.x, k = tid / 48;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // (see epilogue(): per-call thread offsets, not kernel-wide ones)
+  const int k = tid / 48;
   float tot = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -652,7 +712,13 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   f32x4_t acc[RF][3];
   float cs[3][8];
   int tsn = 0;
-  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  // (the pointer is re-read from its SGPR pair at every stamp: as a VGPR address hoisted to the kernel's entry it was the last spill)
+  auto stamp = [&]() {
+    unsigned long long* ts = p.tstamps;
+    asm volatile("" : "+s"(ts));
+    if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[tsn] = __builtin_amdgcn_s_memtime();
+    ++tsn;
+  };
   unsigned long long sbase = 0;
   if constexpr (DROP) { if (p.d_ff1.seed_ptr) sbase = *p.d_ff1.seed_ptr; }
   const DropK d_postln = resolve_drop(p.d_postln, sbase), d_ff1 = resolve_drop(p.d_ff1, sbase), d_ff2 = resolve_drop(p.d_ff2, sbase),
@@ -665,14 +731,19 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
       for (int j = 0; j < 8; ++j) cs[i][j] = 0.f;
   };
 
+  TileRing<RF> R;  // weight ring, carried from pass to pass (gemm_run)
+  // this wave's weight group of a P48 array, from a laundered group index: shared between the passes, `wave * GSZ` was the value hipcc
+  // parked in scratch across the chain (one multiply-add to recompute)
+  auto WG = [&](const bf16_t* base, int grp, long gsz) { asm volatile("" : "+v"(grp)); return base + grp * gsz; };
   if (p.do_pool) {
     // ---- GenPool score MLP backward: dhp_h = (ds_h . W2[h]^T) * GELU'(hp_h) * drop1;  dz = sum_h dhp_h . W1[h]^T + dzp ----
+    gemm_issue(R, WG(p.pw2, wave, GSZ192), lane);
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       load_tile<RF, 24>(As, p.ds, FZ_D, h * (FZ_D / 2), row0);
       __syncthreads();
       zero_acc<RF>(acc);
-      gemm_pass<RF, 6>(As, p.pw2 + (h * 8 + wave) * GSZ192, acc, lane);
+      gemm_run<RF, 6, true>(R, As, WG(p.pw2, h * 8 + wave, GSZ192), h == 0 ? WG(p.pw2, 8 + wave, GSZ192) : WG(p.pw1, 8 + wave, GSZ), acc, lane);
       cs_zero();
       epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
           [&](int row, int col) { return PreRes{gld16(p.hp, (unsigned)(row * (2 * FZ_D) + h * FZ_D + col) * 2u)}; },
@@ -693,11 +764,11 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
     }
     // the tile holds dhp_1 now
     zero_acc<RF>(acc);
-    gemm_pass<RF, 12>(As, p.pw1 + (8 + wave) * GSZ, acc, lane);
+    gemm_run<RF, 12, true>(R, As, WG(p.pw1, 8 + wave, GSZ), WG(p.pw1, wave, GSZ), acc, lane);
     __syncthreads();  // every wave is done with dhp_1; dhp_0 (stored by this workgroup above) is visible
     load_tile<RF>(As, p.dhp, 2 * FZ_D, 0, row0);
     __syncthreads();
-    gemm_pass<RF, 12>(As, p.pw1 + wave * GSZ, acc, lane);
+    gemm_run<RF, 12, true>(R, As, WG(p.pw1, wave, GSZ), WG(p.w2, wave, GSZ), acc, lane);
     epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
         [&](int row, int col) { return PreRes{gld16(p.dzp, (unsigned)(row * FZ_D + col) * 2u)}; },
         [&](int, int, float (&v)[8], const PreRes& pr, int) {
@@ -707,6 +778,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
           for (int j = 0; j < 8; ++j) v[j] += r[j];
         }, true);
   } else {
+    gemm_issue(R, WG(p.w2, wave, GSZ), lane);
     load_tile<RF>(As, p.dz2, FZ_D, 0, row0);
     __syncthreads();
   }
@@ -716,7 +788,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   stamp();
   // ---- dh1 = (df2 . W2) * GELU'(h1) * drop(FF1) ---------------------------------------------------------------------------
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.w2 + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, WG(p.w2, wave, GSZ), WG(p.w1, wave, GSZ), acc, lane);
   cs_zero();
   epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
       [&](int row, int col) { return PreRes{gld16(p.h1, (unsigned)(row * FZ_D + col) * 2u)}; },
@@ -736,7 +808,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   stamp();
   // ---- dz1 = dh1 . W1 + dr2 ----------------------------------------------------------------------------------------------------
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.w1 + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, WG(p.w1, wave, GSZ), WG(p.wo, wave, GSZ), acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
       [&](int row, int col) { return PreRes{gld16(p.dr2, (unsigned)(row * FZ_D + col) * 2u)}; },
       [&](int, int, float (&v)[8], const PreRes& pr, int) {
@@ -751,7 +823,7 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
   stamp();
   // ---- dctx = dr1 . Wo ------------------------------------------------------------------------------------------------------------
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.wo + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, false>(R, As, WG(p.wo, wave, GSZ), nullptr, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, nullptr, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&, int) { gst16(p.dctx, (unsigned)(row * FZ_D + col) * 2u, pack8(v)); }, false);
   stamp();
@@ -858,15 +930,16 @@ __device__ __forceinline__ int glob_tile_or_help(const P& p, const bf16_t* const
 
 // out-proj + residual + LN1 (+ dropout) + FF1 + GELU + FF2 + residual + LN2 on the 32-row tile in As (rows [row0, rowEnd) are
 // real; nothing is stored for the others).  The chain of post_attn_fwd_kernel with row masks and global parameter vectors.
+// R: the carried weight ring, holding the first k-blocks of L.wo on entry and those of `next` (the pass that follows the chain) on exit
 template <bool DROP, bool OUT32>
 __device__ __forceinline__ void glob_chain_fwd(bf16_t* As, float* Stg, const GlobLayerFwd& L, const bf16_t* xres, int row0, int rowEnd,
-                                               float* z2_f32, long ldz2_f32, unsigned long long sbase) {
+                                               float* z2_f32, long ldz2_f32, unsigned long long sbase, TileRing<2>& R, const bf16_t* next) {
   constexpr int RF = 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const DropK d_postln = resolve_drop(L.d_postln, sbase), d_ff1 = resolve_drop(L.d_ff1, sbase), d_ff2 = resolve_drop(L.d_ff2, sbase);
   f32x4_t acc[RF][3];
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, L.wo + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, L.wo + wave * GSZ, L.w1 + wave * GSZ, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, L.bo,
       [&](int row, int col) { return PreRes{row < rowEnd ? gld16(xres, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
@@ -879,7 +952,7 @@ __device__ __forceinline__ void glob_chain_fwd(bf16_t* As, float* Stg, const Glo
   ln_tile<RF, DROP, false, true>(As, L.ln1g, L.ln1b, row0, rowEnd, L.z1, nullptr, 0, d_postln);
   __syncthreads();
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, L.w1 + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, L.w1 + wave * GSZ, L.w2 + wave * GSZ, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, L.b1, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&, int) {
         apply_drop<DROP>(d_ff1, (unsigned long long)row * FZ_D + col, v);
@@ -889,7 +962,7 @@ __device__ __forceinline__ void glob_chain_fwd(bf16_t* As, float* Stg, const Glo
         if (row < rowEnd) gst16(L.a1, (unsigned)(row * FZ_D + col) * 2u, pack8(v));
       }, true);
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, L.w2 + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, L.w2 + wave * GSZ, next, acc, lane);
   __syncthreads();  // z1 (stored by this workgroup in ln_tile) is read back as the residual
   epilogue<RF, 8>(acc, Stg, As, row0, L.b2,
       [&](int row, int col) { return PreRes{row < rowEnd ? gld16(L.z1, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
@@ -936,6 +1009,8 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
   int tsn = 0;
   auto stamp = [&]() { if (p.tstamps && tile == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
   stamp();
+  TileRing<RF> R;  // weight ring, carried through all twelve passes (gemm_run)
+  gemm_issue(R, p.self.wqkv + wave * GSZ, lane);  // (flies during the input LayerNorm)
 
   // ---- z0 = LayerNorm(x) + pe (transformer_legacy.py:222-241; padded items are zero rows: LN gives bias + pe there) ----
   {
@@ -980,7 +1055,7 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
 #pragma unroll 1
   for (int q = 0; q < 3; ++q) {
     zero_acc<RF>(acc);
-    gemm_pass<RF, 12>(As, p.self.wqkv + (q * 8 + wave) * GSZ, acc, lane);
+    gemm_run<RF, 12, true>(R, As, p.self.wqkv + (q * 8 + wave) * GSZ, q < 2 ? p.self.wqkv + ((q + 1) * 8 + wave) * GSZ : p.self.wo + wave * GSZ, acc, lane);
     bf16_t* dst = q == 0 ? Qs : (q == 1 ? Ks : Vs);
     epilogue<RF, 8>(acc, Stg, dst, row0, p.self.bqkv + q * FZ_D, [&](int, int) { return PreNone{}; },
         [&](int row, int col, float (&v)[8], const PreNone&, int) {
@@ -995,8 +1070,11 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
   }
   __syncthreads();
   stamp();
-  if (p.per_token) glob_chain_fwd<DROP, true>(As, Stg, p.self, p.z0, row0, rowEnd, p.per_token, FZ_D, sbase);
-  else glob_chain_fwd<DROP, false>(As, Stg, p.self, p.z0, row0, rowEnd, nullptr, 0, sbase);
+  {
+    const bf16_t* nx = p.ctx.wqkv + (8 + wave) * GSZ;  // the context block's key projection follows
+    if (p.per_token) glob_chain_fwd<DROP, true>(As, Stg, p.self, p.z0, row0, rowEnd, p.per_token, FZ_D, sbase, R, nx);
+    else glob_chain_fwd<DROP, false>(As, Stg, p.self, p.z0, row0, rowEnd, nullptr, 0, sbase, R, nx);
+  }
   stamp();
 
   // ---- avg_special pooling (poolers.py:237-238): the sum runs over ALL Cmax rows, padded ones included -----------------------
@@ -1012,7 +1090,7 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
 #pragma unroll 1
   for (int q = 1; q < 3; ++q) {
     zero_acc<RF>(acc);
-    gemm_pass<RF, 12>(As, p.ctx.wqkv + (q * 8 + wave) * GSZ, acc, lane);
+    gemm_run<RF, 12, true>(R, As, p.ctx.wqkv + (q * 8 + wave) * GSZ, q == 1 ? p.ctx.wqkv + (16 + wave) * GSZ : p.ctx.wqkv + wave * GSZ, acc, lane);
     bf16_t* dst = q == 1 ? Ks : Vs;
     bf16_t* gdst = q == 1 ? p.ctx.k : p.ctx.v;
     const int ldkv = (int)(q == 1 ? p.ctx.ldk : p.ctx.ldv);
@@ -1038,7 +1116,7 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
   }
   __syncthreads();
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, p.ctx.wqkv + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, p.ctx.wqkv + wave * GSZ, p.ctx.wo + wave * GSZ, acc, lane);
   epilogue<RF, 8>(acc, Stg, Qs, v0, p.ctx.bqkv, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&, int) {
         if (row < v0 + nv) gst16(p.ctx.q, (unsigned)(row * (int)p.ctx.ldq + col) * 2u, pack8(v));
@@ -1051,7 +1129,7 @@ __global__ __launch_bounds__(512) void glob_fwd_kernel(GlobFwd p) {
   }
   __syncthreads();
   stamp();
-  glob_chain_fwd<DROP, true>(As, Stg, p.ctx, p.cq_in, v0, v0 + nv, p.pooled + FZ_D, 2 * FZ_D, sbase);
+  glob_chain_fwd<DROP, true>(As, Stg, p.ctx, p.cq_in, v0, v0 + nv, p.pooled + FZ_D, 2 * FZ_D, sbase, R, p.ctx.w2 + wave * GSZ /* nothing follows */);
   stamp();
 }
 
@@ -1189,9 +1267,10 @@ __device__ __forceinline__ void load_rows32(bf16_t* Ts, const bf16_t* src, long 
 // The chain of pre_attn_bwd_kernel on the 32-row tile: LN2 backward, FF2^T, GELU', FF1^T, LN1 backward (through the post-LN
 // dropout), out-proj^T.  In: the gradient wrt the layer output in As (bf16) or dy32 (fp32 rows).  Out: the gradient wrt the
 // attention output in As; dr2 / dr2m / dh1 / dr1 in global memory (the weight-gradient GEMMs read them), parameter gradients added.
+// R: the carried weight ring — the first k-blocks of L.w2_kn on entry, those of `next` (the pass that follows the chain) on exit.
 template <bool DROP, bool DY32>
 __device__ __forceinline__ void glob_chain_bwd(bf16_t* As, float* Stg, const GlobLayerBwd& L, const float* dy32, long lddy32, int row0, int rowEnd,
-                                               unsigned long long sbase) {
+                                               unsigned long long sbase, TileRing<2>& R, const bf16_t* next) {
   constexpr int RF = 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const DropK d_postln = resolve_drop(L.d_postln, sbase), d_ff1 = resolve_drop(L.d_ff1, sbase), d_ff2 = resolve_drop(L.d_ff2, sbase);
@@ -1199,7 +1278,7 @@ __device__ __forceinline__ void glob_chain_bwd(bf16_t* As, float* Stg, const Glo
   glob_ln_bwd<false, DROP, DY32, false>(As, dy32, lddy32, L.r2, L.ln2g, row0, rowEnd, L.dr2, L.dr2m, nullptr, d_ff2, d_ff2, Stg, L.g_ln2g, L.g_ln2b);
   __syncthreads();  // the tile holds df2; dr2 (global) is read back below
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, L.w2_kn + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, L.w2_kn + wave * GSZ, L.w1_kn + wave * GSZ, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
       [&](int row, int col) { return PreRes{row < rowEnd ? gld16(L.h1, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
@@ -1216,7 +1295,7 @@ __device__ __forceinline__ void glob_chain_bwd(bf16_t* As, float* Stg, const Glo
         }
       }, true);
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, L.w1_kn + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, L.w1_kn + wave * GSZ, L.wo_kn + wave * GSZ, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
       [&](int row, int col) { return PreRes{row < rowEnd ? gld16(L.dr2, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
       [&](int, int, float (&v)[8], const PreRes& pr, int) {
@@ -1229,7 +1308,7 @@ __device__ __forceinline__ void glob_chain_bwd(bf16_t* As, float* Stg, const Glo
                                          L.g_ln1b);
   __syncthreads();
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(As, L.wo_kn + wave * GSZ, acc, lane);
+  gemm_run<RF, 12, true>(R, As, L.wo_kn + wave * GSZ, next, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, nullptr, [&](int, int) { return PreNone{}; }, [&](int, int, float (&)[8], const PreNone&, int) {}, true);
   __syncthreads();
 }
@@ -1267,7 +1346,11 @@ __global__ __launch_bounds__(512) void glob_bwd_kernel(GlobBwd p) {
   stamp();
 
   // ---- context block backward: rows = sequences (tile row r = sequence v0 + r) -------------------------------------------------
-  glob_chain_bwd<DROP, true>(As, Stg, p.ctx, p.dpooled + FZ_D, 2 * FZ_D, v0, v0 + nv, sbase);   // As: gradient wrt the attention output
+  TileRing<RF> R;  // weight ring, carried through all twelve passes (gemm_run)
+  const bf16_t* cqkv = p.ctx.wqkv_kn + (long)wave * (36L * 3 * 512);   // this wave's 48-column group at K = 1152: q | k | v slabs of 12 k-blocks
+  const bf16_t* sqkv = p.self.wqkv_kn + (long)wave * (36L * 3 * 512);
+  gemm_issue(R, p.ctx.w2_kn + wave * GSZ, lane);
+  glob_chain_bwd<DROP, true>(As, Stg, p.ctx, p.dpooled + FZ_D, 2 * FZ_D, v0, v0 + nv, sbase, R, cqkv);   // As: gradient wrt the attention output
   stamp();
   load_rows32(Qs, p.ctx.q, p.ctx.ldq, 0, v0, nv);
   load_rows32(Ks, p.ctx.k, p.ctx.ldk, 0, row0, nrows);
@@ -1354,7 +1437,7 @@ __global__ __launch_bounds__(512) void glob_bwd_kernel(GlobBwd p) {
   stamp();
   // ---- gradient wrt the context vectors: dhidden = dq . Wq + dr1 ------------------------------------------------------------------
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(Qs, p.ctx.wqkv_kn + (long)wave * (36L * 3 * 512), acc, lane);
+  gemm_run<RF, 12, true>(R, Qs, cqkv, cqkv + 12L * 3 * 512, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, v0, nullptr,
       [&](int row, int col) { return PreRes{row < v0 + nv ? gld16(p.ctx.dr1, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
       [&](int row, int col, float (&v)[8], const PreRes& pr, int) {
@@ -1369,8 +1452,8 @@ __global__ __launch_bounds__(512) void glob_bwd_kernel(GlobBwd p) {
   stamp();
   // ---- gradient wrt the encoder output: dk . Wk + dv . Wv + avg_special backward (dpooled / len on ALL Cmax rows) ---------------------
   zero_acc<RF>(acc);
-  gemm_pass<RF, 12>(Ks, p.ctx.wqkv_kn + (long)wave * (36L * 3 * 512) + 12L * 3 * 512, acc, lane);
-  gemm_pass<RF, 12>(Vs, p.ctx.wqkv_kn + (long)wave * (36L * 3 * 512) + 24L * 3 * 512, acc, lane);
+  gemm_run<RF, 12, true>(R, Ks, cqkv + 12L * 3 * 512, cqkv + 24L * 3 * 512, acc, lane);
+  gemm_run<RF, 12, true>(R, Vs, cqkv + 24L * 3 * 512, p.self.w2_kn + wave * GSZ, acc, lane);
   epilogue<RF, 8>(acc, Stg, As, row0, nullptr, [&](int, int) { return PreNone{}; },
       [&](int row, int col, float (&v)[8], const PreNone&, int) {
         if (row < rowEnd) {
@@ -1389,7 +1472,7 @@ __global__ __launch_bounds__(512) void glob_bwd_kernel(GlobBwd p) {
   stamp();
 
   // ---- encoder layer backward: rows = tokens -------------------------------------------------------------------------------------
-  glob_chain_bwd<DROP, false>(As, Stg, p.self, nullptr, 0, row0, rowEnd, sbase);   // As: gradient wrt the attention output
+  glob_chain_bwd<DROP, false>(As, Stg, p.self, nullptr, 0, row0, rowEnd, sbase, R, sqkv);   // As: gradient wrt the attention output
   stamp();
   load_rows32(Qs, p.self.q, p.self.ldq, 0, row0, nrows);
   load_rows32(Ks, p.self.k, p.self.ldk, 0, row0, nrows);
@@ -1509,7 +1592,7 @@ __global__ __launch_bounds__(512) void glob_bwd_kernel(GlobBwd p) {
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
     const bf16_t* Ts = c == 0 ? Qs : (c == 1 ? Ks : Vs);
-    gemm_pass<RF, 12>(Ts, p.self.wqkv_kn + (long)wave * (36L * 3 * 512) + (long)c * 12 * 3 * 512, acc, lane);
+    gemm_run<RF, 12, true>(R, Ts, sqkv + (long)c * 12 * 3 * 512, sqkv + (long)(c < 2 ? c + 1 : c) * 12 * 3 * 512, acc, lane);
   }
   epilogue<RF, 8>(acc, Stg, As, row0, nullptr,
       [&](int row, int col) { return PreRes{row < rowEnd ? gld16(p.self.dr1, (unsigned)(row * FZ_D + col) * 2u) : u32x4_t{0u, 0u, 0u, 0u}}; },
@@ -1542,7 +1625,13 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * BT, Din = p.Din;
   int tsn = 48;
-  auto stamp = [&]() { if (p.tstamps && blockIdx.x == 0 && threadIdx.x == 0) p.tstamps[tsn] = __builtin_amdgcn_s_memtime(); ++tsn; };
+  // (the pointer is re-read from its SGPR pair at every stamp: as a VGPR address hoisted to the kernel's entry it was the last spill)
+  auto stamp = [&]() {
+    unsigned long long* ts = p.tstamps;
+    asm volatile("" : "+s"(ts));
+    if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[tsn] = __builtin_amdgcn_s_memtime();
+    ++tsn;
+  };
   stamp();
   if (tid < FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[tid] = reinterpret_cast<const f32x4_t*>(p.bin)[tid];
   else if (tid < 4 * FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[tid] = reinterpret_cast<const f32x4_t*>(p.bqkv)[tid - FZ_D / 4];
@@ -1613,6 +1702,8 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
     if (s + 5 < nslab) slab(s + 5, std::integral_constant<int, 5>{});
   }
   stamp();
+  TileRing<RF> R;  // weight ring of the three QKV passes; the first one's k-blocks fly during the input FC's epilogue
+  gemm_issue(R, p.wqkv + wave * GSZ, lane);
   // ---- epilogue: + folded bias, save h0, GELU, + pe -> z0 (tile + global) ------------------------------------------
   struct PrePe { f32x4_t a, b; };
   epilogue<RF, 8>(acc, Stg, As, row0, Bsm,
@@ -1633,7 +1724,7 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
 #pragma unroll 1
   for (int q = 0; q < 3; ++q) {
     zero_acc<RF>(acc);
-    gemm_pass<RF, 12>(As, p.wqkv + (q * 8 + wave) * GSZ, acc, lane);
+    gemm_run<RF, 12, true>(R, As, p.wqkv + (q * 8 + wave) * GSZ, p.wqkv + ((q < 2 ? q + 1 : q) * 8 + wave) * GSZ, acc, lane);
     epilogue<RF, 8>(acc, Stg, As, row0, Bsm + (1 + q) * FZ_D, [&](int, int) { return PreNone{}; },
         [&](int row, int col, float (&v)[8], const PreNone&, int) { gst16(p.qkv, (unsigned)(row * (3 * FZ_D) + q * FZ_D + col) * 2u, pack8(v)); },
         false);
@@ -1651,13 +1742,15 @@ __global__ __launch_bounds__(512) void qkv_fwd_kernel(QkvFwd p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * BT;
   if (threadIdx.x < 3 * FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(p.bias)[threadIdx.x];
+  TileRing<RF> R;
+  gemm_issue(R, p.wqkv + wave * GSZ, lane);
   load_tile<RF>(As, p.z, FZ_D, 0, row0);
   __syncthreads();
   f32x4_t acc[RF][3];
 #pragma unroll 1
   for (int q = 0; q < 3; ++q) {
     zero_acc<RF>(acc);
-    gemm_pass<RF, 12>(As, p.wqkv + (q * 8 + wave) * GSZ, acc, lane);
+    gemm_run<RF, 12, true>(R, As, p.wqkv + (q * 8 + wave) * GSZ, p.wqkv + ((q < 2 ? q + 1 : q) * 8 + wave) * GSZ, acc, lane);
     epilogue<RF, 8>(acc, Stg, As, row0, Bsm + q * FZ_D, [&](int, int) { return PreNone{}; },
         [&](int row, int col, float (&v)[8], const PreNone&, int) { gst16(p.qkv, (unsigned)(row * (3 * FZ_D) + q * FZ_D + col) * 2u, pack8(v)); },
         false);
@@ -1675,12 +1768,14 @@ __global__ __launch_bounds__(512) void qkv_bwd_kernel(QkvBwd p) {
   f32x4_t acc[RF][3];
   zero_acc<RF>(acc);
   const bf16_t* wg = p.wqkv + (long)wave * (36L * 3 * 512);  // one 48-column group at K = 1152
+  TileRing<RF> R;
+  gemm_issue(R, wg, lane);
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
     if (c) __syncthreads();  // every wave is done with the previous 384-wide slab
     load_tile<RF>(As, p.dqkv, 3 * FZ_D, c * FZ_D, row0);
     __syncthreads();
-    gemm_pass<RF, 12>(As, wg + (long)c * 12 * 3 * 512, acc, lane);
+    gemm_run<RF, 12, true>(R, As, wg + (long)c * 12 * 3 * 512, wg + (long)(c < 2 ? c + 1 : c) * 12 * 3 * 512, acc, lane);
   }
   float cs[3][8];
 #pragma unroll

@@ -12,7 +12,8 @@ import os
 from typing import List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcoot_hip.so")
+# COOT_HIP_LIB: another build of the same library (tools/build_variant.sh: A/B of compile-time kernel variants on one GPU box)
+LIB_PATH = os.environ.get("COOT_HIP_LIB") or os.path.join(_HERE, "lib", "libcoot_hip.so")
 
 EXPORTS = [
     "coot_last_error", "coot_version", "coot_set_option", "coot_get_option", "coot_debug_timestamps", "coot_debug_step_stamps", "coot_debug_dropout_scales", "coot_debug_attn_dropout_scales", "coot_net_param_numel", "coot_net_param_count",
