@@ -232,8 +232,8 @@ def main():
         mode = args.mode if (world == 1 or args.mode != "graph") else "autograd"
         batch.global_max_synced = True  # fixed shapes: every rank has the same Cmax, no MAX all-reduce needed
         two_batches = mode == "native"
-        # (data parallel: measured neutral with one rank — 1.308 against 1.305 ms — and not measurable here with more: off)
-        lookahead = two_batches and dp is None and not args.no_lookahead
+        # (also on the data-parallel phase path: the next batch's input LayerNorm runs under the embedding exchange and the loss)
+        lookahead = two_batches and not args.no_lookahead
         if two_batches:
             # Two DIFFERENT synthetic batches of the workload's shape, used in turn (with and without the lookahead): a step never sees the
             # data of the step before it (a single resident batch would partly live in the 256 MB MALL from step to step), and the batch a

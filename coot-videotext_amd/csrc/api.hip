@@ -17,6 +17,7 @@
 #include "gemm.h"
 #include "loss.h"
 #include "pool.h"
+#include "ref_f32.h"
 #include "rowops.h"
 
 namespace coot {
@@ -77,6 +78,7 @@ static int norm_cfg(const coot_net_config* c, coot_net_config* o) {
     COOT_REQUIRE((o->pool_hidden / o->pool_heads) % 8 == 0 && (o->hidden_dim / o->pool_heads) % 8 == 0, "pooler head dims must be multiples of 8");
   }
   COOT_REQUIRE(o->num_layers >= 1, "num_layers must be >= 1");
+  COOT_REQUIRE(o->dtype == COOT_DTYPE_BF16 || o->dtype == COOT_DTYPE_F32, "dtype %d (COOT_DTYPE_BF16 or COOT_DTYPE_F32)", o->dtype);
   return 0;
 }
 
@@ -130,6 +132,18 @@ static void build_layout(const coot_net_config& c, NetLayout& L) {
     L.pb2 = add("pooler.pools.0.genpool_b2_head", {H, dop});
   }
   L.total = off;
+}
+
+// the fp32 reference mode's view of a network (ref_f32.h)
+static RefNetDesc ref_desc(const coot_net_config& c, const NetLayout& L, int Nmax) {
+  RefNetDesc d;
+  d.Din = c.input_dim; d.D = c.hidden_dim; d.H = c.num_heads; d.F = c.ff_dim; d.num_layers = c.num_layers; d.use_input_fc = c.use_input_fc;
+  d.use_context = c.use_context; d.ctx_num_layers = c.ctx_num_layers; d.pooler = c.pooler; d.pool_hidden = c.pool_hidden; d.pool_heads = c.pool_heads;
+  d.Nmax = Nmax; d.n_gain = L.n_gain; d.n_bias = L.n_bias; d.in_w = L.in_w; d.in_b = L.in_b; d.pw1 = L.pw1; d.pb1 = L.pb1; d.pw2 = L.pw2; d.pb2 = L.pb2;
+  auto cv = [](const LayerP& p) { return RefLayerP{p.wqkv, p.bq, p.bk, p.bv, p.wo, p.bo, p.ln1g, p.ln1b, p.w1, p.b1, p.w2, p.b2, p.ln2g, p.ln2b}; };
+  for (const LayerP& p : L.layers) d.layers.push_back(cv(p));
+  for (const LayerP& p : L.ctx) d.ctx.push_back(cv(p));
+  return d;
 }
 
 // ---- bf16 weight pack layout ----------------------------------------------------------------------
@@ -854,6 +868,10 @@ int coot_net_pack_weights(const coot_net_config* cfg, const float* P, void* wpac
 
 size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int Lseq, int N2, int L2) {
   coot_net_config c; if (norm_cfg(cfg, &c)) return 0;
+  if (c.dtype == COOT_DTYPE_F32) {  // the reference mode's fp32 workspace
+    NetLayout L; build_layout(c, L);
+    return ref_f32_workspace_bytes(ref_desc(c, L, N + N2), (long)N * Lseq + (long)N2 * L2);
+  }
   Arena A(nullptr, 0); Saved S; layout_saved(c, N + N2, (long)N * Lseq + (long)N2 * L2, A, S); return A.off + 256;
 }
 size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int Lseq, int N2, int L2) {
@@ -971,6 +989,13 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   }
   const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
+  if (c.dtype == COOT_DTYPE_F32) {  // fp32 reference mode (ref_f32.hip): the reference's op sequence, forward only
+    COOT_REQUIRE(!train, "net_fwd: the f32 reference mode is an eval-mode checker (train must be 0)");
+    COOT_REQUIRE(!packed || packed->source == COOT_SOURCE_PADDED, "net_fwd: the f32 reference mode reads the reference's padded batch");
+    RefSegs rs; rs.n = sg.n;
+    for (int s_ = 0; s_ < sg.n; ++s_) { rs.N[s_] = sg.N[s_]; rs.L[s_] = sg.L[s_]; rs.lens[s_] = sg.lens[s_]; }
+    return ref_f32_forward(ref_desc(c, L, Ntot), P, pe, feats, feats2, rs, hidden, pooled, per_token, saved, saved_bytes, st);
+  }
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
   PerOpGuardScope perop_guard(c, W, P, wpack);
   Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);  // sized for the padded layout (>= the packed rows)
@@ -1107,6 +1132,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   COOT_REQUIRE(P && wpack && feats && lengths && dpooled && G && saved && scratch, "net_bwd: null pointer");
   if (packed && packed->source != COOT_SOURCE_PADDED && N2 > 0 && !feats2) feats2 = feats;  // (one packed matrix carries both segments)
   COOT_REQUIRE(!(dfeats && c.use_input_fc), "net_bwd: dfeats is only available for networks without input_fc");
+  COOT_REQUIRE(c.dtype == COOT_DTYPE_BF16, "net_bwd: the f32 reference mode is forward-only (gradients: the bf16 path against the fp64 oracle and the reference's fixtures)");
   if (N <= 0) return 0;
   Segs sg; sg.N[0] = N; sg.L[0] = Lseq; sg.lens[0] = (const long long*)lengths;
   if (N2 > 0) {

@@ -7,6 +7,7 @@
 
 #include "../../include/coot_hip.h"
 #include "common.h"
+#include "det.h"
 #include "gemm.h"
 #include "fused.h"
 #include "pool.h"
@@ -326,6 +327,11 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   const int rc_j = tn_deferred_join(st);  // the optimizer / the end of the pass needs the global network's weight gradients
   RUN(rc);
   RUN(rc_j);
+  // deterministic mode (det.h): this side's fixed-point sums -> its two gradient arenas, behind everything that added to them
+  if (det_on()) {
+    RUN(det_flush_range(b.grads[li], (size_t)coot_net_param_numel(&c.net[li]) * sizeof(float), st));
+    RUN(det_flush_range(b.grads[gi], (size_t)coot_net_param_numel(&c.net[gi]) * sizeof(float), st));
+  }
   g_stamps.mark(li == 0 ? "video: local backward done" : "text: local backward done", st);
   return 0;
 }
@@ -572,12 +578,15 @@ int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* b, in
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
-  RUN(adam_nets(*cfg, *b, vnets, 2, step, sv));
-  if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
-  RUN(adam_nets(*cfg, *b, tnets, 2, step, st, losses));
-  if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
+  const bool do_pack = (repack & COOT_UPDATE_REPACK) != 0;
+  // total = contrastive + cycle-consistency rides on the VIDEO side's launch: with COOT_UPDATE_DEFER_TEXT_JOIN main_s is ordered after
+  // that side only, and all three loss words are readable there (as in coot_train_step)
+  RUN(adam_nets(*cfg, *b, vnets, 2, step, sv, losses));
+  if (do_pack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
+  RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
+  if (do_pack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
   RUN(g_hops.hop(4, sv, sm));
-  RUN(g_hops.hop(5, st, sm));
+  if ((repack & COOT_UPDATE_DEFER_TEXT_JOIN) == 0) RUN(g_hops.hop(5, st, sm));
   return 0;
 }
 
@@ -693,6 +702,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   // total = contrastive + cycle-consistency rides on the VIDEO side's update launch: both words are final on this stream (its backward
   // waited for the text stream's loss terms, slot 7), and with COOT_STEP_DEFER_TEXT_JOIN the caller's stream is ordered after the video
   // side only — all three loss words are readable there on return (on the text side's launch, losses[0] raced with a deferred join)
+  if (det_on()) RUN(det_flush_range(losses, 3 * sizeof(float), sv));  // (the cycle-consistency word: 2 B addends, det.h)
   if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv, losses));
   else {
     hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, sv, losses);

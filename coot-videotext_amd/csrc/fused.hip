@@ -8,6 +8,7 @@
 //   weight fragments: one 16-byte global load per lane from the P48 pack (1 KB contiguous per wave-load, L2 resident),
 //   register-prefetched 3 k-blocks ahead; no barrier inside a pass.
 #include "fused.h"
+#include "det.h"
 #include "gemm.h"
 
 #include <type_traits>
@@ -1159,7 +1160,7 @@ __device__ __forceinline__ void rows_colsum_flush(const float (&cs)[NQ][3][8], f
 #pragma unroll 8
       for (int r = 0; r < 32; ++r) v += red[r * (NQ * 128) + threadIdx.x];
       float* d = dst[threadIdx.x / 128];
-      if (d) atomicAdd(d + m * 128 + (threadIdx.x & 127), v);
+      if (d) acc_add(d + m * 128 + (threadIdx.x & 127), v);
     }
   }
   lds_barrier();
@@ -2038,4 +2039,8 @@ int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st) {
   COOT_CHECK_LAUNCH("infc_qkv_fwd");
   return 0;
 }
+}  // namespace coot
+
+namespace coot {
+COOT_DET_DEFINE_SETTER(fused)
 }  // namespace coot

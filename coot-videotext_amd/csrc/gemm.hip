@@ -11,6 +11,7 @@
 // "store what the MFMA layout gives you" epilogue (8-byte stores in 32-byte runs) cost more than the K loop
 // at K = 384 (profiles/README.md).
 #include "gemm.h"
+#include "det.h"
 #include <algorithm>
 #include "rowops.h"
 
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
         e.colsum_ws[(long)(row0 / BM) * e.ld_colsum_ws + zo + col0 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
     } else if (lane < 16 && cok) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(e.colsum + zo + col + j, csum[j]);
+      for (int j = 0; j < 8; ++j) acc_add(e.colsum + zo + col + j, csum[j]);
     }
   }
 }
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmNT g) {
       for (int j = 0; j < 4; ++j) {
         float s = ok ? v[j] : 0.f;
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-        if (l15 == 0 && col < N) atomicAdd(e.colsum + zo + col + j, s);
+        if (l15 == 0 && col < N) acc_add(e.colsum + zo + col + j, s);
       }
     }
   }
@@ -616,7 +617,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& g, int bx, int by, in
       float v = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v += red[r * 128 + tid];
-      atomicAdd(g.a_colsum + m0 + tid, v);
+      acc_add(g.a_colsum + m0 + tid, v);
     }
     __syncthreads();
   }
@@ -631,7 +632,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& g, int bx, int by, in
         const int col = n0 + wn * 64 + b * 16 + (lane >> 4) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (col + j < g.No) atomicAdd(C + (long)row * g.ldc + col + j, acc[a][b][j] * g.alpha);
+          if (col + j < g.No) acc_add(C + (long)row * g.ldc + col + j, acc[a][b][j] * g.alpha);
       }
     }
     return;
@@ -820,7 +821,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int b
         for (int kk = 0; kk < nk; ++kk) tot += red[kk * TNW_BM + tid];
       }
     }
-    if (tid < TNW_BM && m0 + tid < g.Mo) atomicAdd(g.a_colsum + m0 + tid, tot);
+    if (tid < TNW_BM && m0 + tid < g.Mo) acc_add(g.a_colsum + m0 + tid, tot);
   }
   // partial tile straight from the accumulators: direct (single split) C += alpha * tile, else ws[split][z][Mo][No]
   float* dst = direct ? g.C + z * g.zC : ws + ((long)split * g.groups + z) * g.Mo * g.No;
@@ -980,7 +981,7 @@ __device__ __forceinline__ void gemm_tn_dma_body(const GemmTN& g, int bx, int by
     }
     if (do_cs && cid < 192) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(g.a_colsum + m0 + cc * 8 + j, cs[j]);
+      for (int j = 0; j < 8; ++j) acc_add(g.a_colsum + m0 + cc * 8 + j, cs[j]);
     }
     if (lprof && lane == 0) for (int k = 0; k < 3; ++k) g.stamps[8 + k] = lt[k];  // loader wave 0: landing wait, barrier, DMA issue
 #undef TND_LT
@@ -1492,4 +1493,8 @@ int launch_gemm_tn(const GemmTN& g_in, hipStream_t stream) {
   return 0;
 }
 
+}  // namespace coot
+
+namespace coot {
+COOT_DET_DEFINE_SETTER(gemm)
 }  // namespace coot

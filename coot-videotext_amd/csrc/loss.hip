@@ -1,5 +1,6 @@
 // Cycle-consistency loss kernel for gfx950 (the contrastive loss lives in loss_fused.hip).
 #include "loss.h"
+#include "det.h"
 
 namespace coot {
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void cyclecons_kernel(CycleArgs a) {
     float* rows = dir == 0 ? a.rows_clip : a.rows_sent;
     if (rows) rows[(long)b * Csrc + i] = l;
     if (i == isel) {
-      atomicAdd(a.loss, a.weight * a.inv_batch * l);
+      acc_add(a.loss, a.weight * a.inv_batch * l);
       // d loss / d mu
       dd2[CC_MAXC - 1] = 0.f;
       wred[0][0] = a.weight * a.inv_batch * 2.f * (mu - (float)i);
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void cyclecons_kernel(CycleArgs a) {
   }
   __syncthreads();
   // per-thread feature slice d = tid + 256*v (D <= 1024)
-  float nn1[4], dnn1[4], cvec[4];
+  float nn1[4], dnn1[4], cvec[4], ksel[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int d = threadIdx.x + 256 * v;
@@ -120,7 +121,11 @@ __global__ __launch_bounds__(256) void cyclecons_kernel(CycleArgs a) {
       for (int k = 0; k < Csrc; ++k) {
         const float diff = t - src[(long)k * D + d];
         g += dd2[k] * (-2.f * invD) * diff;
-        if (dd2[k] != 0.f) atomicAdd(dsrc + (long)k * D + d, dd2[k] * (2.f * invD) * diff);
+        // ONE add per gradient word and workgroup (the selected row's share waits for its second term below): with the other
+        // direction's workgroup a word then receives exactly two addends on top of its zero — a + b = b + a, the sum does not depend
+        // on who comes first (three or more addends in arrival order would)
+        if (k == isel) ksel[v] = dd2[k] * (2.f * invD) * diff;
+        else if (dd2[k] != 0.f) atomicAdd(dsrc + (long)k * D + d, dd2[k] * (2.f * invD) * diff);
       }
       dnn1[v] = g;
     }
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void cyclecons_kernel(CycleArgs a) {
         gsel += ddist[j] * (-2.f * invD) * diff;
         if (gt != 0.f) atomicAdd(dtgt + (long)j * D + d, gt);
       }
-      atomicAdd(dsrc + (long)isel * D + d, gsel);
+      atomicAdd(dsrc + (long)isel * D + d, gsel + ksel[v]);
     }
   }
 }
@@ -166,4 +171,8 @@ int launch_cyclecons(const CycleArgs& a, hipStream_t st) {
   return 0;
 }
 
+}  // namespace coot
+
+namespace coot {
+COOT_DET_DEFINE_SETTER(loss)
 }  // namespace coot

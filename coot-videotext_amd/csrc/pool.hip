@@ -1,6 +1,7 @@
 // GenPool softmax-over-sequence pooling, avg_special pooling, clip packing (gfx950).
 // All HBM-bound and tiny next to the GEMMs: 16-byte loads, fully coalesced rows, the L loop runs in registers.
 #include "pool.h"
+#include "det.h"
 
 namespace coot {
 
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs2 pp) {
     float v = 0.f;
     for (int g2 = 0; g2 < rgs; ++g2) v += red[g2 * cpb * 8 + cc];
     if (p.part_ws) p.part_ws[(long)n * p.D + ch] = v;
-    else atomicAdd(p.ds_colsum + ch, v);
+    else acc_add(p.ds_colsum + ch, v);
   }
 }
 
@@ -386,4 +387,8 @@ int launch_add_bf16_to_f32(const bf16_t* a, long lda, const bf16_t* b, long ldb,
   return 0;
 }
 
+}  // namespace coot
+
+namespace coot {
+COOT_DET_DEFINE_SETTER(pool)
 }  // namespace coot

@@ -1,6 +1,7 @@
 // Row-wise kernels for gfx950: one 64-lane wave per row, the row lives in registers,
 // 8/16-byte coalesced loads, wave-shuffle reductions (no LDS, no barriers in the forward).
 #include "rowops.h"
+#include "det.h"
 #include "gemm.h"
 #include "fused.h"
 
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* ws, i
     const int k = c / ro.seg;
     float* o = ro.out[k];
     if (o) {
-      if (gridDim.y == 1) o[c - k * ro.seg] += v; else atomicAdd(o + (c - k * ro.seg), v);
+      if (gridDim.y == 1) o[c - k * ro.seg] += v; else acc_add(o + (c - k * ro.seg), v);
     }
   }
 }
@@ -388,9 +389,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
       float* w = p.part_ws + (long)blockIdx.x * 3 * D;
       w[c] = g; w[D + c] = b; w[2 * D + c] = x;
     } else {
-      if (p.dgain) atomicAdd(p.dgain + c, g);
-      if (p.dbias) atomicAdd(p.dbias + c, b);
-      if (p.dxcolsum) atomicAdd(p.dxcolsum + c, x);
+      if (p.dgain) acc_add(p.dgain + c, g);
+      if (p.dbias) acc_add(p.dbias + c, b);
+      if (p.dxcolsum) acc_add(p.dxcolsum + c, x);
     }
   }
 }
@@ -430,8 +431,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* x, long 
     a += bflo(u); b += bfhi(u);
   }
   if (part) { part[(long)blockIdx.y * C + col] = a; if (col + 1 < C) part[(long)blockIdx.y * C + col + 1] = b; return; }
-  atomicAdd(out + col, a);
-  if (col + 1 < C) atomicAdd(out + col + 1, b);
+  acc_add(out + col, a);
+  if (col + 1 < C) acc_add(out + col + 1, b);
 }
 
 int launch_colsum_bf16(const bf16_t* x, long ldx, int R, int C, float* out, hipStream_t stream) {
@@ -610,8 +611,8 @@ __global__ __launch_bounds__(256) void infc_param_grads_kernel(const float* M, c
       sb += cn * w[i];
     }
   }
-  atomicAdd(dg0 + k, sg);
-  atomicAdd(db0 + k, sb);
+  acc_add(dg0 + k, sg);
+  acc_add(db0 + k, sb);
 }
 
 int launch_infc_param_grads(const float* M, const float* W, const float* g0, const float* b0, const float* c,
@@ -648,4 +649,8 @@ int launch_axpy_f32(float* y, const float* x, long n, float a, hipStream_t strea
   return 0;
 }
 
+}  // namespace coot
+
+namespace coot {
+COOT_DET_DEFINE_SETTER(rowops)
 }  // namespace coot

@@ -23,6 +23,7 @@ EXPORTS = [
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_tn_xcd_map", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
     "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_step_input_stage_bytes", "coot_step_set_input_stages", "coot_step_set_next_batch", "coot_contrastive_fwd_bwd_dp", "coot_contrastive_fwd_bwd_dp_blocks", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
+    "coot_det_shadow_bytes", "coot_det_configure", "coot_det_flush",
 ]
 
 
@@ -31,7 +32,7 @@ class NetConfig(C.Structure):
     _fields_ = [("input_dim", C.c_int), ("hidden_dim", C.c_int), ("num_heads", C.c_int), ("ff_dim", C.c_int),
                 ("num_layers", C.c_int), ("use_input_fc", C.c_int), ("use_context", C.c_int),
                 ("ctx_num_layers", C.c_int), ("pooler", C.c_int), ("pool_hidden", C.c_int), ("pool_heads", C.c_int),
-                ("dropout", C.c_float), ("ctx_dropout", C.c_float), ("pool_dropout", C.c_float)]
+                ("dropout", C.c_float), ("ctx_dropout", C.c_float), ("pool_dropout", C.c_float), ("dtype", C.c_int)]
 
 
 class ContrastiveConfig(C.Structure):
@@ -42,8 +43,10 @@ class ContrastiveConfig(C.Structure):
 
 
 SOURCE_PADDED, SOURCE_PACKED_F32, SOURCE_PACKED_BF16 = 0, 1, 2  # COOT_SOURCE_* (include/coot_hip.h)
+DTYPE_BF16, DTYPE_F32 = 0, 1  # COOT_DTYPE_* (coot_net_config.dtype)
 STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH, STEP_DEFER_TEXT_JOIN, STEP_INPUT_STAGES, STEP_STAGE_ANNOUNCED = 1, 2, 4, 8, 16, 32  # coot_train_step do_optimizer bits (include/coot_hip.h)
 FWD_PACKS_FRESH, FWD_INPUT_STAGES, FWD_STAGE_ANNOUNCED = 1, 2, 4  # coot_step_forward packs_fresh bits
+UPDATE_REPACK, UPDATE_DEFER_TEXT_JOIN = 1, 2  # coot_step_update repack bits
 DP_MAX_RANKS = 16  # COOT_DP_MAX_RANKS: ranks whose gathered blocks coot_contrastive_fwd_bwd_dp_blocks addresses in place
 
 
@@ -133,6 +136,10 @@ def load():
     lib.coot_retrieval_workspace_bytes.argtypes = [i32, i32]
     lib.coot_retrieval_workspace_bytes.restype = C.c_size_t
     lib.coot_retrieval_ranks.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.coot_det_shadow_bytes.restype = sz
+    lib.coot_det_shadow_bytes.argtypes = [i32, C.POINTER(sz)]
+    lib.coot_det_configure.argtypes = [i32, C.POINTER(vp), C.POINTER(sz), vp, sz, vp]
+    lib.coot_det_flush.argtypes = [vp, sz, vp]
     lib.coot_gemm_nt.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp, i64, i32, vp]
     lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, sz, vp]
     lib.coot_gemm_tn_batch.argtypes = [C.POINTER(TnProblem), i32, vp, sz, vp, vp]

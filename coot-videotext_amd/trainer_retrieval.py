@@ -356,6 +356,7 @@ class RetrievalTrainer:
             self._step_prepare_seed(batch, nets)
         self._seed_dev += 1  # device-side dropout seed: advances on every step, also under graph replay
         flat_grads = [net.bind_flat_grads() for net in nets]
+        self._det_sync(flat_grads)
         for net, g in zip(nets, flat_grads):
             g.zero_()
             net.accumulate_into_flat = True  # backward kernels accumulate straight into the flat arenas
@@ -377,6 +378,7 @@ class RetrievalTrainer:
         loss = contr_loss + cc_loss
         loss.backward()
         self._join_side_streams()
+        self._det_flush(flat_grads)
         for net in nets:
             net.accumulate_into_flat = False
         if dp is not None:
@@ -552,6 +554,41 @@ class RetrievalTrainer:
         else:
             _lib.check(lib.coot_step_set_next_batch(None, None), "coot_step_set_next_batch")
         return True
+
+    # ---- deterministic mode (include/coot_hip.h: coot_det_configure; tests_nntrainer/integration_deter.py:18-66) -----------------
+    def set_deterministic(self, on: bool = True) -> None:
+        """Run-to-run determinism of the training step: the few fp32 atomic accumulations of the library (bias / LayerNorm parameter
+        gradients, the cycle-consistency loss word) go through order-independent fixed-point accumulators.  Two runs of the same steps
+        from the same state are then bit-identical (parameters, losses); the step computes the same numbers as without it to fp32
+        round-off.  Process-wide (the library's mode is); costs two extra launches and ~60 MB of accumulators per step."""
+        self.deterministic = bool(on)
+        if not on and getattr(self, "_det_key", None) is not None:
+            _lib.check(_lib.load().coot_det_configure(0, None, None, None, 0, torch.cuda.current_stream().cuda_stream), "coot_det_configure")
+            self._det_key, self._det_shadow, self._det_ranges = None, None, []
+
+    def _det_sync(self, tensors) -> None:
+        """(Re)registers the fp32 tensors the step accumulates into — the gradient arenas and the loss words — when they changed."""
+        if not getattr(self, "deterministic", False):
+            return
+        ranges = sorted({(t.data_ptr(), t.numel() * 4) for t in tensors})
+        if ranges == getattr(self, "_det_key", None):
+            return
+        lib = _lib.load()
+        n = len(ranges)
+        bases = (C.c_void_p * n)(*[r[0] for r in ranges])
+        sizes = (C.c_size_t * n)(*[r[1] for r in ranges])
+        nbytes = int(lib.coot_det_shadow_bytes(n, sizes))
+        torch.cuda.synchronize()  # (the old shadow may still be in use on a side stream)
+        self._det_shadow = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.coot_det_configure(n, bases, sizes, self._det_shadow.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
+                   "coot_det_configure")
+        self._det_key, self._det_ranges = ranges, list(tensors)
+
+    def _det_flush(self, tensors) -> None:
+        if getattr(self, "deterministic", False):
+            lib, sp = _lib.load(), torch.cuda.current_stream().cuda_stream
+            for t in tensors:
+                _lib.check(lib.coot_det_flush(t.data_ptr(), t.numel() * 4, sp), "coot_det_flush")
 
     # ---- optimizer state of either path, for optimizer_<epoch>.pth (nntrainer/trainer_base.py:685-707) ------------------------
     def get_opt_state(self) -> Dict[str, Any]:
@@ -786,7 +823,7 @@ class RetrievalTrainer:
         (COOT_STEP_INPUT_STAGES; same results).  Pass the same object to the next call."""
         lib = _lib.load()
         if getattr(self, "dp", None) is not None:
-            return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts, cc_indices, next_batch)
+            return self._train_step_native_dp(batch, do_optimizer, seed, vid_counts, clip_counts, cc_indices, next_batch, defer_join)
         if use_graph and cc_indices is not None:
             raise ValueError("train_step_native: injected cycle-consistency positions are not available under graph replay")
         if use_graph and do_optimizer and seed is None and self.model_mgr.is_train:
@@ -818,6 +855,7 @@ class RetrievalTrainer:
         if cc_indices is not None:  # a given draw of the cycle-consistency positions ([2B] int64: clips, then sentences)
             assert cc_indices.dtype == torch.int64 and cc_indices.is_cuda and cc_indices.numel() == 2 * st.dims.B
             lib.coot_step_set_cycle_indices(cc_indices.data_ptr())
+        self._det_sync([n._grad_flat for n in st.nets] + [st.losses])  # (deterministic mode: the step flushes these ranges itself)
         try:
             _lib.check(lib.coot_train_step(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(st.dims), st.losses.data_ptr(),
                                            st.ws.data_ptr(), st.ws.numel(), train, int(seed), max(st.step, 1), flags,
@@ -831,7 +869,8 @@ class RetrievalTrainer:
         self.total_step += 1
         return st.losses[0], st.losses[1], st.losses[2]
 
-    def _train_step_native_dp(self, batch, do_optimizer=True, seed=None, vid_counts=None, clip_counts=None, cc_indices=None, next_batch=None):
+    def _train_step_native_dp(self, batch, do_optimizer=True, seed=None, vid_counts=None, clip_counts=None, cc_indices=None, next_batch=None,
+                              defer_join=False):
         """Data-parallel native step: this rank's videos through coot_step_forward (C, two streams), ONE
         packed all-gather per embedding level over RCCL, the contrastive loss on the full gathered batch (every rank
         keeps the gradient rows of its own videos — no collective for embedding gradients), the per-video
@@ -895,26 +934,29 @@ class RetrievalTrainer:
             st.cyc_idx = torch.empty(2 * B, dtype=torch.int64, device=dev)
             st.dp_key = key
         if getattr(st, "gall", None) is None or st.gall.device != dev:
-            # ONE gradient arena for the four networks + the loss words: one fill and ONE all-reduce per step
-            # layout: [video global | text global | video local | text local | total, contrastive, cycle-consistency, pad] — the
-            # global networks' gradients are final after the global backward and are reduced on a communication stream under the
-            # local backward; the loss words are per-rank partial sums of global means and ride on the local half's all-reduce
+            # ONE gradient arena for the four networks + the loss words: one fill per step, reduced in THREE buckets in the order the
+            # backward finishes them.  Layout: [video global | text global | text local | video local | total, contrastive,
+            # cycle-consistency, pad] — the global networks' gradients are final after the global backward (two thirds of the pass
+            # before its end) and the text side's local backward ends before the video side's (a third of its tokens): both are
+            # reduced on a communication stream under the backward that is still running; only the last bucket — the video local
+            # network with the loss words, per-rank partial sums of global means — is exposed behind the pass on the main stream
             st.gall = torch.zeros(sum(n.numel for n in st.nets) + 4, **dict(dtype=torch.float32, device=dev))
-            off = 0
-            for i in (1, 3, 0, 2):
+            off, cuts = 0, {}
+            for i in (1, 3, 2, 0):
                 n = st.nets[i]
                 n.rebind_flat_grads(st.gall[off:off + n.numel])
                 st.bufs.grads[i] = n._grad_flat.data_ptr()
+                cuts[i] = off
                 off += n.numel
-                if i == 3:
-                    st.g_glob = st.gall[:off]
-                    off_loc = off
+            st.g_glob = st.gall[:cuts[2]]
+            st.g_loc_t = st.gall[cuts[2]:cuts[0]]
             st.losses = st.gall[off:off + 3]       # (total, contrastive, cycle-consistency): the layout coot_step_update completes
             st.cl_word = st.gall[off + 1:off + 2]  # this rank's share of the contrastive loss (its rows against the gathered batch)
             st.cc_word = st.gall[off + 2:off + 3]
-            st.g_loc = st.gall[off_loc:off + 3]    # local networks + the loss words: per-rank partial sums, reduced with the gradients
+            st.g_loc_v = st.gall[cuts[0]:off + 3]  # video local network + the loss words
             st.comm = torch.cuda.Stream()
             st.ev_glob = (torch.cuda.Event(), torch.cuda.Event())
+            st.ev_text = torch.cuda.Event()
             for e in st.ev_glob:
                 e.record()  # creates the underlying hipEvent
         local_v, local_t, glob_v, glob_t, resh_v, resh_t = st.emb
@@ -930,8 +972,14 @@ class RetrievalTrainer:
             extra = (C.c_void_p * 2)(st.losses.data_ptr(), st.zbuf.data_ptr())
             extra_n = (C.c_int64 * 2)(4, st.zbuf.numel())   # the arena's 4 tail words (loss words + padding)
             st.zero_args, st.zero_key = (cfgs, grads, extra, extra_n), (st.gall.data_ptr(), st.zbuf.data_ptr())
+        self._det_sync([st.gall])  # (deterministic mode: coot_step_backward flushes the arenas, _dp_finish the loss words)
         za = st.zero_args
-        _lib.check(lib.coot_nets_zero_grads_ex(4, za[0], za[1], 1, za[2], za[3], 2, main.cuda_stream), "coot_nets_zero_grads_ex")
+        # ... on the TEXT stream, behind whatever the previous step left running there (with defer_join: the text networks' update, which
+        # reads these buffers) and behind the previous step's work on the main stream (the video networks' update, the gradient buckets'
+        # reduction).  The video side's forward on the main stream touches none of it and starts at once; everything that accumulates into
+        # the zeroed buffers (losses, backward) is ordered after both sides' forward, i.e. after this launch.
+        stt.wait_stream(main)
+        _lib.check(lib.coot_nets_zero_grads_ex(4, za[0], za[1], 1, za[2], za[3], 2, stt.cuda_stream), "coot_nets_zero_grads_ex")
         ws, wsn = st.ws.data_ptr(), st.ws.numel()
         fresh = _lib.FWD_PACKS_FRESH if all(n.pack_is_fresh() for n in st.nets) else 0
         if next_batch is not None and not getattr(next_batch, "global_max_synced", False):
@@ -984,7 +1032,7 @@ class RetrievalTrainer:
                               ws, wsn, train, seed, main, sv, stt)
         finally:
             lib.coot_net_grads_overwrite(0)
-        self._dp_finish(lib, dp, st, main, sv, stt, do_optimizer)
+        self._dp_finish(lib, dp, st, main, sv, stt, do_optimizer, defer_join)
         return st.losses[0], st.losses[1], st.losses[2]
 
     @staticmethod
@@ -994,20 +1042,29 @@ class RetrievalTrainer:
                                           resh_v.data_ptr(), resh_t.data_ptr(), d_local_v.data_ptr(), d_local_t.data_ptr(), d_glob_v.data_ptr(),
                                           d_glob_t.data_ptr(), d_resh_v.data_ptr() if use_cc else None, d_resh_t.data_ptr() if use_cc else None,
                                           ws, wsn, train, int(seed), main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_backward")
+        st.ev_text.record(stt)  # the text side's backward is the last thing on its stream: its local gradients are final from here
 
-    def _dp_finish(self, lib, dp, st, main, sv, stt, do_optimizer):
-        # gradient all-reduce: the global networks' half on the communication stream as soon as both global backward passes are
-        # done (events recorded inside coot_step_backward: it overlaps the local backward), the local half + the cycle-consistency
-        # word (a per-rank partial sum of a global mean) behind the backward on the main stream
+    def _dp_finish(self, lib, dp, st, main, sv, stt, do_optimizer, defer_join=False):
+        # gradient all-reduce in the order the backward produces its results (every rank issues the three collectives in this order):
+        #   1. the global networks' bucket on the communication stream as soon as both global backward passes are done (events recorded
+        #      inside coot_step_backward): it runs under the local backward passes;
+        #   2. the text local network's bucket, also on the communication stream, when the text stream's backward ends (the event the
+        #      text stream recorded behind coot_step_backward): the video side's local backward, three times its tokens, still runs;
+        #   3. the video local network + the loss words behind the pass on the main stream — the only exposed bucket.
         lib.coot_step_set_global_done_events(None, None)  # the events belong to this trainer: no other step may record them
+        self._det_flush([st.losses])  # (deterministic mode: the cycle-consistency word's fixed-point sum, behind the backward on main)
         st.comm.wait_event(st.ev_glob[0]); st.comm.wait_event(st.ev_glob[1])
         with torch.cuda.stream(st.comm):
             dp.all_reduce_sum(st.g_glob)
-        dp.all_reduce_sum(st.g_loc)
+            st.comm.wait_event(st.ev_text)
+            dp.all_reduce_sum(st.g_loc_t)
+        dp.all_reduce_sum(st.g_loc_v)
         main.wait_stream(st.comm)
-        if do_optimizer:  # (the text side's update launch also writes total = contrastive + cycle-consistency)
-            _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), 1, st.losses.data_ptr(), main.cuda_stream,
+        if do_optimizer:  # (the video side's update launch also writes total = contrastive + cycle-consistency)
+            flags = _lib.UPDATE_REPACK | (_lib.UPDATE_DEFER_TEXT_JOIN if defer_join else 0)
+            _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), flags, st.losses.data_ptr(), main.cuda_stream,
                                             sv.cuda_stream, stt.cuda_stream), "coot_step_update")
+            st.join_pending = bool(defer_join)
             for n in st.nets:
                 n.mark_packed()
         else:

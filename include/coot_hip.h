@@ -43,7 +43,16 @@ typedef struct coot_net_config {
   float dropout;      /* selfatn_config.dropout   (used only when train != 0)             */
   float ctx_dropout;  /* crossatn_config.dropout                                          */
   float pool_dropout; /* pooler_config.dropout                                            */
+  int dtype;          /* COOT_DTYPE_BF16 (0, default): bf16 MFMA operands, fp32 accumulation / statistics — the fast path.
+                         COOT_DTYPE_F32: the fp32 REFERENCE MODE of coot_net_fwd — the reference's op sequence
+                         (nntrainer/models/transformer_legacy.py:200-288, eval mode) with every activation, weight and
+                         accumulation in fp32, exact erf GELU, nothing fused or folded: agrees with the reference to ~1e-6 of the
+                         output scale, so a difference between the two modes is bf16 rounding and a difference to the reference in
+                         F32 mode is a logic error.  A checker: forward-only, eval only (train must be 0), never what bench.py
+                         times.  `saved` is its workspace (coot_net_saved_bytes accounts for it); wpack is not read.           */
 } coot_net_config;
+#define COOT_DTYPE_BF16 0
+#define COOT_DTYPE_F32 1
 
 const char* coot_last_error(void);
 int coot_version(void);
@@ -346,9 +355,14 @@ int coot_step_set_device_state(void* state);
  * stays set until changed. */
 int coot_step_set_global_done_events(void* ev_video, void* ev_text);
 /* Optimizer update of the four networks after the gradient all-reduce (cfg->optimizer; `step` 1-based): one launch per side on
- * side_v / side_t, then (repack != 0) the bf16 weight packs are rebuilt so that the next coot_step_forward may skip the packing.
- * losses (may be NULL): the three loss words { total, contrastive, cycle-consistency } of the step; the text side's update launch
+ * side_v / side_t.  repack: bit mask — COOT_UPDATE_REPACK: the bf16 weight packs are rebuilt so that the next coot_step_forward may skip
+ * the packing; COOT_UPDATE_DEFER_TEXT_JOIN: on return main_s is ordered after the VIDEO side only (as COOT_STEP_DEFER_TEXT_JOIN: the
+ * text side's update tail overlaps the next step's forward; the caller orders whatever else touches the text networks or the gradient
+ * arenas after side_t).
+ * losses (may be NULL): the three loss words { total, contrastive, cycle-consistency } of the step; the video side's update launch
  * writes total = contrastive + cycle-consistency (a data-parallel caller keeps the two all-reduced words there: no extra launch). */
+#define COOT_UPDATE_REPACK 1
+#define COOT_UPDATE_DEFER_TEXT_JOIN 2
 int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* bufs, int64_t step, int repack, float* losses,
                      coot_stream_t main_stream, coot_stream_t side_v, coot_stream_t side_t);
 /* One valid clip / sentence position per video for the cycle-consistency loss (th.multinomial(mask, 1), coot/loss_fn.py:306-314),
@@ -376,6 +390,18 @@ int coot_step_set_cycle_indices(const int64_t* idx);
 size_t coot_step_input_stage_bytes(const coot_step_config* cfg, const coot_step_dims* dims);
 int coot_step_set_input_stages(void* stage0, void* stage1, size_t bytes_each);
 int coot_step_set_next_batch(const coot_step_batch* next, const coot_step_dims* next_dims);
+/* Deterministic mode (the reference tests run-to-run determinism: tests_nntrainer/integration_deter.py:18-66).  Everything in the
+ * library is computed in a fixed order except the fp32 atomicAdds by which several workgroups add into one word (bias / LayerNorm
+ * parameter gradients of a few kernels, the cycle-consistency loss word): their arrival order moves the last bits of a gradient, and
+ * Adam amplifies last bits into different trajectories.  coot_det_configure registers up to 8 fp32 ranges (the gradient arenas, the
+ * loss words) and a caller-owned shadow (coot_det_shadow_bytes) of 64-bit fixed-point accumulators: while it is set, every such add
+ * into a registered range goes to the shadow as an INTEGER atomic (order independent) and coot_det_flush — called by coot_train_step /
+ * coot_step_backward for the arenas and loss words they were given, by the caller for anything else — adds the sums into the fp32
+ * words and clears the shadow.  With it two runs of the same steps are bit-identical.  n = 0 switches the mode off.  PROCESS-GLOBAL
+ * (like the option switches); configure synchronises the device. */
+size_t coot_det_shadow_bytes(int n, const size_t* bytes);
+int coot_det_configure(int n, void* const* bases, const size_t* bytes, void* shadow, size_t shadow_bytes, coot_stream_t stream);
+int coot_det_flush(const void* base, size_t bytes, coot_stream_t stream);
 int coot_adam_step(float* params, const float* grads, float* m, float* v, const float* decay_mask, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int64_t step, coot_stream_t stream);
 /* RAdam of nntrainer/optimization.py:79-181 on one flat arena: decoupled decay weight_decay * decay_mask,

@@ -1,0 +1,124 @@
+"""Deterministic mode (include/coot_hip.h: coot_det_configure; RetrievalTrainer.set_deterministic) — the reference tests run-to-run
+determinism of training (tests_nntrainer/integration_deter.py:18-66: two runs from the same seed give the same model).
+
+The library's only order-dependent arithmetic is a handful of fp32 atomic accumulations; with the shipped Adam eps = 1e-8 their last-bit
+noise is amplified into different trajectories (an update is +-lr whatever the gradient's size).  In deterministic mode those sums go
+through order-independent fixed-point accumulators, so:
+  * two runs of the same six optimizer steps end with BIT-IDENTICAL parameters and losses — with the shipped eps, on the fused kernels;
+  * the re-orderings of the timed mode (next batch's input LayerNorm inside the previous step, deferred text join) reproduce the plain
+    run's trajectory exactly, not to a tolerance;
+  * one step's gradients equal the default mode's to fp32 round-off (the mode changes the order of a few sums, nothing else).
+"""
+import numpy as np
+import pytest
+
+from oracle import coot_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+DIMS = (256, 192, 384, 8, 384, 768)  # d_model 384: the fused token-tile chains and the single-launch global networks
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import coot_videotext_amd as cva
+    assert torch.cuda.is_available()
+    cva.lib.load()
+    return torch, cva
+
+
+def _run(torch, cva, cfgs, Ps, batches, det, lookahead=False, defer=False, dp=None, steps=6):
+    cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.1, cc_weight=0.01)
+    mgr.set_all_models_train()
+    tr = cva.RetrievalTrainer(cfg_x, mgr)
+    tr.lookahead_min_stage_bytes = 0
+    tr.set_deterministic(det)
+    if dp is not None:
+        tr.dp = dp
+    losses = []
+    try:
+        for it in range(steps):
+            b = batches[it % len(batches)]
+            nxt = batches[(it + 1) % len(batches)] if lookahead and it + 1 < steps else None
+            kw = {}
+            if dp is not None:
+                b.global_max_synced = True
+                if nxt is not None:
+                    nxt.global_max_synced = True
+                kw = dict(vid_counts=[int(b.clip_num.shape[0])], clip_counts=[int(b.clip_feat_len.shape[0])])
+            out = tr.train_step_native(b, seed=500 + it, next_batch=nxt, defer_join=defer, **kw)
+            tr.join_streams()
+            losses.append([float(v) for v in out])
+        torch.cuda.synchronize()
+        return losses, [n._flat.detach().clone() for n in mgr.model_dict.values()], [n._grad_flat.detach().clone() for n in mgr.model_dict.values()]
+    finally:
+        tr.set_deterministic(False)
+
+
+def _batches(cva, ragged):
+    if ragged:
+        return [cva.synthetic.make_batch(40 + i, 12, cva.synthetic.anet_like_counts(70 + i, 12), 40, 40, 32, 16, DIMS[0], DIMS[1], ragged=True, packed=True)
+                for i in range(3)]
+    return [cva.synthetic.make_batch(40 + i, 12, 4, 40, 40, 32, 16, DIMS[0], DIMS[1], ragged=False) for i in range(3)]
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_two_runs_are_bit_identical_and_reorderings_change_nothing(env, ragged):
+    torch, cva = env
+    cfgs = H.full_cfgs(*DIMS)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batches = _batches(cva, ragged)
+    la, pa, _ = _run(torch, cva, cfgs, Ps, batches, det=True)
+    lb, pb, _ = _run(torch, cva, cfgs, Ps, batches, det=True)
+    assert la == lb, (la, lb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    # the timed mode's re-orderings: same trajectory, exactly
+    lc, pc, _ = _run(torch, cva, cfgs, Ps, batches, det=True, lookahead=True, defer=True)
+    assert la == lc, (la, lc)
+    for a, c in zip(pa, pc):
+        assert torch.equal(a, c)
+    assert np.isfinite(np.array(la)).all() and la[0][0] != la[-1][0]
+
+
+def test_deterministic_mode_computes_the_same_step(env):
+    """One step (no update): gradients with and without the mode agree to fp32 round-off of the accumulated vectors."""
+    torch, cva = env
+    cfgs = H.full_cfgs(*DIMS)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batches = _batches(cva, False)
+    res = []
+    for det in (False, True):
+        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.1, cc_weight=0.01)
+        mgr.set_all_models_train()
+        tr = cva.RetrievalTrainer(cfg_x, mgr)
+        tr.set_deterministic(det)
+        try:
+            out = tr.train_step_native(batches[0], do_optimizer=False, seed=77)
+            torch.cuda.synchronize()
+            res.append(([float(v) for v in out], [n._grad_flat.detach().clone() for n in mgr.model_dict.values()]))
+        finally:
+            tr.set_deterministic(False)
+    (l0, g0), (l1, g1) = res
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-9), (l0, l1)
+    for a, b in zip(g0, g1):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * scale, (float((a - b).abs().max()), scale)
+        assert float(b.abs().max()) > 0
+
+
+def test_data_parallel_phase_path_is_deterministic_too(env):
+    """The phase calls (coot_step_forward / loss on the exchanged block / coot_step_backward / bucketed reduction / coot_step_update)
+    with a one-rank context: two runs bit-identical."""
+    from tests.test_gpu_train_parity import _OneRankDP
+    torch, cva = env
+    cfgs = H.full_cfgs(*DIMS)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batches = _batches(cva, False)
+    la, pa, _ = _run(torch, cva, cfgs, Ps, batches, det=True, dp=_OneRankDP(), steps=4)
+    lb, pb, _ = _run(torch, cva, cfgs, Ps, batches, det=True, dp=_OneRankDP(), steps=4, lookahead=True, defer=True)
+    assert la == lb, (la, lb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../coot-videotext_amd/csrc"
 mkdir -p obj_$TAG ../lib
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -Wno-unused-result $EXTRA"
 pids=()
-for f in gemm rowops attention pool loss loss_fused fused retrieval host_input api api_loss api_step; do
+for f in gemm rowops attention pool loss loss_fused fused ref_f32 det retrieval host_input api api_loss api_step; do
   /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o obj_$TAG/$f.o &
   pids+=($!)
 done
