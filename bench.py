@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-defer-join", action="store_true", help="join the text stream into the main stream at the end of every step (A/B)")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--padded", action="store_true", help="ragged workloads: run the reference's padded layout instead of packed (varlen) rows")
-    ap.add_argument("--mode", default="native", choices=["native", "native-graph", "native-phases", "autograd", "graph"],
+    ap.add_argument("--mode", default="native", choices=["native", "native-graph", "autograd", "graph"],
                     help="native: one C call per step (default); native-graph: that call captured once and replayed as a hipGraph; "
                          "autograd: torch autograd Functions; graph: autograd step in a HIP graph")
     return ap.parse_args()
@@ -249,7 +249,7 @@ def main():
             pair, turn = (batch, other), [0]
 
         def step(graph=None):
-            if mode in ("native", "native-graph", "native-phases") and graph is None:  # N > 1: native phases with the RCCL collectives between them
+            if mode in ("native", "native-graph") and graph is None:  # N > 1: native phases with the RCCL collectives between them
                 # back-to-back steps: the text side's update tail overlaps the next step's forward (COOT_STEP_DEFER_TEXT_JOIN); every
                 # step is complete when the timed region ends (barrier + device synchronisation below)
                 # the data loader's lookahead: the next batch is announced to the step, which runs that batch's parameter-free input
@@ -260,7 +260,7 @@ def main():
                     return trainer.train_step_native(cur, vid_counts=vid_counts, clip_counts=clip_counts, defer_join=not args.no_defer_join,
                                                      next_batch=nxt if lookahead else None)[0]
                 return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, defer_join=not args.no_defer_join,
-                                                 use_graph={"native-graph": True, "native-phases": "phases"}.get(mode, False))[0]
+                                                 use_graph=(mode == "native-graph"))[0]
             return trainer.train_step(batch, vid_counts, clip_counts, use_graph=(mode == "graph") if graph is None else graph)[0]
 
     def barrier():

@@ -376,17 +376,16 @@ static int attention_all(AttnArgs a, const Segs& sg, bool cross, bool bwd, hipSt
 // GenPool score MLP fused behind the last encoder layer (fused path only)
 struct PoolFuse { const bf16_t *pw1, *pw2; const float *pb1, *pb2; bf16_t *hp, *ap, *s; DropCfg d1, d2; };
 struct PoolFuseBwd { const bf16_t *ds, *dzp, *hp, *pw2, *pw1; bf16_t* dhp; float* g_pb1; DropCfg d1; };
-static int g_use_fused_bwd = 1;  // coot_set_option("fused_bwd", 0/1)
 static int g_use_fused_infc = 1;  // coot_set_option("fused_infc", 0/1): input FC + QKV in one launch (+1.4 % on the step once its K loop was pipelined two slabs deep)
 static int g_use_fused = 1;
 static int g_grad_poison = 0;  // coot_set_option("grad_poison", 1) (tests): coot_nets_zero_grads fills the matrices it skips with NaN
-static int g_ln_wgs = 512;  // coot_set_option("ln_prefetch_wgs", n): workgroup cap of the prefetched input LayerNorm (0: one per four rows).  Measured
-                             // (profiles/README.md, round 3): no cap 1.227, 1024: 1.235, 512: 1.217, 256: 1.213-1.228, 128: 1.259 ms per step (1.238 without the prefetch)
-static int g_ln_nt = 1;  // coot_set_option("ln_prefetch_nt", 0/1): the prefetched input LayerNorm (input stages) with streaming loads / stores
+constexpr int g_ln_wgs = 512;  // workgroup cap of the prefetched input LayerNorm.  Measured (profiles/README.md, round 3): no cap 1.227, 1024: 1.235,
+                               // 512: 1.217, 256: 1.213-1.228, 128: 1.259 ms per step (1.238 without the prefetch)
+constexpr int g_ln_nt = 1;     // ... with streaming (non-temporal) loads / stores: next to the global networks it must not evict their weights from L2
 static int g_pack_lazy = 1, g_pack_poison = 0;  // coot_set_option("pack_lazy" / "pack_poison"): lazily packed per-op layouts (below)
 static int g_fz_debug = 0;
 static unsigned long long* g_fz_tstamps = nullptr;
-static int g_fused_fwd_small = 1;  // coot_set_option("fused_fwd_small", 0/1): forward chain on 32-token tiles below fused_min_rows
+constexpr int g_fused_fwd_small = 1;  // forward chain on 32-token tiles below fused_min_rows
 static int g_fused_min_rows = 1024;  // below this many tokens the per-op kernels win (one or two tiles cannot fill the chip)  // coot_set_option("fused", 0/1): A/B switch between the fused chains and the per-op kernels
 
 static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp, const LayerW& lw, const bf16_t* xq, int rows_q,
@@ -465,7 +464,7 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
 struct LayerBwdBufs { bf16_t *dr2, *dr2m, *dh1, *dz1, *dr1, *dctx, *dq; long lddq; bf16_t* dk; long lddk; bf16_t* dv; long lddv; float* delta; };
 
 static bool qkv_bwd_is_fused(const LayerW& lw, int rows_q, bool dxq_is_f32, const float* part_ws) {
-  return lw.f_wqkv_kn && g_use_fused && g_use_fused_bwd && rows_q >= g_fused_min_rows && !dxq_is_f32 && part_ws;
+  return lw.f_wqkv_kn && g_use_fused && rows_q >= g_fused_min_rows && !dxq_is_f32 && part_ws;
 }
 
 static int layer_bwd(const coot_net_config& c, const float* P, float* G, const LayerP& lp, const LayerW& lw, const bf16_t* xq,
@@ -476,7 +475,7 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
   const int D = c.hidden_dim, F = c.ff_dim, H = c.num_heads, dh = D / H;
   const bool self = (xq == xkv);
   const DropCfg d_ff2 = mkdrop(train, pdrop, seed, site_base + SITE_FF2);
-  const bool fused = g_use_fused && g_use_fused_bwd && lw.f_w2_kn && part_ws && rows_q >= g_fused_min_rows && (pool || dz2);
+  const bool fused = g_use_fused && lw.f_w2_kn && part_ws && rows_q >= g_fused_min_rows && (pool || dz2);
   COOT_REQUIRE(!pool || fused, "layer_bwd: fused pooling backward requested on the unfused path");
   if (fused) {  // pooling MLP dX + LN2 bwd + FF dX + LN1 bwd + out-proj dX as ONE launch over token tiles (+ one reduction)
     PreAttnBwd f; f.T = rows_q; f.h1 = b.h1; f.r2 = b.r2; f.r1 = b.r1; f.w2 = lw.f_w2_kn; f.w1 = lw.f_w1_kn; f.wo = lw.f_wo_kn;
@@ -527,8 +526,6 @@ static int layer_bwd(const coot_net_config& c, const float* P, float* G, const L
   a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
   a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
   a.dout = w.dctx; a.lddo = D; a.delta = w.delta; a.dq = w.dq; a.lddq = w.lddq; a.dk = w.dk; a.lddk = w.lddk; a.dv = w.dv; a.lddv = w.lddv;
-  // the weight gradients recorded so far (pooling MLP, FF2, FF1, out-proj) next to the attention backward, if the step gave an aux stream
-  if (fused && self) RUN(tn_batch_flush_aux(st));
   RUN(attention_all(a, sg, !self, true, st));
   if (self) {
     // bq | bk | bv gradients = column sums of dqkv: taken by the weight-gradient GEMM that streams dqkv anyway
@@ -581,7 +578,7 @@ static int g_use_packed = 1;  // coot_set_option("packed", 0/1): honour cu_seqle
 // same decision from the same arguments.
 static bool packed_ok(const coot_net_config& c, const WPack& W, const Segs& sg, const coot_packed_seqs* pk) {
   if (!g_use_packed || !pk || !pk->cu_seqlens || pk->total_tokens <= 0) return false;
-  return g_use_fused && g_use_fused_infc && g_use_fused_bwd && c.use_input_fc && !c.use_context && fused_pool_ok(c) && W.f_in_w && W.f_pw1 &&
+  return g_use_fused && g_use_fused_infc && c.use_input_fc && !c.use_context && fused_pool_ok(c) && W.f_in_w && W.f_pw1 &&
          W.f_pw1_kn && c.input_dim % 64 == 0 && pk->total_tokens >= g_fused_min_rows && pk->total_tokens <= sg.Tpad() &&
          attn_short_path(sg.L[0]) && (sg.n == 1 || attn_short_path(sg.L[1]));
 }
@@ -624,11 +621,7 @@ int coot_debug_attn_dropout_scales(uint64_t seed, unsigned site, unsigned row32,
 }
 int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)dev_u64; return 0; }
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
-extern "C" void coot_step_tn_aux(int sides);
-extern "C" void coot_step_split_loss(int on);
 extern "C" void coot_step_grad_write(int on);
-extern "C" void coot_step_defer_global_tn(int on);
-extern "C" void coot_step_glob_xcd_split(int on);
 extern "C" int coot_internal_stage_hits(void);
 int coot_get_option(const char* name, int* value) {
   if (!value) { set_error("get_option: null result"); return -1; }
@@ -643,32 +636,20 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_mode")) { set_tn_mode(value); return 0; }
   if (!strcmp(name, "step_stamps")) { coot_step_stamps_enable(value); return 0; }
   if (!strcmp(name, "fused")) { g_use_fused = value; return 0; }
-  if (!strcmp(name, "fused_bwd")) { g_use_fused_bwd = value; return 0; }
   if (!strcmp(name, "glob_fused")) { g_use_glob_fused = value; return 0; }
   if (!strcmp(name, "glob_fused_bwd")) { g_use_glob_fused_bwd = value; return 0; }
   if (!strcmp(name, "packed")) { g_use_packed = value; return 0; }
-  if (!strcmp(name, "half_tiles")) { set_half_tiles(value); return 0; }
   if (!strcmp(name, "fused_infc")) { g_use_fused_infc = value; return 0; }
-  if (!strcmp(name, "gemm_small")) { set_gemm_small(value); return 0; }
-  if (!strcmp(name, "attn_short")) { set_attn_short(value); return 0; }
-  if (!strcmp(name, "tn_wide")) { set_tn_wide(value); return 0; }
   if (!strcmp(name, "tn_dma")) { set_tn_dma(value); return 0; }
   if (!strcmp(name, "pack_lazy")) { g_pack_lazy = value; return 0; }
   if (!strcmp(name, "pack_poison")) { g_pack_poison = value; return 0; }
   if (!strcmp(name, "grad_poison")) { g_grad_poison = value; return 0; }
   if (!strcmp(name, "tn_target_wgs")) { set_tn_target_wgs(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
-  if (!strcmp(name, "tn_aux")) { coot_step_tn_aux(value); return 0; }
-  if (!strcmp(name, "split_loss")) { coot_step_split_loss(value); return 0; }
   if (!strcmp(name, "grad_write")) { coot_step_grad_write(value); return 0; }
-  if (!strcmp(name, "defer_global_tn")) { coot_step_defer_global_tn(value); return 0; }
-  if (!strcmp(name, "glob_xcd_split")) { coot_step_glob_xcd_split(value); return 0; }
   if (!strcmp(name, "cl_col_split")) { set_cl_col_split(value); return 0; }
-  if (!strcmp(name, "ln_prefetch_nt")) { g_ln_nt = value; return 0; }
-  if (!strcmp(name, "ln_prefetch_wgs")) { g_ln_wgs = value; return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
-  if (!strcmp(name, "fused_fwd_small")) { g_fused_fwd_small = value; return 0; }
   set_error("unknown option %s", name);
   return -2;
 }
@@ -1209,13 +1190,12 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       RUN(tn(ds.dr1, D, bs.ctx, D, T, D, D, G + lp.wo, G + lp.bo));
       RUN(tn(ds.dq, 3 * D, S.z0, D, T, 3 * D, D, G + lp.wqkv, G + lp.bq));
     }
-    RUN(tn_batch_flush_end(st));
+    RUN(tn_batch_flush(st));
     RUN(colsum_defer_flush(st));
-    RUN(tn_batch_join(st));
     return 0;
   }
   // pooling MLP dX + the last encoder layer's LN / FF / out-proj dX in one fused launch (fused.hip: pre_attn_bwd_kernel)
-  const bool pool_bwd_fused = g_use_fused && g_use_fused_bwd && fused_pool_ok(c) && W.f_pw1_kn && !c.use_context && T >= g_fused_min_rows;
+  const bool pool_bwd_fused = g_use_fused && fused_pool_ok(c) && W.f_pw1_kn && !c.use_context && T >= g_fused_min_rows;
   if (c.pooler == 0) {
     const int H = c.pool_heads, PH = c.pool_hidden, dhp = PH / H, dop = D / H;
     long row = 0; int n0 = 0;
@@ -1301,10 +1281,9 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     l.dx32 = dfeats; l.lddx32 = Din; l.dgain = G + L.n_gain; l.dbias = G + L.n_bias;
     if (!dfeats) { l.dx = dz_other; l.lddx = D; }
     RUN(launch_ln_bwd(l, st));
-    RUN(tn_batch_flush_end(st));  // global networks inside the train step: deferred to the aux stream (gemm.h), else a plain flush
+    RUN(tn_batch_flush(st));
     RUN(colsum_defer_flush(st));
   }
-  RUN(tn_batch_join(st));
   (void)pe; (void)hidden;
   return 0;
 }

@@ -128,32 +128,13 @@ thread_local const uint64_t* g_step_seed_dev = nullptr;  // device base seed of 
 thread_local int g_resh_wait_slot = -1;  // hop slot the video side waits on before it reads d_resh (coot_train_step), -1: none
 thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller events: video / text global backward done
 
-// One extra stream per side for the early weight-gradient flush of the local network's backward (gemm.h: tn_batch_flush_aux)
-// coot_set_option("defer_global_tn", 0/1): the global networks' weight gradients on the aux stream, next to the local backward.
-// Measured (A/B in one session): 173.0k -> 167.5k clip-pairs/s — the global backward does not get shorter (its chain is bound by
-// the dependent launches, the 36-workgroup TN launch overlapped with them anyway) and the aux launch slows the local backward's
-// first kernels.  Off.
-int g_defer_global_tn = 0;
-int g_glob_xcd_split = 1;  // coot_set_option("glob_xcd_split", 0/1): each side's single-launch global passes on its own half of the XCDs (fused.h: glob_xcd_set)
 int g_grad_write = 1;  // coot_set_option("grad_write", 0/1): coot_train_step writes the weight-matrix gradients and zeroes only the rest
-int g_split_loss = 1;  // coot_set_option("split_loss", 0/1): local contrastive terms on the text stream ahead of the join (coot_train_step)
-int g_tn_aux_sides = 0;  // coot_set_option("tn_aux", bits): 1 = video side, 2 = text side.  Measured: 136.6k -> 133k (video) / 131k (both)
-                          // clip-pairs/s — the local backward is area bound, two half batches of weight gradients are less efficient than one
 // bf16 weight packs of `count` networks in one launch
 int pack_nets(const coot_step_config& c, const coot_step_buffers& b, const int* nets, int count, void* stream) {
   const coot_net_config* cfgs[4]; const float* Ps[4]; void* ws[4];
   for (int k = 0; k < count; ++k) { cfgs[k] = &c.net[nets[k]]; Ps[k] = b.params[nets[k]]; ws[k] = b.wpack[nets[k]]; }
   return coot_nets_pack_weights(count, cfgs, Ps, ws, stream);
 }
-
-struct AuxStreams {
-  hipStream_t s[2] = {nullptr, nullptr};
-  hipStream_t get(int side) {
-    if (!s[side] && hipStreamCreateWithFlags(&s[side], hipStreamNonBlocking) != hipSuccess) s[side] = nullptr;
-    return s[side];
-  }
-};
-thread_local AuxStreams g_aux;
 
 // Coarse timeline of one step measured with HIP events (coot_set_option("step_stamps", 1); coot_debug_step_stamps()):
 // a profiler's launch interception makes this path host-bound, so whether the two sides really overlap can only be
@@ -268,8 +249,9 @@ int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, 
   g_stamps.mark(li == 0 ? "video: local forward done" : "text: local forward done", st);
   if (local_done_slot >= 0) RUN(g_hops.record(local_done_slot, st));  // the local embeddings exist: the other side may start on their loss terms
   RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
-  // the two sides' global passes run at the same time: each on its own half of the XCDs (its 3.5 MB of weights then own those L2s)
-  if (g_glob_xcd_split) glob_xcd_set(li == 0 ? 0 : 4, 4);
+  // the two sides' global passes run at the same time: each on its own half of the XCDs (its 3.5 MB of weights then own those L2s;
+  // measured harmless rather than useful: the passes are latency chains, profiles/README.md round 3)
+  glob_xcd_set(li == 0 ? 0 : 4, 4);
   const int rc_gf = coot_net_fwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0,
                                  local_out /* context = first B rows */, glob_out, nullptr, saved_g, sz_g, nullptr, 0, train, seed + 11 * gi,
                                  g_step_seed_dev, st, nullptr);
@@ -289,44 +271,32 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   const int D = c.net[0].hidden_dim;
   g_stamps.mark(li == 0 ? "video: backward starts" : "text: backward starts", st);
   const int side = li == 0 ? 0 : 1;
-  // scratch: [local network | global network].  The global network's weight gradients (one batched TN launch, 36 workgroups)
-  // are not needed before the optimizer: they go to this side's aux stream and run next to the local backward (which leaves
-  // 56 CUs idle in its largest kernel) instead of in front of it; joined below.
+  // scratch: [local network | global network]
   const size_t sz_loc = align256(coot_net_scratch_bytes(&c.net[li], d.B, Lctx, d.Nc, Litem));
   const size_t sz_glob = coot_net_scratch_bytes(&c.net[gi], d.B, Cmax, 0, 0);
   COOT_REQUIRE(sz_loc + sz_glob <= sz_scratch, "step backward: scratch too small (%zu < %zu)", sz_scratch, sz_loc + sz_glob);
-  const bool defer = g_defer_global_tn != 0;
-  set_tn_aux_stream(defer ? g_aux.get(side) : nullptr);
-  set_tn_defer(defer);
-  if (g_glob_xcd_split) glob_xcd_set(side == 0 ? 0 : 4, 4);
+  glob_xcd_set(side == 0 ? 0 : 4, 4);
   const int rc_g = coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
                                 b.grads[gi], dhid, dfeat, saved_g, sz_g, (char*)scratch + sz_loc, sz_glob, train, seed + 11 * gi, g_step_seed_dev, st,
                                 nullptr);
   glob_xcd_set(0, 8);
-  set_tn_defer(false);
-  set_tn_aux_stream(nullptr);
   RUN(rc_g);
   g_stamps.mark(li == 0 ? "video: global backward done" : "text: global backward done", st);
-  // data parallel: the global network's gradients are final here (behind the deferred weight-gradient launch, if any) — the
-  // caller's communication stream may start reducing them under the local backward (coot_step_set_global_done_events)
+  // data parallel: the global network's gradients are final here — the caller's communication stream may start reducing them under
+  // the local backward (coot_step_set_global_done_events)
   if (g_glob_done[side]) {
-    hipStream_t ds = tn_deferred_pending() ? tn_deferred_stream() : nullptr;
-    if (ds) RUN(g_hops.hop(8 + side, st, ds));  // ... and behind everything the pass enqueued on `st` after that launch
-    RUN(check_hip(hipEventRecord((hipEvent_t)g_glob_done[side], ds ? ds : st), "eventRecord"));
+    if (det_on()) RUN(det_flush_range(b.grads[gi], (size_t)coot_net_param_numel(&c.net[gi]) * sizeof(float), st));  // (their fixed-point sums first)
+    RUN(check_hip(hipEventRecord((hipEvent_t)g_glob_done[side], st), "eventRecord"));
   }
   // the cycle-consistency gradients come from the other stream; they are first needed HERE, a whole global backward after the
   // contrastive loss — waiting only now keeps the cross-stream hop off the critical path
   if (g_resh_wait_slot >= 0 && li == 0) RUN(g_hops.wait(g_resh_wait_slot, st));
   // context grad += dhidden, item grads += unpack(global input grad) + unpack(cycle-consistency grad): one launch
   RUN(launch_pack_bwd_join(dfeat, d_resh, dhid, (const long long*)item_num, d.B, Cmax, D, d_local + (size_t)d.B * D, d_local, st));
-  set_tn_aux_stream(((g_tn_aux_sides >> side) & 1) ? g_aux.get(side) : nullptr);
   const int rc = coot_net_bwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
                               nullptr, d_local, b.grads[li], nullptr, nullptr, saved_l, sz_l, scratch, sz_loc, train, seed + 11 * li, g_step_seed_dev,
                               st, pk);
-  set_tn_aux_stream(nullptr);
-  const int rc_j = tn_deferred_join(st);  // the optimizer / the end of the pass needs the global network's weight gradients
   RUN(rc);
-  RUN(rc_j);
   // deterministic mode (det.h): this side's fixed-point sums -> its two gradient arenas, behind everything that added to them
   if (det_on()) {
     RUN(det_flush_range(b.grads[li], (size_t)coot_net_param_numel(&c.net[li]) * sizeof(float), st));
@@ -623,7 +593,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   }
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
-  const bool split_loss = g_split_loss != 0 && sv != st;
+  const bool split_loss = sv != st;  // (the text stream has ~90 us of slack there: +0.2 % on the step, A/B in round 2)
   const bool piped = (do_optimizer & COOT_STEP_INPUT_STAGES) != 0;
   StageScope stage_scope;
   PipeStep ps;
@@ -726,78 +696,6 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   return 0;
 }
 
-// One phase of coot_train_step on ONE stream — the same calls in the same order, cut where the two sides meet — so that each
-// piece is a LINEAR chain of launches: captured and replayed as its own hipGraph on its own stream it keeps the two sides as
-// concurrent as two eager streams are (the whole step captured as one two-branch graph replays slower than it runs eagerly,
-// profiles/README.md), while every dependent launch inside costs a graph node (1.7 us) instead of a stream launch (3.1 us).
-// The caller orders the phases with events:  0 -> {1, 2};  {1, 2} -> 3;  1 -> 4;  {3, 4} -> {5, 6};  0 needs the device state.
-//   0 device step state (counters, optimizer scalars)   1 video forward            2 text forward + zero fills
-//   3 contrastive loss                                  4 cycle-consistency loss   5 video backward + update + packs
-//   6 text backward + update (+ total loss) + packs
-int coot_train_step_phase(const coot_step_config* cfg, const coot_step_buffers* b, const coot_step_batch* x, const coot_step_dims* d,
-                          float* losses, void* workspace, size_t workspace_bytes, int train, uint64_t seed, int64_t step, int do_optimizer,
-                          int phase, coot_stream_t stream) {
-  RUN(check_cfg(*cfg));
-  COOT_REQUIRE(losses && phase >= 0 && phase <= 6, "train_step_phase: bad arguments");
-  Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
-  const SidePacked pk = side_packed(*x, *d);
-  COOT_REQUIRE(!A.overflow, "train_step_phase: workspace too small (%zu < %zu)", workspace_bytes, A.off);
-  hipStream_t s = (hipStream_t)stream;
-  const int D = cfg->net[0].hidden_dim;
-  const bool optimize = (do_optimizer & COOT_STEP_OPTIMIZER) != 0, repack = optimize && (do_optimizer & COOT_STEP_REPACK) != 0;
-  const bool pack_first = (do_optimizer & COOT_STEP_PACKS_FRESH) == 0;
-  const bool cc = cfg->cc_weight != 0.f;
-  const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
-  switch (phase) {
-    case 0:
-      COOT_REQUIRE(g_state_dev && optimize, "train_step_phase 0: needs the device step state and an optimizer step");
-      hipLaunchKernelGGL(step_state_kernel, dim3(1), dim3(1), 0, s, g_state_dev, cfg->optimizer, cfg->radam_degentosgd, cfg->beta1, cfg->beta2,
-                         cfg->eps, cfg->weight_decay, (unsigned long long)7919);
-      COOT_CHECK_LAUNCH("step_state");
-      return 0;
-    case 1:
-      return side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
-                          W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, s, pack_first, &pk.v);
-    case 2:
-      RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
-                       W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, s,
-                       pack_first, &pk.t));
-      for (int i = 0; i < 4; ++i)
-        RUN(check_hip(hipMemsetAsync(b->grads[i], 0, (size_t)coot_net_param_numel(&cfg->net[i]) * sizeof(float), s), "memset grads"));
-      RUN(check_hip(hipMemsetAsync(W.zero_begin, 0, W.zero_bytes, s), "memset embedding grads"));
-      return check_hip(hipMemsetAsync(losses, 0, 3 * sizeof(float), s), "memset losses");
-    case 3:
-      return coot_contrastive_fwd_bwd(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
-                                      W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
-                                      W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t,
-                                      W.loss_scratch, W.sz_loss, stream);
-    case 4:
-      if (!cc) return 0;
-      RUN(draw_cycle_indices(*x, *d, seed, W.idx, s));
-      return coot_cyclecons_fwd_bwd(W.resh_v, W.resh_t, x->clip_num, x->sent_num, (const int64_t*)W.idx, (const int64_t*)(W.idx + d->B), d->B,
-                                    d->Cmax_clip, d->Cmax_sent, D, cfg->cc_weight, 1.0f / (float)d->B, losses + 2, nullptr, nullptr,
-                                    W.d_resh_v, W.d_resh_t, stream);
-    case 5:
-      RUN(side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
-                        W.local_v, W.resh_v, W.d_local_v, W.d_glob_v, cc ? W.d_resh_v : nullptr, W.dhid_v, W.dfeat_v, W.saved_lv, W.sz_lv,
-                        W.saved_gv, W.sz_gv, W.scratch_v, W.sz_sv, train, seed, s, &pk.v));
-      if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, s));
-      if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, stream));
-      return 0;
-    default:
-      RUN(side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
-                        W.local_t, W.resh_t, W.d_local_t, W.d_glob_t, cc ? W.d_resh_t : nullptr, W.dhid_t, W.dfeat_t, W.saved_lt, W.sz_lt,
-                        W.saved_gt, W.sz_gt, W.scratch_t, W.sz_st, train, seed + 1000, s, &pk.t));
-      if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, s, losses));
-      else {
-        hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, s, losses);
-        COOT_CHECK_LAUNCH("loss_total");
-      }
-      if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, stream));
-      return 0;
-  }
-}
-
 void coot_step_stamps_enable(int on) { g_stamps.on = on != 0; }
 int coot_internal_stage_hits(void) { return g_pipe.hits; }
 size_t coot_step_device_state_bytes(void) { return sizeof(StepState); }
@@ -824,11 +722,7 @@ int coot_step_set_next_batch(const coot_step_batch* next, const coot_step_dims* 
   return 0;
 }
 int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
-void coot_step_tn_aux(int sides) { g_tn_aux_sides = sides; }
-void coot_step_split_loss(int on) { g_split_loss = on; }
 void coot_step_grad_write(int on) { g_grad_write = on ? 1 : 0; }
-void coot_step_defer_global_tn(int on) { g_defer_global_tn = on; }
-void coot_step_glob_xcd_split(int on) { g_glob_xcd_split = on; }
 
 // text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.
 int coot_debug_step_stamps(char* buf, int buf_bytes) {

@@ -35,7 +35,6 @@ struct AttnArgs {
 int launch_attn_fwd(const AttnArgs& a, hipStream_t stream);
 int launch_attn_bwd(const AttnArgs& a, hipStream_t stream);
 // 1 (default): self-attention with L <= 128 uses the one-workgroup-per-(sequence, head) kernels; 0: chunked kernels (A/B switch)
-void set_attn_short(int on);
 bool attn_short_path(int L);  // true if self-attention over sequences of length L takes the short kernels
 
 }  // namespace coot

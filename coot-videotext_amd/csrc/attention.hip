@@ -792,12 +792,10 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(AttnArgs a) {
 }
 static bool attn_q1_ok(const AttnArgs& a) { return a.Lq == 1 && a.Lk >= 1 && a.Lk <= 64 && a.Nseq2 == 0; }
 
-static int g_attn_short = 1;
-void set_attn_short(int on) { g_attn_short = on; }
 static bool attn_short_ok(const AttnArgs& a) {
-  return g_attn_short && a.Lq == a.Lk && a.Lk <= 16 * SH_MAXW && a.Lk >= 1 && (a.Nseq2 == 0 || (a.L2 >= 1 && a.L2 <= 16 * SH_MAXW));
+  return a.Lq == a.Lk && a.Lk <= 16 * SH_MAXW && a.Lk >= 1 && (a.Nseq2 == 0 || (a.L2 >= 1 && a.L2 <= 16 * SH_MAXW));
 }
-bool attn_short_path(int L) { return g_attn_short && L >= 1 && L <= 16 * SH_MAXW; }
+bool attn_short_path(int L) { return L >= 1 && L <= 16 * SH_MAXW; }
 
 template <int DH>
 static int attn_fwd_t(const AttnArgs& a_in, hipStream_t st) {

@@ -167,7 +167,6 @@ void glob_xcd_set(int first, int count);
 
 constexpr int FZ_BWD_NCS = 9 * FZ_D;  // floats per tile in PreAttnBwd::part
 bool half_tiles(int T);          // the chains run on 64-row tiles for this many tokens (fused.hip)
-void set_half_tiles(int on);
 int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st);
 
 }  // namespace coot

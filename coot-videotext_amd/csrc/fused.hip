@@ -1857,10 +1857,8 @@ __global__ __launch_bounds__(256) void colsum_scatter_kernel(ScatterArgs a) {
 // Tile height of the token-tile chains.  One workgroup per CU: a launch of <= 256 tiles is ONE wave of workgroups whose duration is
 // the per-tile latency, however few tiles there are.  Up to 16 384 tokens (the text side of every shipped config, ragged batches
 // with packed rows, small batches) 64-row tiles still fit in one wave and each takes about half as long; above, 128-row tiles
-// (half the weight traffic per token) stay one wave up to 32 768 tokens.  coot_set_option("half_tiles", 0) forces 128 rows.
-static int g_half_tiles = 1;
-void set_half_tiles(int on) { g_half_tiles = on; }
-bool half_tiles(int T) { return g_half_tiles && T <= 256 * 64; }
+// (half the weight traffic per token) stay one wave up to 32 768 tokens.
+bool half_tiles(int T) { return T <= 256 * 64; }
 
 int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   COOT_REQUIRE(p.ctx && p.xres && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.ln1g && p.ln1b && p.ln2g && p.ln2b && p.r1 && p.z1 &&

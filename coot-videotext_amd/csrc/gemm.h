@@ -72,18 +72,6 @@ void tn_batch_begin();
 void get_tn_default_workspace(float** ws, size_t* floats);
 int tn_batch_flush(hipStream_t stream);
 void tn_batch_end();
-// optional second stream for early flushes (thread-local, set by the step; nullptr = off)
-void set_tn_aux_stream(hipStream_t aux);
-int tn_batch_flush_aux(hipStream_t st);  // flush what is recorded so far on the aux stream, ordered after `st`
-int tn_batch_join(hipStream_t st);       // `st` waits for the aux flushes of the current scope
-// the last flush of a scope, not joined by it (gemm.hip): used for the global networks' weight gradients
-void set_tn_defer(bool on);
-int tn_batch_flush_end(hipStream_t st);  // = tn_batch_flush(st) unless set_tn_defer(true) and an aux stream is set
-bool tn_deferred_pending();
-hipStream_t tn_deferred_stream();        // the stream the deferred flush runs on (nullptr if there is none)
-int tn_deferred_join(hipStream_t st);    // `st` waits for the deferred flush, if any
-// 1 (default): batched problems with Mo % 384 == 0 use the 384 x 128 output tiles; 0: always 128 x 128 (A/B switch)
-void set_tn_wide(int on);
 // 1: wide tiles fed by LDS-DMA (gemm_tn_dma_kernel); 0: register-staged (A/B switch)
 void set_tn_target_wgs(int n);
 void set_tn_dma(int on);
@@ -102,8 +90,6 @@ void timing_end(void* slot, hipStream_t stream);
 
 // 0 = ds_read_b64_tr_b16 fragments (default), 1 = transposing LDS stores (fallback)
 void set_tn_mode(int mode);
-// 1 (default): M <= 512 problems use the direct-from-L2 small-M kernel; 0: always the LDS-staged kernel (A/B switch)
-void set_gemm_small(int on);
 int get_tn_mode();
 
 }  // namespace coot

@@ -389,8 +389,6 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmNT g) {
 // ---- optional per-launch timing with HIP events (bench.py roofline leg) -------------------------------
 struct TimingSlot { hipEvent_t a, b; double flops; int kind; int big_k; };
 static int g_timing_on = 0;
-static int g_small_on = 1;
-void set_gemm_small(int on) { g_small_on = on; }
 static TimingSlot g_slots[8192];
 static int g_nslots = 0, g_slots_created = 0;
 void gemm_timing_enable(int on) { g_timing_on = on; g_nslots = 0; }
@@ -438,7 +436,7 @@ int launch_gemm_nt(const GemmNT& g_in, hipStream_t stream) {
                "gemm_nt: epilogue strides must be multiples of 8");
   if (g.M <= 0 || g.N <= 0) return 0;
   g.xcd_order = g_xcd_order & 1;
-  if (g.M <= 512 && g_small_on) {  // global networks / loss strips: direct-from-L2 fragments, no LDS
+  if (g.M <= 512) {  // global networks / loss strips: direct-from-L2 fragments, no LDS
     void* ts = timing_begin(TIMING_NT_SMALL, 2.0 * g.M * g.N * g.K * g.groups, 0, stream);
     g.epi.colsum_ws = nullptr;
     if ((long)((g.M + 15) / 16) * ((g.N + 31) / 32) >= 512) {
@@ -1238,16 +1236,9 @@ static thread_local int g_tn_nitems = 0;
 static thread_local GemmTN g_tn_items[TN_MAX_ITEMS];
 
 static thread_local long g_tn_ws_used = 0;  // floats of the default workspace taken by the flushes of the current scope
-static thread_local hipStream_t g_tn_aux = nullptr;
-static thread_local bool g_tn_aux_pending = false;
-static thread_local hipEvent_t g_tn_ev[2];
-static thread_local bool g_tn_ev_made = false;
 
-void tn_batch_begin() { g_tn_collect = true; g_tn_nitems = 0; g_tn_ws_used = 0; g_tn_aux_pending = false; }
-void set_tn_aux_stream(hipStream_t aux) { g_tn_aux = aux; }
+void tn_batch_begin() { g_tn_collect = true; g_tn_nitems = 0; g_tn_ws_used = 0; }
 
-static int g_tn_wide = 1;
-void set_tn_wide(int on) { g_tn_wide = on; }
 static int g_tn_target_wgs = 256;  // wide tiles: workgroups per launch the split count aims at (one per CU)
 void set_tn_target_wgs(int n) { g_tn_target_wgs = n > 0 ? n : 256; }
 static int g_tn_dma = 1;
@@ -1318,7 +1309,7 @@ int tn_batch_flush(hipStream_t stream) {
   bool wide[TN_MAX_ITEMS];
   for (int i = 0; i < n; ++i) {
     const GemmTN& g = g_tn_items[i];
-    wide[i] = g_tn_wide && g_tn_mode == 0 && g.Mo % TNW_BM == 0 && g.No % 4 == 0 && g.ldc % 4 == 0 && g.zC % 4 == 0;
+    wide[i] = g_tn_mode == 0 && g.Mo % TNW_BM == 0 && g.No % 4 == 0 && g.ldc % 4 == 0 && g.zC % 4 == 0;
     if (wide[i]) tiles_w += (long)((g.No + TNW_BN - 1) / TNW_BN) * (g.Mo / TNW_BM) * g.groups;
     else tiles_n += (long)((g.No + TN_BC - 1) / TN_BC) * ((g.Mo + TN_BC - 1) / TN_BC) * g.groups;
   }
@@ -1386,55 +1377,6 @@ int tn_batch_flush(hipStream_t stream) {
   return 0;
 }
 void tn_batch_end() { g_tn_collect = false; g_tn_nitems = 0; }
-
-#define RUN(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
-// The weight gradients recorded so far, launched on the aux stream (ordered after everything enqueued on `st`): they run
-// NEXT TO the rest of the backward chain of `st` (attention backward, QKV dX: memory / latency bound kernels that leave
-// the matrix cores idle) instead of after it.  tn_batch_join() orders `st` after them.
-int tn_batch_flush_aux(hipStream_t st) {
-  if (!g_tn_aux || !g_tn_collect || g_tn_nitems == 0 || g_tn_aux == st) return 0;
-  if (!g_tn_ev_made) {
-    for (int i = 0; i < 2; ++i) RUN(check_hip(hipEventCreateWithFlags(&g_tn_ev[i], hipEventDisableTiming), "hipEventCreate"));
-    g_tn_ev_made = true;
-  }
-  RUN(check_hip(hipEventRecord(g_tn_ev[0], st), "eventRecord"));
-  RUN(check_hip(hipStreamWaitEvent(g_tn_aux, g_tn_ev[0], 0), "streamWait"));
-  RUN(tn_batch_flush(g_tn_aux));
-  RUN(check_hip(hipEventRecord(g_tn_ev[1], g_tn_aux), "eventRecord"));
-  g_tn_aux_pending = true;
-  return 0;
-}
-int tn_batch_join(hipStream_t st) {
-  if (!g_tn_aux_pending) return 0;
-  g_tn_aux_pending = false;
-  return check_hip(hipStreamWaitEvent(st, g_tn_ev[1], 0), "streamWait");
-}
-
-// Deferred flush: the LAST flush of a scope whose results nothing on `st` needs for a long while (the global network's weight
-// gradients: final consumers are the optimizer and the gradient all-reduce, a whole local backward later).  It goes to the aux
-// stream like tn_batch_flush_aux(), but the scope's tn_batch_join() does not wait for it: the owner of the aux stream calls
-// tn_deferred_join(st) where the results are needed (and tn_deferred_record(ev) to publish "done" to another stream).
-static thread_local bool g_tn_defer = false, g_tn_deferred = false;
-static thread_local hipStream_t g_tn_deferred_stream = nullptr;
-void set_tn_defer(bool on) { g_tn_defer = on; }
-int tn_batch_flush_end(hipStream_t st) {
-  if (g_tn_defer && g_tn_aux && g_tn_aux != st && g_tn_collect && g_tn_nitems > 0) {
-    int rc = tn_batch_flush_aux(st);
-    if (rc) return rc;
-    g_tn_aux_pending = false;
-    g_tn_deferred = true;
-    g_tn_deferred_stream = g_tn_aux;
-    return 0;
-  }
-  return tn_batch_flush(st);
-}
-bool tn_deferred_pending() { return g_tn_deferred; }
-hipStream_t tn_deferred_stream() { return g_tn_deferred ? g_tn_deferred_stream : nullptr; }
-int tn_deferred_join(hipStream_t st) {
-  if (!g_tn_deferred) return 0;
-  g_tn_deferred = false;
-  return check_hip(hipStreamWaitEvent(st, g_tn_ev[1], 0), "streamWait");
-}
 
 // set_tn_force_overwrite(true): every problem launched / recorded by this thread WRITES its C (coot_net_bwd inside a step whose
 // caller did not zero the weight-matrix gradients: each is produced by exactly one problem)

@@ -22,7 +22,7 @@ EXPORTS = [
     "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_tn_xcd_map", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
-    "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_train_step_phase", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_step_input_stage_bytes", "coot_step_set_input_stages", "coot_step_set_next_batch", "coot_contrastive_fwd_bwd_dp", "coot_contrastive_fwd_bwd_dp_blocks", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
+    "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_step_input_stage_bytes", "coot_step_set_input_stages", "coot_step_set_next_batch", "coot_contrastive_fwd_bwd_dp", "coot_contrastive_fwd_bwd_dp_blocks", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
     "coot_det_shadow_bytes", "coot_det_configure", "coot_det_flush",
 ]
 
@@ -163,7 +163,6 @@ def load():
     lib.coot_step_device_state_bytes.restype = sz
     lib.coot_step_device_state_bytes.argtypes = []
     lib.coot_step_set_device_state.argtypes = [vp]
-    lib.coot_train_step_phase.argtypes = [scp, sbp, sxp, sdp, vp, vp, sz, i32, u64, i64, i32, i32, vp]
     lib.coot_collate_level.argtypes = [vp, vp, i64, i64, i64, i32, vp, vp, i32]
     lib.coot_collate_packed.argtypes = [vp, vp, i64, i64, i32, vp, vp, i32]
     lib.coot_sample_cycle_indices.argtypes = [vp, vp, i32, u64, vp, vp]

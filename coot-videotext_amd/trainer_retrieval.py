@@ -676,7 +676,7 @@ class RetrievalTrainer:
         seed = (torch.initial_seed() * 1000003 + 7919 * self.total_step) & 0xFFFFFFFFFFFFFFFF  # the kernel adds 7919 first
         return struct.pack("<QQfi", seed, int(st.step), float(lr), 0)
 
-    def _train_step_native_graph(self, batch: RetrievalDataBatchTuple, phases: bool = False):
+    def _train_step_native_graph(self, batch: RetrievalDataBatchTuple):
         """coot_train_step captured ONCE per batch shape and replayed (torch.cuda.CUDAGraph around the C call): a dependent
         launch costs 1.7 us in a replay against 3.1 us launched one by one (tools/micro/launchgap.hip), and the step is a
         chain of ~150 of them.  Per-step scalars (dropout seed, optimizer step count and its scalars, learning rate) live in a
@@ -691,7 +691,7 @@ class RetrievalTrainer:
         st, x = self._native_setup(batch)
         lr = float(self.optimizer.param_groups[0]["lr"]) if self.optimizer is not None else float(st.cfg.lr)
         ptrs = tuple(int(st.bufs.params[i]) for i in range(4)) + tuple(int(st.bufs.wpack[i]) for i in range(4))
-        key = (st.dims_key, ptrs, st.ws.data_ptr(), bool(phases))
+        key = (st.dims_key, ptrs, st.ws.data_ptr())
         graphs = st.__dict__.setdefault("graphs", {})
         g = graphs.get(key)
         if g is None:
@@ -718,32 +718,14 @@ class RetrievalTrainer:
             torch.cuda.synchronize()
             g.flags = flags
 
-            def phase_call(ph, stream):
-                _lib.check(lib.coot_train_step_phase(C.byref(g.cfg), C.byref(st.bufs), C.byref(g.x), C.byref(g.dims), st.losses.data_ptr(),
-                                                     st.ws.data_ptr(), st.ws.numel(), 1, 0, 1, flags, ph, stream.cuda_stream),
-                           f"coot_train_step_phase {ph}")
-
-            g.phase_call = phase_call
             lib.coot_step_set_device_state(g.state.data_ptr())
             try:
-                if phases:
-                    # every piece between two meeting points of the sides is a linear chain: its own graph, replayed on its side's
-                    # stream; the events below are the hops of coot_train_step
-                    g.ph = {}
-                    for ph in range(1, 7):
-                        if ph == 4 and st.cfg.cc_weight == 0.0:
-                            continue  # no cycle-consistency loss: nothing to capture
-                        g.ph[ph] = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g.ph[ph]):
-                            phase_call(ph, torch.cuda.current_stream())
-                    g.ev = {k: torch.cuda.Event() for k in ("s", "vf", "tf", "c", "cc", "t6")}
-                else:
-                    g.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g.graph):
-                        cur = torch.cuda.current_stream()
-                        _lib.check(lib.coot_train_step(C.byref(g.cfg), C.byref(st.bufs), C.byref(g.x), C.byref(g.dims), st.losses.data_ptr(),
-                                                       st.ws.data_ptr(), st.ws.numel(), 1, 0, 1, flags, cur.cuda_stream, cur.cuda_stream,
-                                                       st.streams[1].cuda_stream), "coot_train_step (capture)")
+                g.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g.graph):
+                    cur = torch.cuda.current_stream()
+                    _lib.check(lib.coot_train_step(C.byref(g.cfg), C.byref(st.bufs), C.byref(g.x), C.byref(g.dims), st.losses.data_ptr(),
+                                                   st.ws.data_ptr(), st.ws.numel(), 1, 0, 1, flags, cur.cuda_stream, cur.cuda_stream,
+                                                   st.streams[1].cuda_stream), "coot_train_step (capture)")
             finally:
                 lib.coot_step_set_device_state(None)
             graphs[key] = g
@@ -760,38 +742,7 @@ class RetrievalTrainer:
         if g.mirror != want:
             hdr = torch.frombuffer(bytearray(self._graph_state_bytes(st, lr)), dtype=torch.uint8)
             g.state[:24].copy_(hdr)
-        if phases:
-            main, text, E = torch.cuda.current_stream(), st.streams[1], g.ev
-            cc = st.cfg.cc_weight != 0.0
-            lib.coot_step_set_device_state(g.state.data_ptr())
-            try:
-                g.phase_call(0, main)  # one eager launch: counters + optimizer scalars
-            finally:
-                lib.coot_step_set_device_state(None)
-            E["s"].record(main)
-            g.ph[1].replay()
-            E["vf"].record(main)
-            with torch.cuda.stream(text):
-                text.wait_event(E["s"])
-                g.ph[2].replay()
-                E["tf"].record(text)
-            main.wait_event(E["tf"])
-            g.ph[3].replay()
-            E["c"].record(main)
-            with torch.cuda.stream(text):
-                if cc:
-                    text.wait_event(E["vf"])
-                    g.ph[4].replay()
-                    E["cc"].record(text)
-                text.wait_event(E["c"])
-                g.ph[6].replay()
-                E["t6"].record(text)
-            if cc:
-                main.wait_event(E["cc"])
-            g.ph[5].replay()
-            main.wait_event(E["t6"])
-        else:
-            g.graph.replay()
+        g.graph.replay()
         st.step += 1
         self.total_step += 1
         g.mirror = (self.total_step, st.step, lr)
@@ -827,7 +778,7 @@ class RetrievalTrainer:
         if use_graph and cc_indices is not None:
             raise ValueError("train_step_native: injected cycle-consistency positions are not available under graph replay")
         if use_graph and do_optimizer and seed is None and self.model_mgr.is_train:
-            out = self._train_step_native_graph(batch, phases=(use_graph == "phases"))
+            out = self._train_step_native_graph(batch)
             if out is not None:
                 return out
         st, x = self._native_setup(batch)

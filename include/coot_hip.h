@@ -341,13 +341,6 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* buf
  * launched one by one (tools/micro/launchgap.hip).  The host initialises seed / step / lr before the first step and rewrites
  * lr when the schedule changes it.  NULL returns to argument-driven steps.  Thread-local. */
 size_t coot_step_device_state_bytes(void);
-/* One phase of coot_train_step on ONE stream (same calls, cut where the two sides meet), so that each piece is a linear chain
- * that can be captured and replayed as its own hipGraph on its own stream.  phase: 0 device step state, 1 video forward,
- * 2 text forward + zero fills, 3 contrastive loss, 4 cycle-consistency loss, 5 video backward + update + packs, 6 text backward
- * + update + packs.  The caller orders them with events: 0 -> {1, 2}; {1, 2} -> 3; 1 -> 4; {3, 4} -> {5, 6}. */
-int coot_train_step_phase(const coot_step_config* cfg, const coot_step_buffers* bufs, const coot_step_batch* batch,
-                          const coot_step_dims* dims, float* losses, void* workspace, size_t workspace_bytes, int train,
-                          uint64_t seed, int64_t step, int do_optimizer, int phase, coot_stream_t stream);
 int coot_step_set_device_state(void* state);
 /* Data parallel: hipEvent_t handles (or NULL) that coot_step_backward records on the video / text stream as soon as that side's
  * GLOBAL network backward is enqueued — its parameter gradients (networks 1 and 3) are final from there on, so a communication

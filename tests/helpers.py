@@ -170,13 +170,15 @@ def rank_flips(e1, e2, r1, r2):
     return flips, worst
 
 
-def import_reference(ref_root="/root/reference"):
+def import_reference(ref_root=None):
     """The unmodified reference, imported with the shims of SURVEY 8c (removed collections aliases, absent GPUtil / h5py /
     tensorboard).  Returns a namespace of its modules, or None where the reference tree does not exist (the GPU box)."""
     import collections
     import collections.abc
     import sys
     import types
+    if ref_root is None:  # COOT_REFERENCE_ROOT: a copy of the reference's coot/ + nntrainer/ + config/ shipped to the GPU box for one run
+        ref_root = os.environ.get("COOT_REFERENCE_ROOT", "/root/reference")
     if not os.path.isdir(os.path.join(ref_root, "coot")):
         return None
     for n in ("Iterable", "Mapping", "Sequence", "MutableMapping"):
