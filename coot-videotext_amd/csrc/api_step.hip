@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) opt_update_range(k, p, g, m, v, decay, i, n);
 }
 
-struct AdamSegs { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; const float* decay[4]; long n[4]; int blk0[5]; float* losses; };
+struct AdamSegs { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; const float* decay[4]; const unsigned char* all1[4]; long n[4]; int blk0[5]; float* losses; };
 __global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, OptK k_arg, const OptK* k_dev) {
   const OptK k = k_dev ? *k_dev : k_arg;
   int s = 0;
@@ -374,9 +374,13 @@ __global__ __launch_bounds__(256) void adam4_kernel(AdamSegs sg, OptK k_arg, con
   // rider: total = contrastive + cycle-consistency (both final long before any update; was a 1-thread launch in front of the text backward)
   if (sg.losses && blockIdx.x == 0 && threadIdx.x == 0) sg.losses[0] = sg.losses[1] + sg.losses[2];
   const long n = sg.n[s];
-  const long i = ((long)(blockIdx.x - sg.blk0[s]) * 256 + threadIdx.x) * 4;
+  const int blk = (int)blockIdx.x - sg.blk0[s];
+  const long i = ((long)blk * 256 + threadIdx.x) * 4;
   if (i >= n) return;
-  opt_update_range(k, sg.p[s], sg.g[s], sg.m[s], sg.v[s], sg.decay[s], i, n);
+  // a workgroup = 1 024 consecutive elements: where the caller marked the decay multiplier as 1.0 on all of them (everything but
+  // the blocks that touch a bias vector) the mask is not read (coot_step_buffers.decay_block_all)
+  const float* decay = (sg.all1[s] && sg.all1[s][blk]) ? nullptr : sg.decay[s];
+  opt_update_range(k, sg.p[s], sg.g[s], sg.m[s], sg.v[s], decay, i, n);
 }
 
 // the scalars of the rules above (host, or thread 0 of step_state_kernel); optimizer: 0 = Adam, 1 = RAdam
@@ -424,6 +428,7 @@ int adam_nets(const coot_step_config& cfg, const coot_step_buffers& b, const int
     const int i = nets[k < count ? k : count - 1];
     const long n = k < count ? (long)coot_net_param_numel(&cfg.net[i]) : 0;
     sg.p[k] = b.params[i]; sg.g[k] = b.grads[i]; sg.m[k] = b.adam_m[i]; sg.v[k] = b.adam_v[i]; sg.decay[k] = b.decay_mask[i]; sg.n[k] = n;
+    sg.all1[k] = b.decay_mask[i] ? b.decay_block_all[i] : nullptr;
     sg.blk0[k] = blk;
     blk += (int)((n / 4 + 255) / 256);
   }

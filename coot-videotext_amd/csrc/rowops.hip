@@ -23,11 +23,13 @@ __device__ __forceinline__ void store4_bf(bf16_t* p, f32x4_t v) {
 //   y = gain * (x - mean) / (std_unbiased + 1e-6) + bias
 // min 8 waves per SIMD: left alone hipcc keeps the 8-chunk row AND all unrolled epilogue temporaries live (239 VGPRs, 2 waves
 // per SIMD, 64 KB in flight per CU: the input LayerNorm ran at 2.4 TB/s); 64 VGPRs are enough and fill the CU
+// (rows of more than 2 048 elements — NV = 16: 64 row registers per lane — get 128 registers: at 64 the row itself was spilled, 228 B/lane)
 template <int NV>
-__global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
+__global__ __launch_bounds__(256, NV <= 8 ? 8 : 4) void ln_fwd_kernel(LnFwd p) {
   const unsigned dkey = p.drop.thr ? drop_site_key(p.drop.seed, p.drop.seed_ptr, p.drop.site) : 0u;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (wave-uniform: as a scalar the row's base addresses live in SGPRs — as per-lane 64-bit values one of them was parked in scratch)
+  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (row >= p.R) return;
   const int D = p.D, nch = D >> 2;
   bool second = p.x2 && row >= p.R0;
@@ -91,10 +93,10 @@ __global__ __launch_bounds__(256, 8) void ln_fwd_kernel(LnFwd p) {
 // source and stores of the bf16 output, on a capped grid that walks the rows.  A kernel of its own: the plain variant's 64-VGPR budget
 // does not survive a row loop around its body (58 VGPRs spilled even for a loop of one trip, 1 800 with the body in a function).
 template <int NV>
-__global__ __launch_bounds__(256, 4) void ln_fwd_stream_kernel(LnFwd p) {
+__global__ __launch_bounds__(256, NV <= 8 ? 4 : 2) void ln_fwd_stream_kernel(LnFwd p) {
   const unsigned dkey = p.drop.thr ? drop_site_key(p.drop.seed, p.drop.seed_ptr, p.drop.site) : 0u;
   const int lane = threadIdx.x & 63;
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < p.R; row += gridDim.x * 4) {
+  for (int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); row < p.R; row += gridDim.x * 4) {
   const int D = p.D, nch = D >> 2;
   bool second = p.x2 && row >= p.R0;
   long xrow = second ? row - p.R0 : row;

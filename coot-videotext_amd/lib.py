@@ -75,7 +75,7 @@ class PackedSeqs(C.Structure):
 
 
 class StepBuffers(C.Structure):
-    _fields_ = [(n, C.c_void_p * 4) for n in ("params", "grads", "wpack", "adam_m", "adam_v", "decay_mask", "pe")]
+    _fields_ = [(n, C.c_void_p * 4) for n in ("params", "grads", "wpack", "adam_m", "adam_v", "decay_mask", "pe", "decay_block_all")]
 
 
 class StepBatch(C.Structure):

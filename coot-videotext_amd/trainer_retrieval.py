@@ -423,6 +423,14 @@ class RetrievalTrainer:
                     if wd_bias and "bias" in name:
                         mask[off:off + int(np.prod(shape))] = 0.0
                 st.decay.append(mask)
+            # one byte per 1 024 elements: "the mask is 1.0 on this whole block" — the update launch then skips the mask there
+            # (coot_step_buffers.decay_block_all; the mask is 0 only on bias vectors)
+            st.decay_all = []
+            for mask in st.decay:
+                nb = (mask.numel() + 1023) // 1024
+                pad = torch.ones(nb * 1024, dtype=mask.dtype, device=mask.device)
+                pad[:mask.numel()] = mask
+                st.decay_all.append((pad.view(nb, 1024).min(dim=1).values == 1.0).to(torch.uint8).contiguous())
             st.bufs = _lib.StepBuffers()
             st.losses = torch.zeros(3, dtype=torch.float32, device=dev)
             # text side: a LOW priority stream — it has slack, the video side is the critical path of the step
@@ -447,6 +455,7 @@ class RetrievalTrainer:
         for i, n in enumerate(nets):  # arenas move when a module is re-flattened (.cuda()/load): refresh every call
             st.bufs.params[i], st.bufs.grads[i], st.bufs.wpack[i] = n._flat.data_ptr(), n._grad_flat.data_ptr(), n._wpack.data_ptr()
             st.bufs.adam_m[i], st.bufs.adam_v[i], st.bufs.decay_mask[i] = st.m[i].data_ptr(), st.v[i].data_ptr(), st.decay[i].data_ptr()
+            st.bufs.decay_block_all[i] = st.decay_all[i].data_ptr()
             st.bufs.pe[i] = n.embedding.pe.data_ptr()
         kept = getattr(self, "_next_desc", None)
         # this very object was announced as `next_batch` by the previous native step (COOT_STEP_STAGE_ANNOUNCED: only then may the step

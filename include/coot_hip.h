@@ -282,6 +282,11 @@ typedef struct coot_step_buffers {
   float* adam_m[4]; float* adam_v[4];                      /* Adam moments, same layout                            */
   const float* decay_mask[4];                              /* 1.0 / 0.0 per element (decay_mult), or NULL = all 1  */
   const float* pe[4];                                      /* embedding.pe tables                                  */
+  const uint8_t* decay_block_all[4];                       /* optional, one byte per 1 024 consecutive elements of the arena
+                                                              (the last block may be partial): non-zero = decay_mask is 1.0 on
+                                                              the whole block — the update then does not read the mask there
+                                                              (the mask is 0 on the bias vectors only: > 99 % of the blocks;
+                                                              30 MB of the step's HBM reads).  NULL = read the mask everywhere */
 } coot_step_buffers;
 typedef struct coot_step_batch {                           /* RetrievalDataBatchTuple (coot/dataset_retrieval.py:64-102) */
   const float *vid_feat, *clip_feat, *par_feat, *sent_feat;
