@@ -218,6 +218,7 @@ def main():
     vid_counts = [w["B"]] * world
     clip_pairs = sum(clip_counts)
 
+    la_on = [False]
     if args.eval:
         mgr.set_all_models_eval()
 
@@ -247,6 +248,7 @@ def main():
                 other = cva.synthetic.make_batch(9234 + rank, w["B"], w["C"], w["Lv"], w["Lc"], w["Lp"], w["Ls"], w["Dv"], w["Dt"], ragged=False)
             other.global_max_synced = True
             pair, turn = (batch, other), [0]
+        la_on = [lookahead]  # (the roofline leg of hbm_stress also times the input LayerNorm launched the plain way)
 
         def step(graph=None):
             if mode in ("native", "native-graph") and graph is None:  # N > 1: native phases with the RCCL collectives between them
@@ -258,7 +260,7 @@ def main():
                     cur, nxt = pair[turn[0] & 1], pair[(turn[0] + 1) & 1]
                     turn[0] += 1
                     return trainer.train_step_native(cur, vid_counts=vid_counts, clip_counts=clip_counts, defer_join=not args.no_defer_join,
-                                                     next_batch=nxt if lookahead else None)[0]
+                                                     next_batch=nxt if la_on[0] else None)[0]
                 return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, defer_join=not args.no_defer_join,
                                                  use_graph=(mode == "native-graph"))[0]
             return trainer.train_step(batch, vid_counts, clip_counts, use_graph=(mode == "graph") if graph is None else graph)[0]
@@ -356,6 +358,21 @@ def main():
         allk, infc = collect(0), collect(1)
         inln = collect(7)  # input LayerNorm: "achieved" is TB/s here (the slot carries algorithmic bytes)
         lib.coot_timing_enable(0)
+        inln_plain = None
+        if args.workload == "hbm_stress" and not args.eval and la_on[0]:
+            # the same kernel launched the plain way (at the head of its own step, one workgroup per four rows, normal loads) next to the
+            # prefetched launch above (capped grid, streaming loads, beside the global networks): two different operating points of the
+            # HBM-roofline kernel of BASELINE.json configs[4], reported separately
+            la_on[0] = False
+            step()  # (this batch was still announced by the step before it: no LayerNorm launch here)
+            torch.cuda.synchronize()
+            lib.coot_timing_enable(1)
+            for _ in range(nst):
+                step()
+            torch.cuda.synchronize()
+            inln_plain = collect(7)
+            lib.coot_timing_enable(0)
+            la_on[0] = True
         dom = max(by, key=lambda k: by[k]["ms_per_step"])  # the kernel the step spends most MFMA time in
         # HBM bytes per launch of that family from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py)
@@ -395,7 +412,13 @@ def main():
                         "traffic": None, "launches_per_step": inln["launches_per_step"], "avg_launch_us": inln["avg_launch_us"],
                         "algorithmic_bytes_per_launch": int(inln["algorithmic_gflop_per_step"] * 1e9 / max(inln["launches_per_step"], 1)),
                         "note": "algorithmic bytes (fp32 features read once + bf16 normalised features written once) / HIP-event duration; "
-                                "mfma families under by_kernel", "by_kernel": by, "all_mfma_kernels": allk}
+                                "mfma families under by_kernel", "by_kernel": by, "all_mfma_kernels": allk,
+                        "launch": ("prefetched for the NEXT batch inside the step (ln_fwd_stream_kernel: 512 workgroups, streaming loads / stores, beside "
+                                   "the global networks)" if la_on[0] else "plain (ln_fwd_kernel at the head of the step)")}
+            if inln_plain is not None and inln_plain["launches_per_step"]:
+                roofline["plain_launch"] = {"kernel": "ln_fwd_kernel at the head of its own step (--no-lookahead operating point)",
+                                            "achieved": round(inln_plain["achieved"] * 1e3, 1), "unit": "GB/s", "frac": round(inln_plain["achieved"] / 8.0, 4),
+                                            "avg_launch_us": inln_plain["avg_launch_us"], "launches_per_step": inln_plain["launches_per_step"]}
     if dp is not None:
         torch.distributed.barrier()
 
