@@ -107,7 +107,11 @@ struct Hops {
   hipEvent_t ev[N]; bool made = false;
   int init() {
     if (made) return 0;
-    for (int i = 0; i < N; ++i) RUN(check_hip(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "hipEventCreate"));
+    // hipEventDisableSystemFence: by default every hipEventRecord performs a SYSTEM-scope release — an L2 writeback / invalidation
+    // that makes device memory visible to the host.  These events only order streams of one device (kernel boundaries already release
+    // at device scope), and the fences evicted what the latency-bound global passes keep in L2: step 1.207 -> 1.201 ms
+    // (profiles/r04_ab_event_fence.txt)
+    for (int i = 0; i < N; ++i) RUN(check_hip(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate"));
     made = true; return 0;
   }
   // everything enqueued on `to` after this call runs after everything enqueued on `from` before it
@@ -179,7 +183,7 @@ struct InputPipe {
   int init() {
     if (stream) return 0;
     RUN(check_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate"));
-    return check_hip(hipEventCreateWithFlags(&done, hipEventDisableTiming), "hipEventCreate");
+    return check_hip(hipEventCreateWithFlags(&done, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate");
   }
 };
 thread_local InputPipe g_pipe;
@@ -727,6 +731,43 @@ int coot_step_set_next_batch(const coot_step_batch* next, const coot_step_dims* 
   return 0;
 }
 int coot_step_set_global_done_events(void* ev_video, void* ev_text) { g_glob_done[0] = ev_video; g_glob_done[1] = ev_text; return 0; }
+
+// caller-visible fence-free events (include/coot_hip.h: COOT_SYNC_EVENTS) + a ring for coot_stream_hop
+namespace {
+struct SyncEvents {
+  static constexpr int RING = 16;
+  hipEvent_t ev[COOT_SYNC_EVENTS + RING]; bool made = false; int next = 0;
+  int init() {
+    if (made) return 0;
+    for (int i = 0; i < COOT_SYNC_EVENTS + RING; ++i)
+      RUN(check_hip(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate"));
+    made = true; return 0;
+  }
+};
+thread_local SyncEvents g_sync;
+}  // namespace
+int coot_event_record(int slot, coot_stream_t stream) {
+  COOT_REQUIRE(slot >= 0 && slot < COOT_SYNC_EVENTS, "event_record: slot %d", slot);
+  RUN(g_sync.init());
+  return check_hip(hipEventRecord(g_sync.ev[slot], (hipStream_t)stream), "eventRecord");
+}
+int coot_event_wait(int slot, coot_stream_t stream) {
+  COOT_REQUIRE(slot >= 0 && slot < COOT_SYNC_EVENTS, "event_wait: slot %d", slot);
+  RUN(g_sync.init());
+  return check_hip(hipStreamWaitEvent((hipStream_t)stream, g_sync.ev[slot], 0), "streamWait");
+}
+void* coot_event_handle(int slot) {
+  if (slot < 0 || slot >= COOT_SYNC_EVENTS || g_sync.init()) return nullptr;
+  return (void*)g_sync.ev[slot];
+}
+int coot_stream_hop(coot_stream_t from, coot_stream_t to) {
+  if (from == to) return 0;
+  RUN(g_sync.init());
+  hipEvent_t e = g_sync.ev[COOT_SYNC_EVENTS + g_sync.next];
+  g_sync.next = (g_sync.next + 1) % SyncEvents::RING;  // (a waiter captures the record it was enqueued behind: re-recording later is safe)
+  RUN(check_hip(hipEventRecord(e, (hipStream_t)from), "eventRecord"));
+  return check_hip(hipStreamWaitEvent((hipStream_t)to, e, 0), "streamWait");
+}
 void coot_step_grad_write(int on) { g_grad_write = on ? 1 : 0; }
 
 // text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.

@@ -23,7 +23,7 @@ EXPORTS = [
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_tn_xcd_map", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
     "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_step_input_stage_bytes", "coot_step_set_input_stages", "coot_step_set_next_batch", "coot_contrastive_fwd_bwd_dp", "coot_contrastive_fwd_bwd_dp_blocks", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
-    "coot_det_shadow_bytes", "coot_det_configure", "coot_det_flush",
+    "coot_det_shadow_bytes", "coot_det_configure", "coot_det_flush", "coot_event_record", "coot_event_wait", "coot_event_handle", "coot_stream_hop",
 ]
 
 
@@ -140,6 +140,11 @@ def load():
     lib.coot_det_shadow_bytes.argtypes = [i32, C.POINTER(sz)]
     lib.coot_det_configure.argtypes = [i32, C.POINTER(vp), C.POINTER(sz), vp, sz, vp]
     lib.coot_det_flush.argtypes = [vp, sz, vp]
+    lib.coot_event_record.argtypes = [i32, vp]
+    lib.coot_event_wait.argtypes = [i32, vp]
+    lib.coot_event_handle.restype = vp
+    lib.coot_event_handle.argtypes = [i32]
+    lib.coot_stream_hop.argtypes = [vp, vp]
     lib.coot_gemm_nt.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp, i64, i32, vp]
     lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, sz, vp]
     lib.coot_gemm_tn_batch.argtypes = [C.POINTER(TnProblem), i32, vp, sz, vp, vp]

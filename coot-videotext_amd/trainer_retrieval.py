@@ -915,10 +915,9 @@ class RetrievalTrainer:
             st.cc_word = st.gall[off + 2:off + 3]
             st.g_loc_v = st.gall[cuts[0]:off + 3]  # video local network + the loss words
             st.comm = torch.cuda.Stream()
-            st.ev_glob = (torch.cuda.Event(), torch.cuda.Event())
-            st.ev_text = torch.cuda.Event()
-            for e in st.ev_glob:
-                e.record()  # creates the underlying hipEvent
+            # stream ordering through the library's fence-free events (include/coot_hip.h: coot_event_* / coot_stream_hop): a default event
+            # — torch.cuda.Event, wait_stream — performs a system-scope L2 writeback / invalidation at every record
+            st.EV_GLOB_V, st.EV_GLOB_T, st.EV_TEXT = 0, 1, 2
         local_v, local_t, glob_v, glob_t, resh_v, resh_t = st.emb
         d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t = st.demb
         main = torch.cuda.current_stream()
@@ -938,7 +937,8 @@ class RetrievalTrainer:
         # reads these buffers) and behind the previous step's work on the main stream (the video networks' update, the gradient buckets'
         # reduction).  The video side's forward on the main stream touches none of it and starts at once; everything that accumulates into
         # the zeroed buffers (losses, backward) is ordered after both sides' forward, i.e. after this launch.
-        stt.wait_stream(main)
+        hop = lambda a, b: _lib.check(lib.coot_stream_hop(a.cuda_stream, b.cuda_stream), "coot_stream_hop")
+        hop(main, stt)
         _lib.check(lib.coot_nets_zero_grads_ex(4, za[0], za[1], 1, za[2], za[3], 2, stt.cuda_stream), "coot_nets_zero_grads_ex")
         ws, wsn = st.ws.data_ptr(), st.ws.numel()
         fresh = _lib.FWD_PACKS_FRESH if all(n.pack_is_fresh() for n in st.nets) else 0
@@ -951,7 +951,7 @@ class RetrievalTrainer:
         # cycle-consistency (per video, no exchange) on the text stream, next to the gathers and the contrastive loss on the main stream
         use_cc = st.cfg.cc_weight != 0.0
         if use_cc:
-            stt.wait_stream(main)  # main is ordered after both sides' forward and the zero fills
+            hop(main, stt)  # main is ordered after both sides' forward and the zero fills
             with torch.cuda.stream(stt):
                 if cc_indices is not None:  # a given draw ([2B] int64: this rank's clip positions, then its sentence positions)
                     st.cyc_idx.copy_(cc_indices)
@@ -984,8 +984,8 @@ class RetrievalTrainer:
                                                        C.byref(st.down), v0, B, c0, Nc, st.loss_scratch.data_ptr(), st.loss_scratch.numel(), sp),
                        "coot_contrastive_fwd_bwd_dp")
         if use_cc:
-            main.wait_stream(stt)  # the backward reads d_resh / the cycle-consistency word
-        lib.coot_step_set_global_done_events(st.ev_glob[0].cuda_event, st.ev_glob[1].cuda_event)
+            hop(stt, main)  # the backward reads d_resh / the cycle-consistency word
+        lib.coot_step_set_global_done_events(lib.coot_event_handle(st.EV_GLOB_V), lib.coot_event_handle(st.EV_GLOB_T))
         lib.coot_net_grads_overwrite(1)
         try:
             self._dp_backward(lib, st, x, d, local_v, local_t, resh_v, resh_t, d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t, use_cc,
@@ -1002,7 +1002,7 @@ class RetrievalTrainer:
                                           resh_v.data_ptr(), resh_t.data_ptr(), d_local_v.data_ptr(), d_local_t.data_ptr(), d_glob_v.data_ptr(),
                                           d_glob_t.data_ptr(), d_resh_v.data_ptr() if use_cc else None, d_resh_t.data_ptr() if use_cc else None,
                                           ws, wsn, train, int(seed), main.cuda_stream, sv.cuda_stream, stt.cuda_stream), "coot_step_backward")
-        st.ev_text.record(stt)  # the text side's backward is the last thing on its stream: its local gradients are final from here
+        _lib.check(lib.coot_event_record(st.EV_TEXT, stt.cuda_stream), "coot_event_record")  # the text side's backward is the last thing on its stream
 
     def _dp_finish(self, lib, dp, st, main, sv, stt, do_optimizer, defer_join=False):
         # gradient all-reduce in the order the backward produces its results (every rank issues the three collectives in this order):
@@ -1013,13 +1013,14 @@ class RetrievalTrainer:
         #   3. the video local network + the loss words behind the pass on the main stream — the only exposed bucket.
         lib.coot_step_set_global_done_events(None, None)  # the events belong to this trainer: no other step may record them
         self._det_flush([st.losses])  # (deterministic mode: the cycle-consistency word's fixed-point sum, behind the backward on main)
-        st.comm.wait_event(st.ev_glob[0]); st.comm.wait_event(st.ev_glob[1])
+        for slot in (st.EV_GLOB_V, st.EV_GLOB_T):
+            _lib.check(lib.coot_event_wait(slot, st.comm.cuda_stream), "coot_event_wait")
         with torch.cuda.stream(st.comm):
             dp.all_reduce_sum(st.g_glob)
-            st.comm.wait_event(st.ev_text)
+            _lib.check(lib.coot_event_wait(st.EV_TEXT, st.comm.cuda_stream), "coot_event_wait")
             dp.all_reduce_sum(st.g_loc_t)
         dp.all_reduce_sum(st.g_loc_v)
-        main.wait_stream(st.comm)
+        _lib.check(lib.coot_stream_hop(st.comm.cuda_stream, main.cuda_stream), "coot_stream_hop")
         if do_optimizer:  # (the video side's update launch also writes total = contrastive + cycle-consistency)
             flags = _lib.UPDATE_REPACK | (_lib.UPDATE_DEFER_TEXT_JOIN if defer_join else 0)
             _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), flags, st.losses.data_ptr(), main.cuda_stream,

@@ -352,6 +352,18 @@ int coot_step_set_device_state(void* state);
  * stream can wait on the events and reduce them while the local backward (two thirds of the pass) still runs.  Thread-local,
  * stays set until changed. */
 int coot_step_set_global_done_events(void* ev_video, void* ev_text);
+/* Stream ordering without system-scope fences.  A default HIP event (what hipEventCreate, torch.cuda.Event and torch's wait_stream
+ * use) performs a system-scope release at every record: an L2 writeback / invalidation that makes device memory visible to the host and
+ * other devices — and evicts what the step's latency-bound kernels keep in L2.  Ordering two streams of ONE device needs none of it.
+ * The library owns COOT_SYNC_EVENTS events created with hipEventDisableTiming | hipEventDisableSystemFence: coot_event_record /
+ * coot_event_wait (slot 0 .. COOT_SYNC_EVENTS - 1; coot_event_handle returns the hipEvent_t, e.g. for
+ * coot_step_set_global_done_events), coot_stream_hop = everything enqueued on `to` afterwards runs behind everything enqueued on `from`
+ * before (internal event ring).  Thread-local, like the streams' owner. */
+#define COOT_SYNC_EVENTS 8
+int coot_event_record(int slot, coot_stream_t stream);
+int coot_event_wait(int slot, coot_stream_t stream);
+void* coot_event_handle(int slot);
+int coot_stream_hop(coot_stream_t from, coot_stream_t to);
 /* Optimizer update of the four networks after the gradient all-reduce (cfg->optimizer; `step` 1-based): one launch per side on
  * side_v / side_t.  repack: bit mask — COOT_UPDATE_REPACK: the bf16 weight packs are rebuilt so that the next coot_step_forward may skip
  * the packing; COOT_UPDATE_DEFER_TEXT_JOIN: on return main_s is ordered after the VIDEO side only (as COOT_STEP_DEFER_TEXT_JOIN: the
