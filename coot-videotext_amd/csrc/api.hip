@@ -648,6 +648,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "grad_write")) { coot_step_grad_write(value); return 0; }
   if (!strcmp(name, "cl_col_split")) { set_cl_col_split(value); return 0; }
+  if (!strcmp(name, "cl_small")) { set_cl_small(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   set_error("unknown option %s", name);

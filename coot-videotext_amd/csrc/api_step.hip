@@ -602,7 +602,6 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   }
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
-  const bool split_loss = sv != st;  // (the text stream has ~90 us of slack there: +0.2 % on the step, A/B in round 2)
   const bool piped = (do_optimizer & COOT_STEP_INPUT_STAGES) != 0;
   StageScope stage_scope;
   PipeStep ps;
@@ -613,7 +612,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   if (piped) coot_internal_set_input_stage(SL.xv, SL.pv, hit ? 2 : 0);
   RUN(side_forward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
                    W.local_v, W.glob_v, W.resh_v, W.mask_v, W.lens_v, W.saved_lv, W.sz_lv, W.saved_gv, W.sz_gv, train, seed, sv, pack_first, &pk.v,
-                   (split_loss || prefetch) ? 9 : -1));
+                   prefetch ? 9 : -1));
   if (piped) coot_internal_set_input_stage(SL.xt, SL.pt, hit ? 2 : 0);
   RUN(side_forward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d,
                    W.local_t, W.glob_t, W.resh_t, W.mask_t, W.lens_t, W.saved_lt, W.sz_lt, W.saved_gt, W.sz_gt, train, seed + 1000, st,
@@ -621,55 +620,65 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   coot_internal_set_input_stage(nullptr, nullptr, 0);
   // x^ of the next batch, behind both local forward passes (the chip's memory system is idle from there to the local backward)
   if (prefetch) RUN(pipe_prefetch(*cfg, *b, ps, W.local_v, W.local_t, W.saved_lv, W.saved_lt, train, seed));
-  // Zero the parameter gradients (4 arenas), the embedding gradients (one block) and the loss words at the END of the text
-  // forward: the text side shares the chip with the three times larger video side and, started at the same time, finishes its
-  // forward ~75 us earlier (HIP-event timeline), so the six fills are free there.  (At the head of the text stream they delayed
-  // its start by 70 us; behind the video forward they sat on the critical path.)  Everything that accumulates into these
-  // buffers is ordered after hop 2: the losses on the video stream, the text side through hop 6 / hop 3.
-  // (weight-matrix gradients are written, not accumulated, by this step's backward: only the vectors are zeroed — g_grad_write)
+  // ---- losses.  The text side's forward is the later one (it gets the CUs the three times larger video side leaves: global forward
+  // done at ~450 us against ~405 us, profiles/r04_step_timeline.txt) and the video side's backward the longer one (it ends ~200 us
+  // after the text side's).  So the video stream carries as little as possible between the text side's last forward launch and its own
+  // backward: the zero fill runs there BEFORE the join (in the gap the video side waits anyway), behind the join only the (vid, par)
+  // terms (64 rows).  Everything else — the cycle-consistency loss, the contrastive terms on the clip / sentence embeddings and on
+  // the context vectors — runs on the text stream next to the video side's global backward, which does not read their gradients
+  // (slot 7 is waited for where d_resh_v / d_local_v are first read: behind it).  (Until round 4 the fill and the local terms sat on
+  // the text stream in front of the join — a layout from when the text side finished first: join 26 us behind the text forward.)
+  //
+  // Zero fill (ONE launch): the vectors of the 4 gradient arenas (weight-matrix gradients are written, not accumulated, by this step's
+  // backward — g_grad_write), the embedding-gradient block and the loss words.  Their previous readers: the last step's backward,
+  // update and loss rider — on the video stream, or on the text stream BEFORE this step's local forward there (slot 10; also with a
+  // deferred text join).  Everything that accumulates into them is ordered behind this launch: the (vid, par) terms on this stream,
+  // the text stream's losses through slot 6, the text backward through slot 3.
+  // (without a next batch to prepare there is no record on the text stream behind its local forward, and adding one costs more than
+  // the fill: a marker in the middle of the forward's critical stream — profiles/README.md round 4; the fill then stays where it was,
+  // at the end of the text stream's forward)
+  const hipStream_t sz = prefetch ? sv : st;
+  if (prefetch) RUN(g_hops.wait(10, sv));
   {
     const coot_net_config* cfgs[4] = {&cfg->net[0], &cfg->net[1], &cfg->net[2], &cfg->net[3]};
-    float* extra[2] = {W.zero_begin, losses};  // + the embedding-gradient block and the loss words: ONE launch (was six fills)
+    float* extra[2] = {W.zero_begin, losses};
     const int64_t extra_n[2] = {(int64_t)(W.zero_bytes / sizeof(float)), 3};
-    RUN(coot_nets_zero_grads_ex(4, cfgs, b->grads, g_grad_write, extra, extra_n, 2, side_t));
+    RUN(coot_nets_zero_grads_ex(4, cfgs, b->grads, g_grad_write, extra, extra_n, 2, (coot_stream_t)sz));
   }
-  g_stamps.mark("text: gradients zeroed", st);
-  RUN(g_hops.hop(2, st, sv));
-  g_stamps.mark("video: text forward joined", sv);
+  g_stamps.mark(prefetch ? "video: gradients zeroed" : "text: gradients zeroed", sz);
+  // slot 6: the video side's embeddings exist (and, recorded behind the fill, every word the text stream's losses add to is zero)
+  RUN(g_hops.record(6, sv));
   const bool cc = cfg->cc_weight != 0.f;
-  // The contrastive terms on the clip / sentence embeddings and on the context vectors need the LOCAL networks only: they run
-  // here on the text stream (whose forward finishes ~90 us before the video side's: the device is nearly idle while the video
-  // side's global network runs) instead of behind the video side's global forward — only the (vid, par) terms, 64 rows, stay
-  // on the critical path.  coot_set_option("split_loss", 0): the whole loss behind the join (A/B).
-  if (split_loss) {
-    RUN(g_hops.wait(9, st));  // the video side's local embeddings
-    RUN(coot_contrastive_fwd_bwd_part(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
-                                      W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
-                                      W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
-                                      W.sz_loss, COOT_CONTRASTIVE_LOCAL, side_t));
-    g_stamps.mark("text: local contrastive terms done", st);
-    if (!cc) RUN(g_hops.record(7, st));  // the video side's backward waits for these gradients (with cc: behind the cycle-consistency loss)
-  }
-  if (cc) {  // cycle-consistency -> losses[2] on the text stream, next to the contrastive loss on the video stream
-    RUN(g_hops.hop(6, sv, st));
+  RUN(g_hops.record(2, st));  // the text side's forward is done
+  RUN(g_hops.wait(6, st));
+  if (cc) {  // cycle-consistency -> losses[2]
     RUN(draw_cycle_indices(*x, *d, seed, W.idx, st));
     RUN(coot_cyclecons_fwd_bwd(W.resh_v, W.resh_t, x->clip_num, x->sent_num, (const int64_t*)W.idx, (const int64_t*)(W.idx + d->B), d->B,
                                d->Cmax_clip, d->Cmax_sent, D, cfg->cc_weight, 1.0f / (float)d->B, losses + 2, nullptr, nullptr, W.d_resh_v,
                                W.d_resh_t, side_t));
-    RUN(g_hops.record(7, st));
     g_stamps.mark("text: cycle-consistency done", st);
   }
-  // contrastive loss on the video stream -> losses[1]
+  // (clip, sent) and (vid_ctx, par_ctx) terms -> losses[1] (added atomically next to the (vid, par) terms'; in deterministic mode
+  // through the fixed-point shadow: any order gives the same bits)
   RUN(coot_contrastive_fwd_bwd_part(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
                                     W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
                                     W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
-                                    W.sz_loss, split_loss ? COOT_CONTRASTIVE_GLOBAL : (COOT_CONTRASTIVE_GLOBAL | COOT_CONTRASTIVE_LOCAL), side_v));
+                                    W.sz_loss, COOT_CONTRASTIVE_LOCAL, side_t));
+  g_stamps.mark("text: local contrastive terms done", st);
+  RUN(g_hops.record(7, st));
+  RUN(g_hops.wait(2, sv));
+  g_stamps.mark("video: text forward joined", sv);
+  // (vid, par) terms -> losses[1]
+  RUN(coot_contrastive_fwd_bwd_part(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
+                                    W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
+                                    W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
+                                    W.sz_loss, COOT_CONTRASTIVE_GLOBAL, side_v));
   g_stamps.mark("video: contrastive done", sv);
-  RUN(g_hops.hop(3, sv, st));  // text backward needs the contrastive gradients
+  RUN(g_hops.hop(3, sv, st));  // text backward needs the (vid, par) gradients
   const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
-  // what the text stream produced for the video side's backward (cycle-consistency gradients d_resh_v, the local contrastive
-  // terms' gradients) was recorded in slot 7; side_backward waits where it is first read
-  g_resh_wait_slot = (cc || split_loss) ? 7 : -1;
+  // what the text stream produced for the video side's backward (the cycle-consistency gradient d_resh_v, the local contrastive
+  // terms' gradients d_local_v) was recorded in slot 7; side_backward waits where it is first read
+  g_resh_wait_slot = 7;
   (void)coot_net_grads_overwrite(g_grad_write);
   if (piped) coot_internal_set_input_stage(SL.xv, SL.pv, 0);  // the weight gradient of the input FC reads x^ there
   const int rc_v = side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,

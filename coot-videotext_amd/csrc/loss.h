@@ -28,6 +28,7 @@ int launch_cyclecons(const CycleArgs& a, hipStream_t st);
 // alignment / cluster weight of pair p (high, low, context); w_self already carries the 1/2 of compute_cluster_loss.
 size_t contrastive_fused_scratch_bytes(int n_high, int n_low, int d_high, int d_low);
 void set_cl_col_split(int k);  // 0: column splits of a strip by batch size; k >= 1: forced (set BEFORE sizing the scratch)
+void set_cl_small(int on);     // 0: sets that fit the LDS take the three-launch path too (default 1: cl_small_kernel + cl_finish)
 // ldv (optional): row strides of the six input sets (default dense).  window (optional) = {high row0, high rows, low row0, low
 // rows}: only these rows of the per-video sets (0, 1, 4, 5) / per-clip sets (2, 3) receive gradients, dv[] are compact
 // [rows, d] arrays (data parallel: the loss is over the gathered batch, a rank keeps the rows of its own videos).

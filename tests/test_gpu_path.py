@@ -930,6 +930,48 @@ def test_contrastive_parts_add_up(env):
         assert torch.equal(a, b), n
 
 
+@pytest.mark.parametrize("n,d", [(64, 768), (50, 768), (7, 32), (100, 384), (128, 384), (33, 1024)])
+def test_contrastive_small_sets_one_launch_equals_three(env, n, d):
+    """Sets that fit the LDS take cl_small_kernel (row normalisation + both MFMA products of a half-term in one launch, operands in
+    LDS) in front of cl_finish instead of cl_norm + cl_half: the same arithmetic in the same order — loss word and gradients are
+    bit-identical to the three-launch path's (coot_set_option("cl_small", 0)), with ragged row counts and with the cluster terms
+    on and off."""
+    import ctypes as C
+    torch, cva = env
+    lib = cva.lib.load()
+    rs = np.random.RandomState(n * 1000 + d)
+    shared = rs.randn(1, d)
+    a = shared + 0.6 * rs.randn(n, d)
+    ts = [torch.from_numpy(e).float().cuda() for e in (a, a + 0.9 * rs.randn(n, d))]
+    low = [torch.zeros(16, 32, device="cuda") for _ in range(4)]  # the other pairs: not part of the call (mask 1)
+    scratch = torch.empty(lib.coot_contrastive_scratch_bytes(n, 16, d, 32), dtype=torch.uint8, device="cuda")
+    for w_self in (1.0, 0.0):
+        cfg = cva.lib.ContrastiveConfig(0.2, 1.0, w_self, 1.0, 1.0, 1.0, 0.5)
+        out = []
+        for small in (1, 0):
+            lib.coot_set_option(b"cl_small", small)
+            try:
+                loss = torch.zeros(1, device="cuda")
+                grads = [torch.zeros_like(t) for t in ts + low]
+                cva.lib.check(lib.coot_contrastive_fwd_bwd_part(C.byref(cfg), n, 16, d, 32, *[t.data_ptr() for t in ts + low], loss.data_ptr(),
+                                                                *[g.data_ptr() for g in grads], scratch.data_ptr(), scratch.numel(), 1,
+                                                                torch.cuda.current_stream().cuda_stream), "contrastive_part")
+                torch.cuda.synchronize()
+                out.append((float(loss), grads))
+            finally:
+                lib.coot_set_option(b"cl_small", 1)
+        (l1, g1), (l0, g0) = out
+        print(f"n={n} d={d} cluster terms {w_self}: loss {l1:.7f} (one launch) {l0:.7f} (three)")
+        assert l1 > 0 and float(g1[0].abs().max()) > 0
+        assert l1 == l0
+        for k, (x, y) in enumerate(zip(g1[:2], g0[:2])):
+            if not torch.equal(x, y):
+                bad = (x != y)
+                rows = bad.any(dim=1).nonzero().flatten().tolist()
+                print(f"set {k}: {int(bad.sum())} elements differ in rows {rows[:40]}, max |diff| {float((x - y).abs().max()):.3e} of {float(y.abs().max()):.3e}")
+            assert torch.equal(x, y)
+
+
 def test_deferred_text_join_gives_the_same_training_trajectory(env):
     """train_step_native(defer_join=True) (COOT_STEP_DEFER_TEXT_JOIN: the text side's update tail overlaps the next step's forward)
     is a re-ordering only: after the same steps the parameters of all four networks equal the joined run's, and join_streams() makes
