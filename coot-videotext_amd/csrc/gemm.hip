@@ -1184,8 +1184,14 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_reduce_kernel(TnBatch b, co
     const int z = (int)(e / per);
     const long r = e % per;
     const int m = (int)(r / g.No), n = (int)(r % g.No);
+    // all partials of the element first (<= 8 splits, tn_batch_flush; a split past the last re-reads it), then the sum in split order:
+    // one load at a time per thread left this launch at a third of the memory system's rate
+    f32x4_t part[8];
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp) part[sp] = *reinterpret_cast<const f32x4_t*>(ws + ((long)min(sp, it.splits - 1) * g.groups + z) * per + r);
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < it.splits; ++sp) s += *reinterpret_cast<const f32x4_t*>(ws + ((long)sp * g.groups + z) * per + r);
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp) if (sp < it.splits) s += part[sp];
     float* c = g.C + z * g.zC + (long)m * g.ldc + n;
     if (g.overwrite) { c[0] = s[0] * g.alpha; c[1] = s[1] * g.alpha; c[2] = s[2] * g.alpha; c[3] = s[3] * g.alpha; }
     else { c[0] += s[0] * g.alpha; c[1] += s[1] * g.alpha; c[2] += s[2] * g.alpha; c[3] += s[3] * g.alpha; }
