@@ -103,7 +103,7 @@ int check_cfg(const coot_step_config& c) {
 // video side on ONE stream from its first launch to its Adam update: the caller may pass side_v == main (hops between equal streams
 // vanish), the losses run on the video stream, and waits sit where the data is first read.
 struct Hops {
-  static constexpr int N = 12;
+  static constexpr int N = 16;
   hipEvent_t ev[N]; bool made = false;
   int init() {
     if (made) return 0;
@@ -132,6 +132,17 @@ thread_local const uint64_t* g_step_seed_dev = nullptr;  // device base seed of 
 thread_local int g_resh_wait_slot = -1;  // hop slot the video side waits on before it reads d_resh (coot_train_step), -1: none
 thread_local void* g_glob_done[2] = {nullptr, nullptr};  // optional caller events: video / text global backward done
 
+// Early update of the global networks (coot_train_step): their gradients are final behind the global backward, a whole local backward
+// before the step's end — Adam + weight pack of that network run on the internal stream under the local backward instead of at the
+// tail of the side's stream (the video side's tail is the end of the step's critical path).  side_backward fires it; slots 11 / 12
+// (global backward done), 13 / 14 (update done) per side.  Per side, and only when its local network has kEarlyMinTokens rows or
+// more: the two hops and two launches on a third stream take ~60 us, which a long local backward hides (ActivityNet shape 1.192 ->
+// 1.184 ms, yc2_2d3d 1.344 -> 1.333) and a short one does not (yc2_100m, 3 840 / 3 072 rows: 0.734 -> 0.751 ms with it);
+// profiles/r04_ab_early_update.txt.
+constexpr long kEarlyMinTokens = 8192;
+struct EarlyUpdate { bool on[2] = {false, false}; const coot_step_config* cfg = nullptr; const coot_step_buffers* b = nullptr; int64_t step = 0; bool repack = false; };
+thread_local EarlyUpdate g_early;
+int early_update_fire(int side, int gi, hipStream_t st);  // below (needs adam_nets)
 int g_grad_write = 1;  // coot_set_option("grad_write", 0/1): coot_train_step writes the weight-matrix gradients and zeroes only the rest
 // bf16 weight packs of `count` networks in one launch
 int pack_nets(const coot_step_config& c, const coot_step_buffers& b, const int* nets, int count, void* stream) {
@@ -292,6 +303,7 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
     if (det_on()) RUN(det_flush_range(b.grads[gi], (size_t)coot_net_param_numel(&c.net[gi]) * sizeof(float), st));  // (their fixed-point sums first)
     RUN(check_hip(hipEventRecord((hipEvent_t)g_glob_done[side], st), "eventRecord"));
   }
+  if (g_early.on[side]) RUN(early_update_fire(side, gi, st));
   // the cycle-consistency gradients come from the other stream; they are first needed HERE, a whole global backward after the
   // contrastive loss — waiting only now keeps the cross-stream hop off the critical path
   if (g_resh_wait_slot >= 0 && li == 0) RUN(g_hops.wait(g_resh_wait_slot, st));
@@ -454,6 +466,15 @@ int draw_cycle_indices(const coot_step_batch& x, const coot_step_dims& d, uint64
                      d.B, (unsigned long long)seed, idx, (const unsigned long long*)g_step_seed_dev);
   COOT_CHECK_LAUNCH("sample_idx");
   return 0;
+}
+
+int early_update_fire(int side, int gi, hipStream_t st) {
+  RUN(g_pipe.init());
+  RUN(g_hops.hop(11 + side, st, g_pipe.stream));
+  const int nets[1] = {gi};
+  RUN(adam_nets(*g_early.cfg, *g_early.b, nets, 1, g_early.step, g_pipe.stream));
+  if (g_early.repack) RUN(pack_nets(*g_early.cfg, *g_early.b, nets, 1, g_pipe.stream));
+  return g_hops.record(13 + side, g_pipe.stream);
 }
 
 }  // namespace
@@ -679,6 +700,12 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   // what the text stream produced for the video side's backward (the cycle-consistency gradient d_resh_v, the local contrastive
   // terms' gradients d_local_v) was recorded in slot 7; side_backward waits where it is first read
   g_resh_wait_slot = 7;
+  // (not in deterministic mode: the fixed-point sums of an arena are flushed at the end of its side's backward; not in a captured step)
+  const bool early = optimize && !det_on() && !g_state_dev;
+  const bool early_v = early && (long)d->B * d->Lv + (long)d->Nc * d->Lc >= kEarlyMinTokens;
+  const bool early_t = early && (long)d->B * d->Lp + (long)d->Nc * d->Ls >= kEarlyMinTokens;
+  struct EarlyScope { ~EarlyScope() { g_early = EarlyUpdate{}; } } early_scope;
+  g_early.on[0] = early_v; g_early.on[1] = early_t; g_early.cfg = cfg; g_early.b = b; g_early.step = step; g_early.repack = repack;
   (void)coot_net_grads_overwrite(g_grad_write);
   if (piped) coot_internal_set_input_stage(SL.xv, SL.pv, 0);  // the weight gradient of the input FC reads x^ there
   const int rc_v = side_backward(*cfg, *b, 0, 1, x->vid_feat, x->vid_len, d->Lv, x->clip_feat, x->clip_len, d->Lc, x->clip_num, d->Cmax_clip, *d,
@@ -691,12 +718,13 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   // waited for the text stream's loss terms, slot 7), and with COOT_STEP_DEFER_TEXT_JOIN the caller's stream is ordered after the video
   // side only — all three loss words are readable there on return (on the text side's launch, losses[0] raced with a deferred join)
   if (det_on()) RUN(det_flush_range(losses, 3 * sizeof(float), sv));  // (the cycle-consistency word: 2 B addends, det.h)
-  if (optimize) RUN(adam_nets(*cfg, *b, vnets, 2, step, sv, losses));
+  if (optimize) RUN(adam_nets(*cfg, *b, vnets, early_v ? 1 : 2, step, sv, losses));  // (early: the global network is being updated already)
   else {
     hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, sv, losses);
     COOT_CHECK_LAUNCH("loss_total");
   }
-  if (repack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
+  if (repack) RUN(pack_nets(*cfg, *b, vnets, early_v ? 1 : 2, side_v));
+  if (early_v) RUN(g_hops.wait(13, sv));
   g_stamps.mark("video: updated", sv);
   if (piped) coot_internal_set_input_stage(SL.xt, SL.pt, 0);
   const int rc_t = side_backward(*cfg, *b, 2, 3, x->par_feat, x->par_len, d->Lp, x->sent_feat, x->sent_len, d->Ls, x->sent_num, d->Cmax_sent, *d, W.local_t,
@@ -705,8 +733,9 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   (void)coot_net_grads_overwrite(0);
   coot_internal_set_input_stage(nullptr, nullptr, 0);
   RUN(rc_t);
-  if (optimize) RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
-  if (repack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
+  if (optimize) RUN(adam_nets(*cfg, *b, tnets, early_t ? 1 : 2, step, st));
+  if (repack) RUN(pack_nets(*cfg, *b, tnets, early_t ? 1 : 2, side_t));
+  if (early_t) RUN(g_hops.wait(14, st));
   g_stamps.mark("text: updated", st);
   RUN(g_hops.hop(4, sv, sm));
   if ((do_optimizer & COOT_STEP_DEFER_TEXT_JOIN) == 0) RUN(g_hops.hop(5, st, sm));  // else: the caller (or the next step's text side) orders it
