@@ -184,7 +184,9 @@ int coot_contrastive_fwd_bwd(const coot_contrastive_config* cfg, int n_high, int
  * the global networks (trainer_retrieval.py:168-171); COOT_CONTRASTIVE_LOCAL = the terms on (clip_emb, sent_emb) and
  * (vid_ctx, par_ctx) (:172-182), which need the local networks only.  Two calls with the two parts on the same scratch buffer
  * add up to the full call (disjoint scratch regions and gradient outputs, *loss added atomically) and may run on different
- * streams: coot_train_step computes the local part on the text stream while the video side's global network still runs. */
+ * streams: coot_train_step computes the local part on the text stream next to the video side's global backward (which does not
+ * read its gradients).  A part whose sets all fit the LDS (<= 128 rows, (rows + 16) (d + 8) bf16 <= 150 KB: the global part at the
+ * paper shapes) takes two launches instead of three, with bit-identical results (coot_set_option("cl_small", 0): three). */
 #define COOT_CONTRASTIVE_GLOBAL 1
 #define COOT_CONTRASTIVE_LOCAL 2
 int coot_contrastive_fwd_bwd_part(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low,
@@ -299,7 +301,11 @@ size_t coot_step_workspace_bytes(const coot_step_config* cfg, const coot_step_di
  * cycle-consistency losses (cycle indices drawn on the device), backward, Adam (`step` is the 1-based step count for the
  * bias correction).  losses[3] = {total, contrastive, cycle-consistency} (device, overwritten).
  * do_optimizer: bit mask of COOT_STEP_*.  side_v may be the same stream as main_s (recommended: the heavier video side then
- * runs without any cross-stream hop); side_t must differ from side_v.  On return main_s is ordered after both sides. */
+ * runs without any cross-stream hop); side_t must differ from side_v.  On return main_s is ordered after both sides.
+ * The call also uses one internal stream of the calling thread (created on first use): for the next batch's input LayerNorm
+ * (COOT_STEP_INPUT_STAGES) and for the update of the GLOBAL networks, which starts behind their backward and runs next to the local
+ * backward (sides whose local network has >= 8192 rows; not in deterministic mode, not in a captured step); side_v / side_t are
+ * ordered after it before the call's last launches, so the ordering guarantees above hold unchanged. */
 #define COOT_STEP_OPTIMIZER 1   /* Adam update of all four networks                                                          */
 #define COOT_STEP_REPACK 2      /* rebuild the bf16 weight packs right after the update (off the next step's critical path)  */
 #define COOT_STEP_PACKS_FRESH 4 /* wpack[] is current (previous step ran with REPACK and nothing else touched the parameters):
