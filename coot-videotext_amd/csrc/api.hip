@@ -1273,8 +1273,8 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     { GemmTN t; t.A = dz; t.lda = D; t.B = S.xhat; t.ldb = Din; t.T = T; t.Mo = D; t.No = Din; t.C = X.Mbuf; t.ldc = Din;
       t.overwrite = 1;  // M = dh0^T . xhat: written, not accumulated (was a zero-fill launch in front of the batch)
       RUN(launch_gemm_tn(t, st)); }
-    RUN(tn_batch_flush(st));  // all weight gradients of the pass (the parameter-gradient kernel below reads Mbuf)
-    RUN(colsum_defer_flush(st));  // ... and every deferred column sum (it reads cvec)
+    RUN(tn_batch_flush(st, true));  // all weight gradients of the pass (the parameter-gradient kernel below reads Mbuf) and, in the
+                                    // same reduce launch, every deferred column sum (it reads cvec)
     RUN(launch_infc_param_grads(X.Mbuf, P + L.in_w, P + L.n_gain, P + L.n_bias, X.cvec, D, Din, G + L.in_w, G + L.n_gain, G + L.n_bias,
                                 G + L.in_b /* db_in += colsum(dh0) */, st, g_grad_overwrite));
   } else {
@@ -1282,8 +1282,7 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     l.dx32 = dfeats; l.lddx32 = Din; l.dgain = G + L.n_gain; l.dbias = G + L.n_bias;
     if (!dfeats) { l.dx = dz_other; l.lddx = D; }
     RUN(launch_ln_bwd(l, st));
-    RUN(tn_batch_flush(st));
-    RUN(colsum_defer_flush(st));
+    RUN(tn_batch_flush(st, true));  // (+ the deferred column sums, in its reduce launch)
   }
   (void)pe; (void)hidden;
   return 0;

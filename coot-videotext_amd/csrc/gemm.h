@@ -70,7 +70,7 @@ size_t gemm_tn_workspace_floats(int T, int Mo, int No, int groups);
 // stay untouched until the flush.  tn_batch_end() leaves the collecting mode.
 void tn_batch_begin();
 void get_tn_default_workspace(float** ws, size_t* floats);
-int tn_batch_flush(hipStream_t stream);
+int tn_batch_flush(hipStream_t stream, bool take_colsums = false);  // take_colsums: the thread's deferred column sums (rowops.h) run inside the reduce launch
 void tn_batch_end();
 // 1: wide tiles fed by LDS-DMA (gemm_tn_dma_kernel); 0: register-staged (A/B switch)
 void set_tn_target_wgs(int n);

@@ -1172,7 +1172,9 @@ __global__ __launch_bounds__(768) void gemm_tn_dma_kernel(TnBatch b, TnMap m, fl
   gemm_tn_dma_body(it.g, bx, by, bz, it.t_per_split, it.direct ? nullptr : ws_base + it.ws_off, it.direct);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_batch_reduce_kernel(TnBatch b, const float* ws_base) {
+// grid rows [0, b.n): the problems of the batch; rows b.n .. : the deferred column sums that ride in this launch (da.nseg of them)
+__global__ __launch_bounds__(256) void gemm_tn_batch_reduce_kernel(TnBatch b, const float* ws_base, DeferArgs da) {
+  if ((int)blockIdx.y >= b.n) { colsum_defer_block(da, (int)blockIdx.y - b.n, (int)blockIdx.x); return; }
   const TnItem& it = b.it[blockIdx.y];
   if (it.direct) return;
   const GemmTN& g = it.g;
@@ -1305,10 +1307,10 @@ int tn_debug_xcd_map(int n, const int* gx, const int* gy, const int* groups, con
   return grid;
 }
 
-int tn_batch_flush(hipStream_t stream) {
+int tn_batch_flush(hipStream_t stream, bool take_colsums) {
   const int n = g_tn_nitems;
   g_tn_nitems = 0;
-  if (n == 0) return 0;
+  if (n == 0) return take_colsums ? colsum_defer_flush(stream) : 0;
   // two launches at most: problems whose m extent is a multiple of 384 take the wide 384 x 128 tiles, the rest 128 x 128
   TnBatch bw, bn; bw.n = 0; bn.n = 0;
   long tiles_w = 0, tiles_n = 0;
@@ -1351,7 +1353,7 @@ int tn_batch_flush(hipStream_t stream) {
     g_tn_collect = false;
     for (int i = 0; i < n; ++i) { GemmTN g = g_tn_items[i]; int rc = launch_gemm_tn(g, stream); if (rc) { g_tn_collect = true; return rc; } }
     g_tn_collect = true;
-    return 0;
+    return take_colsums ? colsum_defer_flush(stream) : 0;
   }
   g_tn_ws_used = ws_off;
   double flops = 0;
@@ -1371,15 +1373,21 @@ int tn_batch_flush(hipStream_t stream) {
     else hipLaunchKernelGGL(gemm_tn_batch_kernel<1>, dim3(blk_n), dim3(256), 0, stream, bn, ws);
     COOT_CHECK_LAUNCH("gemm_tn_batch");
   }
+  // the caller's deferred column sums (independent of the GEMMs) ride in the first reduce launch as extra grid rows: a launch of its
+  // own costs ~5 us of the stream whatever it does (profiles/README.md round 4).  256 column blocks of 16 cover 4 096 columns.
+  DeferArgs da; da.nseg = 0;
+  bool ride = take_colsums && (ws_w || ws_n) && colsum_defer_take(&da, 256 * 16);
   if (ws_w) {
-    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(256, bw.n), dim3(256), 0, stream, bw, (const float*)ws);
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(256, bw.n + (ride ? da.nseg : 0)), dim3(256), 0, stream, bw, (const float*)ws, da);
     COOT_CHECK_LAUNCH("gemm_tn_batch_reduce");
+    if (ride) { ride = false; da.nseg = 0; }
   }
   if (ws_n) {
-    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(256, bn.n), dim3(256), 0, stream, bn, (const float*)ws);
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(256, bn.n + (ride ? da.nseg : 0)), dim3(256), 0, stream, bn, (const float*)ws, da);
     COOT_CHECK_LAUNCH("gemm_tn_batch_reduce");
   }
   timing_end(ts, stream);
+  if (take_colsums) return colsum_defer_flush(stream);  // whatever did not ride (no reduce launch, or a very wide sum): its own launch; else a no-op
   return 0;
 }
 void tn_batch_end() { g_tn_collect = false; g_tn_nitems = 0; }

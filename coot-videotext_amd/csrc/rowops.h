@@ -87,7 +87,41 @@ int launch_reduce_partials(const float* ws, int nparts, long ld, int C, float* o
 // runs all recorded reductions as ONE launch.  A reduction launch between two large kernels costs far more than its 5 us
 // (drain, launch, ramp-up): the local backward had three of them.  Outside a scope (or with the table / workspace full)
 // colsum_defer_add returns false and the producer launches its reduction itself.
+constexpr int DEFER_MAX = 24;
+struct DeferSeg { float* dst; const float* src; long ld; int nparts, n, overwrite; };
+struct DeferArgs { DeferSeg s[DEFER_MAX]; int nseg; };
+#ifdef __HIPCC__
+// one workgroup (256 threads) of the deferred column sums: segment `seg`, columns 16 bx .. 16 bx + 15 — 16 columns x 16 partial-row
+// groups (a serial walk over the partial rows is a chain of load latencies).  Body of colsum_defer_kernel; also the extra grid rows
+// of the weight-gradient split reduction (gemm.hip: tn_batch_flush with take_colsums), which saves the launch.
+__device__ __forceinline__ void colsum_defer_block(const DeferArgs& a, int seg, int bx) {
+  __shared__ float red[16][17];
+  const DeferSeg& sg = a.s[seg];
+  const int cl = threadIdx.x & 15, pg = threadIdx.x >> 4, c = bx * 16 + cl;
+  if (bx * 16 >= sg.n) return;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  if (c < sg.n) {
+    const float* src = sg.src + c;
+    int t = pg;
+    for (; t + 48 < sg.nparts; t += 64) {
+      v0 += src[(long)t * sg.ld]; v1 += src[(long)(t + 16) * sg.ld]; v2 += src[(long)(t + 32) * sg.ld]; v3 += src[(long)(t + 48) * sg.ld];
+    }
+    for (; t < sg.nparts; t += 16) v0 += src[(long)t * sg.ld];
+  }
+  red[pg][cl] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (pg == 0 && c < sg.n) {
+    float r = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) r += red[g][cl];
+    sg.dst[c] = sg.overwrite ? r : sg.dst[c] + r;
+  }
+}
+#endif
 void colsum_defer_begin();
+// hands the recorded reductions to a caller that runs them inside a launch of its own (resets the table like a flush); false: none
+// recorded, or one of them has more than max_cols columns (nothing is taken then)
+bool colsum_defer_take(DeferArgs* out, int max_cols);
 float* partials_workspace_top(size_t need_floats);
 bool colsum_defer_add(float* dst, const float* src, long ld, int nparts, int n, int overwrite);
 int colsum_defer_room();  // free slots of the table (0 outside a scope)

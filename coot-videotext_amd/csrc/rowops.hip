@@ -196,9 +196,6 @@ void set_partials_workspace(float* ws, size_t floats, size_t low_floats) { g_par
 float* partials_workspace(size_t need) { return (g_part_ws && need + g_part_top <= g_part_floats) ? g_part_ws : nullptr; }
 
 // ---- deferred column-sum reductions (rowops.h) ----------------------------------------------------------------
-constexpr int DEFER_MAX = 24;
-struct DeferSeg { float* dst; const float* src; long ld; int nparts, n, overwrite; };
-struct DeferArgs { DeferSeg s[DEFER_MAX]; int nseg; };
 static thread_local bool g_defer = false;
 static thread_local DeferArgs g_defer_args;
 
@@ -217,29 +214,14 @@ bool colsum_defer_add(float* dst, const float* src, long ld, int nparts, int n, 
   g_defer_args.s[g_defer_args.nseg++] = DeferSeg{dst, src, ld, nparts, n, overwrite};
   return true;
 }
-// 16 columns x 16 partial-row groups per workgroup (a serial walk over the partial rows is a chain of load latencies)
-__global__ __launch_bounds__(256) void colsum_defer_kernel(DeferArgs a) {
-  __shared__ float red[16][17];
-  const DeferSeg& sg = a.s[blockIdx.y];
-  const int cl = threadIdx.x & 15, pg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
-  if (blockIdx.x * 16 >= sg.n) return;
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  if (c < sg.n) {
-    const float* src = sg.src + c;
-    int t = pg;
-    for (; t + 48 < sg.nparts; t += 64) {
-      v0 += src[(long)t * sg.ld]; v1 += src[(long)(t + 16) * sg.ld]; v2 += src[(long)(t + 32) * sg.ld]; v3 += src[(long)(t + 48) * sg.ld];
-    }
-    for (; t < sg.nparts; t += 16) v0 += src[(long)t * sg.ld];
-  }
-  red[pg][cl] = (v0 + v1) + (v2 + v3);
-  __syncthreads();
-  if (pg == 0 && c < sg.n) {
-    float r = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) r += red[g][cl];
-    sg.dst[c] = sg.overwrite ? r : sg.dst[c] + r;
-  }
+__global__ __launch_bounds__(256) void colsum_defer_kernel(DeferArgs a) { colsum_defer_block(a, blockIdx.y, blockIdx.x); }
+bool colsum_defer_take(DeferArgs* out, int max_cols) {
+  const int n = g_defer_args.nseg;
+  if (n == 0) return false;
+  for (int i = 0; i < n; ++i) if (g_defer_args.s[i].n > max_cols) return false;  // (stays recorded: colsum_defer_flush runs it)
+  *out = g_defer_args;
+  g_defer_args.nseg = 0; g_part_top = 0;
+  return true;
 }
 int colsum_defer_flush(hipStream_t stream) {
   const int n = g_defer_args.nseg;
