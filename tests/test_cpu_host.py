@@ -490,3 +490,27 @@ def test_input_stage_layout_and_argument_checks(cva):
     assert rc != 0 and b"ranks" in lib.coot_last_error()
     rc = lib.coot_contrastive_fwd_bwd_dp_blocks(C.byref(cc), 2, 2, counts, counts, 64, 32, dummy, base, C.byref(ld), dummy, C.byref(down), dummy, 1 << 20, None)
     assert rc != 0
+
+
+def test_option_switches_named_in_the_integration_notes_exist(cva):
+    """Every A/B / test switch INTEGRATION.md lists is a name coot_set_option knows (host globals: no GPU needed), an unknown name is
+    refused with a message, and the read-back ones answer — the documents and the library's switch table do not drift apart."""
+    lib = cva.lib.load()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    para = text[text.index("A/B and profiling switches"):]
+    para = para[:para.index("`coot_get_option` reads")]
+    names = [n for n in re.findall(r"`([a-z0-9_]+)`", para) if not n.startswith("coot_") and n != "gemm_nt"]  # (`gemm_nt`: a kernel named in the text)
+    assert {"fused", "cl_small", "cl_col_split", "grad_write", "pack_lazy", "xcd_order", "step_stamps"} <= set(names)
+    value = {"cl_col_split": 0, "pack_poison": 0, "grad_poison": 0, "fz_debug": 0, "step_stamps": 0}  # defaults that are not 1
+    sizes = {"fused_min_rows", "tn_target_wgs"}  # a size, not a switch: left alone (no read-back)
+    for n in names:
+        if n in sizes:
+            continue
+        v = ctypes.c_int32(-1)
+        had = lib.coot_get_option(n.encode(), ctypes.byref(v)) == 0
+        assert lib.coot_set_option(n.encode(), v.value if had else value.get(n, 1)) == 0, n  # (set to what it is / to its default)
+    assert lib.coot_set_option(b"half_tiles", 1) != 0  # removed in round 4
+    assert b"unknown option" in lib.coot_last_error()
+    v = ctypes.c_int32(-1)
+    for n in ("tn_dma", "xcd_order", "tn_mode", "stage_hits"):
+        assert lib.coot_get_option(n.encode(), ctypes.byref(v)) == 0 and v.value >= 0, n
