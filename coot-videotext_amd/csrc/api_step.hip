@@ -679,8 +679,8 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
                                W.d_resh_t, side_t));
     g_stamps.mark("text: cycle-consistency done", st);
   }
-  // (clip, sent) and (vid_ctx, par_ctx) terms -> losses[1] (added atomically next to the (vid, par) terms'; in deterministic mode
-  // through the fixed-point shadow: any order gives the same bits)
+  // (clip, sent) and (vid_ctx, par_ctx) terms -> losses[1] (one atomic add per call next to the (vid, par) terms' on the zeroed word:
+  // two addends commute, the same bits in either order)
   RUN(coot_contrastive_fwd_bwd_part(&cfg->contr, d->B, d->Nc, 2 * D, D, W.glob_v, W.glob_t, W.local_v + (size_t)d->B * D,
                                     W.local_t + (size_t)d->B * D, W.local_v, W.local_t, losses + 1, W.d_glob_v, W.d_glob_t,
                                     W.d_local_v + (size_t)d->B * D, W.d_local_t + (size_t)d->B * D, W.d_local_v, W.d_local_t, W.loss_scratch,
