@@ -21,7 +21,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.environ.get("COOT_REFERENCE", "/root/reference")
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("COOT_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))  # (tests regenerate into a scratch directory and compare)
 
 # ---- import shims (no reference edits) -------------------------------------------------------
 for _n in ("Iterable", "Mapping", "Sequence", "MutableMapping"):

@@ -237,3 +237,27 @@ def test_torch_cpu_port_matches_numpy_oracle():
     for P, G in zip(Pt, Gs):
         bad, table = H.grad_report([(n, P[n].grad.numpy()) for n in G if P[n].grad is not None], G, cos_min=0.9999, ratio_tol=1e-3)
         assert not bad, "\n".join(bad)
+
+
+def test_committed_fixtures_regenerate_from_the_reference(golden_dir, tmp_path):
+    """The pin of the pin: where the unmodified reference is present (the build container: /root/reference or COOT_REFERENCE), the
+    committed generator re-run into a scratch directory reproduces the committed fixtures BIT FOR BIT — the end-to-end eval
+    fixture, a train-mode fixture with the library's dropout masks injected into the reference's nn.Dropout sites, and the host-side
+    ones (collate, LR schedules, RAdam, masks, retrieval metrics).  On the GPU box the reference does not exist: skipped."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.environ.get("COOT_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "coot")):
+        pytest.skip("no reference checkout here")
+    names = ["full_small", "bench_yc2_100m_2layer_train", "collate", "lr_schedule", "radam", "mask_semantics", "retrieval_metrics"]
+    env = dict(os.environ, COOT_GOLDEN_OUT=str(tmp_path), COOT_REFERENCE=ref)
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py")] + names, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for n in names:
+        new, old = np.load(os.path.join(str(tmp_path), n + ".npz")), np.load(os.path.join(golden_dir, n + ".npz"))
+        assert sorted(new.files) == sorted(old.files), n
+        for k in new.files:
+            a, b = new[k], old[k]
+            assert a.dtype == b.dtype and a.shape == b.shape, (n, k)
+            assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind in "fc" else np.array_equal(a, b), (n, k)
