@@ -46,6 +46,18 @@ def parse():
     ap.add_argument("--clock-monitor", action="store_true", help="after the timed loop: sample the shader clock on a side stream while more steps run (stderr)")
     ap.add_argument("--no-lookahead", action="store_true", help="do not announce the next batch to the step: its input LayerNorm runs at the head of its own step instead of next to the previous step's global networks (A/B)")
     ap.add_argument("--no-defer-join", action="store_true", help="join the text stream into the main stream at the end of every step (A/B)")
+    ap.add_argument("--repeat", type=int, default=1, help="regime probe: time R blocks of K steps back to back (each bracketed like the first); the JSON "
+                    "line is the FIRST block (the contract's), the others go to stderr and to 'blocks_ms_per_step'")
+    ap.add_argument("--per-step-events", action="store_true", help="regime probe: a timing event on the main stream behind every step (warm-up "
+                    "included); per-step device times to stderr.  Perturbs the step slightly: not for reported numbers")
+    ap.add_argument("--clock-monitor-early", action="store_true", help="regime probe: sample the shader clock (one wave on a side stream, every "
+                    "100 us) from BEFORE the warm-up through the timed steps; to stderr")
+    ap.add_argument("--pre-burn", default="", help="regime probe: KIND:MS — keep the device busy for MS milliseconds right before the warm-up with "
+                    "'hbm' (1 GB device copies) or 'alu' (L2-resident elementwise launches); tests whether the slow first steps are a clock governor")
+    ap.add_argument("--sysfs-clocks", action="store_true", help="regime probe: print the DPM clock tables of the device (sysfs) before the warm-up, after it "
+                    "and after the timed steps, to stderr")
+    ap.add_argument("--idle-ms", type=float, default=0.0, help="regime probe: leave the device idle for this long between the warm-up and the timed steps")
+    ap.add_argument("--lr0", action="store_true", help="regime probe: learning rate and weight decay 0 — every step computes on the same weights")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--padded", action="store_true", help="ragged workloads: run the reference's padded layout instead of packed (varlen) rows")
     ap.add_argument("--mode", default="native", choices=["native", "native-graph", "autograd", "graph"],
@@ -200,6 +212,8 @@ def main():
     w = cva.synthetic.WORKLOADS[args.workload]
     cfg = cva.load_named_config(*cva.synthetic.WORKLOAD_CONFIG[args.workload])
     torch.manual_seed(0)  # identical initial weights on every rank
+    if args.lr0:
+        cfg.optimizer.lr, cfg.optimizer.weight_decay = 0.0, 0.0
     mgr = cva.RetrievalModelManager(cfg).cuda()
     trainer = cva.RetrievalTrainer(cfg, mgr, is_test=args.eval)
     if dp is not None:
@@ -270,22 +284,114 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def sysfs_clocks(tag):
+        if not (args.sysfs_clocks and rank == 0):
+            return
+        import glob as _g
+        out = []
+        for f in sorted(_g.glob("/sys/class/drm/card*/device/pp_dpm_*clk")):
+            try:
+                cur = [ln.strip() for ln in open(f).read().splitlines() if "*" in ln]
+                out.append(f.split("/")[4] + ":" + os.path.basename(f)[7:] + "=" + ",".join(cur))
+            except OSError:
+                pass
+        sys.stderr.write(f"sysfs clocks [{tag}]: " + " ".join(out) + "\n")
+
+    if args.pre_burn:
+        kind, ms_b = args.pre_burn.split(":")
+        ms_b = float(ms_b)
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        if kind == "hbm":
+            a_ = torch.empty(256 << 20, dtype=torch.float32, device="cuda"); b_ = torch.empty_like(a_)
+            while time.perf_counter() - tb0 < ms_b * 1e-3:
+                for _ in range(8):
+                    b_.copy_(a_)
+                torch.cuda.synchronize()
+            del a_, b_
+        else:
+            a_ = torch.ones(1 << 20, dtype=torch.float32, device="cuda")
+            while time.perf_counter() - tb0 < ms_b * 1e-3:
+                for _ in range(200):
+                    a_.mul_(1.0001)
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+    sysfs_clocks("before warm-up")
+    mon_early = None
+    if args.clock_monitor_early and rank == 0:
+        nsamp_e = int((args.warmup + args.steps) * 1.4 * 10) + 300   # 100 us samples: ~1.4 ms per step + margin
+        mon_early = torch.zeros(2 * nsamp_e, dtype=torch.int64, device="cuda")
+        side_e = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side_e):
+            cva.lib.check(lib.coot_debug_clock_monitor(mon_early.data_ptr(), nsamp_e, 10000, side_e.cuda_stream), "clock_monitor")
+        time.sleep(0.002)  # the first samples are the idle device
+    evs, host_t = [], []
+
+    def stamp():
+        if args.per_step_events:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+            host_t.append(time.perf_counter())
+
+    stamp()
     for _ in range(args.warmup):
         step()
+        stamp()
     barrier()
+    if args.idle_ms > 0:
+        time.sleep(args.idle_ms * 1e-3)
+    sysfs_clocks("after warm-up")
+    stamp()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
         last = step()
+        stamp()
     host_issue = time.perf_counter() - t0  # CPU time to enqueue K steps (informational)
     barrier()
     elapsed = time.perf_counter() - t0
+    sysfs_clocks("after the timed steps")
+    blocks = [1e3 * elapsed / args.steps]
+    for _ in range(args.repeat - 1):  # regime probe: the same bracket again, in the same process
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            stamp()
+        barrier()
+        blocks.append(1e3 * (time.perf_counter() - tb) / args.steps)
+    if rank == 0 and args.repeat > 1:
+        sys.stderr.write("blocks of %d steps, ms/step: %s\n" % (args.steps, " ".join(f"{b:.4f}" for b in blocks)))
+    if mon_early is not None:
+        torch.cuda.synchronize()
+        m = mon_early.cpu().numpy().reshape(-1, 2).astype(np.float64)
+        ghz = np.diff(m[:, 1]) / (np.diff(m[:, 0]) * 10.0)
+        sys.stderr.write("shader clock from before the warm-up, GHz per 1 ms (10 samples of 100 us): " +
+                         " ".join(f"{ghz[i:i + 10].mean():.2f}" for i in range(0, len(ghz) - 9, 10)) + "\n")
+    if rank == 0 and evs:
+        dts = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]
+        sys.stderr.write("per-step device ms (event to event; warm-up first, then the barrier gap, then the timed steps):\n  " +
+                         " ".join(f"{t:.3f}" for t in dts) + "\n")
+        sys.stderr.write("per-step HOST ms (enqueue time between the same points):\n  " +
+                         " ".join(f"{1e3 * (host_t[i + 1] - host_t[i]):.3f}" for i in range(len(host_t) - 1)) + "\n")
     if dp is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(last)
     if args.step_stamps and rank == 0 and not args.eval:
+        # (regime probe) the FIRST step after an idle device: the host is not ahead, every launch arrives just in time
+        lib.coot_set_option(b"step_stamps", 1)
+        torch.cuda.synchronize()
+        step()
+        buf = C.create_string_buffer(8192)
+        lib.coot_debug_step_stamps(buf, 8192)
+        lib.coot_set_option(b"step_stamps", 0)
+        sys.stderr.write("step timeline of the FIRST step after a device synchronisation (host not ahead):\n" + buf.value.decode())
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
         # HIP-event timeline of one more step, enqueued behind two others so the host is ahead as in the timed loop
         lib.coot_set_option(b"step_stamps", 1)
         for _ in range(3):
@@ -299,7 +405,6 @@ def main():
     if args.clock_monitor and rank == 0:
         # shader clock the device delivers under this load (outside the timed region): one wave on a side stream samples the
         # 100 MHz real-time counter and the shader clock counter every 10 us while 8 more steps run
-        import numpy as np
         nsamp = int(8 * ms_per_step * 100) + 200
         mon = torch.zeros(2 * nsamp, dtype=torch.int64, device="cuda")
         side = torch.cuda.Stream()
@@ -449,7 +554,8 @@ def main():
                                              batch.par_feat.shape[0] * batch.par_feat.shape[1] + batch.sent_feat.shape[0] * batch.sent_feat.shape[1]]}
                           if ragged else {}),
                        "final_loss": round(loss_val, 5)},
-            "per_gpu": round(value / world, 1), "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
+            "per_gpu": round(value / world, 1), **({"blocks_ms_per_step": [round(b, 4) for b in blocks]} if args.repeat > 1 else {}),
+            "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
             "algorithmic_tflops_per_s": round((fwd_flops if args.eval else train_flops) * world / (ms_per_step * 1e-3) / 1e12, 2),
         }
         if roofline is not None:

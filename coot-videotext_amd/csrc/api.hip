@@ -601,7 +601,7 @@ using namespace coot;
 extern "C" {
 
 const char* coot_last_error(void) { return coot::g_err; }
-int coot_version(void) { return 1; }
+int coot_version(void) { return COOT_ABI_VERSION; }
 // host-only (tests): the keep-scales (0 or 1 / keep) the kernels draw for n consecutive elements idx0 .. of an element-wise
 // dropout site, resp. for the attention probabilities (row32, k = 0 .. n - 1) — evaluated by the SAME functions (common.h) and
 // the same quantisation of p (mkdrop) as on the device

@@ -513,6 +513,7 @@ int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, c
                       size_t workspace_bytes, int train, uint64_t seed, int packs_fresh, coot_stream_t main_s, coot_stream_t side_v,
                       coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
+  COOT_REQUIRE((packs_fresh & ~(COOT_FWD_PACKS_FRESH | COOT_FWD_INPUT_STAGES | COOT_FWD_STAGE_ANNOUNCED)) == 0, "step_forward: unknown bits in packs_fresh (%d)", packs_fresh);
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
   const SidePacked pk = side_packed(*x, *d);
   COOT_REQUIRE(!A.overflow, "step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
@@ -574,6 +575,7 @@ int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* b, in
                      coot_stream_t side_v, coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
   COOT_REQUIRE(step >= 1, "step_update: step counts from 1");
+  COOT_REQUIRE((repack & ~(COOT_UPDATE_REPACK | COOT_UPDATE_DEFER_TEXT_JOIN)) == 0, "step_update: unknown bits in repack (%d): a bit mask since ABI 5", repack);
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
@@ -605,6 +607,8 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
                     coot_stream_t main_s, coot_stream_t side_v, coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
   COOT_REQUIRE(losses, "train_step: losses pointer");
+  COOT_REQUIRE((do_optimizer & ~(COOT_STEP_OPTIMIZER | COOT_STEP_REPACK | COOT_STEP_PACKS_FRESH | COOT_STEP_DEFER_TEXT_JOIN | COOT_STEP_INPUT_STAGES |
+                                 COOT_STEP_STAGE_ANNOUNCED)) == 0, "train_step: unknown bits in do_optimizer (%d)", do_optimizer);
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
   const SidePacked pk = side_packed(*x, *d);
   COOT_REQUIRE(!A.overflow, "train_step: workspace too small (%zu < %zu)", workspace_bytes, A.off);

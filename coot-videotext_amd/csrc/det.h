@@ -10,6 +10,8 @@
 // depend on the order — and coot_det_flush adds the sums into the fp32 words (one float addition per word, in stream order behind every
 // adder) and clears the shadow.  Addresses outside the registered ranges, and everything while the mode is off, take the plain float
 // atomic.  Resolution 9.1e-13 absolute, range +-8.4e6 per word: below fp32 round-off for any gradient entry above 1e-5 in magnitude.
+// An addend that is NaN, Inf or >= 2^22 in magnitude bypasses the shadow (plain float atomic on the fp32 word): a diverged step shows
+// up as NaN / Inf in the gradients and the loss exactly as without the mode (the run is no longer bit-reproducible then — it is lost anyway).
 #pragma once
 #include "common.h"
 
@@ -18,6 +20,7 @@ namespace coot {
 struct DetRange { const char* base; size_t bytes; long long* shadow; };
 struct DetTable { int n; DetRange r[8]; };
 constexpr double kDetScale = 1099511627776.0;  // 2^40
+constexpr float kDetMaxAddend = 4194304.0f;    // 2^22: one addend; the 64-bit word itself holds sums up to +-8.4e6
 
 // one table per translation unit (the library is built without relocatable device code): COOT_DET_DEFINE_SETTER(name) defines
 // det_set_table_<name>(), det.hip installs the same table in all of them
@@ -28,6 +31,10 @@ __device__ __forceinline__ void acc_add(float* p, float v) {
   for (int i = 0; i < n; ++i) {
     const size_t off = (size_t)(reinterpret_cast<const char*>(p) - g_det_dev.r[i].base);  // (wraps to a huge value below the base)
     if (off < g_det_dev.r[i].bytes) {
+      // outside the fixed-point range (|v| >= 2^22: a single addend that large is an exploding gradient; words that accumulate up to
+      // +-8.4e6 stay exact) or not finite: llrint would be undefined (LLONG_MIN in practice — a finite garbage word that hides the
+      // NaN from the trainer's loss checks).  Such an addend takes the plain float atomic: NaN / Inf reach the fp32 word.
+      if (!(fabsf(v) < kDetMaxAddend)) break;
       atomicAdd(reinterpret_cast<unsigned long long*>(g_det_dev.r[i].shadow + (off >> 2)), (unsigned long long)llrint((double)v * kDetScale));
       return;
     }

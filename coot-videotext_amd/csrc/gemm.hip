@@ -1105,6 +1105,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int t_per_split,
 // problem needs only a few splits over the token axis (4 instead of 32: an eighth of the fp32 partial-tile traffic, 8x
 // longer pipelined loops per workgroup), and the global networks' eight tiny problems cost one launch instead of sixteen.
 constexpr int TN_MAX_ITEMS = 10;
+constexpr int TN_MAX_SPLITS = 8;  // token splits of one weight-gradient problem: the clamp in tn_batch_flush and the reduce kernel's partial loads
 struct TnItem { GemmTN g; int blk0, gx, gy, t_per_split, splits, direct; long ws_off; };
 struct TnBatch { int n; TnItem it[TN_MAX_ITEMS]; };
 
@@ -1188,12 +1189,12 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_reduce_kernel(TnBatch b, co
     const int m = (int)(r / g.No), n = (int)(r % g.No);
     // all partials of the element first (<= 8 splits, tn_batch_flush; a split past the last re-reads it), then the sum in split order:
     // one load at a time per thread left this launch at a third of the memory system's rate
-    f32x4_t part[8];
+    f32x4_t part[TN_MAX_SPLITS];
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp) part[sp] = *reinterpret_cast<const f32x4_t*>(ws + ((long)min(sp, it.splits - 1) * g.groups + z) * per + r);
+    for (int sp = 0; sp < TN_MAX_SPLITS; ++sp) part[sp] = *reinterpret_cast<const f32x4_t*>(ws + ((long)min(sp, it.splits - 1) * g.groups + z) * per + r);
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp) if (sp < it.splits) s += part[sp];
+    for (int sp = 0; sp < TN_MAX_SPLITS; ++sp) if (sp < it.splits) s += part[sp];
     float* c = g.C + z * g.zC + (long)m * g.ldc + n;
     if (g.overwrite) { c[0] = s[0] * g.alpha; c[1] = s[1] * g.alpha; c[2] = s[2] * g.alpha; c[3] = s[3] * g.alpha; }
     else { c[0] += s[0] * g.alpha; c[1] += s[1] * g.alpha; c[2] += s[2] * g.alpha; c[3] += s[3] * g.alpha; }
@@ -1336,11 +1337,12 @@ int tn_batch_flush(hipStream_t stream, bool take_colsums) {
     int splits = w ? (int)(g_tn_target_wgs / tiles) : (int)((512 + tiles - 1) / tiles);
     const int max_splits = g.T / 512 > 0 ? g.T / 512 : 1;
     if (splits > max_splits) splits = max_splits;
-    if (splits > 8) splits = 8;
+    if (splits > TN_MAX_SPLITS) splits = TN_MAX_SPLITS;
     if (splits < 1) splits = 1;
     int tps = (g.T + splits - 1) / splits;
     tps = (tps + TN_BT - 1) / TN_BT * TN_BT;
     splits = (g.T + tps - 1) / tps;
+    COOT_REQUIRE(splits <= TN_MAX_SPLITS, "tn_batch_flush: %d splits (the reduce kernel loads %d partials)", splits, TN_MAX_SPLITS);
     it.t_per_split = tps; it.splits = splits;
     it.direct = (splits == 1 && g.ldc % 4 == 0 && g.No % 4 == 0 && g.zC % 4 == 0) ? 1 : 0;
     int& blk = w ? blk_w : blk_n;

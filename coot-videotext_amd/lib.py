@@ -84,6 +84,7 @@ class StepBatch(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 5  # include/coot_hip.h: COOT_ABI_VERSION
 
 
 def build_hint() -> str:
@@ -103,6 +104,9 @@ def load():
     lib.coot_last_error.restype = C.c_char_p
     lib.coot_last_error.argtypes = []
     lib.coot_version.restype = i32
+    lib.coot_version.argtypes = []
+    if lib.coot_version() != ABI_VERSION:  # struct layouts and flag words of include/coot_hip.h (COOT_ABI_VERSION) this binding was written for
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.coot_version()}, this binding needs {ABI_VERSION}; rebuild: {build_hint()}")
     lib.coot_set_option.argtypes = [C.c_char_p, i32]
     lib.coot_get_option.argtypes = [C.c_char_p, C.POINTER(i32)]
     lib.coot_debug_timestamps.argtypes = [vp]

@@ -98,6 +98,17 @@ class ContrastiveLoss(torch.nn.Module):
         return _TotalContrastiveFn.apply(cfg, im, s, dummy, dummy, ctxd, ctxd)
 
 
+# Deterministic mode (RetrievalTrainer.set_deterministic): the cycle-consistency loss word is the sum of 2 B atomic addends.  A
+# persistent word the trainer registered with the library's fixed-point accumulators (coot_det_configure) takes them; it is flushed
+# and copied out right here, so the returned loss is bit-reproducible like the gradients.
+_DET_LOSS_WORD: Optional[torch.Tensor] = None
+
+
+def set_det_loss_word(word: Optional[torch.Tensor]) -> None:
+    global _DET_LOSS_WORD
+    _DET_LOSS_WORD = word
+
+
 class _CycleConsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, clip, sent, clip_lens, sent_lens, idx_clip, idx_sent, weight: float, inv_batch: float, want_rows: bool):
@@ -106,7 +117,10 @@ class _CycleConsFn(torch.autograd.Function):
         B, Cc, D = clip.shape
         Cs = sent.shape[1]
         dev = clip.device
-        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        word = _DET_LOSS_WORD if (_DET_LOSS_WORD is not None and _DET_LOSS_WORD.device == dev) else None
+        if word is not None:
+            word.zero_()
+        loss = word if word is not None else torch.zeros((), dtype=torch.float32, device=dev)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dclip = torch.zeros_like(clip) if need_grad else None
         dsent = torch.zeros_like(sent) if need_grad else None
@@ -117,6 +131,9 @@ class _CycleConsFn(torch.autograd.Function):
                                               _lib.ptr(idx_sent.contiguous().long()), B, Cc, Cs, D, float(weight), float(inv_batch),
                                               _lib.ptr(loss), _lib.ptr(rows_c), _lib.ptr(rows_s), _lib.ptr(dclip), _lib.ptr(dsent),
                                               _lib.stream_ptr()), "coot_cyclecons_fwd_bwd")
+        if word is not None:
+            _lib.check(lib.coot_det_flush(word.data_ptr(), 4, _lib.stream_ptr()), "coot_det_flush")
+            loss = word.clone().reshape(())
         ctx.grads = (dclip, dsent)
         ctx.mark_non_differentiable(*[r for r in (rows_c, rows_s) if r is not None])
         return loss, rows_c, rows_s

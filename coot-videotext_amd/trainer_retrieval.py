@@ -211,7 +211,9 @@ class RetrievalTrainer:
             # its step count and rectification scalars are host values: a replay would freeze them (the native step keeps them in a
             # device block instead: train_step_native(use_graph=True))
             raise NotImplementedError("train_step(use_graph=True) supports torch.optim.Adam only; use train_step_native for RAdam")
-        key = self._graph_key(batch)
+        if getattr(self, "deterministic", False):  # configure BEFORE a capture, never inside it (it synchronises and copies a symbol)
+            self._det_sync([net.bind_flat_grads() for net in self.model_mgr.model_dict.values()] + self._det_extra(batch.vid_feat.device))
+        key = (self._graph_key(batch), self._det_state())
         graphs = self.__dict__.get("_graphs")
         if graphs is None:
             import collections
@@ -356,7 +358,8 @@ class RetrievalTrainer:
             self._step_prepare_seed(batch, nets)
         self._seed_dev += 1  # device-side dropout seed: advances on every step, also under graph replay
         flat_grads = [net.bind_flat_grads() for net in nets]
-        self._det_sync(flat_grads)
+        det_extra = self._det_extra(flat_grads[0].device)
+        self._det_sync(flat_grads + det_extra)
         for net, g in zip(nets, flat_grads):
             g.zero_()
             net.accumulate_into_flat = True  # backward kernels accumulate straight into the flat arenas
@@ -570,10 +573,42 @@ class RetrievalTrainer:
         gradients, the cycle-consistency loss word) go through order-independent fixed-point accumulators.  Two runs of the same steps
         from the same state are then bit-identical (parameters, losses); the step computes the same numbers as without it to fp32
         round-off.  Process-wide (the library's mode is); costs two extra launches and ~60 MB of accumulators per step."""
+        if bool(on) != getattr(self, "deterministic", False):
+            self._drop_graphs()  # captured steps carry the mode they were captured in (flush nodes, the shadow's address)
         self.deterministic = bool(on)
         if not on and getattr(self, "_det_key", None) is not None:
+            torch.cuda.synchronize()  # (no launch of any stream may still add into — or flush — the shadow that is freed below)
             _lib.check(_lib.load().coot_det_configure(0, None, None, None, 0, torch.cuda.current_stream().cuda_stream), "coot_det_configure")
             self._det_key, self._det_shadow, self._det_ranges = None, None, []
+
+    def _drop_graphs(self) -> None:
+        """Forgets every captured step (autograd route and native route).  The library consults its process-wide deterministic table
+        at RUN time and a captured step holds the flush launches — or their absence — and the shadow's address of the mode it was
+        captured in: a replay under another configuration would drop gradient addends (no flush node) or read a freed shadow."""
+        graphs = self.__dict__.get("_graphs")
+        if graphs:
+            torch.cuda.synchronize()
+            graphs.clear()
+        st = getattr(self, "_native", None)
+        if st is not None and st.__dict__.get("graphs"):
+            torch.cuda.synchronize()
+            st.graphs.clear()
+
+    def _det_extra(self, device) -> list:
+        """The fp32 words outside the gradient arenas that several workgroups add into on the autograd route: the cycle-consistency
+        loss word (loss_fn._CycleConsFn) — a persistent word, registered with the arenas."""
+        if not getattr(self, "deterministic", False):
+            loss_fn.set_det_loss_word(None)
+            return []
+        w = getattr(self, "_det_loss_word", None)
+        if w is None or w.device != device:
+            w = self._det_loss_word = torch.zeros(1, dtype=torch.float32, device=device)
+        loss_fn.set_det_loss_word(w)
+        return [w]
+
+    def _det_state(self):
+        """What a captured step depends on besides shapes: the deterministic mode and the configuration it was captured under."""
+        return (bool(getattr(self, "deterministic", False)), getattr(self, "_det_epoch", 0))
 
     def _det_sync(self, tensors) -> None:
         """(Re)registers the fp32 tensors the step accumulates into — the gradient arenas and the loss words — when they changed."""
@@ -582,6 +617,10 @@ class RetrievalTrainer:
         ranges = sorted({(t.data_ptr(), t.numel() * 4) for t in tensors})
         if ranges == getattr(self, "_det_key", None):
             return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("deterministic mode must be configured before a step is captured (the registered ranges changed inside a capture)")
+        self._drop_graphs()
+        self._det_epoch = getattr(self, "_det_epoch", 0) + 1
         lib = _lib.load()
         n = len(ranges)
         bases = (C.c_void_p * n)(*[r[0] for r in ranges])
@@ -700,7 +739,10 @@ class RetrievalTrainer:
         st, x = self._native_setup(batch)
         lr = float(self.optimizer.param_groups[0]["lr"]) if self.optimizer is not None else float(st.cfg.lr)
         ptrs = tuple(int(st.bufs.params[i]) for i in range(4)) + tuple(int(st.bufs.wpack[i]) for i in range(4))
-        key = (st.dims_key, ptrs, st.ws.data_ptr())
+        # deterministic mode: configured here, BEFORE any capture (a reconfiguration drops every cached graph, _det_sync); the key carries
+        # the mode and its configuration epoch, so a graph captured under another one is never replayed
+        self._det_sync([n._grad_flat for n in st.nets] + [st.losses])
+        key = (st.dims_key, ptrs, st.ws.data_ptr(), self._det_state())
         graphs = st.__dict__.setdefault("graphs", {})
         g = graphs.get(key)
         if g is None:

@@ -55,6 +55,10 @@ typedef struct coot_net_config {
 #define COOT_DTYPE_F32 1
 
 const char* coot_last_error(void);
+/* ABI version of this header: struct layouts (coot_net_config gained `dtype`, coot_step_buffers `decay_block_all` in round 4) and the
+ * meaning of flag words (coot_step_update's `repack` is a bit mask since round 4).  coot_version() returns the value the library was
+ * built with; a binding compares the two when it loads the library (coot-videotext_amd/lib.py does) and refuses a mismatch. */
+#define COOT_ABI_VERSION 5
 int coot_version(void);
 /* Option switches for A/B measurements and tests ("fused", "packed", "tn_dma", "grad_poison", ...: the names coot_set_option
  * accepts are listed in csrc/api.hip).  They are PROCESS-GLOBAL ints read at launch time without synchronisation: set them

@@ -712,6 +712,101 @@ def gen_rk_parity(train_steps=160):
     print("wrote rk_parity")
 
 
+# ---- a composed training trajectory: k optimizer steps of the reference's own step body ------------------------------------
+from nntrainer import optimization  # noqa: E402
+
+
+def gen_train_trajectory(name, dims, B, counts, Ls, seed, steps, p, step_seed0, scale=0.05, ragged=True, cc_weight=None, adam_eps=None,
+                         full=True, sub_step=29, layers=1):
+    """`steps` consecutive optimizer steps of the reference's step body (coot/trainer_retrieval.py:253-291: zero_grad, encode_visual,
+    encode_text, total contrastive + cycle-consistency loss, backward, optimizer.step) on TWO seeded batches used in turn (as bench.py
+    does: the loss of step s then shows what steps s - 2, s - 4, ... did to the parameters), with the
+    optimizer the reference builds for the shipped configuration (nntrainer/optimization.py:45-74 over the parameter groups of
+    nntrainer/models/model_manager_base.py:130-164: Adam lr 1e-3, betas (0.9, 0.999), weight decay 2e-5 with decay_mult 0 on every
+    parameter whose name contains 'bias' — weight_decay_for_bias: true, sic; no gradient clipping: anet_coot.yaml clip_gradient -1).
+    TRAIN mode at dropout p, the masks being the library's for the step seeds step_seed0 + 7919 s (oracle/dropout_masks.py), the
+    cycle-consistency positions drawn by th.multinomial under th.manual_seed(seed + 7 + s) and stored.
+    Stored: the two loss values of every step and final - initial of every parameter (full, or sub-sampled + norms).
+    adam_eps: the shipped 1e-8 makes the first updates +-lr whatever the gradient's size (a sign function: it amplifies any
+    difference between two implementations' small gradient entries); the fixtures also come at eps = 1e-3 (>= the typical
+    gradient entry), where the update is a smooth function of the gradient and a per-tensor cosine bound has power."""
+    dv, dt, hidden, heads, ff, pool_hidden = dims
+    Lv, Lc, Lp, Lsent = Ls
+    cfg = ref_config(*dims, layers=layers, dropout=p)
+    if cc_weight is not None:
+        cfg.train.loss_cycle_cons = cc_weight
+    if adam_eps is not None:
+        cfg.optimizer.adam_eps = adam_eps
+    assert cfg.optimizer.name == "adam" and cfg.train.clip_gradient == -1
+    ocfgs = oracle_cfgs(*dims, layers=layers)
+    th.manual_seed(0)
+    mgr = model_retrieval.RetrievalModelManager(cfg)
+    for i, k in enumerate(NET_KEYS):
+        load_params(mgr.model_dict[k], O.make_params(ocfgs[i], seed + 10 * i, scale=scale))
+    mgr.set_all_models_train()
+    states = [inject_dropout(mgr.model_dict[k], 0, float(p)) for k in NET_KEYS]
+    params, _names, _flat = mgr.get_all_params()
+    opt = optimization.make_optimizer(cfg.optimizer, params)
+    init = {(k, n): q.detach().clone() for k in NET_KEYS for n, q in mgr.model_dict[k].named_parameters()}
+    tr = _FakeTrainer(cfg)
+    losses, idxs, seeds = [], [], []
+    for s in range(steps):
+        step_seed = int(step_seed0) + 7919 * s
+        for stt, net_seed in zip(states, DM.step_net_seeds(step_seed)):
+            stt.update(seed=net_seed, calls=0, row_next=0, tok_next=0, layout=None)
+        batch = to_batch(O.make_batch(seed + 100 + (s & 1), B, counts, Lv, Lc, Lp, Lsent, dv, dt, ragged=ragged, corr=0.5))
+        opt.zero_grad()
+        vis = mgr.encode_visual(batch)
+        txt = mgr.encode_text(batch)
+        contr = tr.compute_total_constrastive_loss(vis, txt)
+        ic, isent = draw_cc_indices(seed + 7 + s, vis.clip_emb_mask, txt.sent_emb_mask)
+        th.manual_seed(seed + 7 + s)
+        cc = tr.compute_cyclecons_loss(vis, txt)
+        (contr + cc).backward()
+        opt.step()
+        losses.append([float(contr), float(cc)])
+        idxs.append(np.stack([ic, isent]))
+        seeds.append(step_seed)
+        print(f"  {name} step {s}: contrastive {float(contr):.5f} cycle-consistency {float(cc):.6f}", flush=True)
+    out = dict(losses=np.array(losses, dtype=np.float64), cc_idx=np.array(idxs, dtype=np.int64), step_seeds=np.array(seeds, dtype=np.uint64),
+               meta=np.array([seed, B, Lv, Lc, Lp, Lsent, dv, dt, hidden, heads, ff, pool_hidden]), ragged=np.array(int(ragged)),
+               cc_weight=np.array(float(cfg.train.loss_cycle_cons)), param_scale=np.array(scale), counts=np.asarray(counts),
+               layers=np.array(layers), train_p=np.array(float(p)), steps=np.array(steps), sub_step=np.array(sub_step),
+               adam=np.array([cfg.optimizer.lr, cfg.optimizer.momentum, cfg.optimizer.adam_beta2, cfg.optimizer.adam_eps,
+                              cfg.optimizer.weight_decay, float(cfg.optimizer.weight_decay_for_bias)], dtype=np.float64))
+    for k in NET_KEYS:
+        for n, q in mgr.model_dict[k].named_parameters():
+            d = (q.detach() - init[(k, n)]).numpy()
+            out[f"dnorm:{k}:{n}"] = np.array(np.linalg.norm(d.astype(np.float64)))
+            out[f"delta:{k}:{n}"] = d if (full or d.size <= 4096) else subsample(d, sub_step)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+TRAJ_SMALL = dict(dims=(40, 24, 32, 4, 32, 64), B=4, counts=[2, 1, 3, 2], Ls=(9, 7, 8, 5), seed=71, steps=8, p=0.1, step_seed0=5150001)
+TRAJ_ANET = dict(dims=ANET_DIMS, B=64, counts=[4] * 64, Ls=(80, 80, 64, 16), seed=73, steps=3, p=0.1, step_seed0=5150101, ragged=False,
+                 full=False)
+
+
+def gen_traj_small():
+    """8 optimizer steps at small dims (the per-op kernels), every parameter's final - initial in full, shipped Adam (eps 1e-8)."""
+    gen_train_trajectory("traj_small", **TRAJ_SMALL)
+
+
+def gen_traj_small_eps():
+    """... and at eps = 1e-3 (smooth updates: the bound on the parameter deltas is tight there)."""
+    gen_train_trajectory("traj_small_eps", adam_eps=1e-3, **TRAJ_SMALL)
+
+
+def gen_traj_anet():
+    """3 optimizer steps at the benchmark's shapes (64 videos x 4 clips, d_model 384: the fused chains), shipped Adam."""
+    gen_train_trajectory("traj_anet", **TRAJ_ANET)
+
+
+def gen_traj_anet_eps():
+    gen_train_trajectory("traj_anet_eps", adam_eps=1e-3, **TRAJ_ANET)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]  # e.g. "lr_schedule": regenerate just that fixture
@@ -740,6 +835,10 @@ def main():
     gen_bench_hbm_stress_train()
     gen_bench_yc2_100m_2layer_train()
     gen_bench_yc2_2d3d_2816()
+    gen_traj_small()
+    gen_traj_small_eps()
+    gen_traj_anet()
+    gen_traj_anet_eps()
     gen_rk_parity()
     gen_retrieval_metrics()
     gen_radam()

@@ -83,8 +83,8 @@ ANET_W = dict(weight_high=1.0, weight_high_internal=1.0, weight_low=1.0, weight_
               weight_context=1.0, weight_context_internal=0.0)
 
 
-def make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.01, device="cuda"):
-    """RetrievalModelManager + RetrievalTrainer for four oracle configs/param sets."""
+def make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.01, device="cuda", optimizer=None):
+    """RetrievalModelManager + RetrievalTrainer for four oracle configs/param sets.  optimizer: overrides of the optimizer section."""
     import torch
     import coot_videotext_amd as cva
     raw = dict(train=dict(batch_size=4, loss_func="contrastive", contrastive_loss_config=dict(margin=0.2, **ANET_W),
@@ -93,6 +93,7 @@ def make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.01, device="cuda"):
                optimizer=dict(name="adam", lr=1e-3, weight_decay=2e-5, weight_decay_for_bias=True, momentum=0.9,
                               adam_beta2=0.999, adam_eps=1e-8),
                use_cuda=True, fp16_train=True, fp16_val=True)
+    raw["optimizer"].update(optimizer or {})
     for k, c in zip(NET_KEYS, cfgs):
         raw[k] = ocfg_to_dict(c, dropout=dropout)
     cfg = cva.RetrievalConfig(raw)

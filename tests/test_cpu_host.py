@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(cva):
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(cva.lib.EXPORTS) <= declared
-    assert lib.coot_version() >= 1
+    assert lib.coot_version() == cva.lib.ABI_VERSION == int(re.search(r"#define COOT_ABI_VERSION (\d+)", hdr).group(1))
     # ... and nothing else leaves the shared object (-fvisibility=hidden + csrc/exports.map): no C++ internals, no kernel handles
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", cva.lib.LIB_PATH], capture_output=True, text=True, check=True).stdout

@@ -1,0 +1,128 @@
+"""The COMPOSED training loop against the reference's own step body (coot/trainer_retrieval.py:253-291; optimizer of
+nntrainer/optimization.py:45-74 over the parameter groups of nntrainer/models/model_manager_base.py:130-164).
+
+oracle/gen_golden.py: gen_train_trajectory ran the unmodified reference for k optimizer steps — zero_grad, encode_visual, encode_text,
+contrastive + cycle-consistency loss, backward, Adam (lr 1e-3, weight decay 2e-5 with decay_mult 0 on 'bias' parameters) — on two
+batches used in turn, in TRAIN mode with the library's dropout masks of the step seeds it stored, and wrote the losses of every step
+and final - initial of every parameter.  Here the library runs the same k steps (loss -> backward -> Adam -> weight repack -> next
+step) through its three step routes and must reproduce the loss curve and the parameter deltas.
+
+Two fixtures per shape.  At the shipped eps = 1e-8 Adam's first updates are lr * sign(g) whatever |g|: an entry whose gradient is
+smaller than the bf16 path's rounding noise takes a full +-lr step in a direction the noise decides, so the per-tensor cosine of the
+deltas is bounded by the share of such entries, not by the quality of the gradients (the bound below is the measured one, with margin).
+At eps = 1e-3 (>= the typical gradient entry) the update is a smooth function of the gradient and the bound is tight (0.999): a wrong
+decay mask, bias correction, moment update, repack or step count fails it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import coot_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+# fixture -> (loss tolerance rel, min per-tensor cosine of the parameter deltas, max relative error of a tensor's delta norm)
+CASES = {"traj_small": (2e-3, 0.97, 0.05), "traj_small_eps": (2e-3, 0.999, 0.02),
+         "traj_anet": (2e-3, 0.90, 0.10), "traj_anet_eps": (2e-3, 0.999, 0.02)}
+
+
+class _OneRankDP:
+    """dist.DataParallelContext of a one-rank job without torch.distributed (tests/test_gpu_train_parity.py)."""
+    rank, world, group = 0, 1, None
+
+    def gather_block(self, send, recv):
+        recv[:send.numel()].copy_(send)
+
+    def all_reduce_sum(self, t):
+        pass
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import coot_videotext_amd as cva
+    assert torch.cuda.is_available()
+    cva.lib.load()
+    return torch, cva
+
+
+def _setup(torch, cva, golden_dir, name):
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    seed, B, Lv, Lc, Lp, Ls, dv, dt, hidden, heads, ff, ph = [int(v) for v in g["meta"]]
+    cfgs = H.full_cfgs(dv, dt, hidden, heads, ff, ph, layers=int(g["layers"]))
+    Ps = [O.make_params(cfgs[i], seed + 10 * i, scale=float(g["param_scale"])) for i in range(4)]
+    lr, b1, b2, eps, wd, wdb = [float(v) for v in g["adam"]]
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=float(g["train_p"]), cc_weight=float(g["cc_weight"]),
+                              optimizer=dict(lr=lr, momentum=b1, adam_beta2=b2, adam_eps=eps, weight_decay=wd, weight_decay_for_bias=bool(wdb)))
+    mgr.set_all_models_train()
+    trainer = cva.RetrievalTrainer(cfg, mgr)
+    batches = []
+    for s in range(2):
+        b = O.make_batch(seed + 100 + s, B, g["counts"], Lv, Lc, Lp, Ls, dv, dt, ragged=bool(int(g["ragged"])), corr=0.5)
+        bt = cva.synthetic.batch_from_numpy(b)
+        bt.global_max_synced = True
+        batches.append(bt)
+    return g, cfgs, Ps, mgr, trainer, batches
+
+
+@pytest.mark.parametrize("route", ["single", "timed", "dp1"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_k_optimizer_steps_vs_the_reference_trainer(env, golden_dir, name, route):
+    torch, cva = env
+    g, cfgs, Ps, mgr, trainer, batches = _setup(torch, cva, golden_dir, name)
+    loss_tol, cos_min, norm_tol = CASES[name]
+    steps = int(g["steps"])
+    B, Nc = int(batches[0].clip_num.shape[0]), int(batches[0].clip_feat_len.shape[0])
+    if route == "dp1":
+        trainer.dp = _OneRankDP()
+    if route == "timed":
+        trainer.lookahead_min_stage_bytes = 0
+    got = []
+    for s in range(steps):
+        idx = torch.from_numpy(np.concatenate([g["cc_idx"][s, 0], g["cc_idx"][s, 1]]).astype(np.int64)).cuda()
+        kw = dict(seed=int(g["step_seeds"][s]), cc_indices=idx)
+        if route == "dp1":
+            kw.update(vid_counts=[B], clip_counts=[Nc])
+        if route == "timed":  # the mode bench.py times: the text side's join deferred, the next batch's input LayerNorm run by this step
+            kw.update(defer_join=True, next_batch=batches[(s + 1) & 1] if s + 1 < steps else None)
+        losses = trainer.train_step_native(batches[s & 1], **kw)
+        got.append([float(losses[1]), float(losses[2])])  # (reads are ordered on the caller's stream)
+    trainer.join_streams()
+    torch.cuda.synchronize()
+    got, ref = np.array(got), g["losses"]
+    for s in range(steps):
+        print(f"[{name}/{route}] step {s}: contrastive {got[s, 0]:.5f} vs {ref[s, 0]:.5f}   cycle-consistency {got[s, 1]:.6f} vs {ref[s, 1]:.6f}")
+    assert np.all(np.abs(got[:, 0] - ref[:, 0]) <= loss_tol * np.abs(ref[:, 0])), (got[:, 0], ref[:, 0])
+    assert np.all(np.abs(got[:, 1] - ref[:, 1]) <= 3 * loss_tol * np.abs(ref[:, 1]) + 1e-6), (got[:, 1], ref[:, 1])
+
+    # ---- final - initial of every parameter ----
+    sub = int(g["sub_step"])
+    lr = float(g["adam"][0])
+    dmax = max(float(g[k]) for k in g if k.startswith("dnorm:"))
+    bad, checked, cmin, worst_norm = [], 0, 1.0, 0.0
+    for i, k in enumerate(H.NET_KEYS):
+        net = mgr.model_dict[k]
+        flat = net._flat.detach().cpu().numpy()
+        for (pname, off, shape) in net.table:
+            n = int(np.prod(shape))
+            delta = flat[off:off + n].astype(np.float64) - np.asarray(Ps[i][pname], dtype=np.float32).reshape(-1).astype(np.float64)
+            key = f"{k}:{pname}"
+            rn = float(g["dnorm:" + key])
+            refd = g["delta:" + key].reshape(-1)
+            if rn < 1e-3 * lr * np.sqrt(n):
+                # the reference's gradient of this tensor is zero up to rounding (the key bias under a softmax): what Adam makes of
+                # rounding noise at eps = 1e-8 is not comparable; it cannot exceed full-sign steps
+                assert np.linalg.norm(delta) <= 1.01 * lr * steps * np.sqrt(n), key
+                continue
+            c = H.cosine_flat(delta[::(1 if refd.size == n else sub)], refd)
+            nr = float(np.linalg.norm(delta)) / rn
+            checked += 1
+            cmin = min(cmin, c)
+            worst_norm = max(worst_norm, abs(nr - 1))
+            if not (c >= cos_min and abs(nr - 1) <= norm_tol):
+                bad.append((key, round(c, 5), round(nr, 4)))
+    print(f"[{name}/{route}] {checked} parameter deltas after {steps} steps: min cosine {cmin:.5f}, worst norm error {worst_norm:.4f}; {len(bad)} out of tolerance")
+    assert not bad, bad
+    assert checked >= 100

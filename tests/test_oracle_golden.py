@@ -242,7 +242,8 @@ def test_torch_cpu_port_matches_numpy_oracle():
 def test_committed_fixtures_regenerate_from_the_reference(golden_dir, tmp_path):
     """The pin of the pin: where the unmodified reference is present (the build container: /root/reference or COOT_REFERENCE), the
     committed generator re-run into a scratch directory reproduces the committed fixtures BIT FOR BIT — the end-to-end eval
-    fixture, a train-mode fixture with the library's dropout masks injected into the reference's nn.Dropout sites, and the host-side
+    fixture, a train-mode fixture with the library's dropout masks injected into the reference's nn.Dropout sites, the 8-step training
+    trajectories of the reference's step body + optimizer (round 5), and the host-side
     ones (collate, LR schedules, RAdam, masks, retrieval metrics).  On the GPU box the reference does not exist: skipped."""
     import subprocess
     import sys
@@ -250,7 +251,7 @@ def test_committed_fixtures_regenerate_from_the_reference(golden_dir, tmp_path):
     ref = os.environ.get("COOT_REFERENCE", "/root/reference")
     if not os.path.isdir(os.path.join(ref, "coot")):
         pytest.skip("no reference checkout here")
-    names = ["full_small", "bench_yc2_100m_2layer_train", "collate", "lr_schedule", "radam", "mask_semantics", "retrieval_metrics"]
+    names = ["full_small", "bench_yc2_100m_2layer_train", "traj_small", "traj_small_eps", "collate", "lr_schedule", "radam", "mask_semantics", "retrieval_metrics"]
     env = dict(os.environ, COOT_GOLDEN_OUT=str(tmp_path), COOT_REFERENCE=ref)
     r = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py")] + names, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
