@@ -42,6 +42,13 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="library A/B switch name=value (coot_set_option), repeatable")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (phase calls + RCCL collectives) even with one rank")
+    ap.add_argument("--dp-backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend of the data-parallel step: nccl = RCCL over xGMI "
+                    "(the product path); gloo stages the collectives through host memory (dist.py: _host_staged) — for --share-device")
+    ap.add_argument("--share-device", action="store_true", help="TEST MODE, not a benchmark: all N ranks run on device 0 (RCCL refuses two ranks on one "
+                    "device, hence --dp-backend gloo).  Exercises the launcher, the rendezvous, the gloo side group, R-rank block offsets, the "
+                    "three-bucket reduce and the JSON line exactly as an N-GPU run does, on a one-GPU box; the line carries share_device = true")
+    ap.add_argument("--no-dropout", action="store_true", help="run the train step with the networks in eval mode (no dropout masks): the loss of a "
+                    "data-parallel job is then comparable with a single-process step on the union batch (tests)")
     ap.add_argument("--step-stamps", action="store_true", help="print a HIP-event timeline of one training step to stderr")
     ap.add_argument("--clock-monitor", action="store_true", help="after the timed loop: sample the shader clock on a side stream while more steps run (stderr)")
     ap.add_argument("--no-lookahead", action="store_true", help="do not announce the next batch to the step: its input LayerNorm runs at the head of its own step instead of next to the previous step's global networks (A/B)")
@@ -155,7 +162,8 @@ def spawn_ranks(n: int) -> int:
     import socket
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n:
+    share = "--share-device" in sys.argv
+    if have < (1 if share else n):
         raise RuntimeError(f"bench.py --gpus {n}: only {have} GPU(s) visible — refusing to report a {n}-GPU number from fewer devices")
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
@@ -175,7 +183,9 @@ def main():
         sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_device and args.dp_backend != "gloo":
+        raise RuntimeError("bench.py --share-device needs --dp-backend gloo (RCCL refuses two ranks on one device)")
     if world != args.gpus:
         raise RuntimeError(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if not torch.cuda.is_available():
@@ -199,7 +209,7 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world)
+            dist.init_process_group(args.dp_backend, rank=rank, world_size=world)
             dist.barrier()  # creates the communicator now, inside the redirection
             torch.cuda.synchronize()
         finally:
@@ -243,6 +253,8 @@ def main():
             return v.vid_emb.sum() + t.par_emb.sum()
     else:
         mgr.set_all_models_train()
+        if args.no_dropout:
+            mgr.set_all_models_eval()  # train_step_native passes train = model_mgr.is_train: same step, no masks
 
         mode = args.mode if (world == 1 or args.mode != "graph") else "autograd"
         batch.global_max_synced = True  # fixed shapes: every rank has the same Cmax, no MAX all-reduce needed
@@ -377,9 +389,12 @@ def main():
                          " ".join(f"{1e3 * (host_t[i + 1] - host_t[i]):.3f}" for i in range(len(host_t) - 1)) + "\n")
     if dp is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        cdist._all_reduce(t, torch.distributed.ReduceOp.MAX)  # (host-staged under gloo)
         elapsed = float(t.item())
     loss_val = float(last)
+    loss_words = None
+    if not args.eval and getattr(trainer, "_native", None) is not None and getattr(trainer._native, "losses", None) is not None:
+        loss_words = [float(v) for v in trainer._native.losses[:3].tolist()]  # (total, contrastive, cycle-consistency) of the last step
     if args.step_stamps and rank == 0 and not args.eval:
         # (regime probe) the FIRST step after an idle device: the host is not ahead, every launch arrives just in time
         lib.coot_set_option(b"step_stamps", 1)
@@ -553,7 +568,9 @@ def main():
                            "padded_tokens": [batch.vid_feat.shape[0] * batch.vid_feat.shape[1] + batch.clip_feat.shape[0] * batch.clip_feat.shape[1],
                                              batch.par_feat.shape[0] * batch.par_feat.shape[1] + batch.sent_feat.shape[0] * batch.sent_feat.shape[1]]}
                           if ragged else {}),
-                       "final_loss": round(loss_val, 5)},
+                       "final_loss": round(loss_val, 5), **({"final_losses": loss_words} if loss_words else {}),
+                       **({"share_device": True, "note": "TEST MODE: all ranks share device 0 through gloo (host-staged collectives); not a scaling number"}
+                          if args.share_device else {})},
             "per_gpu": round(value / world, 1), **({"blocks_ms_per_step": [round(b, 4) for b in blocks]} if args.repeat > 1 else {}),
             "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
             "algorithmic_tflops_per_s": round((fwd_flops if args.eval else train_flops) * world / (ms_per_step * 1e-3) / 1e12, 2),

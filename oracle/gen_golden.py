@@ -783,7 +783,7 @@ def gen_train_trajectory(name, dims, B, counts, Ls, seed, steps, p, step_seed0, 
     print("wrote", name)
 
 
-TRAJ_SMALL = dict(dims=(40, 24, 32, 4, 32, 64), B=4, counts=[2, 1, 3, 2], Ls=(9, 7, 8, 5), seed=71, steps=8, p=0.1, step_seed0=5150001)
+TRAJ_SMALL = dict(dims=(64, 48, 64, 4, 64, 128), B=4, counts=[2, 1, 3, 2], Ls=(9, 7, 8, 5), seed=71, steps=8, p=0.1, step_seed0=5150001)  # (the library's d_head: 16, 32, 48, 64)
 TRAJ_ANET = dict(dims=ANET_DIMS, B=64, counts=[4] * 64, Ls=(80, 80, 64, 16), seed=73, steps=3, p=0.1, step_seed0=5150101, ragged=False,
                  full=False)
 

@@ -111,16 +111,23 @@ def test_k_optimizer_steps_vs_the_reference_trainer(env, golden_dir, name, route
             key = f"{k}:{pname}"
             rn = float(g["dnorm:" + key])
             refd = g["delta:" + key].reshape(-1)
-            if rn < 1e-3 * lr * np.sqrt(n):
-                # the reference's gradient of this tensor is zero up to rounding (the key bias under a softmax): what Adam makes of
-                # rounding noise at eps = 1e-8 is not comparable; it cannot exceed full-sign steps
+            if rn < 0.05 * lr * steps * np.sqrt(n) and float(g["adam"][3]) < 1e-6:
+                # shipped eps only: the reference moved this tensor by less than 5 % of full-sign steps, i.e. its gradient entries are
+                # below Adam's eps = 1e-8 — zero up to fp32 rounding (the key bias under a softmax: 1e-11).  What Adam makes of
+                # rounding noise there is not comparable between two implementations (the bf16 path's noise is above eps: full-sign
+                # steps); it cannot exceed them.  At eps = 1e-3 these tensors stay where they are in both and are compared below.
                 assert np.linalg.norm(delta) <= 1.01 * lr * steps * np.sqrt(n), key
+                continue
+            if rn < 1e-4 * dmax:  # the reference left it where it was (zero gradient, smooth update): so must the library
+                assert np.linalg.norm(delta) <= 1e-3 * dmax, (key, float(np.linalg.norm(delta)))
                 continue
             c = H.cosine_flat(delta[::(1 if refd.size == n else sub)], refd)
             nr = float(np.linalg.norm(delta)) / rn
             checked += 1
             cmin = min(cmin, c)
             worst_norm = max(worst_norm, abs(nr - 1))
+            if c < 0.999 or abs(nr - 1) > 0.01:
+                print(f"[{name}/{route}]   {key}: delta cosine {c:.5f}  norm ratio {nr:.4f}  |delta_ref| {rn:.3e}")
             if not (c >= cos_min and abs(nr - 1) <= norm_tol):
                 bad.append((key, round(c, 5), round(nr, 4)))
     print(f"[{name}/{route}] {checked} parameter deltas after {steps} steps: min cosine {cmin:.5f}, worst norm error {worst_norm:.4f}; {len(bad)} out of tolerance")
