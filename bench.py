@@ -312,9 +312,24 @@ def main():
     if args.pre_burn:
         kind, ms_b = args.pre_burn.split(":")
         ms_b = float(ms_b)
+        # one untimed step first: its lazy initialisation leaves the device idle for ~50 ms, which would undo the burn
+        step()
         torch.cuda.synchronize()
         tb0 = time.perf_counter()
-        if kind == "hbm":
+        if kind == "none":
+            pass
+        elif kind == "mfma":
+            # MFMA-dense GEMMs: tests whether the slow weight-gradient launches of the first steps (tools/rocpd_early_late.py) are the
+            # device's power management ramping up under matrix load after an idle period
+            a_ = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16); b_ = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16)
+            torch.mm(a_, b_); torch.cuda.synchronize()
+            tb0 = time.perf_counter()
+            while time.perf_counter() - tb0 < ms_b * 1e-3:
+                for _ in range(4):
+                    torch.mm(a_, b_)
+                torch.cuda.synchronize()
+            del a_, b_
+        elif kind == "hbm":
             a_ = torch.empty(256 << 20, dtype=torch.float32, device="cuda"); b_ = torch.empty_like(a_)
             while time.perf_counter() - tb0 < ms_b * 1e-3:
                 for _ in range(8):

@@ -10,7 +10,8 @@ step) through its three step routes and must reproduce the loss curve and the pa
 Two fixtures per shape.  At the shipped eps = 1e-8 Adam's first updates are lr * sign(g) whatever |g|: an entry whose gradient is
 smaller than the bf16 path's rounding noise takes a full +-lr step in a direction the noise decides, so the per-tensor cosine of the
 deltas is bounded by the share of such entries, not by the quality of the gradients (the bound below is the measured one, with margin).
-At eps = 1e-3 (>= the typical gradient entry) the update is a smooth function of the gradient and the bound is tight (0.999): a wrong
+At eps = 1e-3 (>= the typical gradient entry) the update is a smooth function of the gradient and the bound is tight (0.999 at the
+benchmark's shapes, 0.998 at the small ones): a wrong
 decay mask, bias correction, moment update, repack or step count fails it.
 """
 import os
@@ -24,8 +25,11 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 # fixture -> (loss tolerance rel, min per-tensor cosine of the parameter deltas, max relative error of a tensor's delta norm)
-CASES = {"traj_small": (2e-3, 0.97, 0.05), "traj_small_eps": (2e-3, 0.999, 0.02),
-         "traj_anet": (2e-3, 0.90, 0.10), "traj_anet_eps": (2e-3, 0.999, 0.02)}
+# Measured (profiles/r05_train_trajectory.log): traj_anet_eps min delta cosine 0.99982 / norm error 0.002, losses within 8e-5; traj_anet (shipped
+# eps) 0.9936 / 0.005, losses within 1.3e-4; traj_small 0.9929 / 0.017; traj_small_eps 0.9985 / 0.004.  The small sets' loss is a hinge sum over 4
+# videos / 8 clips: one pair crossing the margin under bf16 rounding moves it by 1e-3 (step 0, before any update: 4.6e-4).
+CASES = {"traj_small": (4e-3, 0.98, 0.03), "traj_small_eps": (4e-3, 0.998, 0.02),
+         "traj_anet": (5e-4, 0.985, 0.02), "traj_anet_eps": (5e-4, 0.999, 0.01)}
 
 
 class _OneRankDP:
@@ -119,7 +123,7 @@ def test_k_optimizer_steps_vs_the_reference_trainer(env, golden_dir, name, route
                 assert np.linalg.norm(delta) <= 1.01 * lr * steps * np.sqrt(n), key
                 continue
             if rn < 1e-4 * dmax:  # the reference left it where it was (zero gradient, smooth update): so must the library
-                assert np.linalg.norm(delta) <= 1e-3 * dmax, (key, float(np.linalg.norm(delta)))
+                assert np.linalg.norm(delta) <= 5e-3 * dmax, (key, float(np.linalg.norm(delta)))
                 continue
             c = H.cosine_flat(delta[::(1 if refd.size == n else sub)], refd)
             nr = float(np.linalg.norm(delta)) / rn
