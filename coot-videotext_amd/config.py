@@ -90,7 +90,7 @@ class TransformerConfig:
         self.pool_hidden: int = pc.get("hidden_dim", 0) or self.hidden_dim
         self.pool_heads: int = pc.get("num_heads", 1)
         self.pool_dropout: float = float(pc.get("dropout", 0))
-        # compute mode of the HIP network (not a reference key): "bf16" = the fast path, "f32" = the forward-only fp32 reference
+        # compute mode of the HIP network (not a reference key): "bf16" = the fast path, "f32" = the fp32 reference
         # mode (include/coot_hip.h: coot_net_config.dtype), e.g. to tell bf16 rounding from a logic error
         self.dtype: str = d.get("dtype", "bf16")
         _require(self.dtype in ("bf16", "f32"), f"dtype {self.dtype} (bf16 or f32)")

@@ -858,6 +858,10 @@ size_t coot_net_saved_bytes(const coot_net_config* cfg, int N, int Lseq, int N2,
 }
 size_t coot_net_scratch_bytes(const coot_net_config* cfg, int N, int Lseq, int N2, int L2) {
   coot_net_config c; if (norm_cfg(cfg, &c)) return 0;
+  if (c.dtype == COOT_DTYPE_F32) {  // the reference mode's backward temporaries
+    NetLayout L; build_layout(c, L);
+    return ref_f32_scratch_bytes(ref_desc(c, L, N + N2), (long)N * Lseq + (long)N2 * L2);
+  }
   Arena A(nullptr, 0); Scratch S; layout_scratch(c, N + N2, (long)N * Lseq + (long)N2 * L2, A, S); return A.off + 256;
 }
 
@@ -971,7 +975,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   }
   const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
-  if (c.dtype == COOT_DTYPE_F32) {  // fp32 reference mode (ref_f32.hip): the reference's op sequence, forward only
+  if (c.dtype == COOT_DTYPE_F32) {  // fp32 reference mode (ref_f32.hip): the reference's op sequence in fp32
     COOT_REQUIRE(!train, "net_fwd: the f32 reference mode is an eval-mode checker (train must be 0)");
     COOT_REQUIRE(!packed || packed->source == COOT_SOURCE_PADDED, "net_fwd: the f32 reference mode reads the reference's padded batch");
     RefSegs rs; rs.n = sg.n;
@@ -1114,7 +1118,6 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   COOT_REQUIRE(P && wpack && feats && lengths && dpooled && G && saved && scratch, "net_bwd: null pointer");
   if (packed && packed->source != COOT_SOURCE_PADDED && N2 > 0 && !feats2) feats2 = feats;  // (one packed matrix carries both segments)
   COOT_REQUIRE(!(dfeats && c.use_input_fc), "net_bwd: dfeats is only available for networks without input_fc");
-  COOT_REQUIRE(c.dtype == COOT_DTYPE_BF16, "net_bwd: the f32 reference mode is forward-only (gradients: the bf16 path against the fp64 oracle and the reference's fixtures)");
   if (N <= 0) return 0;
   Segs sg; sg.N[0] = N; sg.L[0] = Lseq; sg.lens[0] = (const long long*)lengths;
   if (N2 > 0) {
@@ -1123,6 +1126,14 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   }
   const int Ntot = sg.Ntot();
   NetLayout L; build_layout(c, L);
+  if (c.dtype == COOT_DTYPE_F32) {  // fp32 reference mode (ref_f32.hip): the derivative of the reference's op sequence, all fp32
+    COOT_REQUIRE(!train, "net_bwd: the f32 reference mode is an eval-mode checker (train must be 0)");
+    COOT_REQUIRE(!packed || packed->source == COOT_SOURCE_PADDED, "net_bwd: the f32 reference mode reads the reference's padded batch");
+    COOT_REQUIRE(!c.use_context || hidden, "net_bwd: context network needs hidden state (transformer_legacy.py:252)");
+    RefSegs rs; rs.n = sg.n;
+    for (int s_ = 0; s_ < sg.n; ++s_) { rs.N[s_] = sg.N[s_]; rs.L[s_] = sg.L[s_]; rs.lens[s_] = sg.lens[s_]; }
+    return ref_f32_backward(ref_desc(c, L, Ntot), P, G, feats, feats2, rs, hidden, dpooled, dhidden, dfeats, saved, saved_bytes, scratch, scratch_bytes, st);
+  }
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
   PerOpGuardScope perop_guard(c, W, P, wpack);
   Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);

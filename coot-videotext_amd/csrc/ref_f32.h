@@ -1,4 +1,4 @@
-// fp32 reference mode of a network forward (ref_f32.hip): the op sequence of TransformerLegacy.forward in eval mode, all fp32.
+// fp32 reference mode of a network (ref_f32.hip): the op sequence of TransformerLegacy.forward in eval mode and its backward, all fp32.
 #pragma once
 #include <vector>
 
@@ -15,9 +15,16 @@ struct RefNetDesc {
 };
 struct RefSegs { int n = 1; int N[2] = {0, 0}; int L[2] = {0, 0}; const long long* lens[2] = {nullptr, nullptr}; };
 
+// bytes of the `saved` buffer (every intermediate of the forward: the backward reads them there) and of the backward's `scratch`
 size_t ref_f32_workspace_bytes(const RefNetDesc& d, long T);
+size_t ref_f32_scratch_bytes(const RefNetDesc& d, long T);
 // feats / feats2: the (up to two) padded fp32 segments [N, L, Din]; pooled [Ntot, out_dim]; per_token [N0 L0, D] or null
 int ref_f32_forward(const RefNetDesc& d, const float* P, const float* pe, const float* feats, const float* feats2, const RefSegs& sg,
                     const float* hidden, float* pooled, float* per_token, void* ws, size_t ws_bytes, hipStream_t st);
+// backward of the forward that filled `ws`: ACCUMULATES the parameter gradients into G (same offsets as P), writes dhidden [N, D]
+// (context networks) and dfeats [T, Din] (networks without input FC), both optional
+int ref_f32_backward(const RefNetDesc& d, const float* P, float* G, const float* feats, const float* feats2, const RefSegs& sg,
+                     const float* hidden, const float* dpooled, float* dhidden, float* dfeats, void* ws, size_t ws_bytes, void* scratch,
+                     size_t scratch_bytes, hipStream_t st);
 
 }  // namespace coot

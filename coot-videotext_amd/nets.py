@@ -123,9 +123,9 @@ class TransformerHip(nn.Module):
         return out
 
     def set_compute_dtype(self, dtype: str) -> None:
-        """"bf16" (default): the fast path.  "f32": the forward-only fp32 reference mode of the library (coot_net_config.dtype =
-        COOT_DTYPE_F32: the reference's op sequence in fp32, eval mode) — outputs agree with the reference to ~1e-6 of their scale, so
-        comparing the two modes measures the bf16 rounding of the fast path."""
+        """"bf16" (default): the fast path.  "f32": the fp32 reference mode of the library (coot_net_config.dtype = COOT_DTYPE_F32: the
+        reference's op sequence and its derivative in fp32, eval mode) — outputs agree with the reference to ~1e-6 of their scale,
+        parameter gradients to ~1e-5, so comparing the two modes measures the bf16 rounding of the fast path."""
         assert dtype in ("bf16", "f32"), dtype
         self.cfg.dtype = dtype
         self.c_cfg = self.cfg.to_c()

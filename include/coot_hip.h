@@ -44,12 +44,14 @@ typedef struct coot_net_config {
   float ctx_dropout;  /* crossatn_config.dropout                                          */
   float pool_dropout; /* pooler_config.dropout                                            */
   int dtype;          /* COOT_DTYPE_BF16 (0, default): bf16 MFMA operands, fp32 accumulation / statistics — the fast path.
-                         COOT_DTYPE_F32: the fp32 REFERENCE MODE of coot_net_fwd — the reference's op sequence
+                         COOT_DTYPE_F32: the fp32 REFERENCE MODE of coot_net_fwd / coot_net_bwd — the reference's op sequence
                          (nntrainer/models/transformer_legacy.py:200-288, eval mode) with every activation, weight and
                          accumulation in fp32, exact erf GELU, nothing fused or folded: agrees with the reference to ~1e-6 of the
                          output scale, so a difference between the two modes is bf16 rounding and a difference to the reference in
-                         F32 mode is a logic error.  A checker: forward-only, eval only (train must be 0), never what bench.py
-                         times.  `saved` is its workspace (coot_net_saved_bytes accounts for it); wpack is not read.           */
+                         F32 mode is a logic error.  coot_net_bwd in this mode is the derivative of exactly that sequence in fp32
+                         (parameter gradients to ~1e-5 of the reference's).  A checker: eval only (train must be 0), never what
+                         bench.py times.  `saved` keeps every intermediate of the forward (coot_net_saved_bytes accounts for it),
+                         `scratch` the backward's temporaries (coot_net_scratch_bytes); wpack is not read.                       */
 } coot_net_config;
 #define COOT_DTYPE_BF16 0
 #define COOT_DTYPE_F32 1

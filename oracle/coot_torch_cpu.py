@@ -138,7 +138,7 @@ def contrastive(im, s, margin):
     """ContrastiveLoss.forward (coot/loss_fn.py:63-100), max_violation False."""
     scores = im @ s.t()
     diag = scores.diag().view(-1, 1)
-    eye = torch.eye(scores.shape[0], dtype=torch.bool)
+    eye = torch.eye(scores.shape[0], dtype=torch.bool, device=scores.device)
     cost_s = (margin + scores - diag).clamp(min=0).masked_fill(eye, 0)
     cost_im = (margin + scores - diag.t()).clamp(min=0).masked_fill(eye, 0)
     return (cost_s.sum() + cost_im.sum()) / (scores.shape[0] ** 2)
@@ -173,12 +173,12 @@ def cyclecons(clip, clip_pad, sent, sent_pad, idx_clip, idx_sent):
     def rows(a, ap, b, bp):
         nn1, _ = _soft_nn(a, ap, b, bp)
         _, beta = _soft_nn(nn1, ap, a, ap)
-        ar = torch.arange(a.shape[1]).float()
+        ar = torch.arange(a.shape[1], device=a.device).float()
         mu = (beta * ar[None, None, :]).sum(-1)
         return ((mu - ar[None, :]) ** 2).masked_fill(ap, 0)
     B = clip.shape[0]
     lc, ls = rows(clip, clip_pad, sent, sent_pad), rows(sent, sent_pad, clip, clip_pad)
-    ar = torch.arange(B)
+    ar = torch.arange(B, device=clip.device)
     return lc[ar, idx_clip].mean(), ls[ar, idx_sent].mean()
 
 
