@@ -522,8 +522,27 @@ def main():
                 traffic_src = os.path.relpath(cands[-1], os.path.dirname(os.path.abspath(__file__)))
             except (KeyError, ValueError, OSError):
                 traffic = None
+        # The same family in the committed rocprofv3 kernel trace of this command (profiles/*_kernel_stats_bench_train_anet.csv: sum of the
+        # four chain kernels' total time / steps in the trace): a launch's duration there runs from its first workgroup's start to its last
+        # one's end under the profiler's own interleaving of the two streams, and differs from the HIP-event figure of the free-running
+        # step by how long the text side's 64-row launches wait for CUs.  Both are reported; `frac` is the live one.
+        trace = None
+        if fam_key == "fused" and args.workload == "anet" and not args.eval:
+            csvs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_kernel_stats_bench_train_anet.csv")))
+            try:
+                import csv as _csv
+                rows = list(_csv.DictReader(open(csvs[-1])))
+                nsteps = next(int(r["calls"]) for r in rows if "sample_idx_kernel" in r["kernel"])
+                fam_us = sum(float(r["total_us"]) for r in rows if any(k in r["kernel"] for k in ("infc_qkv_fwd", "post_attn_fwd", "pre_attn_bwd", "qkv_bwd"))) / nsteps
+                tf_tr = by[dom]["algorithmic_gflop_per_step"] / fam_us / 1e3
+                trace = {"frac": round(tf_tr / 2500.0, 4), "achieved": round(tf_tr, 1), "us_per_step": round(fam_us, 1), "steps_in_trace": nsteps,
+                         "source": os.path.relpath(csvs[-1], os.path.dirname(os.path.abspath(__file__))),
+                         "note": "committed rocprofv3 --kernel-trace of this command, not measured in this run"}
+            except (IndexError, StopIteration, KeyError, ValueError, OSError, ZeroDivisionError):
+                trace = None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": by[dom]["achieved"], "peak": 2500.0, "unit": "TFLOP/s",
-                    "frac": by[dom]["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, "
+                    "frac": by[dom]["frac"], "frac_method": "HIP events around every launch of the family, on its launch stream, in " + str(nst) + " extra steps of this run",
+                    "trace": trace, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, "
                     "family average)", "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": by[dom].get("algorithmic_bytes_per_launch"),
                     "launches_per_step": by[dom]["launches_per_step"],

@@ -575,18 +575,29 @@ int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* b, in
                      coot_stream_t side_v, coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
   COOT_REQUIRE(step >= 1, "step_update: step counts from 1");
-  COOT_REQUIRE((repack & ~(COOT_UPDATE_REPACK | COOT_UPDATE_DEFER_TEXT_JOIN)) == 0, "step_update: unknown bits in repack (%d): a bit mask since ABI 5", repack);
+  COOT_REQUIRE((repack & ~(COOT_UPDATE_REPACK | COOT_UPDATE_DEFER_TEXT_JOIN | COOT_UPDATE_SKIP_GLOBAL | COOT_UPDATE_GLOBAL_ONLY)) == 0,
+               "step_update: unknown bits in repack (%d): a bit mask since ABI 5", repack);
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
+  const bool do_pack = (repack & COOT_UPDATE_REPACK) != 0;
+  if (repack & COOT_UPDATE_GLOBAL_ONLY) {
+    // the two GLOBAL networks only, on main_s alone: their gradients are final (and, data parallel, reduced) a whole local backward
+    // before the step's end — the caller runs this on its communication stream behind their bucket (as coot_train_step's early update)
+    COOT_REQUIRE((repack & (COOT_UPDATE_SKIP_GLOBAL | COOT_UPDATE_DEFER_TEXT_JOIN)) == 0, "step_update: GLOBAL_ONLY excludes SKIP_GLOBAL / DEFER_TEXT_JOIN");
+    const int gnets[2] = {1, 3};
+    RUN(adam_nets(*cfg, *b, gnets, 2, step, sm));
+    if (do_pack) RUN(pack_nets(*cfg, *b, gnets, 2, main_s));
+    return 0;
+  }
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   const int vnets[2] = {0, 1}, tnets[2] = {2, 3};
-  const bool do_pack = (repack & COOT_UPDATE_REPACK) != 0;
+  const int per_side = (repack & COOT_UPDATE_SKIP_GLOBAL) ? 1 : 2;  // (SKIP_GLOBAL: a GLOBAL_ONLY call of this step already updated them)
   // total = contrastive + cycle-consistency rides on the VIDEO side's launch: with COOT_UPDATE_DEFER_TEXT_JOIN main_s is ordered after
   // that side only, and all three loss words are readable there (as in coot_train_step)
-  RUN(adam_nets(*cfg, *b, vnets, 2, step, sv, losses));
-  if (do_pack) RUN(pack_nets(*cfg, *b, vnets, 2, side_v));
-  RUN(adam_nets(*cfg, *b, tnets, 2, step, st));
-  if (do_pack) RUN(pack_nets(*cfg, *b, tnets, 2, side_t));
+  RUN(adam_nets(*cfg, *b, vnets, per_side, step, sv, losses));
+  if (do_pack) RUN(pack_nets(*cfg, *b, vnets, per_side, side_v));
+  RUN(adam_nets(*cfg, *b, tnets, per_side, step, st));
+  if (do_pack) RUN(pack_nets(*cfg, *b, tnets, per_side, side_t));
   RUN(g_hops.hop(4, sv, sm));
   if ((repack & COOT_UPDATE_DEFER_TEXT_JOIN) == 0) RUN(g_hops.hop(5, st, sm));
   return 0;

@@ -46,7 +46,7 @@ SOURCE_PADDED, SOURCE_PACKED_F32, SOURCE_PACKED_BF16 = 0, 1, 2  # COOT_SOURCE_* 
 DTYPE_BF16, DTYPE_F32 = 0, 1  # COOT_DTYPE_* (coot_net_config.dtype)
 STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH, STEP_DEFER_TEXT_JOIN, STEP_INPUT_STAGES, STEP_STAGE_ANNOUNCED = 1, 2, 4, 8, 16, 32  # coot_train_step do_optimizer bits (include/coot_hip.h)
 FWD_PACKS_FRESH, FWD_INPUT_STAGES, FWD_STAGE_ANNOUNCED = 1, 2, 4  # coot_step_forward packs_fresh bits
-UPDATE_REPACK, UPDATE_DEFER_TEXT_JOIN = 1, 2  # coot_step_update repack bits
+UPDATE_REPACK, UPDATE_DEFER_TEXT_JOIN, UPDATE_SKIP_GLOBAL, UPDATE_GLOBAL_ONLY = 1, 2, 4, 8  # coot_step_update repack bits
 DP_MAX_RANKS = 16  # COOT_DP_MAX_RANKS: ranks whose gathered blocks coot_contrastive_fwd_bwd_dp_blocks addresses in place
 
 

@@ -119,6 +119,12 @@ def _with_next(iterable):
 
 
 class RetrievalTrainer:
+    # data-parallel native step: Adam + weight pack of the global networks on the communication stream behind their gradient bucket
+    # (COOT_UPDATE_GLOBAL_ONLY), as coot_train_step does on one GPU.  Built and parity-tested in round 5; with ONE rank it measured 0.5 %
+    # slower than updating all four networks at the tail (1.258 against 1.252 ms, profiles/r05_ab_dp_early_update.txt: two more launches
+    # on a third stream with nothing to hide behind them), and no multi-GPU box was available to measure it where the bucket's
+    # all-reduce takes ~100 us: off unless COOT_DP_EARLY=1.
+    dp_early_global_update = os.environ.get("COOT_DP_EARLY", "0") == "1"
     lookahead_min_stage_bytes = 32 << 20  # train_step_native(next_batch=): only batches whose normalised features reach this size
 
     def __init__(self, cfg: RetrievalConfig, model_mgr: RetrievalModelManager, is_test: bool = False,
@@ -1057,14 +1063,25 @@ class RetrievalTrainer:
         self._det_flush([st.losses])  # (deterministic mode: the cycle-consistency word's fixed-point sum, behind the backward on main)
         for slot in (st.EV_GLOB_V, st.EV_GLOB_T):
             _lib.check(lib.coot_event_wait(slot, st.comm.cuda_stream), "coot_event_wait")
+        # The global networks are updated EARLY, as in coot_train_step: their reduced gradients exist a whole local backward before the
+        # step's end, so Adam + weight pack of those two networks run on the communication stream right behind their bucket and the
+        # tail of the step updates the local networks only.  Same rule as the single call: only when the local backward is long enough
+        # to hide the two extra launches (kEarlyMinTokens rows on the video side), and not in deterministic mode.
+        d = st.dims
+        early = (do_optimizer and self.dp_early_global_update and not getattr(self, "deterministic", False)
+                 and d.B * d.Lv + d.Nc * d.Lc >= 8192)
         with torch.cuda.stream(st.comm):
             dp.all_reduce_sum(st.g_glob)
+            if early:
+                cs = st.comm.cuda_stream
+                _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), _lib.UPDATE_REPACK | _lib.UPDATE_GLOBAL_ONLY,
+                                                None, cs, cs, cs), "coot_step_update (global networks)")
             _lib.check(lib.coot_event_wait(st.EV_TEXT, st.comm.cuda_stream), "coot_event_wait")
             dp.all_reduce_sum(st.g_loc_t)
         dp.all_reduce_sum(st.g_loc_v)
         _lib.check(lib.coot_stream_hop(st.comm.cuda_stream, main.cuda_stream), "coot_stream_hop")
         if do_optimizer:  # (the video side's update launch also writes total = contrastive + cycle-consistency)
-            flags = _lib.UPDATE_REPACK | (_lib.UPDATE_DEFER_TEXT_JOIN if defer_join else 0)
+            flags = _lib.UPDATE_REPACK | (_lib.UPDATE_DEFER_TEXT_JOIN if defer_join else 0) | (_lib.UPDATE_SKIP_GLOBAL if early else 0)
             _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), flags, st.losses.data_ptr(), main.cuda_stream,
                                             sv.cuda_stream, stt.cuda_stream), "coot_step_update")
             st.join_pending = bool(defer_join)

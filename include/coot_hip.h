@@ -385,6 +385,10 @@ int coot_stream_hop(coot_stream_t from, coot_stream_t to);
  * writes total = contrastive + cycle-consistency (a data-parallel caller keeps the two all-reduced words there: no extra launch). */
 #define COOT_UPDATE_REPACK 1
 #define COOT_UPDATE_DEFER_TEXT_JOIN 2
+#define COOT_UPDATE_SKIP_GLOBAL 4  /* the two global networks are left alone: a COOT_UPDATE_GLOBAL_ONLY call of the same step updated them */
+#define COOT_UPDATE_GLOBAL_ONLY 8  /* update (and repack) the two GLOBAL networks only, on main_s alone (side_v / side_t unused, losses untouched):
+                                      their gradients are final behind the global backward (data parallel: behind their all-reduce bucket), a whole
+                                      local backward before the step's end — as coot_train_step's early update of the global networks         */
 int coot_step_update(const coot_step_config* cfg, const coot_step_buffers* bufs, int64_t step, int repack, float* losses,
                      coot_stream_t main_stream, coot_stream_t side_v, coot_stream_t side_t);
 /* One valid clip / sentence position per video for the cycle-consistency loss (th.multinomial(mask, 1), coot/loss_fn.py:306-314),

@@ -122,3 +122,56 @@ def test_data_parallel_phase_path_is_deterministic_too(env):
     assert la == lb, (la, lb)
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
+
+
+def _plan_run(torch, cva, cfgs, Ps, batches, plan, use_graph):
+    """One trainer, one native step per entry of `plan` (the deterministic flag of that step), seeds from the step counter (what a
+    captured step can replay).  Returns (losses, parameters, number of cached graphs after every step)."""
+    torch.manual_seed(4321)
+    cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.1, cc_weight=0.01)
+    mgr.set_all_models_train()
+    tr = cva.RetrievalTrainer(cfg_x, mgr)
+    losses, cached = [], []
+    try:
+        for it, det in enumerate(plan):
+            if det != bool(getattr(tr, "deterministic", False)):
+                tr.set_deterministic(det)
+                assert not getattr(getattr(tr, "_native", None), "graphs", None), "a change of the deterministic mode must drop every captured step"
+            out = tr.train_step_native(batches[it % len(batches)], use_graph=use_graph)
+            losses.append([float(v) for v in out])
+            cached.append(len(getattr(tr._native, "graphs", {}) or {}))
+        torch.cuda.synchronize()
+        return losses, [n._flat.detach().clone() for n in mgr.model_dict.values()], cached
+    finally:
+        tr.set_deterministic(False)
+
+
+def test_captured_steps_follow_the_deterministic_mode(env):
+    """the library consults its process-wide deterministic table at RUN time, a captured step holds the flush launches
+    (or their absence) and the shadow's address of the mode it was captured in.  RetrievalTrainer therefore keys its captured steps
+    by the mode + configuration epoch, configures the mode before a capture and drops every cached graph when it changes:
+      * deterministic + graph replay: two runs are bit-identical, and identical to the eager deterministic run (same launches);
+      * toggling the mode between replays re-captures (a graph captured with the mode off has no flush nodes: replayed with the mode
+        on it would drop the bias / LayerNorm gradients; one captured with it on reads a shadow that is freed when it goes off) and
+        follows the eager run of the same plan to fp32 round-off."""
+    torch, cva = env
+    cfgs = H.full_cfgs(*DIMS)
+    Ps = [O.make_params(cfgs[i], 3 + 10 * i) for i in range(4)]
+    batches = _batches(cva, ragged=False)[:1]  # one shape: one captured step per mode
+    det_plan = [True] * 5
+    l1, p1, c1 = _plan_run(torch, cva, cfgs, Ps, batches, det_plan, use_graph=True)
+    l2, p2, _ = _plan_run(torch, cva, cfgs, Ps, batches, det_plan, use_graph=True)
+    le, pe, _ = _plan_run(torch, cva, cfgs, Ps, batches, det_plan, use_graph=False)
+    assert c1[-1] == 1, c1  # (step 0 runs eagerly and creates the lazy state, step 1 captures, the rest replay)
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(p1, p2)), "deterministic graph replays differ between two runs"
+    assert l1 == le and all(torch.equal(a, b) for a, b in zip(p1, pe)), "deterministic graph replay differs from the eager deterministic run"
+    plan = [False, False, False, True, True, True, False, False]
+    lg, pg, cg = _plan_run(torch, cva, cfgs, Ps, batches, plan, use_graph=True)
+    lq, pq, _ = _plan_run(torch, cva, cfgs, Ps, batches, plan, use_graph=False)
+    assert cg == [0, 1, 1, 1, 1, 1, 1, 1], cg  # (dropped at each change of the mode — asserted in _plan_run — and captured again by the next step)
+    for a, b in zip(lg, lq):
+        assert np.allclose(a, b, rtol=2e-3, atol=1e-6), (a, b)
+    for a, b in zip(pg, pq):
+        assert torch.isfinite(a).all()
+        # (Adam at eps = 1e-8 turns last-bit differences of the non-deterministic steps into +-lr per entry: compare at that scale)
+        assert float((a - b).abs().max()) <= 8 * 2e-3, float((a - b).abs().max())

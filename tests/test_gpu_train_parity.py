@@ -38,6 +38,10 @@ def env():
 
 
 _cache = {}
+# Gradient bounds per parameter tensor (sub-sampled cosine, norm ratio) against the reference's train-mode gradients.  Measured on the
+# six fixtures, three routes (profiles/r05_gpu_tests.log): min cosine 0.9997, norm within 0.6 % — the bounds sit a factor ~3 outside
+# that, so a 1 % error in a gradient fails (round 4 had cos > 0.99 / 3 %, which a 10 % error in a small tensor passed).
+GRAD_COS_MIN, GRAD_NORM_TOL = 0.999, 0.015
 
 
 def _case(golden_dir, name):
@@ -114,7 +118,7 @@ def test_train_mode_native_step_vs_reference_with_injected_masks(env, golden_dir
 
     step = int(g["sub_step"])
     gmax = max(float(g[k]) for k in g if k.startswith("gnorm:"))
-    bad, checked, cmin = [], 0, 1.0
+    bad, checked, cmin, nmax = [], 0, 1.0, 0.0
     for k in H.NET_KEYS:
         net = mgr.model_dict[k]
         flat = net._grad_flat.detach().cpu().numpy()
@@ -131,11 +135,12 @@ def test_train_mode_native_step_vs_reference_with_injected_masks(env, golden_dir
             nr = float(np.linalg.norm(got.astype(np.float64))) / gn
             checked += 1
             cmin = min(cmin, c)
-            if c < 0.995 or abs(nr - 1) > 0.02:
-                print(f"[{name}]   {key}: cos(sub) {c:.4f}  norm ratio {nr:.4f}  |g_ref| / max |g_ref| = {gn / gmax:.2e}")
-            if not (c > 0.99 and 0.97 < nr < 1.03):
+            nmax = max(nmax, abs(nr - 1))
+            if c < 0.9995 or abs(nr - 1) > 0.005:
+                print(f"[{name}]   {key}: cos(sub) {c:.5f}  norm ratio {nr:.4f}  |g_ref| / max |g_ref| = {gn / gmax:.2e}")
+            if not (c > GRAD_COS_MIN and abs(nr - 1) < GRAD_NORM_TOL):
                 bad.append((key, round(c, 4), round(nr, 4)))
-    print(f"[{name}] {checked} parameter gradients checked (min cosine {cmin:.4f}), {len(bad)} out of tolerance")
+    print(f"[{name}] {checked} parameter gradients checked (min cosine {cmin:.5f}, worst norm error {nmax:.4f}), {len(bad)} out of tolerance")
     assert not bad, bad
     assert checked >= 100
 
@@ -208,7 +213,7 @@ def test_timed_mode_lookahead_and_deferred_join_vs_reference(env, golden_dir, na
             c = H.cosine_flat(got[::(1 if ref.size == got.size else step)], ref)
             nr = float(np.linalg.norm(got.astype(np.float64))) / gn
             checked += 1
-            if not (c > 0.99 and 0.97 < nr < 1.03):
+            if not (c > GRAD_COS_MIN and abs(nr - 1) < GRAD_NORM_TOL):
                 bad.append((key, round(c, 4), round(nr, 4)))
     print(f"[{name}] timed mode: {checked} parameter gradients checked, {len(bad)} out of tolerance")
     assert not bad, bad
@@ -276,7 +281,7 @@ def test_dp_phase_calls_at_bench_shapes_vs_reference(env, golden_dir, name):
             c = H.cosine_flat(got[::(1 if ref.size == got.size else step)], ref)
             nr = float(np.linalg.norm(got.astype(np.float64))) / gn
             checked += 1
-            if not (c > 0.99 and 0.97 < nr < 1.03):
+            if not (c > GRAD_COS_MIN and abs(nr - 1) < GRAD_NORM_TOL):
                 bad.append((key, round(c, 4), round(nr, 4)))
     print(f"[{name}] DP phases: {checked} parameter gradients checked, {len(bad)} out of tolerance")
     assert not bad, bad
