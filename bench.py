@@ -534,7 +534,7 @@ def main():
                 rows = list(_csv.DictReader(open(csvs[-1])))
                 nsteps = next(int(r["calls"]) for r in rows if "sample_idx_kernel" in r["kernel"])
                 fam_us = sum(float(r["total_us"]) for r in rows if any(k in r["kernel"] for k in ("infc_qkv_fwd", "post_attn_fwd", "pre_attn_bwd", "qkv_bwd"))) / nsteps
-                tf_tr = by[dom]["algorithmic_gflop_per_step"] / fam_us / 1e3
+                tf_tr = by[dom]["algorithmic_gflop_per_step"] / fam_us * 1e3  # GFLOP / us = PFLOP/s
                 trace = {"frac": round(tf_tr / 2500.0, 4), "achieved": round(tf_tr, 1), "us_per_step": round(fam_us, 1), "steps_in_trace": nsteps,
                          "source": os.path.relpath(csvs[-1], os.path.dirname(os.path.abspath(__file__))),
                          "note": "committed rocprofv3 --kernel-trace of this command, not measured in this run"}

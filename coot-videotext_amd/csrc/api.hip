@@ -656,6 +656,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "cl_small")) { set_cl_small(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
   if (!strcmp(name, "ln_stream_wgs")) { g_ln_wgs = value; return 0; }
+  if (!strncmp(name, "half_tiles_", 11) && name[11] >= '0' && name[11] <= '3' && !name[12]) { set_half_tiles_max(name[11] - '0', value); return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   set_error("unknown option %s", name);
   return -2;

@@ -1864,7 +1864,12 @@ __global__ __launch_bounds__(256) void colsum_scatter_kernel(ScatterArgs a) {
 // the per-tile latency, however few tiles there are.  Up to 16 384 tokens (the text side of every shipped config, ragged batches
 // with packed rows, small batches) 64-row tiles still fit in one wave and each takes about half as long; above, 128-row tiles
 // (half the weight traffic per token) stay one wave up to 32 768 tokens.
-bool half_tiles(int T) { return T <= 256 * 64; }
+// (per kernel — 0 input FC + QKV, 1 forward chain, 2 backward chain, 3 QKV dX — so that a threshold can be A/B-ed on its own:
+// coot_set_option("half_tiles_<k>", max tokens); round 5 measured the forward kernels of the 25 600-token video side on 64-row tiles
+// too, profiles/README.md)
+static int g_half_max[4] = {256 * 64, 256 * 64, 256 * 64, 256 * 64};
+bool half_tiles(int T, int kernel) { return T <= g_half_max[kernel & 3]; }
+void set_half_tiles_max(int kernel, int max_tokens) { g_half_max[kernel & 3] = max_tokens; }
 
 int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   COOT_REQUIRE(p.ctx && p.xres && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.ln1g && p.ln1b && p.ln2g && p.ln2b && p.r1 && p.z1 &&
@@ -1882,7 +1887,7 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   if (small) {
     if (drop) hipLaunchKernelGGL((post_attn_fwd_kernel<2, true>), dim3((p.T + 31) / 32), dim3(NTHR), 0, st, p);
     else hipLaunchKernelGGL((post_attn_fwd_kernel<2, false>), dim3((p.T + 31) / 32), dim3(NTHR), 0, st, p);
-  } else if (half_tiles(p.T)) {
+  } else if (half_tiles(p.T, 1)) {
     if (drop) hipLaunchKernelGGL((post_attn_fwd_kernel<4, true>), dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
     else hipLaunchKernelGGL((post_attn_fwd_kernel<4, false>), dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
   } else if (drop) {
@@ -1904,7 +1909,7 @@ int launch_pre_attn_bwd(const PreAttnBwd& p_in, hipStream_t st) {
                "pre_attn_bwd: null pointer");
   COOT_REQUIRE(p.do_pool ? (p.ds && p.dzp && p.hp && p.pw2 && p.pw1 && p.dhp) : (p.dz2 != nullptr), "pre_attn_bwd: input gradient pointers");
   if (p.T <= 0) return 0;
-  const bool half = half_tiles(p.T);
+  const bool half = half_tiles(p.T, 2);
   const int tiles = half ? (p.T + 63) / 64 : (p.T + 127) / 128;
   // the per-tile partial rows: kept until the pass's single reduction launch if the caller opened a deferred scope (rowops.h)
   float* top = colsum_defer_room() >= 8 ? partials_workspace_top((size_t)tiles * FZ_BWD_NCS) : nullptr;
@@ -1952,7 +1957,7 @@ int launch_qkv_bwd(const QkvBwd& p_in, hipStream_t st) {
   COOT_REQUIRE(p.dqkv && p.wqkv && p.res && p.dz, "qkv_bwd: null pointer");
   COOT_REQUIRE(!p.aux || (p.colsum && p.part), "qkv_bwd: GELU' needs the column-sum buffers");
   if (p.T <= 0) return 0;
-  const bool half = half_tiles(p.T);
+  const bool half = half_tiles(p.T, 3);
   const int tiles = half ? (p.T + 63) / 64 : (p.T + 127) / 128;
   bool deferred = false;
   if (p.aux) {  // per-tile column sums -> the pass's single deferred reduction, if a scope is open (rowops.h)
@@ -2037,7 +2042,7 @@ int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st) {
   COOT_REQUIRE(p.Din % 64 == 0 && p.Din >= 128 && p.L1 > 0 && p.L2 > 0, "infc_qkv_fwd: Din = %d must be a multiple of 64, >= 128", p.Din);
   if (p.T <= 0) return 0;
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * (p.Din + 1152.0), 0, st);
-  if (half_tiles(p.T)) hipLaunchKernelGGL(infc_qkv_fwd_kernel<4>, dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
+  if (half_tiles(p.T, 0)) hipLaunchKernelGGL(infc_qkv_fwd_kernel<4>, dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
   else hipLaunchKernelGGL(infc_qkv_fwd_kernel<8>, dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("infc_qkv_fwd");
