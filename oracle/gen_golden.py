@@ -717,7 +717,7 @@ from nntrainer import optimization  # noqa: E402
 
 
 def gen_train_trajectory(name, dims, B, counts, Ls, seed, steps, p, step_seed0, scale=0.05, ragged=True, cc_weight=None, adam_eps=None,
-                         full=True, sub_step=29, layers=1):
+                         full=True, sub_step=29, layers=1, packed=False):
     """`steps` consecutive optimizer steps of the reference's step body (coot/trainer_retrieval.py:253-291: zero_grad, encode_visual,
     encode_text, total contrastive + cycle-consistency loss, backward, optimizer.step) on TWO seeded batches used in turn (as bench.py
     does: the loss of step s then shows what steps s - 2, s - 4, ... did to the parameters), with the
@@ -744,7 +744,8 @@ def gen_train_trajectory(name, dims, B, counts, Ls, seed, steps, p, step_seed0, 
     for i, k in enumerate(NET_KEYS):
         load_params(mgr.model_dict[k], O.make_params(ocfgs[i], seed + 10 * i, scale=scale))
     mgr.set_all_models_train()
-    states = [inject_dropout(mgr.model_dict[k], 0, float(p)) for k in NET_KEYS]
+    # packed: the masks of the PACKED token-row layout of the local networks (cu_seqlens: what bench.py --workload anet_ragged runs)
+    states = [inject_dropout(mgr.model_dict[k], 0, float(p), packed=packed and k.endswith("local")) for k in NET_KEYS]
     params, _names, _flat = mgr.get_all_params()
     opt = optimization.make_optimizer(cfg.optimizer, params)
     init = {(k, n): q.detach().clone() for k in NET_KEYS for n, q in mgr.model_dict[k].named_parameters()}
@@ -772,6 +773,7 @@ def gen_train_trajectory(name, dims, B, counts, Ls, seed, steps, p, step_seed0, 
                meta=np.array([seed, B, Lv, Lc, Lp, Lsent, dv, dt, hidden, heads, ff, pool_hidden]), ragged=np.array(int(ragged)),
                cc_weight=np.array(float(cfg.train.loss_cycle_cons)), param_scale=np.array(scale), counts=np.asarray(counts),
                layers=np.array(layers), train_p=np.array(float(p)), steps=np.array(steps), sub_step=np.array(sub_step),
+               train_packed=np.array(int(bool(packed))),
                adam=np.array([cfg.optimizer.lr, cfg.optimizer.momentum, cfg.optimizer.adam_beta2, cfg.optimizer.adam_eps,
                               cfg.optimizer.weight_decay, float(cfg.optimizer.weight_decay_for_bias)], dtype=np.float64))
     for k in NET_KEYS:
@@ -807,6 +809,13 @@ def gen_traj_anet_eps():
     gen_train_trajectory("traj_anet_eps", adam_eps=1e-3, **TRAJ_ANET)
 
 
+def gen_traj_anet_ragged_packed_eps():
+    """3 optimizer steps on RAGGED ActivityNet-shaped batches (clip counts ~ annotation statistics, ragged lengths) with the masks of the
+    packed token-row layout — the composed loop of `bench.py --workload anet_ragged` — at eps = 1e-3."""
+    gen_train_trajectory("traj_anet_ragged_packed_eps", adam_eps=1e-3, dims=ANET_DIMS, B=64, counts=anet_like_counts(43, 64), Ls=(80, 80, 64, 30), seed=79,
+                         steps=3, p=0.1, step_seed0=5150201, ragged=True, full=False, packed=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]  # e.g. "lr_schedule": regenerate just that fixture
@@ -839,6 +848,7 @@ def main():
     gen_traj_small_eps()
     gen_traj_anet()
     gen_traj_anet_eps()
+    gen_traj_anet_ragged_packed_eps()
     gen_rk_parity()
     gen_retrieval_metrics()
     gen_radam()

@@ -169,8 +169,8 @@ def test_captured_steps_follow_the_deterministic_mode(env):
     lg, pg, cg = _plan_run(torch, cva, cfgs, Ps, batches, plan, use_graph=True)
     lq, pq, _ = _plan_run(torch, cva, cfgs, Ps, batches, plan, use_graph=False)
     assert cg == [0, 1, 1, 1, 1, 1, 1, 1], cg  # (dropped at each change of the mode — asserted in _plan_run — and captured again by the next step)
-    for a, b in zip(lg, lq):
-        assert np.allclose(a, b, rtol=2e-3, atol=1e-6), (a, b)
+    for a, b in zip(lg, lq):  # (one batch trained for 8 steps: by then the loss is a few hinge violations, sensitive to the last bits the
+        assert np.allclose(a, b, rtol=3e-2, atol=3e-3), (a, b)  # non-deterministic steps differ in; a dropped gradient or a freed shadow moves it by O(1))
     for a, b in zip(pg, pq):
         assert torch.isfinite(a).all()
         # (Adam at eps = 1e-8 turns last-bit differences of the non-deterministic steps into +-lr per entry: compare at that scale)

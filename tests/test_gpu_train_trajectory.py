@@ -29,7 +29,9 @@ pytestmark = pytest.mark.gpu
 # eps) 0.9936 / 0.005, losses within 1.3e-4; traj_small 0.9929 / 0.017; traj_small_eps 0.9985 / 0.004.  The small sets' loss is a hinge sum over 4
 # videos / 8 clips: one pair crossing the margin under bf16 rounding moves it by 1e-3 (step 0, before any update: 4.6e-4).
 CASES = {"traj_small": (4e-3, 0.98, 0.03), "traj_small_eps": (4e-3, 0.998, 0.02),
-         "traj_anet": (5e-4, 0.985, 0.02), "traj_anet_eps": (5e-4, 0.999, 0.01)}
+         "traj_anet": (5e-4, 0.985, 0.02), "traj_anet_eps": (5e-4, 0.999, 0.01),
+         # ragged batches on the PACKED token rows (cu_seqlens), the layout bench.py --workload anet_ragged runs
+         "traj_anet_ragged_packed_eps": (5e-4, 0.999, 0.01)}
 
 
 class _OneRankDP:
@@ -65,7 +67,7 @@ def _setup(torch, cva, golden_dir, name):
     batches = []
     for s in range(2):
         b = O.make_batch(seed + 100 + s, B, g["counts"], Lv, Lc, Lp, Ls, dv, dt, ragged=bool(int(g["ragged"])), corr=0.5)
-        bt = cva.synthetic.batch_from_numpy(b)
+        bt = cva.synthetic.batch_from_numpy(b, packed=bool(int(g["train_packed"])) if "train_packed" in g else False)
         bt.global_max_synced = True
         batches.append(bt)
     return g, cfgs, Ps, mgr, trainer, batches

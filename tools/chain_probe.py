@@ -16,7 +16,9 @@ lib = cva.lib.load()
 cfg = O.NetConfig(input_dim=2048, hidden_dim=384, num_heads=8, ff_dim=384, pool_hidden=768, pool_heads=2)
 net = H.make_hip_net(cfg, O.make_params(cfg, 3), dropout=0.025)
 net.train(True)
-for N in (320, 200):
+import numpy as np
+side = torch.cuda.Stream()
+for N in (320, 200, 100):
     x = torch.randn(N, 80, 2048, device="cuda")
     lens = torch.full((N,), 80, dtype=torch.long, device="cuda")
     mask = torch.zeros(N, 80, dtype=torch.bool, device="cuda")
@@ -25,12 +27,21 @@ for N in (320, 200):
             for _ in range(3):
                 net(x, mask, lens, None, seed=1)
             torch.cuda.synchronize()
+            # shader clock during the launches (round 5): one wave on a side stream samples s_memtime against the 100 MHz counter every 20 us
+            nsamp = 400
+            mon = torch.zeros(2 * nsamp, dtype=torch.int64, device="cuda")
+            with torch.cuda.stream(side):
+                cva.lib.check(lib.coot_debug_clock_monitor(mon.data_ptr(), nsamp, 2000, side.cuda_stream), "clock_monitor")
             lib.coot_timing_enable(1)
             for _ in range(10):
                 net(x, mask, lens, None, seed=1)
             torch.cuda.synchronize()
+            m = mon.cpu().numpy().reshape(-1, 2).astype(np.float64)
+            ghz = np.diff(m[:, 1]) / (np.diff(m[:, 0]) * 10.0)
+            busy_ghz = ghz[5:120]
             ms, fl, n = C.c_double(), C.c_double(), C.c_int()
             cva.lib.check(lib.coot_timing_collect(5, C.byref(ms), C.byref(fl), C.byref(n)), "timing_collect")
             lib.coot_timing_enable(0)
         print(f"N={N} sequences x 80 frames ({N * 80 // 128} tiles): fused chain launches (infc_qkv_fwd + post_attn_fwd) "
-              f"{1e3 * ms.value / 10:.1f} us per forward, {n.value // 10} launches")
+              f"{1e3 * ms.value / 10:.1f} us per forward, {n.value // 10} launches; shader clock while they run {busy_ghz.mean():.2f} GHz "
+              f"(p10 {np.percentile(busy_ghz, 10):.2f}, p90 {np.percentile(busy_ghz, 90):.2f}; idle tail {ghz[-40:].mean():.2f})")
