@@ -51,6 +51,22 @@ __device__ __forceinline__ void gst16(void* base, unsigned boff, u32x4_t v) {
   *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(base) + boff) = v;
 }
 
+// Measurement build only (tools/build_variant.sh xcd5 "-DFZ_XCDS=5"): the forward chain kernels' tiles are dealt to the first FZ_XCDS
+// XCDs only (workgroup b runs on XCD b % 8; the launchers widen the grid, the other XCDs' workgroups return at once) — does a tile's
+// latency at a given NUMBER of resident tiles depend on how many share one XCD's L2 (profiles/README.md round 5)?
+#ifdef FZ_XCDS
+__device__ __forceinline__ int fz_tile_index(int ntiles) {
+  const int x = blockIdx.x & 7;
+  if (x >= FZ_XCDS) return -1;
+  const int t = (blockIdx.x >> 3) * FZ_XCDS + x;
+  return t < ntiles ? t : -1;
+}
+static inline int fz_grid(int tiles) { return (tiles + FZ_XCDS - 1) / FZ_XCDS * 8; }
+#else
+__device__ __forceinline__ int fz_tile_index(int) { return blockIdx.x; }
+static inline int fz_grid(int tiles) { return tiles; }
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter (s_waitcnt
 // vmcnt(0)): inside the epilogue rounds that made every round wait for the previous round's global STORES to be
 // acknowledged and for the next round's prefetched loads to land — the rounds ran at one memory round trip each.
@@ -415,7 +431,9 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
   float* Bsm = reinterpret_cast<float*>(smem + BT * APITCH * 2 + RR * SPITCH * 4);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = blockIdx.x * BT, T = p.T;
+  const int tile_idx = fz_tile_index((p.T + BT - 1) / BT);
+  if (tile_idx < 0) return;
+  const int row0 = tile_idx * BT, T = p.T;
   f32x4_t acc[RF][3];
   {
     const float* vecs[7] = {p.bo, p.b1, p.b2, p.ln1g, p.ln1b, p.ln2g, p.ln2b};
@@ -1630,7 +1648,9 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
   float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
   float* Bsm = reinterpret_cast<float*>(smem + BT * APITCH * 2 + RR * SPITCH * 4);  // bin | bq | bk | bv
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * BT, Din = p.Din;
+  const int tile_idx = fz_tile_index((p.T + BT - 1) / BT);
+  if (tile_idx < 0) return;
+  const int row0 = tile_idx * BT, Din = p.Din;
   int tsn = 48;
   // (the pointer is re-read from its SGPR pair at every stamp: as a VGPR address hoisted to the kernel's entry it was the last spill)
   auto stamp = [&]() {
@@ -1888,12 +1908,12 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
     if (drop) hipLaunchKernelGGL((post_attn_fwd_kernel<2, true>), dim3((p.T + 31) / 32), dim3(NTHR), 0, st, p);
     else hipLaunchKernelGGL((post_attn_fwd_kernel<2, false>), dim3((p.T + 31) / 32), dim3(NTHR), 0, st, p);
   } else if (half_tiles(p.T, 1)) {
-    if (drop) hipLaunchKernelGGL((post_attn_fwd_kernel<4, true>), dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
-    else hipLaunchKernelGGL((post_attn_fwd_kernel<4, false>), dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
+    if (drop) hipLaunchKernelGGL((post_attn_fwd_kernel<4, true>), dim3(fz_grid((p.T + 63) / 64)), dim3(NTHR), 0, st, p);
+    else hipLaunchKernelGGL((post_attn_fwd_kernel<4, false>), dim3(fz_grid((p.T + 63) / 64)), dim3(NTHR), 0, st, p);
   } else if (drop) {
-    hipLaunchKernelGGL((post_attn_fwd_kernel<8, true>), dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+    hipLaunchKernelGGL((post_attn_fwd_kernel<8, true>), dim3(fz_grid((p.T + 127) / 128)), dim3(NTHR), 0, st, p);
   } else {
-    hipLaunchKernelGGL((post_attn_fwd_kernel<8, false>), dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+    hipLaunchKernelGGL((post_attn_fwd_kernel<8, false>), dim3(fz_grid((p.T + 127) / 128)), dim3(NTHR), 0, st, p);
   }
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("post_attn_fwd");
@@ -2042,8 +2062,8 @@ int launch_infc_qkv_fwd(const InfcQkvFwd& p, hipStream_t st) {
   COOT_REQUIRE(p.Din % 64 == 0 && p.Din >= 128 && p.L1 > 0 && p.L2 > 0, "infc_qkv_fwd: Din = %d must be a multiple of 64, >= 128", p.Din);
   if (p.T <= 0) return 0;
   void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * (p.Din + 1152.0), 0, st);
-  if (half_tiles(p.T, 0)) hipLaunchKernelGGL(infc_qkv_fwd_kernel<4>, dim3((p.T + 63) / 64), dim3(NTHR), 0, st, p);
-  else hipLaunchKernelGGL(infc_qkv_fwd_kernel<8>, dim3((p.T + 127) / 128), dim3(NTHR), 0, st, p);
+  if (half_tiles(p.T, 0)) hipLaunchKernelGGL(infc_qkv_fwd_kernel<4>, dim3(fz_grid((p.T + 63) / 64)), dim3(NTHR), 0, st, p);
+  else hipLaunchKernelGGL(infc_qkv_fwd_kernel<8>, dim3(fz_grid((p.T + 127) / 128)), dim3(NTHR), 0, st, p);
   timing_end(ts, st);
   COOT_CHECK_LAUNCH("infc_qkv_fwd");
   return 0;
