@@ -434,6 +434,9 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   const int tile_idx = fz_tile_index((p.T + BT - 1) / BT);
   if (tile_idx < 0) return;
   const int row0 = tile_idx * BT, T = p.T;
+#ifdef FZ_TILE_LOG  // measurement build: where (XCD, shader engine, CU) every tile ran and how long it took (tools/tile_log.py)
+  const unsigned long long fz_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   f32x4_t acc[RF][3];
   {
     const float* vecs[7] = {p.bo, p.b1, p.b2, p.ln1g, p.ln1b, p.ln2g, p.ln2b};
@@ -556,6 +559,18 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
       stamp();
     }
   }
+#ifdef FZ_TILE_LOG
+  {
+    unsigned long long* ts = p.tstamps;
+    asm volatile("" : "+s"(ts));
+    if (ts && threadIdx.x == 0) {
+      unsigned long long* e = ts + 128 + 4 * tile_idx;
+      e[0] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+      e[1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+      e[2] = fz_t0; e[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+#endif
 }
 
 // ---- backward chain --------------------------------------------------------------------------------------------------
