@@ -104,7 +104,8 @@ def _grads_vs_fixture(g, mgr, tag):
     return worst, checked
 
 
-@pytest.mark.parametrize("name", ["full_anet", "bench_anet"])
+# (ragged batches, the fixed benchmark shape, two encoder layers per local network, Cmax = 64)
+@pytest.mark.parametrize("name", ["full_anet", "bench_anet", "bench_anet_ragged", "bench_yc2_100m_2layer", "bench_hbm_stress"])
 def test_f32_reference_mode_gradients_match_the_reference(env, golden_dir, name):
     """coot_net_bwd in the fp32 reference mode (csrc/ref_f32.hip: the derivative of the reference's op sequence, all fp32) against the
     parameter gradients the unmodified reference wrote (eval-mode fixtures, dropout off): every one of the 108 non-zero gradients to
