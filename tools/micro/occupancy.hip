@@ -5,6 +5,8 @@
 //   mode 1  LDS only: ds_read_b128 / ds_write_b128 rounds over a 96 KB tile (conflict free)
 //   mode 2  L2 stream: every workgroup reads the same 2.4 MB (the weights of a chain pass) with 16-byte loads, 3 in flight per wave
 //   mode 3  straight-line VALU: the mode-0 work as ~48 KB of unrolled code (instruction fetch)
+//   mode 6 / 7  the mode-3 code executed ONCE per launch, the two (identical, separately compiled) kernels launched alternately so
+//           that each launch finds the instruction cache (64 KB per CU pair) holding the other one: cold straight-line code
 //   mode 4  MFMA only: 12 independent v_mfma_f32_16x16x32_bf16 accumulators per wave, back to back
 //   mode 5  a chain-like mix per repetition: an MFMA pass (96 MFMAs per wave), then an "epilogue" of 1 536 VALU ops and 48 LDS round trips
 // Reported per G: median / max workgroup time in shader clocks (s_memtime) and in us (100 MHz counter).
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* stamp, 
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) a[i & 7] += acc[i][0] + acc[i][3];
-  } else {
+  } else {  // modes 3, 6, 7
     for (int r = 0; r < reps; ++r) {
 #pragma unroll
       for (int j = 0; j < 768; ++j)
@@ -120,6 +122,30 @@ void run(const char* name, int reps, float* out, unsigned long long* stamp, cons
   }
 }
 
+void run_cold(float* out, unsigned long long* stamp, const f32x4* wts) {
+  hipFuncSetAttribute((const void*)k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  hipFuncSetAttribute((const void*)k<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  printf("mode 6 / 7: ~48 KB of straight-line VALU executed ONCE per launch, two copies of the kernel launched alternately (cold instruction cache)\n");
+  const int Gs[] = {8, 64, 96, 128, 160, 200, 256};
+  for (int G : Gs) {
+    std::vector<double> med;
+    for (int it = 0; it < 6; ++it) {
+      if (it & 1) hipLaunchKernelGGL(k<7>, dim3(G), dim3(512), 150 * 1024, 0, out, stamp, wts, 1, 1.0001f);
+      else hipLaunchKernelGGL(k<6>, dim3(G), dim3(512), 150 * 1024, 0, out, stamp, wts, 1, 1.0001f);
+      hipDeviceSynchronize();
+      std::vector<unsigned long long> h(2 * G);
+      hipMemcpy(h.data(), stamp, 2 * G * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      std::vector<double> cyc;
+      for (int b = 0; b < G; ++b) cyc.push_back((double)h[2 * b]);
+      std::sort(cyc.begin(), cyc.end());
+      if (it >= 2) med.push_back(cyc[G / 2]);
+    }
+    std::sort(med.begin(), med.end());
+    printf("  G = %3d (%4.1f per XCD): clocks for the one pass, median workgroup, over 4 launches: min %8.0f max %8.0f   (warm, mode 3: ~29 500)\n", G, G / 8.0,
+           med.front(), med.back());
+  }
+}
+
 int main() {
   float* out; unsigned long long* stamp; f32x4* wts;
   hipMalloc(&out, 256 * 512 * sizeof(float)); hipMalloc(&stamp, 2 * 256 * sizeof(unsigned long long)); hipMalloc(&wts, 2400 * 1024);
@@ -128,6 +154,7 @@ int main() {
   run<1>("mode 1: LDS only (ds_read_b128 + ds_write_b128 rounds)", 1024, out, stamp, wts);
   run<2>("mode 2: L2 stream (every workgroup reads the same 2.4 MB, 16 B per lane, 3 loads in flight per wave)", 24, out, stamp, wts);
   run<3>("mode 3: straight-line VALU (~48 KB of unrolled v_fma_f32)", 24, out, stamp, wts);
+  run_cold(out, stamp, wts);
   run<4>("mode 4: MFMA only (12 accumulators per wave, 2 waves per SIMD)", 2048, out, stamp, wts);
   run<5>("mode 5: chain-like mix (96 MFMAs, then 1 536 VALU ops + 48 LDS round trips, per repetition)", 256, out, stamp, wts);
   return 0;
