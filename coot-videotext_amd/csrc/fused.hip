@@ -91,21 +91,15 @@ __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RF][3]) {
 //   PD: small tiles (the global networks, RF <= 2) do almost no MFMA work per k-block, a pass is the latency of streaming 295 KB of
 //   weights: 5 k-blocks (15 KB per wave) in flight.  Full tiles: a pass is at the MFMA time of 2 waves/SIMD, PD = 2 (3 / 4: no faster).
 //   NB must divide every pass's KB (12, 6): a pass then starts at ring slot 0 whatever preceded it.
-#ifndef FZ_PD_FULL
-#define FZ_PD_FULL 2
-#endif
-#ifndef FZ_CARRY
-#define FZ_CARRY 1   // 0: every pass loads its own first k-blocks (A/B)
-#endif
+constexpr int kPdFull = 2;       // k-blocks in flight on full tiles (3 / 4 measured no faster)
 //   CARRY: 128-row tiles do not carry (the PD x 12 ring registers live across an epilogue that already holds 96 accumulators + its
-//   chunk registers: 104-148 B of scratch per lane); their passes start with their own first k-blocks.  A ring type's CARRY decides
-//   for every pass run on it.
-#ifndef FZ_CARRY_MAX_RF
-#define FZ_CARRY_MAX_RF 4
-#endif
+//   chunk registers: 104-148 B of scratch per lane; measured 0.25 % faster WITH the spills, profiles/r04_ab_carry_ring.txt — not
+//   adopted); their passes start with their own first k-blocks.  A ring type's CARRY decides for every pass run on it.  (Round 4 kept
+//   these as -D experiment macros; the measured settings are now constants.)
+constexpr int kCarryMaxRF = 4;
 template <int PD_, bool CARRY_>
 struct WRing { static constexpr int PD = PD_, NB = PD_ + 1; static constexpr bool CARRY = CARRY_; bf16x8_t w[PD_ + 1][3]; };
-template <int RF> using TileRing = WRing<(RF <= 2 ? 5 : FZ_PD_FULL), (FZ_CARRY != 0 && RF <= FZ_CARRY_MAX_RF)>;
+template <int RF> using TileRing = WRing<(RF <= 2 ? 5 : kPdFull), (RF <= kCarryMaxRF)>;
 
 // the first PD k-blocks of weight group wg -> ring slots 0 .. PD - 1 (the first pass of a kernel; later passes inherit theirs)
 template <typename Ring>
