@@ -32,3 +32,38 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _device_hygiene_between_modules():
+    """Behind every test module on a GPU box: collect dead trainers, drop what the library's thread-local step state still points at
+    (input stages, the announced next batch, caller events, injected cycle indices, the deterministic table — all owned by trainers
+    that no longer exist) and return the caching allocator's blocks.  Round 5: `test_gpu_train_parity.py test_gpu_train_trajectory.py
+    test_gpu_path.py` in ONE process ended in a segmentation fault inside hipGraphLaunch (torch.cuda.CUDAGraph.replay of the autograd
+    route's captured step) although every pair of the three files passes and the suite in its own (alphabetical) order passes every time.
+    The crash is timing dependent (the same command under rocgdb: 74 passed) and survives this clean-up — a hipGraph launch race in the
+    runtime, on the autograd route's graph mode only (bench.py and train_model use the native step) — but dangling library state between
+    modules is not something a test-suite should rely on being harmless.  COOT_TEST_NO_HYGIENE=1 switches this off."""
+    yield
+    if os.environ.get("COOT_TEST_NO_HYGIENE") == "1" or "torch" not in sys.modules:
+        return
+    import gc
+    import torch
+    if not torch.cuda.is_available():
+        return
+    gc.collect()
+    torch.cuda.synchronize()
+    try:
+        import coot_videotext_amd as cva
+        lib = cva.lib.load()
+        lib.coot_step_set_next_batch(None, None)
+        lib.coot_step_set_input_stages(None, None, 0)
+        lib.coot_step_set_global_done_events(None, None)
+        lib.coot_step_set_cycle_indices(None)
+        lib.coot_step_set_device_state(None)
+        lib.coot_det_configure(0, None, None, None, 0, None)
+    except Exception:  # (a CPU-only module never loaded the library)
+        pass
+    torch.cuda.empty_cache()
+    if os.environ.get("COOT_TEST_MEM_REPORT") == "1":
+        sys.stderr.write(f"[hygiene] reserved after the module: {torch.cuda.memory_reserved() / 2**30:.2f} GiB\n")
