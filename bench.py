@@ -545,6 +545,10 @@ def main():
                     "trace": trace, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, "
                     "family average)", "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": by[dom].get("algorithmic_bytes_per_launch"),
+                    # measured in THIS run without counters: the bytes the family's launches read and write as built, from the sizes of
+                    # the tensors this run actually launched (every saved / operand tensor once per token); `traffic` next to it is the
+                    # PMC figure of the committed profile (a run under the driver cannot collect counters)
+                    "traffic_live_estimate": by[dom].get("algorithmic_bytes_per_launch"),
                     "launches_per_step": by[dom]["launches_per_step"],
                     "avg_launch_us": by[dom]["avg_launch_us"], "ms_per_step": by[dom]["ms_per_step"],
                     # the same launches against the OTHER roofline: their algorithmic bytes over the same durations (the chains save
