@@ -717,7 +717,7 @@ from nntrainer import optimization  # noqa: E402
 
 
 def gen_train_trajectory(name, dims, B, counts, Ls, seed, steps, p, step_seed0, scale=0.05, ragged=True, cc_weight=None, adam_eps=None,
-                         full=True, sub_step=29, layers=1, packed=False):
+                         full=True, sub_step=29, layers=1, packed=False, optimizer=None):
     """`steps` consecutive optimizer steps of the reference's step body (coot/trainer_retrieval.py:253-291: zero_grad, encode_visual,
     encode_text, total contrastive + cycle-consistency loss, backward, optimizer.step) on TWO seeded batches used in turn (as bench.py
     does: the loss of step s then shows what steps s - 2, s - 4, ... did to the parameters), with the
@@ -735,9 +735,12 @@ def gen_train_trajectory(name, dims, B, counts, Ls, seed, steps, p, step_seed0, 
     cfg = ref_config(*dims, layers=layers, dropout=p)
     if cc_weight is not None:
         cfg.train.loss_cycle_cons = cc_weight
+    for k_, v_ in (optimizer or {}).items():  # e.g. the YouCook2 configurations' RAdam (yc2_100m_coot.yaml:136-148)
+        assert hasattr(cfg.optimizer, k_), k_
+        setattr(cfg.optimizer, k_, v_)
     if adam_eps is not None:
         cfg.optimizer.adam_eps = adam_eps
-    assert cfg.optimizer.name == "adam" and cfg.train.clip_gradient == -1
+    assert cfg.optimizer.name in ("adam", "radam") and cfg.train.clip_gradient == -1
     ocfgs = oracle_cfgs(*dims, layers=layers)
     th.manual_seed(0)
     mgr = model_retrieval.RetrievalModelManager(cfg)
@@ -773,7 +776,8 @@ def gen_train_trajectory(name, dims, B, counts, Ls, seed, steps, p, step_seed0, 
                meta=np.array([seed, B, Lv, Lc, Lp, Lsent, dv, dt, hidden, heads, ff, pool_hidden]), ragged=np.array(int(ragged)),
                cc_weight=np.array(float(cfg.train.loss_cycle_cons)), param_scale=np.array(scale), counts=np.asarray(counts),
                layers=np.array(layers), train_p=np.array(float(p)), steps=np.array(steps), sub_step=np.array(sub_step),
-               train_packed=np.array(int(bool(packed))),
+               train_packed=np.array(int(bool(packed))), opt_name=np.array(cfg.optimizer.name),
+               radam_degentosgd=np.array(int(bool(cfg.optimizer.radam_degentosgd))),
                adam=np.array([cfg.optimizer.lr, cfg.optimizer.momentum, cfg.optimizer.adam_beta2, cfg.optimizer.adam_eps,
                               cfg.optimizer.weight_decay, float(cfg.optimizer.weight_decay_for_bias)], dtype=np.float64))
     for k in NET_KEYS:
@@ -798,6 +802,20 @@ def gen_traj_small():
 def gen_traj_small_eps():
     """... and at eps = 1e-3 (smooth updates: the bound on the parameter deltas is tight there)."""
     gen_train_trajectory("traj_small_eps", adam_eps=1e-3, **TRAJ_SMALL)
+
+
+YC2_RADAM = dict(name="radam", lr=9e-4, weight_decay=0.0, momentum=0.56, adam_beta2=0.98, adam_eps=1.5e-9, radam_degentosgd=False)
+
+
+def gen_traj_small_radam():
+    """10 optimizer steps with the YouCook2 configurations' optimizer (yc2_100m_coot.yaml / yc2_2d3d_coot.yaml:136-148: the in-file RAdam of
+    nntrainer/optimization.py:79-181, lr 9e-4, betas (0.56, 0.98), eps 1.5e-9, no weight decay, not degenerated to SGD): with beta2 =
+    0.98 the variance rectification switches on at step 6 — steps 1-5 move only the moments, steps 6-10 the parameters."""
+    gen_train_trajectory("traj_small_radam", optimizer=YC2_RADAM, **dict(TRAJ_SMALL, steps=10, seed=83, step_seed0=5150301))
+
+
+def gen_traj_small_radam_eps():
+    gen_train_trajectory("traj_small_radam_eps", optimizer=dict(YC2_RADAM, adam_eps=1e-3), **dict(TRAJ_SMALL, steps=10, seed=83, step_seed0=5150301))
 
 
 def gen_traj_anet():
@@ -849,6 +867,8 @@ def main():
     gen_traj_anet()
     gen_traj_anet_eps()
     gen_traj_anet_ragged_packed_eps()
+    gen_traj_small_radam()
+    gen_traj_small_radam_eps()
     gen_rk_parity()
     gen_retrieval_metrics()
     gen_radam()

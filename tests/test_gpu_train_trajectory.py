@@ -26,12 +26,15 @@ pytestmark = pytest.mark.gpu
 
 # fixture -> (loss tolerance rel, min per-tensor cosine of the parameter deltas, max relative error of a tensor's delta norm)
 # Measured (profiles/r05_train_trajectory.log): traj_anet_eps min delta cosine 0.99982 / norm error 0.002, losses within 8e-5; traj_anet (shipped
-# eps) 0.9936 / 0.005, losses within 1.3e-4; traj_small 0.9929 / 0.017; traj_small_eps 0.9985 / 0.004.  The small sets' loss is a hinge sum over 4
+# eps) 0.9936 / 0.005, losses within 1.3e-4; traj_small 0.9929 / 0.017; traj_small_eps 0.9985 / 0.004; traj_small_radam 0.9871 / 0.037,
+# traj_small_radam_eps 0.9991 / 0.014 (RAdam's first rectified steps are a fraction of lr: a given absolute error weighs more).  The small sets' loss is a hinge sum over 4
 # videos / 8 clips: one pair crossing the margin under bf16 rounding moves it by 1e-3 (step 0, before any update: 4.6e-4).
 CASES = {"traj_small": (6e-3, 0.975, 0.04), "traj_small_eps": (5e-3, 0.998, 0.02),
          "traj_anet": (5e-4, 0.985, 0.02), "traj_anet_eps": (5e-4, 0.999, 0.01),
          # ragged batches on the PACKED token rows (cu_seqlens), the layout bench.py --workload anet_ragged runs
-         "traj_anet_ragged_packed_eps": (5e-4, 0.999, 0.01)}
+         "traj_anet_ragged_packed_eps": (5e-4, 0.999, 0.01),
+         # the YouCook2 configurations' RAdam (nntrainer/optimization.py:79-181; rectification from step 6 at beta2 = 0.98), 10 steps
+         "traj_small_radam": (6e-3, 0.97, 0.07), "traj_small_radam_eps": (5e-3, 0.998, 0.03)}
 
 
 class _OneRankDP:
@@ -60,8 +63,10 @@ def _setup(torch, cva, golden_dir, name):
     cfgs = H.full_cfgs(dv, dt, hidden, heads, ff, ph, layers=int(g["layers"]))
     Ps = [O.make_params(cfgs[i], seed + 10 * i, scale=float(g["param_scale"])) for i in range(4)]
     lr, b1, b2, eps, wd, wdb = [float(v) for v in g["adam"]]
-    cfg, mgr = H.make_manager(cfgs, Ps, dropout=float(g["train_p"]), cc_weight=float(g["cc_weight"]),
-                              optimizer=dict(lr=lr, momentum=b1, adam_beta2=b2, adam_eps=eps, weight_decay=wd, weight_decay_for_bias=bool(wdb)))
+    opt = dict(lr=lr, momentum=b1, adam_beta2=b2, adam_eps=eps, weight_decay=wd, weight_decay_for_bias=bool(wdb))
+    if "opt_name" in g:
+        opt.update(name=str(g["opt_name"]), radam_degentosgd=bool(int(g["radam_degentosgd"])))
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=float(g["train_p"]), cc_weight=float(g["cc_weight"]), optimizer=opt)
     mgr.set_all_models_train()
     trainer = cva.RetrievalTrainer(cfg, mgr)
     batches = []
@@ -107,6 +112,13 @@ def test_k_optimizer_steps_vs_the_reference_trainer(env, golden_dir, name, route
     sub = int(g["sub_step"])
     lr = float(g["adam"][0])
     dmax = max(float(g[k]) for k in g if k.startswith("dnorm:"))
+    # the typical per-entry move of a parameter tensor in the reference's run (median over the tensors): what "it hardly moved" is measured
+    # against (Adam's +-lr steps, RAdam's rectified — much smaller — first steps)
+    per_entry = []
+    for i_, k_ in enumerate(H.NET_KEYS):
+        for (pname_, _off, shape_) in mgr.model_dict[k_].table:
+            per_entry.append(float(g[f"dnorm:{k_}:{pname_}"]) / np.sqrt(float(np.prod(shape_))))
+    typical = float(np.median(per_entry))
     bad, checked, cmin, worst_norm = [], 0, 1.0, 0.0
     for i, k in enumerate(H.NET_KEYS):
         net = mgr.model_dict[k]
@@ -117,11 +129,11 @@ def test_k_optimizer_steps_vs_the_reference_trainer(env, golden_dir, name, route
             key = f"{k}:{pname}"
             rn = float(g["dnorm:" + key])
             refd = g["delta:" + key].reshape(-1)
-            if rn < 0.05 * lr * steps * np.sqrt(n) and float(g["adam"][3]) < 1e-6:
-                # shipped eps only: the reference moved this tensor by less than 5 % of full-sign steps, i.e. its gradient entries are
-                # below Adam's eps = 1e-8 — zero up to fp32 rounding (the key bias under a softmax: 1e-11).  What Adam makes of
-                # rounding noise there is not comparable between two implementations (the bf16 path's noise is above eps: full-sign
-                # steps); it cannot exceed them.  At eps = 1e-3 these tensors stay where they are in both and are compared below.
+            if rn / np.sqrt(n) < 0.25 * typical and float(g["adam"][3]) < 1e-6:
+                # shipped eps only: the reference moved this tensor by less than a quarter of what a tensor typically moves (the key biases sit at <= 7 %, everything else at >= 74 %), i.e. its gradient
+                # entries are below the optimizer's eps — zero up to fp32 rounding (the key bias under a softmax: 1e-11).  What Adam /
+                # RAdam make of rounding noise there is not comparable between two implementations (the bf16 path's noise is above eps:
+                # full-size steps); it cannot exceed them.  At eps = 1e-3 these tensors stay where they are in both and are compared below.
                 assert np.linalg.norm(delta) <= 1.01 * lr * steps * np.sqrt(n), key
                 continue
             if rn < 1e-4 * dmax:  # the reference left it where it was (zero gradient, smooth update): so must the library
