@@ -818,6 +818,14 @@ def gen_traj_small_radam_eps():
     gen_train_trajectory("traj_small_radam_eps", optimizer=dict(YC2_RADAM, adam_eps=1e-3), **dict(TRAJ_SMALL, steps=10, seed=83, step_seed0=5150301))
 
 
+def gen_traj_yc2_100m_radam_eps():
+    """BASELINE.json configs[0] as it words it (YouCook2-100m shapes, 2-layer local / 1-layer global encoders, batch 16 x 8 clips,
+    d_model 384: the fused chains, cycle weight 0.001) trained for 8 steps with that configuration's RAdam — steps 6-8 move the
+    parameters — at eps = 1e-3."""
+    gen_train_trajectory("traj_yc2_100m_radam_eps", optimizer=dict(YC2_RADAM, adam_eps=1e-3), dims=(512, 1536, 384, 8, 384, 768), B=16, counts=[8] * 16,
+                         Ls=(80, 20, 96, 12), seed=89, steps=8, p=0.1, step_seed0=5150401, ragged=False, cc_weight=0.001, full=False, layers=2)
+
+
 def gen_traj_anet():
     """3 optimizer steps at the benchmark's shapes (64 videos x 4 clips, d_model 384: the fused chains), shipped Adam."""
     gen_train_trajectory("traj_anet", **TRAJ_ANET)
@@ -869,6 +877,7 @@ def main():
     gen_traj_anet_ragged_packed_eps()
     gen_traj_small_radam()
     gen_traj_small_radam_eps()
+    gen_traj_yc2_100m_radam_eps()
     gen_rk_parity()
     gen_retrieval_metrics()
     gen_radam()

@@ -34,7 +34,9 @@ CASES = {"traj_small": (6e-3, 0.975, 0.04), "traj_small_eps": (5e-3, 0.998, 0.02
          # ragged batches on the PACKED token rows (cu_seqlens), the layout bench.py --workload anet_ragged runs
          "traj_anet_ragged_packed_eps": (5e-4, 0.999, 0.01),
          # the YouCook2 configurations' RAdam (nntrainer/optimization.py:79-181; rectification from step 6 at beta2 = 0.98), 10 steps
-         "traj_small_radam": (6e-3, 0.97, 0.07), "traj_small_radam_eps": (5e-3, 0.998, 0.03)}
+         "traj_small_radam": (6e-3, 0.97, 0.07), "traj_small_radam_eps": (5e-3, 0.998, 0.03),
+         # BASELINE.json configs[0]: YouCook2-100m shapes, two encoder layers per local network (fused chains), RAdam, 8 steps
+         "traj_yc2_100m_radam_eps": (5e-4, 0.999, 0.01)}
 
 
 class _OneRankDP:
