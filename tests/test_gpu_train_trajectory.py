@@ -80,7 +80,9 @@ def _setup(torch, cva, golden_dir, name):
     return g, cfgs, Ps, mgr, trainer, batches
 
 
-@pytest.mark.parametrize("route", ["single", "timed", "dp1"])
+# dp1_early: the one-rank data-parallel path with the global networks updated on the communication stream behind their gradient bucket
+# (coot_step_update: COOT_UPDATE_GLOBAL_ONLY, then COOT_UPDATE_SKIP_GLOBAL at the tail; off by default, RetrievalTrainer.dp_early_global_update)
+@pytest.mark.parametrize("route", ["single", "timed", "dp1", "dp1_early"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_k_optimizer_steps_vs_the_reference_trainer(env, golden_dir, name, route):
     torch, cva = env
@@ -88,15 +90,18 @@ def test_k_optimizer_steps_vs_the_reference_trainer(env, golden_dir, name, route
     loss_tol, cos_min, norm_tol = CASES[name]
     steps = int(g["steps"])
     B, Nc = int(batches[0].clip_num.shape[0]), int(batches[0].clip_feat_len.shape[0])
-    if route == "dp1":
+    if route == "dp1_early" and name not in ("traj_anet_eps", "traj_small_eps"):
+        pytest.skip("the early-update variant runs on one small and one benchmark-shape fixture")
+    if route in ("dp1", "dp1_early"):
         trainer.dp = _OneRankDP()
+        trainer.dp_early_global_update = route == "dp1_early"
     if route == "timed":
         trainer.lookahead_min_stage_bytes = 0
     got = []
     for s in range(steps):
         idx = torch.from_numpy(np.concatenate([g["cc_idx"][s, 0], g["cc_idx"][s, 1]]).astype(np.int64)).cuda()
         kw = dict(seed=int(g["step_seeds"][s]), cc_indices=idx)
-        if route == "dp1":
+        if route in ("dp1", "dp1_early"):
             kw.update(vid_counts=[B], clip_counts=[Nc])
         if route == "timed":  # the mode bench.py times: the text side's join deferred, the next batch's input LayerNorm run by this step
             kw.update(defer_join=True, next_batch=batches[(s + 1) & 1] if s + 1 < steps else None)
