@@ -67,9 +67,9 @@ def parse():
     ap.add_argument("--lr0", action="store_true", help="regime probe: learning rate and weight decay 0 — every step computes on the same weights")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--padded", action="store_true", help="ragged workloads: run the reference's padded layout instead of packed (varlen) rows")
-    ap.add_argument("--mode", default="native", choices=["native", "native-graph", "autograd", "graph"],
+    ap.add_argument("--mode", default="native", choices=["native", "native-graph", "autograd"],
                     help="native: one C call per step (default); native-graph: that call captured once and replayed as a hipGraph; "
-                         "autograd: torch autograd Functions; graph: autograd step in a HIP graph")
+                         "autograd: torch autograd Functions (eager)")
     return ap.parse_args()
 
 
@@ -256,7 +256,7 @@ def main():
         if args.no_dropout:
             mgr.set_all_models_eval()  # train_step_native passes train = model_mgr.is_train: same step, no masks
 
-        mode = args.mode if (world == 1 or args.mode != "graph") else "autograd"
+        mode = args.mode
         batch.global_max_synced = True  # fixed shapes: every rank has the same Cmax, no MAX all-reduce needed
         two_batches = mode == "native"
         # (also on the data-parallel phase path: the next batch's input LayerNorm runs under the embedding exchange and the loss)
@@ -276,8 +276,8 @@ def main():
             pair, turn = (batch, other), [0]
         la_on = [lookahead]  # (the roofline leg of hbm_stress also times the input LayerNorm launched the plain way)
 
-        def step(graph=None):
-            if mode in ("native", "native-graph") and graph is None:  # N > 1: native phases with the RCCL collectives between them
+        def step():
+            if mode in ("native", "native-graph"):  # N > 1: native phases with the RCCL collectives between them
                 # back-to-back steps: the text side's update tail overlaps the next step's forward (COOT_STEP_DEFER_TEXT_JOIN); every
                 # step is complete when the timed region ends (barrier + device synchronisation below)
                 # the data loader's lookahead: the next batch is announced to the step, which runs that batch's parameter-free input
@@ -289,7 +289,7 @@ def main():
                                                      next_batch=nxt if la_on[0] else None)[0]
                 return trainer.train_step_native(batch, vid_counts=vid_counts, clip_counts=clip_counts, defer_join=not args.no_defer_join,
                                                  use_graph=(mode == "native-graph"))[0]
-            return trainer.train_step(batch, vid_counts, clip_counts, use_graph=(mode == "graph") if graph is None else graph)[0]
+            return trainer.train_step(batch, vid_counts, clip_counts)[0]
 
     def barrier():
         if dp is not None:

@@ -984,6 +984,7 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   NetLayout L; build_layout(c, L);
   if (c.dtype == COOT_DTYPE_F32) {  // fp32 reference mode (ref_f32.hip): the reference's op sequence in fp32
     COOT_REQUIRE(!train, "net_fwd: the f32 reference mode is an eval-mode checker (train must be 0)");
+    COOT_REQUIRE(!(c.use_input_fc && g_input_stage.xhat != nullptr), "net_fwd: the f32 reference mode normalises its own input (no input stage may be announced)");
     COOT_REQUIRE(!packed || packed->source == COOT_SOURCE_PADDED, "net_fwd: the f32 reference mode reads the reference's padded batch");
     RefSegs rs; rs.n = sg.n;
     for (int s_ = 0; s_ < sg.n; ++s_) { rs.N[s_] = sg.N[s_]; rs.L[s_] = sg.L[s_]; rs.lens[s_] = sg.lens[s_]; }
@@ -1135,6 +1136,10 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
   NetLayout L; build_layout(c, L);
   if (c.dtype == COOT_DTYPE_F32) {  // fp32 reference mode (ref_f32.hip): the derivative of the reference's op sequence, all fp32
     COOT_REQUIRE(!train, "net_bwd: the f32 reference mode is an eval-mode checker (train must be 0)");
+    // ref_f32_backward ACCUMULATES every parameter gradient into G: under coot_net_grads_overwrite(1) (the step API's mode: only the
+    // bias / LayerNorm vectors are zeroed, the weight-matrix gradients are expected to be WRITTEN) it would add each step's matrices
+    // onto the previous step's — refuse instead of doing that silently
+    COOT_REQUIRE(!g_grad_overwrite, "net_bwd: the f32 reference mode accumulates into zeroed gradient arenas (coot_net_grads_overwrite must be 0)");
     COOT_REQUIRE(!packed || packed->source == COOT_SOURCE_PADDED, "net_bwd: the f32 reference mode reads the reference's padded batch");
     COOT_REQUIRE(!c.use_context || hidden, "net_bwd: context network needs hidden state (transformer_legacy.py:252)");
     RefSegs rs; rs.n = sg.n;

@@ -72,6 +72,26 @@ int coot_contrastive_fwd_bwd_part(const coot_contrastive_config* cfg, int n_high
                                   nullptr, pair_mask);
 }
 
+size_t coot_contrastive_f32_scratch_bytes(int n_high, int n_low, int d_high, int d_low) {
+  return contrastive_f32_scratch_bytes(n_high, n_low, d_high, d_low);
+}
+
+int coot_contrastive_fwd_bwd_f32(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low, const float* vid_emb,
+                                 const float* par_emb, const float* clip_emb, const float* sent_emb, const float* vid_ctx,
+                                 const float* par_ctx, float* loss, float* d_vid_emb, float* d_par_emb, float* d_clip_emb,
+                                 float* d_sent_emb, float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes,
+                                 coot_stream_t stream) {
+  COOT_REQUIRE(cfg && vid_emb && par_emb && clip_emb && sent_emb && vid_ctx && par_ctx && loss && scratch, "contrastive_f32: null pointer");
+  const bool bwd = d_vid_emb != nullptr;
+  COOT_REQUIRE(!bwd || (d_par_emb && d_clip_emb && d_sent_emb && d_vid_ctx && d_par_ctx), "contrastive_f32: gradient pointers must be all set or all null");
+  const float* vs[6] = {vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx};
+  float* dvs[6] = {d_vid_emb, d_par_emb, d_clip_emb, d_sent_emb, d_vid_ctx, d_par_ctx};
+  const float w_pair[3] = {cfg->weight_high, cfg->weight_low, cfg->weight_context};
+  const float w_self[3] = {0.5f * cfg->weight_high_internal, 0.5f * cfg->weight_low_internal,
+                           cfg->weight_context_internal != 0.f ? 0.5f * cfg->weight_low_internal : 0.f};  // (:181, as the fast path)
+  return launch_contrastive_f32(vs, dvs, n_high, n_low, d_high, d_low, w_pair, w_self, cfg->margin, loss, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
 int coot_contrastive_fwd_bwd_dp(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low, const float* const sets[6],
                                 const int64_t ld[6], float* loss, float* const d_own[6], int own_high0, int own_high, int own_low0, int own_low,
                                 void* scratch, size_t scratch_bytes, coot_stream_t stream) {

@@ -89,6 +89,9 @@ SidePacked side_packed(const coot_step_batch& x, const coot_step_dims& d) {
 
 int check_cfg(const coot_step_config& c) {
   const int D = c.net[0].hidden_dim;
+  for (int i = 0; i < 4; ++i)  // the fp32 reference mode is a per-network checker (coot_net_fwd / coot_net_bwd, eval): not a mode of the step
+    COOT_REQUIRE(c.net[i].dtype == COOT_DTYPE_BF16, "step: network %d has dtype %d — the step API runs the bf16 path only (COOT_DTYPE_F32 is the "
+                 "checker mode of coot_net_fwd / coot_net_bwd)", i, c.net[i].dtype);
   COOT_REQUIRE(c.net[1].hidden_dim == D && c.net[2].hidden_dim == D && c.net[3].hidden_dim == D, "step: the four networks must share hidden_dim");
   COOT_REQUIRE(c.net[0].use_input_fc && c.net[2].use_input_fc && !c.net[0].use_context && !c.net[2].use_context &&
                c.net[0].pooler == 0 && c.net[2].pooler == 0, "step: local networks = input_fc + atn pooler, no context");

@@ -7,7 +7,7 @@ mkdir -p "$OUT" obj
 # -fvisibility=hidden: only what include/coot_hip.h declares (visibility push(default)) is exported
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -Wno-unused-result $EXTRA_FLAGS"
 pids=()
-for f in gemm rowops attention pool loss loss_fused fused ref_f32 det retrieval host_input api api_loss api_step; do
+for f in gemm rowops attention pool loss loss_fused loss_f32 fused ref_f32 det retrieval host_input api api_loss api_step; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer obj/$f.o)" ] || [ ../../include/coot_hip.h -nt obj/$f.o ]; then
     /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o obj/$f.o &
     pids+=($!)

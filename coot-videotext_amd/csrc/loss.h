@@ -41,4 +41,9 @@ int launch_contrastive_fused(const float* const v[6], float* const dv[6], int n_
                              const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st,
                              const long* ldv = nullptr, const int* window = nullptr, int pair_mask = 7, const ClBlocks* blk = nullptr);
 
+// fp32 reference mode of the same loss (loss_f32.hip): plain FMA kernels, fixed summation order, no bf16 anywhere; full batch only
+size_t contrastive_f32_scratch_bytes(int n_high, int n_low, int d_high, int d_low);
+int launch_contrastive_f32(const float* const v[6], float* const dv[6], int n_high, int n_low, int d_high, int d_low, const float w_pair[3],
+                           const float w_self[3], float margin, float* loss, void* scratch, size_t scratch_bytes, hipStream_t st);
+
 }  // namespace coot

@@ -19,7 +19,7 @@ EXPORTS = [
     "coot_last_error", "coot_version", "coot_set_option", "coot_get_option", "coot_debug_timestamps", "coot_debug_step_stamps", "coot_debug_dropout_scales", "coot_debug_attn_dropout_scales", "coot_net_param_numel", "coot_net_param_count",
     "coot_net_param_info", "coot_net_out_dim", "coot_net_wpack_bytes", "coot_net_pack_weights", "coot_nets_pack_weights",
     "coot_net_saved_bytes", "coot_net_scratch_bytes", "coot_net_fwd", "coot_net_bwd", "coot_net_grads_overwrite", "coot_nets_zero_grads", "coot_nets_zero_grads_ex", "coot_debug_written_matrices", "coot_pack_fwd",
-    "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_cyclecons_fwd_bwd",
+    "coot_pack_bwd", "coot_contrastive_scratch_bytes", "coot_contrastive_fwd_bwd", "coot_contrastive_fwd_bwd_part", "coot_contrastive_f32_scratch_bytes", "coot_contrastive_fwd_bwd_f32", "coot_cyclecons_fwd_bwd",
     "coot_gemm_nt", "coot_gemm_tn", "coot_gemm_tn_batch", "coot_debug_tn_xcd_map", "coot_debug_clock_monitor", "coot_gemm_tn_workspace_bytes", "coot_ln_fwd", "coot_attn_fwd", "coot_probe_tr16", "coot_timing_enable",
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
     "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_step_input_stage_bytes", "coot_step_set_input_stages", "coot_step_set_next_batch", "coot_contrastive_fwd_bwd_dp", "coot_contrastive_fwd_bwd_dp_blocks", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
@@ -84,7 +84,7 @@ class StepBatch(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 5  # include/coot_hip.h: COOT_ABI_VERSION
+ABI_VERSION = 6  # include/coot_hip.h: COOT_ABI_VERSION
 
 
 def build_hint() -> str:
@@ -136,6 +136,9 @@ def load():
     lib.coot_contrastive_scratch_bytes.argtypes = [i32, i32, i32, i32]
     lib.coot_contrastive_fwd_bwd.argtypes = [C.POINTER(ContrastiveConfig), i32, i32, i32, i32] + [vp] * 6 + [vp] + [vp] * 6 + [vp, sz, vp]
     lib.coot_contrastive_fwd_bwd_part.argtypes = lib.coot_contrastive_fwd_bwd.argtypes[:-1] + [i32, vp]
+    lib.coot_contrastive_f32_scratch_bytes.restype = sz
+    lib.coot_contrastive_f32_scratch_bytes.argtypes = [i32, i32, i32, i32]
+    lib.coot_contrastive_fwd_bwd_f32.argtypes = list(lib.coot_contrastive_fwd_bwd.argtypes)
     lib.coot_cyclecons_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp]
     lib.coot_retrieval_workspace_bytes.argtypes = [i32, i32]
     lib.coot_retrieval_workspace_bytes.restype = C.c_size_t

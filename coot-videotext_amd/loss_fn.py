@@ -39,8 +39,9 @@ class _TotalContrastiveFn(torch.autograd.Function):
     by ONE C call (the backward is computed eagerly into saved buffers)."""
 
     @staticmethod
-    def forward(ctx, cfg: ContrastiveLossConfig, vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx):
+    def forward(ctx, cfg: ContrastiveLossConfig, vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx, dtype: str = "bf16"):
         lib = _lib.load()
+        assert dtype in ("bf16", "f32"), dtype
         embs = [t.contiguous().float() for t in (vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx)]
         n_high, d_high = embs[0].shape
         n_low, d_low = embs[2].shape
@@ -50,21 +51,27 @@ class _TotalContrastiveFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[1:])
         loss = torch.zeros((), dtype=torch.float32, device=dev)
         grads = [torch.zeros_like(e) for e in embs] if need_grad else [None] * 6
-        scratch = torch.empty(lib.coot_contrastive_scratch_bytes(n_high, n_low, d_high, d_low), dtype=torch.uint8, device=dev)
+        # "f32": the fp32 reference mode of the loss (coot_contrastive_fwd_bwd_f32: plain FMA kernels, no bf16 operand) — the loss-side
+        # counterpart of TransformerHip.set_compute_dtype("f32"); a checker, not a fast path
+        size_fn, call, name = ((lib.coot_contrastive_f32_scratch_bytes, lib.coot_contrastive_fwd_bwd_f32, "coot_contrastive_fwd_bwd_f32")
+                               if dtype == "f32" else
+                               (lib.coot_contrastive_scratch_bytes, lib.coot_contrastive_fwd_bwd, "coot_contrastive_fwd_bwd"))
+        scratch = torch.empty(size_fn(n_high, n_low, d_high, d_low), dtype=torch.uint8, device=dev)
         ccfg = cfg.to_c()
-        _lib.check(lib.coot_contrastive_fwd_bwd(C.byref(ccfg), n_high, n_low, d_high, d_low, *[_lib.ptr(e) for e in embs],
-                                                _lib.ptr(loss), *[_lib.ptr(g) for g in grads], _lib.ptr(scratch),
-                                                scratch.numel(), _lib.stream_ptr()), "coot_contrastive_fwd_bwd")
+        _lib.check(call(C.byref(ccfg), n_high, n_low, d_high, d_low, *[_lib.ptr(e) for e in embs],
+                        _lib.ptr(loss), *[_lib.ptr(g) for g in grads], _lib.ptr(scratch),
+                        scratch.numel(), _lib.stream_ptr()), name)
         ctx.grads = grads
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        return (None,) + tuple(None if g is None else g * dloss for g in ctx.grads)
+        return (None,) + tuple(None if g is None else g * dloss for g in ctx.grads) + (None,)
 
 
-def total_contrastive_loss(cfg: ContrastiveLossConfig, vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx):
-    return _TotalContrastiveFn.apply(cfg, vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx)
+def total_contrastive_loss(cfg: ContrastiveLossConfig, vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx, dtype: str = "bf16"):
+    """dtype "f32": the library's fp32 reference mode of the loss (include/coot_hip.h: coot_contrastive_fwd_bwd_f32)."""
+    return _TotalContrastiveFn.apply(cfg, vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx, dtype)
 
 
 class ContrastiveLoss(torch.nn.Module):

@@ -126,6 +126,7 @@ class RetrievalTrainer:
     # all-reduce takes ~100 us: off unless COOT_DP_EARLY=1.
     dp_early_global_update = os.environ.get("COOT_DP_EARLY", "0") == "1"
     lookahead_min_stage_bytes = 32 << 20  # train_step_native(next_batch=): only batches whose normalised features reach this size
+    _stage_owner = None  # id() of the trainer whose input stages the library currently holds (thread-local there; one training thread here)
 
     def __init__(self, cfg: RetrievalConfig, model_mgr: RetrievalModelManager, is_test: bool = False,
                  world_size: int = 1):
@@ -150,6 +151,39 @@ class RetrievalTrainer:
         self.infos_val_is_good: list = []
         self.lr_scheduler = None
 
+    # ---- ownership of what the library retains (include/coot_hip.h: "Retained pointers") ------------------------------------------
+    def close(self) -> None:
+        """Withdraws every pointer of THIS trainer that the library keeps between calls — the input stages and a pending next-batch
+        announcement (thread-local), the deterministic table (process-global) — and drops the captured native steps, whose nodes
+        carry this trainer's buffers.  Called by __del__; a caller that frees the trainer's tensors earlier calls it first.
+        Idempotent; a trainer that never ran a native step has nothing registered."""
+        st = self.__dict__.get("_native")
+        if st is None and not self.__dict__.get("deterministic", False):
+            return
+        try:
+            lib = _lib.load()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()  # (the library's internal stream may still be writing a stage)
+            if st is not None:
+                if st.__dict__.get("graphs"):
+                    st.graphs.clear()
+                if getattr(st, "stages", None) is not None:
+                    # the registration is thread-local and one per thread: withdraw it only if it is still this trainer's (another
+                    # trainer of the thread may have registered its own stages since)
+                    if RetrievalTrainer._stage_owner == id(self):
+                        lib.coot_step_set_next_batch(None, None)
+                        lib.coot_step_set_input_stages(None, None, 0)
+                        RetrievalTrainer._stage_owner = None
+                    st.stages = None
+            self._next_desc = None
+            if self.__dict__.get("deterministic", False):
+                self.set_deterministic(False)
+        except Exception:  # (interpreter shutdown: the library or torch may already be gone)
+            pass
+
+    def __del__(self):
+        self.close()
+
     # ---- loss hooks ------------------------------------------------------------------------------------
     def compute_align_loss(self, visual_emb: torch.Tensor, text_emb: torch.Tensor) -> torch.Tensor:
         return self.loss_contr(visual_emb, text_emb)
@@ -159,8 +193,12 @@ class RetrievalTrainer:
 
     def compute_total_constrastive_loss(self, visual_data: RetrievalVisualEmbTuple,
                                         text_data: RetrievalTextEmbTuple) -> torch.Tensor:
+        # networks in the fp32 reference mode (TransformerHip.set_compute_dtype("f32")) take the fp32 mode of the loss with them: the
+        # checker then runs forward, loss and backward in the library in fp32 end to end (tests/test_gpu_f32_mode.py)
+        dts = {getattr(net.cfg, "dtype", "bf16") for net in self.model_mgr.model_dict.values()}
         return loss_fn.total_contrastive_loss(self.loss_cfg, visual_data.vid_emb, text_data.par_emb, visual_data.clip_emb,
-                                              text_data.sent_emb, visual_data.vid_context, text_data.par_context)
+                                              text_data.sent_emb, visual_data.vid_context, text_data.par_context,
+                                              dtype="f32" if dts == {"f32"} else "bf16")
 
     def compute_cyclecons_loss(self, visual_data: RetrievalVisualEmbTuple, text_data: RetrievalTextEmbTuple,
                                idx_clip: Optional[torch.Tensor] = None, idx_sent: Optional[torch.Tensor] = None):
@@ -204,115 +242,16 @@ class RetrievalTrainer:
                 main.wait_stream(s)
 
     # ---- one optimisation step (coot/trainer_retrieval.py:253-291) ---------------------------------------
-    def train_step(self, batch: RetrievalDataBatchTuple, vid_counts=None, clip_counts=None, use_graph: bool = False
+    def train_step(self, batch: RetrievalDataBatchTuple, vid_counts=None, clip_counts=None
                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """forward + losses + backward (+ gradient all-reduce) + optimizer step; returns (loss, contr_loss,
         cc_loss) as 0-dim device tensors (no host sync; the reference's per-step .item() logging is the
         caller's choice).  With ``self.dp`` set (dist.DataParallelContext) the batch is this rank's shard.
-        use_graph=True replays the whole step as ONE captured HIP graph (captured on first use for this batch's
-        shapes; a new batch of the same shapes is copied into the captured input buffers)."""
-        if not use_graph:
-            return self._step_impl(batch, vid_counts, clip_counts)
-        if isinstance(self.optimizer, RAdam):
-            # its step count and rectification scalars are host values: a replay would freeze them (the native step keeps them in a
-            # device block instead: train_step_native(use_graph=True))
-            raise NotImplementedError("train_step(use_graph=True) supports torch.optim.Adam only; use train_step_native for RAdam")
-        if getattr(self, "deterministic", False):  # configure BEFORE a capture, never inside it (it synchronises and copies a symbol)
-            self._det_sync([net.bind_flat_grads() for net in self.model_mgr.model_dict.values()] + self._det_extra(batch.vid_feat.device))
-        key = (self._graph_key(batch), self._det_state())
-        graphs = self.__dict__.get("_graphs")
-        if graphs is None:
-            import collections
-            graphs = self._graphs = collections.OrderedDict()
-        g = graphs.get(key)
-        if g is None:
-            # one graph per batch SHAPE (tensor shapes, host-side maxima and — packed batches — the valid-token totals the
-            # captured launches carry as host scalars).  The learning rate is NOT part of the key: the captured Adam reads it
-            # from a device tensor per parameter group that is rewritten before a replay when the scheduler moved it.
-            g = graphs[key] = self._capture(batch, vid_counts, clip_counts)
-            while len(graphs) > self.max_graphs:  # least recently used first; dropping the CUDAGraph frees its private pool
-                graphs.popitem(last=False)
-        else:
-            graphs.move_to_end(key)
-        for group, lr_dev, mirror in zip(self.optimizer.param_groups, g["lr_dev"], g["lr_host"]):
-            lr = float(group["lr"])  # a python float: the reference's schedulers write floats (nntrainer/lr_scheduler.py)
-            if lr != mirror[0]:
-                lr_dev.fill_(lr)
-                mirror[0] = lr
-        if batch is not g["batch"]:
-            for name, value in batch.__dict__.items():
-                if torch.is_tensor(value):
-                    getattr(g["batch"], name).copy_(value, non_blocking=True)
-        g["graph"].replay()
-        self.total_step += 1
-        return g["out"]
-
-    max_graphs = 8  # captured whole-step graphs kept alive (ragged batches: one per shape)
-
-    @staticmethod
-    def _graph_key(batch):
-        return (tuple((k, tuple(v.shape)) for k, v in sorted(batch.__dict__.items()) if torch.is_tensor(v)), batch.max_clip_num,
-                batch.max_sent_num, getattr(batch, "tok_vis", None), getattr(batch, "tok_txt", None))
-
-    def _capture(self, batch, vid_counts, clip_counts, warmup: int = 3):
-        """Whole-step capture.  The eager warm-up (allocator, RCCL, lazy optimizer state) runs on a SNAPSHOT: parameters,
-        optimizer state, step counters and the dropout seed are restored afterwards, so the first call for a shape applies exactly
-        one update — the replay's — like every other call.  (The warm-up used to be three real optimizer steps per capture.)"""
-        if batch.max_clip_num is None or batch.max_sent_num is None:
-            raise RuntimeError("graph capture needs batch.max_clip_num / max_sent_num on the host (no device sync inside a graph)")
-        import copy
-        nets = list(self.model_mgr.model_dict.values())
-        if getattr(self, "_seed_dev", None) is None:
-            self._step_prepare_seed(batch, nets)
-        had_state = len(self.optimizer.state) > 0
-        # parameters first: the warm-up steps below (and, without optimizer state yet, the steps that create it) all move them
-        snap = dict(params=[n._flat.detach().clone() for n in nets], total_step=self.total_step, seed=self._seed_dev.clone())
-        snap["opt"] = copy.deepcopy(self.optimizer.state_dict()) if had_state else None
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._step_impl(batch, vid_counts, clip_counts)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-
-        def restore():
-            with torch.no_grad():
-                for n, p0 in zip(nets, snap["params"]):
-                    n._flat.copy_(p0)
-            if had_state:
-                # in place, so that the state tensors the graph captured stay the optimizer's
-                cur = self.optimizer.state_dict()["state"]
-                for idx, st in snap["opt"]["state"].items():
-                    for name, val in st.items():
-                        if torch.is_tensor(val):
-                            cur[idx][name].copy_(val)
-            else:
-                for st in self.optimizer.state.values():
-                    for name, val in st.items():
-                        if torch.is_tensor(val):
-                            val.zero_()
-            self.total_step = snap["total_step"]
-            self._seed_dev.copy_(snap["seed"])
-            self.model_mgr.mark_weights_dirty()
-
-        restore()
-        # the learning rate as a device tensor per parameter group for the capture (torch.optim.Adam(capturable=True) accepts
-        # tensors): replays read whatever train_step wrote there; the groups get their floats back for the schedulers
-        host_lrs = [float(gr["lr"]) for gr in self.optimizer.param_groups]
-        lr_dev = [torch.full((), lr, dtype=torch.float32, device=batch.vid_feat.device) for lr in host_lrs]
-        graph = torch.cuda.CUDAGraph()
-        try:
-            for gr, t in zip(self.optimizer.param_groups, lr_dev):
-                gr["lr"] = t
-            with torch.cuda.graph(graph):
-                out = self._step_impl(batch, vid_counts, clip_counts)
-        finally:
-            for gr, lr in zip(self.optimizer.param_groups, host_lrs):
-                gr["lr"] = lr
-        # the capture itself executed nothing, but host-side bookkeeping of _step_impl ran: put the counters back
-        self.total_step = snap["total_step"]
-        return dict(graph=graph, out=out, batch=batch, lr_dev=lr_dev, lr_host=[[lr] for lr in host_lrs])
+        This is the AUTOGRAD route (torch autograd + torch.optim around the library's per-network calls): always eager.  A captured
+        (hipGraph) step exists on the native route only — train_step_native(use_graph=True), one C call inside the capture; the
+        autograd route's whole-step capture (rounds 1-5) was removed in round 6: its replay crashed inside hipGraphLaunch under one
+        test ordering and was never root-caused, and nothing defaulted to it."""
+        return self._step_impl(batch, vid_counts, clip_counts)
 
     def _step_prepare_seed(self, batch, nets) -> None:
         self._seed_dev = torch.zeros(1, dtype=torch.int64, device=batch.vid_feat.device)
@@ -567,6 +506,7 @@ class RetrievalTrainer:
             dev = st.ws.device
             st.stages = (torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev), torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev))
         _lib.check(lib.coot_step_set_input_stages(st.stages[0].data_ptr(), st.stages[1].data_ptr(), st.stages[0].numel()), "coot_step_set_input_stages")
+        RetrievalTrainer._stage_owner = id(self)  # (close() withdraws the registration only while it is still this trainer's)
         if next_batch is not None:
             _lib.check(lib.coot_step_set_next_batch(C.byref(desc[2]), C.byref(nd)), "coot_step_set_next_batch")
         else:
@@ -588,13 +528,9 @@ class RetrievalTrainer:
             self._det_key, self._det_shadow, self._det_ranges = None, None, []
 
     def _drop_graphs(self) -> None:
-        """Forgets every captured step (autograd route and native route).  The library consults its process-wide deterministic table
+        """Forgets every captured native step.  The library consults its process-wide deterministic table
         at RUN time and a captured step holds the flush launches — or their absence — and the shadow's address of the mode it was
         captured in: a replay under another configuration would drop gradient addends (no flush node) or read a freed shadow."""
-        graphs = self.__dict__.get("_graphs")
-        if graphs:
-            torch.cuda.synchronize()
-            graphs.clear()
         st = getattr(self, "_native", None)
         if st is not None and st.__dict__.get("graphs"):
             torch.cuda.synchronize()

@@ -2,8 +2,32 @@
  * coot_hip.h — C ABI of libcoot_hip.so: the MI355X (gfx950) implementation of the COOT retrieval
  * training hot path.  Plain pointers and sizes only; every pointer is DEVICE memory unless stated
  * otherwise; every call enqueues asynchronously on the given hipStream_t (pass
- * torch.cuda.current_stream().cuda_stream) and never allocates, frees, synchronises or retains
- * pointers.  Return value: 0 = ok, negative = error (message via coot_last_error()).
+ * torch.cuda.current_stream().cuda_stream) and never allocates, frees or synchronises.  Return value: 0 = ok,
+ * negative = error (message via coot_last_error()).
+ *
+ * Retained pointers (ownership contract).  A compute call keeps NO pointer of its arguments after it returns (the
+ * launches it enqueued read them, in stream order: the caller keeps the memory alive until those launches ran, as with any
+ * asynchronous call).  The ONLY entry points that store a caller pointer beyond their own return are these setters; the memory
+ * stays the caller's and must outlive the registration:
+ *   coot_step_set_device_state(state)         thread-local; read by every later coot_train_step of the thread (and by every
+ *                                             replay of a step captured while it was set) until reset with NULL
+ *   coot_step_set_input_stages(s0, s1, n)     thread-local; written / read by steps that carry COOT_STEP_INPUT_STAGES or
+ *                                             COOT_FWD_INPUT_STAGES until reset with (NULL, NULL, 0); a reset also forgets which
+ *                                             stage holds which batch
+ *   coot_step_set_next_batch(next, dims)      thread-local, ONE-SHOT: the two structs are COPIED at the call, the feature
+ *                                             pointers inside them are read by the next coot_train_step / coot_step_forward of the
+ *                                             thread (which consumes the announcement) and by nothing after it; (NULL, NULL) drops
+ *                                             a pending announcement
+ *   coot_step_set_global_done_events(ev, ev)  thread-local hipEvent_t handles, recorded by every later coot_step_backward of the
+ *                                             thread until reset with (NULL, NULL)
+ *   coot_step_set_cycle_indices(idx)          thread-local; read at every later coot_train_step / cycle-consistency phase of the
+ *                                             thread until reset with NULL
+ *   coot_det_configure(n, bases, bytes, shadow, ...)  PROCESS-GLOBAL; the base / size arrays are copied, the ranges and the shadow
+ *                                             are consulted by every accumulating kernel of every thread until coot_det_configure(0,
+ *                                             ...), which synchronises the device before it returns
+ * A caller that frees such memory resets the registration first (RetrievalTrainer.close() does; tests/conftest.py does between
+ * modules).  A captured step (hipStreamBeginCapture around coot_train_step) additionally bakes every argument pointer and the
+ * registrations above into its nodes: all of them must stay valid for as long as the graph may be replayed.
  *
  * The reference (simon-ging/coot-videotext) is pure Python/PyTorch and has no FFI for this path;
  * each entry point names the reference code it replaces (file:line relative to the reference
@@ -60,7 +84,7 @@ const char* coot_last_error(void);
 /* ABI version of this header: struct layouts (coot_net_config gained `dtype`, coot_step_buffers `decay_block_all` in round 4) and the
  * meaning of flag words (coot_step_update's `repack` is a bit mask since round 4).  coot_version() returns the value the library was
  * built with; a binding compares the two when it loads the library (coot-videotext_amd/lib.py does) and refuses a mismatch. */
-#define COOT_ABI_VERSION 5
+#define COOT_ABI_VERSION 6
 int coot_version(void);
 /* Option switches for A/B measurements and tests ("fused", "packed", "tn_dma", "grad_poison", ...: the names coot_set_option
  * accepts are listed in csrc/api.hip).  They are PROCESS-GLOBAL ints read at launch time without synchronisation: set them
@@ -201,6 +225,21 @@ int coot_contrastive_fwd_bwd_part(const coot_contrastive_config* cfg, int n_high
                                   float* d_vid_emb, float* d_par_emb, float* d_clip_emb, float* d_sent_emb,
                                   float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes, int part,
                                   coot_stream_t stream);
+
+/* fp32 REFERENCE MODE of coot_contrastive_fwd_bwd (the COOT_DTYPE_F32 of the losses; csrc/loss_f32.hip): the same arguments and
+ * semantics — F.normalize, the seven ContrastiveLoss terms of coot/trainer_retrieval.py:148-182 / coot/loss_fn.py:63-100, *loss and
+ * the six gradients ACCUMULATED — computed by plain fp32 FMA kernels in a fixed summation order: no MFMA, no bf16 operand, no
+ * atomics.  With coot_net_config.dtype = COOT_DTYPE_F32 networks around it (and coot_cyclecons_fwd_bwd, which is fp32 VALU code in
+ * both modes) the whole forward + loss + backward runs in the library in fp32: every parameter gradient of the reference's eval
+ * fixtures to <= 1e-4 relative (tests/test_gpu_f32_mode.py).  A checker: one GPU, the full batch, never what bench.py times.
+ * scratch: coot_contrastive_f32_scratch_bytes (NOT coot_contrastive_scratch_bytes). */
+size_t coot_contrastive_f32_scratch_bytes(int n_high, int n_low, int d_high, int d_low);
+int coot_contrastive_fwd_bwd_f32(const coot_contrastive_config* cfg, int n_high, int n_low, int d_high, int d_low,
+                                 const float* vid_emb, const float* par_emb, const float* clip_emb,
+                                 const float* sent_emb, const float* vid_ctx, const float* par_ctx, float* loss,
+                                 float* d_vid_emb, float* d_par_emb, float* d_clip_emb, float* d_sent_emb,
+                                 float* d_vid_ctx, float* d_par_ctx, void* scratch, size_t scratch_bytes,
+                                 coot_stream_t stream);
 
 /* The same loss for data-parallel training: sets[i] are the six GATHERED sets (row stride ld[i] floats: they may be column
  * slices of the all-gather buffers), the loss is the mean over the global batch — *loss receives THIS RANK'S SHARE of it (the

@@ -38,12 +38,10 @@ def golden_dir():
 def _device_hygiene_between_modules():
     """Behind every test module on a GPU box: collect dead trainers, drop what the library's thread-local step state still points at
     (input stages, the announced next batch, caller events, injected cycle indices, the deterministic table — all owned by trainers
-    that no longer exist) and return the caching allocator's blocks.  Round 5: `test_gpu_train_parity.py test_gpu_train_trajectory.py
-    test_gpu_path.py` in ONE process ended in a segmentation fault inside hipGraphLaunch (torch.cuda.CUDAGraph.replay of the autograd
-    route's captured step) although every pair of the three files passes and the suite in its own (alphabetical) order passes every time.
-    The crash is timing dependent (the same command under rocgdb: 74 passed) and survives this clean-up — a hipGraph launch race in the
-    runtime, on the autograd route's graph mode only (bench.py and train_model use the native step) — but dangling library state between
-    modules is not something a test-suite should rely on being harmless.  COOT_TEST_NO_HYGIENE=1 switches this off."""
+    that no longer exist; include/coot_hip.h "Retained pointers" lists these setters and how long each pointer is kept) and return
+    the caching allocator's blocks.  (Round 5 added this while chasing a crash of the autograd route's captured step; that graph mode
+    was removed in round 6.)  Dangling library state between modules is not something a test-suite should rely on being harmless.
+    COOT_TEST_NO_HYGIENE=1 switches this off."""
     yield
     if os.environ.get("COOT_TEST_NO_HYGIENE") == "1" or "torch" not in sys.modules:
         return

@@ -107,18 +107,20 @@ def _grads_vs_fixture(g, mgr, tag):
 # (ragged batches, the fixed benchmark shape, two encoder layers per local network, Cmax = 64)
 @pytest.mark.parametrize("name", ["full_anet", "bench_anet", "bench_anet_ragged", "bench_yc2_100m_2layer", "bench_hbm_stress"])
 def test_f32_reference_mode_gradients_match_the_reference(env, golden_dir, name):
-    """coot_net_bwd in the fp32 reference mode (csrc/ref_f32.hip: the derivative of the reference's op sequence, all fp32) against the
-    parameter gradients the unmodified reference wrote (eval-mode fixtures, dropout off): every one of the 108 non-zero gradients to
-    <= 1e-4 relative — the bf16 path's bound is cosine > 0.999 / norm within 1 %, i.e. its error is reported below as a multiple of
-    this mode's.  Encoders: TransformerHip in f32 mode through torch.autograd.  Losses: the torch restatement of the reference's loss
-    modules (oracle/coot_torch_cpu.py: ATen fp32 ops, here on the GPU) — the library's fused loss kernels compute similarities on the
-    bf16 MFMA and would put 1e-3 into every gradient; they are pinned on their own (tests/test_gpu_loss.py)."""
+    """The library END TO END in its fp32 reference mode against the parameter gradients the unmodified reference wrote (eval-mode
+    fixtures, dropout off): every one of the 108+ non-zero gradients to <= 1e-4 relative — the bf16 path's bound is cosine > 0.999 /
+    norm within 1 %, i.e. its error is reported below as a multiple of this mode's.
+      encoders: TransformerHip in f32 mode through torch.autograd (coot_net_fwd / coot_net_bwd, csrc/ref_f32.hip)
+      losses:   the trainer's own hooks — coot_contrastive_fwd_bwd_f32 (csrc/loss_f32.hip; round 6: rounds 4-5 borrowed the torch
+                restatement of oracle/coot_torch_cpu.py here because the fused loss computes similarities on the bf16 MFMA) and
+                coot_cyclecons_fwd_bwd (fp32 VALU code in both modes), with the fixture's th.multinomial draws injected.
+    Nothing under oracle/ takes part in the forward or backward of this test (it only rebuilds the fixture's inputs)."""
     torch, cva = env
-    from oracle import coot_torch_cpu as T
     g, cfgs, Ps, b = _load(golden_dir, name)
     cc_w = float(g["cc_weight"]) if "cc_weight" in g else 0.01
     cfg, mgr = H.make_manager(cfgs, Ps, cc_weight=cc_w)
     mgr.set_all_models_eval()
+    trainer = cva.RetrievalTrainer(cfg, mgr, is_test=True)
     batch = cva.synthetic.batch_from_numpy(b)
     idx_c = torch.from_numpy(g["cc_idx_clip"].astype(np.int64)).cuda()
     idx_s = torch.from_numpy(g["cc_idx_sent"].astype(np.int64)).cuda()
@@ -129,11 +131,8 @@ def test_f32_reference_mode_gradients_match_the_reference(env, golden_dir, name)
             for prm in net.parameters():
                 prm.grad = None
         vis, txt = mgr.encode_visual(batch), mgr.encode_text(batch)
-        v = dict(global_emb=vis.vid_emb, item_emb=vis.clip_emb, context=vis.vid_context)
-        t = dict(global_emb=txt.par_emb, item_emb=txt.sent_emb, context=txt.par_context)
-        contr = T.total_contrastive(v, t, H.ANET_W, 0.2)
-        c1, c2 = T.cyclecons(vis.clip_emb_reshape, vis.clip_emb_mask, txt.sent_emb_reshape, txt.sent_emb_mask, idx_c, idx_s)
-        cc = cc_w * (c1 + c2)
+        contr = trainer.compute_total_constrastive_loss(vis, txt)  # (follows the networks' mode: f32 -> coot_contrastive_fwd_bwd_f32)
+        cc = trainer.compute_cyclecons_loss(vis, txt, idx_c, idx_s)
         (contr + cc).backward()
         torch.cuda.synchronize()
         return float(contr.detach()), float(cc.detach())
@@ -147,5 +146,60 @@ def test_f32_reference_mode_gradients_match_the_reference(env, golden_dir, name)
     assert n32 >= 100 and worst32 <= 1e-4, worst32
     run("bf16")
     worst16, _ = _grads_vs_fixture(g, mgr, name + " bf16")
-    print(f"[{name}] bf16 path, same losses: worst relative error {worst16:.2e} = {worst16 / max(worst32, 1e-12):.0f} x the f32 mode's")
+    print(f"[{name}] bf16 path (fused bf16 losses): worst relative error {worst16:.2e} = {worst16 / max(worst32, 1e-12):.0f} x the f32 mode's")
     assert worst16 > 10 * worst32
+
+
+def test_f32_loss_mode_matches_torch_ops_and_the_step_api_refuses_f32(env):
+    """coot_contrastive_fwd_bwd_f32 on its own against the same loss written with ATen fp32 ops ON THE GPU (F.normalize, the seven
+    ContrastiveLoss terms of coot/trainer_retrieval.py:148-182 incl. the :181 weight quirk, autograd): loss and all six gradients to
+    fp32 round-off, for the shipped weights and for a set that switches every term on; and the ADVICE round-5 guard — the step API
+    refuses networks in the f32 checker mode instead of accumulating their weight-matrix gradients across steps."""
+    torch, cva = env
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    nh, nl, dh, dl = 24, 70, 96, 40
+
+    def contr(a, b_, m):
+        sc = a @ b_.t()
+        d = sc.diag().view(-1, 1)
+        eye = torch.eye(sc.shape[0], dtype=torch.bool, device=sc.device)
+        return ((m + sc - d).clamp(min=0).masked_fill(eye, 0).sum() + (m + sc - d.t()).clamp(min=0).masked_fill(eye, 0).sum()) / sc.shape[0] ** 2
+
+    for w in (H.ANET_W, dict(weight_high=0.7, weight_high_internal=0.3, weight_low=1.1, weight_low_internal=0.6, weight_context=0.9,
+                             weight_context_internal=1.0)):
+        base = torch.randn(nl, dl, device="cuda", generator=gen)
+        sets = [torch.randn(nh, dh, device="cuda", generator=gen), None, base.clone(), None, torch.randn(nh, dl, device="cuda", generator=gen), None]
+        for k in (1, 3, 5):  # correlated partners: some hinge terms violated, some not
+            sets[k] = sets[k - 1] + 0.8 * torch.randn(sets[k - 1].shape, device="cuda", generator=gen)
+        ref_in = [t.clone().double().requires_grad_(True) for t in sets]
+        ve, pe, ce, se, vc, pc = [F.normalize(t) for t in ref_in]
+        loss_ref = 0
+        for wt, a, b_ in ((w["weight_high"], ve, pe), (w["weight_low"], ce, se), (w["weight_context"], vc, pc)):
+            loss_ref = loss_ref + wt * contr(a, b_, 0.2)
+        for wt, a, b_ in ((w["weight_high_internal"], ve, pe), (w["weight_low_internal"], ce, se),
+                          (w["weight_low_internal"] if w["weight_context_internal"] != 0 else 0, vc, pc)):
+            if wt != 0:
+                loss_ref = loss_ref + wt * (contr(a, a, 0.2) + contr(b_, b_, 0.2)) / 2
+        loss_ref.backward()
+        got_in = [t.clone().requires_grad_(True) for t in sets]
+        lcfg = cva.loss_fn.ContrastiveLossConfig(margin=0.2, **w)
+        loss = cva.total_contrastive_loss(lcfg, *got_in, dtype="f32")
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(loss_ref)) <= 2e-6 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+        for k, (a, r) in enumerate(zip(got_in, ref_in)):
+            err = float((a.grad.double() - r.grad).norm() / r.grad.norm())
+            assert err <= 5e-6, (k, err)
+    # the step API refuses the checker mode
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batch = cva.synthetic.make_batch(7, 6, [1, 2, 3, 4, 2, 1], 12, 10, 9, 6, dims[0], dims[1], ragged=False)
+    cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+    mgr.set_all_models_eval()
+    for net in mgr.model_dict.values():
+        net.set_compute_dtype("f32")
+    tr = cva.RetrievalTrainer(cfg_x, mgr)
+    with pytest.raises(RuntimeError, match="bf16 path only"):
+        tr.train_step_native(batch)

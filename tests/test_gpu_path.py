@@ -738,49 +738,15 @@ def test_global_network_single_launch_matches_per_op_kernels(env, N, L, train):
     assert not bad, "\n".join(bad)
 
 
-def test_autograd_graph_step_is_one_update_per_call(env):
-    """train_step(use_graph=True) (the autograd step captured as one HIP graph): the capture's eager warm-up runs on a snapshot, so
-    every call — the first one for a shape included — applies exactly ONE optimizer update; a learning-rate change between calls
-    is applied by the SAME graph (the captured Adam reads the rate from a device tensor: a per-step schedule must not re-capture
-    every step), checked against the eager run's trajectory; packed batches with other token totals get their own graph, the cache
-    is bounded; RAdam (host-side step scalars) is refused."""
+def test_autograd_route_has_no_graph_mode(env):
+    """Round 6: the autograd route's whole-step capture (train_step(use_graph=True)) is gone — its replay crashed inside hipGraphLaunch
+    under one module ordering and was never root-caused.  The captured step is the native route's
+    (train_step_native(use_graph=True): test_native_step_graph_replay_matches_eager, tests/test_gpu_determinism.py)."""
+    import inspect
     torch, cva = env
-    dims = (64, 48, 64, 4, 64, 128)
-    cfgs = H.full_cfgs(*dims)
-    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
-    counts = [1, 2, 3, 4, 2, 1]
-    batch = cva.synthetic.make_batch(7, 6, counts, 12, 10, 9, 6, dims[0], dims[1], ragged=False)
-    res = []
-    for graph in (False, True):
-        cfg_x, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
-        mgr.set_all_models_train()
-        tr = cva.RetrievalTrainer(cfg_x, mgr)
-        losses = []
-        for it in range(4):
-            if it == 2:
-                for grp in tr.optimizer.param_groups:
-                    grp["lr"] = 2e-4
-            losses.append(float(tr.train_step(batch, use_graph=graph)[0]))
-        torch.cuda.synchronize()
-        assert tr.total_step == 4
-        if graph:
-            assert len(tr._graphs) == 1  # the learning rate is not part of the key
-            k0 = tr._graph_key(batch)
-            batch.tok_vis, batch.tok_txt = 100, 50  # host scalars a captured packed step bakes into its launches
-            assert tr._graph_key(batch) != k0
-            batch.tok_vis = batch.tok_txt = None
-            assert tr.max_graphs >= 1
-        res.append((losses, [n._flat.clone() for n in mgr.model_dict.values()]))
-    (la, pa), (lb, pb) = res
-    assert np.allclose(la, lb, rtol=2e-3, atol=2e-5), (la, lb)  # loss BEFORE each update: equal only if the update counts are
-    for a, b in zip(pa, pb):
-        d = (a - b).abs()
-        assert float((d > 1e-6).float().mean()) < 2e-2 and float(d.max()) <= 2.5e-3, (float((d > 1e-6).float().mean()), float(d.max()))
-    cfg_r, mgr_r = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
-    cfg_r.optimizer.name = "radam"
-    tr_r = cva.RetrievalTrainer(cfg_r, mgr_r)
-    with pytest.raises(NotImplementedError):
-        tr_r.train_step(batch, use_graph=True)
+    assert "use_graph" not in inspect.signature(cva.RetrievalTrainer.train_step).parameters
+    assert "use_graph" in inspect.signature(cva.RetrievalTrainer.train_step_native).parameters
+    assert not hasattr(cva.RetrievalTrainer, "_capture")
 
 
 def test_native_optimizer_state_round_trip(env):
