@@ -511,15 +511,27 @@ def main():
         dom = max(by, key=lambda k: by[k]["ms_per_step"])  # the kernel the step spends most MFMA time in
         # HBM bytes per launch of that family from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_stale = None, None, None
         fam_key = {2: "gemm_nt", 3: "gemm_nt_small", 4: "gemm_tn", 5: "fused", 6: "glob"}[[k for k in names if names[k] == dom][0]]
         import glob
-        cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, os.path.join(here, "tools"))
+        from sources_hash import sources_sha16
+        live_sha = sources_sha16(here)
+        cands = sorted(glob.glob(os.path.join(here, "profiles", "r*_traffic.json")))
         if cands:
             try:
                 tj = json.load(open(cands[-1]))
-                traffic = tj["families"][fam_key]["hbm_bytes_per_launch"]
-                traffic_src = os.path.relpath(cands[-1], os.path.dirname(os.path.abspath(__file__)))
+                traffic_src = os.path.relpath(cands[-1], here)
+                if tj.get("kernel_sources_sha16") == live_sha:
+                    traffic = tj["families"][fam_key]["hbm_bytes_per_launch"]
+                else:
+                    # the counters were collected on other kernel sources than this run's: not quoted (a traffic regression must not hide
+                    # behind an old profile); re-run tools/profile_round.sh and commit its traffic.json
+                    traffic_stale = {"profile_kernel_sources_sha16": tj.get("kernel_sources_sha16"), "this_run_kernel_sources_sha16": live_sha,
+                                     "stale_value": tj["families"][fam_key]["hbm_bytes_per_launch"]}
+                    sys.stderr.write(f"bench.py: STALE TRAFFIC PROFILE {traffic_src}: taken on kernel sources {tj.get('kernel_sources_sha16')}, this run "
+                                     f"is {live_sha}; roofline.traffic = null (tools/profile_round.sh <tag>, then commit profiles/<tag>_traffic.json)\n")
             except (KeyError, ValueError, OSError):
                 traffic = None
         # The same family in the committed rocprofv3 kernel trace of this command (profiles/*_kernel_stats_bench_train_anet.csv: sum of the
@@ -537,18 +549,19 @@ def main():
                 tf_tr = by[dom]["algorithmic_gflop_per_step"] / fam_us * 1e3  # GFLOP / us = PFLOP/s
                 trace = {"frac": round(tf_tr / 2500.0, 4), "achieved": round(tf_tr, 1), "us_per_step": round(fam_us, 1), "steps_in_trace": nsteps,
                          "source": os.path.relpath(csvs[-1], os.path.dirname(os.path.abspath(__file__))),
-                         "note": "committed rocprofv3 --kernel-trace of this command, not measured in this run"}
+                         "note": "committed rocprofv3 --kernel-trace of this command (the newest profiles/r*_kernel_stats_bench_train_anet.csv by "
+                                 "name), NOT measured in this run"}
             except (IndexError, StopIteration, KeyError, ValueError, OSError, ZeroDivisionError):
                 trace = None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": by[dom]["achieved"], "peak": 2500.0, "unit": "TFLOP/s",
                     "frac": by[dom]["frac"], "frac_method": "HIP events around every launch of the family, on its launch stream, in " + str(nst) + " extra steps of this run",
-                    "trace": trace, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, "
-                    "family average)", "traffic_source": traffic_src,
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, family average; separate "
+                    "rocprofv3 --pmc passes of this command on THESE kernel sources: the profile carries their hash, another hash => null)",
+                    "traffic_source": traffic_src, **({"traffic_stale": traffic_stale} if traffic_stale else {}),
+                    "kernel_sources_sha16": live_sha,
                     "algorithmic_bytes_per_launch": by[dom].get("algorithmic_bytes_per_launch"),
-                    # measured in THIS run without counters: the bytes the family's launches read and write as built, from the sizes of
-                    # the tensors this run actually launched (every saved / operand tensor once per token); `traffic` next to it is the
-                    # PMC figure of the committed profile (a run under the driver cannot collect counters)
-                    "traffic_live_estimate": by[dom].get("algorithmic_bytes_per_launch"),
+                    # NOT measured in this run: figures read from files committed under profiles/
+                    "committed_profile": {"kernel_trace": trace},
                     "launches_per_step": by[dom]["launches_per_step"],
                     "avg_launch_us": by[dom]["avg_launch_us"], "ms_per_step": by[dom]["ms_per_step"],
                     # the same launches against the OTHER roofline: their algorithmic bytes over the same durations (the chains save

@@ -628,12 +628,14 @@ int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)d
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
 extern "C" void coot_step_grad_write(int on);
 extern "C" int coot_internal_stage_hits(void);
+extern "C++" { namespace coot { int det_bypass_count(); } }  // det.hip
 int coot_get_option(const char* name, int* value) {
   if (!value) { set_error("get_option: null result"); return -1; }
   if (!strcmp(name, "tn_dma")) { *value = get_tn_dma(); return 0; }
   if (!strcmp(name, "xcd_order")) { *value = get_xcd_order(); return 0; }
   if (!strcmp(name, "tn_mode")) { *value = get_tn_mode(); return 0; }
   if (!strcmp(name, "stage_hits")) { *value = coot_internal_stage_hits(); return 0; }  // steps of this thread that used a prepared input stage
+  if (!strcmp(name, "det_bypasses")) { *value = det_bypass_count(); return 0; }  // deterministic mode: addends that took the float atomic (synchronises; -1: mode off)
   set_error("get_option: unknown or write-only option %s", name);
   return -2;
 }

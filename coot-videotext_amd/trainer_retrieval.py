@@ -522,10 +522,20 @@ class RetrievalTrainer:
         if bool(on) != getattr(self, "deterministic", False):
             self._drop_graphs()  # captured steps carry the mode they were captured in (flush nodes, the shadow's address)
         self.deterministic = bool(on)
+        if not on:
+            loss_fn.set_det_loss_word(None)  # (module-global in loss_fn: must not outlive the mode it belongs to)
         if not on and getattr(self, "_det_key", None) is not None:
             torch.cuda.synchronize()  # (no launch of any stream may still add into — or flush — the shadow that is freed below)
             _lib.check(_lib.load().coot_det_configure(0, None, None, None, 0, torch.cuda.current_stream().cuda_stream), "coot_det_configure")
             self._det_key, self._det_shadow, self._det_ranges = None, None, []
+
+    def det_bypass_count(self) -> int:
+        """Deterministic mode: how many gradient / loss addends since the mode was configured were NaN, Inf or >= 2^22 and therefore took the
+        plain float atomic instead of the fixed-point shadow (csrc/det.h) — a run with a non-zero count is not bit-reproducible.
+        Synchronises the device; -1 while the mode is off."""
+        v = C.c_int(0)
+        _lib.check(_lib.load().coot_get_option(b"det_bypasses", C.byref(v)), "coot_get_option")
+        return int(v.value)
 
     def _drop_graphs(self) -> None:
         """Forgets every captured native step.  The library consults its process-wide deterministic table

@@ -57,6 +57,17 @@ def _run(torch, cva, cfgs, Ps, batches, det, lookahead=False, defer=False, dp=No
         tr.set_deterministic(False)
 
 
+def _inject_nonfinite_addend(torch, cva, arena):
+    """One non-finite addend through an accumulating kernel of the library into the first word of a registered arena: the
+    cycle-consistency loss word of coot_cyclecons_fwd_bwd (csrc/loss.hip: acc_add) with an infinite loss weight."""
+    lib = cva.lib.load()
+    clip, sent = torch.randn(1, 2, 8, device="cuda"), torch.randn(1, 2, 8, device="cuda")
+    lens, idx = torch.tensor([2], device="cuda"), torch.tensor([0], device="cuda")
+    p = cva.lib.ptr
+    cva.lib.check(lib.coot_cyclecons_fwd_bwd(p(clip), p(sent), p(lens), p(lens), p(idx), p(idx), 1, 2, 2, 8, float("inf"), 1.0, arena.data_ptr(),
+                                             None, None, None, None, cva.lib.stream_ptr()), "coot_cyclecons_fwd_bwd")
+
+
 def _batches(cva, ragged):
     if ragged:
         return [cva.synthetic.make_batch(40 + i, 12, cva.synthetic.anet_like_counts(70 + i, 12), 40, 40, 32, 16, DIMS[0], DIMS[1], ragged=True, packed=True)
@@ -99,8 +110,16 @@ def test_deterministic_mode_computes_the_same_step(env):
             out = tr.train_step_native(batches[0], do_optimizer=False, seed=77)
             torch.cuda.synchronize()
             res.append(([float(v) for v in out], [n._grad_flat.detach().clone() for n in mgr.model_dict.values()]))
+            # an addend outside the fixed-point range silently leaves the deterministic path — it is counted now
+            assert tr.det_bypass_count() == (0 if det else -1)
+            if det:  # one Inf gradient addend through an accumulating kernel of the library: counted, and visible in the fp32 word
+                g = mgr.model_dict["net_video_global"]._grad_flat
+                _inject_nonfinite_addend(torch, cva, g)
+                torch.cuda.synchronize()
+                assert tr.det_bypass_count() >= 1 and not bool(torch.isfinite(g[0]))
         finally:
             tr.set_deterministic(False)
+            assert cva.loss_fn._DET_LOSS_WORD is None  # (cleared with the mode, not at the next autograd-route step)
     (l0, g0), (l1, g1) = res
     assert np.allclose(l0, l1, rtol=1e-6, atol=1e-9), (l0, l1)
     for a, b in zip(g0, g1):

@@ -168,10 +168,11 @@ def test_f32_loss_mode_matches_torch_ops_and_the_step_api_refuses_f32(env):
 
     for w in (H.ANET_W, dict(weight_high=0.7, weight_high_internal=0.3, weight_low=1.1, weight_low_internal=0.6, weight_context=0.9,
                              weight_context_internal=1.0)):
-        base = torch.randn(nl, dl, device="cuda", generator=gen)
-        sets = [torch.randn(nh, dh, device="cuda", generator=gen), None, base.clone(), None, torch.randn(nh, dl, device="cuda", generator=gen), None]
-        for k in (1, 3, 5):  # correlated partners: some hinge terms violated, some not
-            sets[k] = sets[k - 1] + 0.8 * torch.randn(sets[k - 1].shape, device="cuda", generator=gen)
+        def rows(n, d):  # a component common to all rows: negatives at cosine ~0.67, partners at ~0.92 -> some hinge terms violated, some not
+            return torch.randn(1, d, device="cuda", generator=gen) + 0.7 * torch.randn(n, d, device="cuda", generator=gen)
+        sets = [rows(nh, dh), None, rows(nl, dl), None, rows(nh, dl), None]
+        for k in (1, 3, 5):
+            sets[k] = sets[k - 1] + 0.5 * torch.randn(sets[k - 1].shape, device="cuda", generator=gen)
         ref_in = [t.clone().double().requires_grad_(True) for t in sets]
         ve, pe, ce, se, vc, pc = [F.normalize(t) for t in ref_in]
         loss_ref = 0
@@ -189,6 +190,7 @@ def test_f32_loss_mode_matches_torch_ops_and_the_step_api_refuses_f32(env):
         torch.cuda.synchronize()
         assert abs(float(loss) - float(loss_ref)) <= 2e-6 * abs(float(loss_ref)), (float(loss), float(loss_ref))
         for k, (a, r) in enumerate(zip(got_in, ref_in)):
+            assert float(r.grad.norm()) > 0, k  # (the data above violates some hinge terms of every set)
             err = float((a.grad.double() - r.grad).norm() / r.grad.norm())
             assert err <= 5e-6, (k, err)
     # the step API refuses the checker mode

@@ -9,7 +9,12 @@ known byte counts: FETCH_SIZE reported 82,241 KiB for 163,840 KiB read, WRITE_SI
 Usage: python tools/pmc_traffic.py fetch.csv write.csv out.json"""
 import csv
 import json
+import os
+import subprocess
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from sources_hash import sources_sha16  # noqa: E402
 
 FAMILIES = {
     "fused": ("post_attn_fwd_kernel", "pre_attn_bwd_kernel", "qkv_fwd_kernel", "qkv_bwd_kernel", "infc_qkv_fwd_kernel"),
@@ -28,7 +33,13 @@ def read(path):
 
 def main(fetch_csv, write_csv, out_json):
     f, w = read(fetch_csv), read(write_csv)
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+    except OSError:
+        head = None
     res = {"source": {"fetch": fetch_csv, "write": write_csv},
+           # what bench.py compares with the sources of ITS run: another value means these counters were taken on other kernels
+           "kernel_sources_sha16": sources_sha16(), "git_head_at_collection": head,
            "correction": "read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950, calibrated on ln_fwd_kernel<8>); write bytes = WRITE_SIZE KiB x 1024",
            "families": {}, "kernels": {}}
     for k in sorted(set(f) | set(w)):
