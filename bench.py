@@ -604,7 +604,7 @@ def main():
             "metric": "clip-pairs/sec (COOT retrieval " + ("eval forward" if args.eval else "train step") + ", whole job)",
             "value": round(value, 1), "unit": "clip-pairs/s", "n_gpus": (torch.distributed.get_world_size() if dp is not None else 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": cva.lib.operand(), "data": "synthetic",  # the loaded build's MFMA operand format (COOT_OPERAND=f16: forward-only, --eval)
             "config": {"workload": f"{cva.synthetic.WORKLOAD_LABEL[args.workload]}: {w['B']} videos x "
                                    f"{(str(w['C']) + ' clips') if not ragged else (str(clip_counts[0]) + ' clips in total (rank 0)')} per GPU, "
                                    f"Lc=Lv={w['Lc']}, Ls={w['Ls']}, Lp={w['Lp']}, Dv={w['Dv']}, Dt={w['Dt']}, d_model=384",

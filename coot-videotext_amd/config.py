@@ -92,8 +92,10 @@ class TransformerConfig:
         self.pool_dropout: float = float(pc.get("dropout", 0))
         # compute mode of the HIP network (not a reference key): "bf16" = the fast path, "f32" = the fp32 reference
         # mode (include/coot_hip.h: coot_net_config.dtype), e.g. to tell bf16 rounding from a logic error
-        self.dtype: str = d.get("dtype", "bf16")
-        _require(self.dtype in ("bf16", "f32"), f"dtype {self.dtype} (bf16 or f32)")
+        # "f16": IEEE half operands = the second build of the library (COOT_OPERAND=f16 -> libcoot_hip_f16.so, forward-only); the default
+        # is the format of the library the process selected, and a configuration that names the other one is refused by the library
+        self.dtype: str = d.get("dtype", _lib.OPERAND_ENV)
+        _require(self.dtype in ("bf16", "f16", "f32"), f"dtype {self.dtype} (bf16, f16 or f32)")
         self.weight_init_type: str = d.get("weight_init_type", "truncnorm")
         self.weight_init_std: float = d.get("weight_init_std", 0.01)
         # options of the reference that no shipped config enables and the HIP path does not implement
@@ -118,7 +120,7 @@ class TransformerConfig:
         return _lib.NetConfig(self.input_dim, self.hidden_dim, self.num_heads, self.ff_dim, self.num_layers,
                               int(self.use_input_fc), int(self.use_context), self.ctx_num_layers,
                               0 if self.pooler == "atn" else 1, self.pool_hidden, self.pool_heads,
-                              self.dropout, self.ctx_dropout, self.pool_dropout, _lib.DTYPE_F32 if self.dtype == "f32" else _lib.DTYPE_BF16)
+                              self.dropout, self.ctx_dropout, self.pool_dropout, {"bf16": _lib.DTYPE_BF16, "f32": _lib.DTYPE_F32, "f16": _lib.DTYPE_F16}[self.dtype])
 
 
 def _require(cond: bool, msg: str):

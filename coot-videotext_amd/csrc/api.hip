@@ -78,7 +78,12 @@ static int norm_cfg(const coot_net_config* c, coot_net_config* o) {
     COOT_REQUIRE((o->pool_hidden / o->pool_heads) % 8 == 0 && (o->hidden_dim / o->pool_heads) % 8 == 0, "pooler head dims must be multiples of 8");
   }
   COOT_REQUIRE(o->num_layers >= 1, "num_layers must be >= 1");
-  COOT_REQUIRE(o->dtype == COOT_DTYPE_BF16 || o->dtype == COOT_DTYPE_F32, "dtype %d (COOT_DTYPE_BF16 or COOT_DTYPE_F32)", o->dtype);
+  // the 16-bit operand format is a property of the BUILD (common.h: libcoot_hip.so = bfloat16, libcoot_hip_f16.so = IEEE half): a
+  // configuration that names the other one is refused, never silently computed in this build's format
+  COOT_REQUIRE(o->dtype == COOT_DTYPE_NATIVE || o->dtype == COOT_DTYPE_F32,
+               "dtype %d: this build of the library computes on %s operands (dtype %d) or in the fp32 reference mode (%d); the other 16-bit "
+               "format is the other build (libcoot_hip.so / libcoot_hip_f16.so)", o->dtype, COOT_OPERAND_IS_F16 ? "IEEE half" : "bfloat16",
+               COOT_DTYPE_NATIVE, COOT_DTYPE_F32);
   return 0;
 }
 
@@ -635,6 +640,7 @@ int coot_get_option(const char* name, int* value) {
   if (!strcmp(name, "xcd_order")) { *value = get_xcd_order(); return 0; }
   if (!strcmp(name, "tn_mode")) { *value = get_tn_mode(); return 0; }
   if (!strcmp(name, "stage_hits")) { *value = coot_internal_stage_hits(); return 0; }  // steps of this thread that used a prepared input stage
+  if (!strcmp(name, "operand_f16")) { *value = COOT_OPERAND_IS_F16; return 0; }  // which build this is (common.h)
   if (!strcmp(name, "det_bypasses")) { *value = det_bypass_count(); return 0; }  // deterministic mode: addends that took the float atomic (synchronises; -1: mode off)
   set_error("get_option: unknown or write-only option %s", name);
   return -2;
@@ -1148,6 +1154,8 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
     for (int s_ = 0; s_ < sg.n; ++s_) { rs.N[s_] = sg.N[s_]; rs.L[s_] = sg.L[s_]; rs.lens[s_] = sg.lens[s_]; }
     return ref_f32_backward(ref_desc(c, L, Ntot), P, G, feats, feats2, rs, hidden, dpooled, dhidden, dfeats, saved, saved_bytes, scratch, scratch_bytes, st);
   }
+  COOT_REQUIRE(!COOT_OPERAND_IS_F16, "net_bwd: the f16 operand build is forward-only — the reference trains its fp16 path under a GradScaler "
+               "(coot/trainer_retrieval.py:277-285, nntrainer/trainer_base.py:106-109); unscaled half gradients underflow and are not offered");
   Arena AW((void*)wpack, (size_t)-1); WPack W; layout_wpack(c, AW, W);
   PerOpGuardScope perop_guard(c, W, P, wpack);
   Arena AS(saved, saved_bytes); Saved S; layout_saved(c, Ntot, sg.Tpad(), AS, S);

@@ -90,8 +90,8 @@ SidePacked side_packed(const coot_step_batch& x, const coot_step_dims& d) {
 int check_cfg(const coot_step_config& c) {
   const int D = c.net[0].hidden_dim;
   for (int i = 0; i < 4; ++i)  // the fp32 reference mode is a per-network checker (coot_net_fwd / coot_net_bwd, eval): not a mode of the step
-    COOT_REQUIRE(c.net[i].dtype == COOT_DTYPE_BF16, "step: network %d has dtype %d — the step API runs the bf16 path only (COOT_DTYPE_F32 is the "
-                 "checker mode of coot_net_fwd / coot_net_bwd)", i, c.net[i].dtype);
+    COOT_REQUIRE(c.net[i].dtype == COOT_DTYPE_NATIVE, "step: network %d has dtype %d — the step API runs the bf16 path only (this build's 16-bit operand "
+                 "format, dtype %d; COOT_DTYPE_F32 is the checker mode of coot_net_fwd / coot_net_bwd)", i, c.net[i].dtype, COOT_DTYPE_NATIVE);
   COOT_REQUIRE(c.net[1].hidden_dim == D && c.net[2].hidden_dim == D && c.net[3].hidden_dim == D, "step: the four networks must share hidden_dim");
   COOT_REQUIRE(c.net[0].use_input_fc && c.net[2].use_input_fc && !c.net[0].use_context && !c.net[2].use_context &&
                c.net[0].pooler == 0 && c.net[2].pooler == 0, "step: local networks = input_fc + atn pooler, no context");
@@ -550,6 +550,7 @@ int coot_step_backward(const coot_step_config* cfg, const coot_step_buffers* b, 
                        void* workspace, size_t workspace_bytes, int train, uint64_t seed, coot_stream_t main_s, coot_stream_t side_v,
                        coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
+  COOT_REQUIRE(!COOT_OPERAND_IS_F16, "coot_step_backward: the f16 operand build is forward-only (no GradScaler: coot/trainer_retrieval.py:277-285); coot_step_forward runs");
   Bump A(workspace, workspace_bytes); StepWs W; layout_step(*cfg, *d, A, W);
   const SidePacked pk = side_packed(*x, *d);
   COOT_REQUIRE(!A.overflow, "step: workspace too small");
@@ -620,6 +621,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
                     float* losses, void* workspace, size_t workspace_bytes, int train, uint64_t seed, int64_t step, int do_optimizer,
                     coot_stream_t main_s, coot_stream_t side_v, coot_stream_t side_t) {
   RUN(check_cfg(*cfg));
+  COOT_REQUIRE(!COOT_OPERAND_IS_F16, "coot_train_step: the f16 operand build is forward-only (no GradScaler: coot/trainer_retrieval.py:277-285); coot_step_forward runs");
   COOT_REQUIRE(losses, "train_step: losses pointer");
   COOT_REQUIRE((do_optimizer & ~(COOT_STEP_OPTIMIZER | COOT_STEP_REPACK | COOT_STEP_PACKS_FRESH | COOT_STEP_DEFER_TEXT_JOIN | COOT_STEP_INPUT_STAGES |
                                  COOT_STEP_STAGE_ANNOUNCED)) == 0, "train_step: unknown bits in do_optimizer (%d)", do_optimizer);

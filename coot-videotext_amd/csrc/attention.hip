@@ -25,7 +25,7 @@ struct AttnSmem {
 };
 
 __device__ __forceinline__ f32x4_t mfma16(s16x4_t a, s16x4_t b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  return COOT_MFMA_16x16x16(a, b, c);
 }
 __device__ __forceinline__ s16x4_t pack4(float a, float b, float c, float d) {
   unsigned lo = pack2bf(a, b), hi = pack2bf(c, d);

@@ -6,31 +6,61 @@
 
 namespace coot {
 
-typedef unsigned short bf16_t;  // raw bfloat16 bits in HBM / LDS
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// ---- the 16-bit operand type of the MFMA path ---------------------------------------------------------------------------------
+// The library is built twice from these sources (csrc/build.sh): libcoot_hip.so with bfloat16 operands (the default, what bench.py
+// times) and libcoot_hip_f16.so (-DCOOT_OPERAND_F16) with IEEE half operands — the arithmetic of the reference's GPU path (fp16
+// autocast, coot/trainer_retrieval.py:264; BASELINE.json configs[3] "fp16 MFMA path").  Same MFMA rate (v_mfma_f32_16x16x32_f16 /
+// _bf16), same storage size, fp32 accumulation in both; everything that knows the format is in this block: the conversions and the
+// two MFMA wrappers.  The names keep "bf16" (they mean "the 16-bit operand"); raw bits travel as unsigned short either way.
+typedef unsigned short bf16_t;  // raw 16-bit operand bits in HBM / LDS (bfloat16, or IEEE half in the f16 build)
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr float kMaskFill = -32752.0f;  // nntrainer/typext.py:24 (INF), used as -INF mask fill
 constexpr float kLnEps = 1e-6f;         // nntrainer/models/normalizations.py:89
 
+#ifndef COOT_OPERAND_F16
+#define COOT_OPERAND_IS_F16 0
+#define COOT_DTYPE_NATIVE 0  // COOT_DTYPE_BF16 (include/coot_hip.h)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // ---- bf16 <-> f32 (round-to-nearest-even, same as v_cvt_pk_bf16_f32) ----------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 // fp32 -> bf16 pairs: the gfx950 hardware conversion (v_cvt_pk_bf16_f32, round to nearest even).  The software form
 // (add 0x7FFF + lsb, shift) costs 5 VALU ops per element — with two or three bf16 stores per element in the fused
 // epilogues that was a third of their instruction count.
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
   const f32x2_t f = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
 }
-__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.0f) & 0xFFFFu); }
 __device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+// D = A (16 x 32) . B (32 x 16) + C on the matrix pipe, and the 16 x 16 x 16 form of the attention kernels (operands as raw 16-bit lanes)
+#define COOT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define COOT_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+#else
+#define COOT_OPERAND_IS_F16 1
+#define COOT_DTYPE_NATIVE 2  // COOT_DTYPE_F16
+typedef _Float16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x2_t __attribute__((ext_vector_type(2)));
+// ---- IEEE half <-> f32 (round-to-nearest-even: v_cvt_f16_f32 / v_cvt_pk_f16_f32; values beyond 65504 become Inf, as under autocast) ----
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+}
+__device__ __forceinline__ float bflo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu)); }
+__device__ __forceinline__ float bfhi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+typedef _Float16 f16x4_op_t __attribute__((ext_vector_type(4)));
+#define COOT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define COOT_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_op_t, (a)), __builtin_bit_cast(f16x4_op_t, (b)), (c), 0, 0, 0)
+#endif
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.0f) & 0xFFFFu); }
 
 // ---- erf GELU (nn.GELU(), nntrainer/models/activations.py:29-30) and derivative -----------------------
 // Phi(x) = 0.5 erfc(-x / sqrt 2) with erfc by Abramowitz-Stegun 7.1.25 (|error| <= 2.5e-5 on erf, two orders below the
@@ -46,6 +76,9 @@ __device__ __forceinline__ GeluParts gelu_parts(float x) {
   return GeluParts{poly * e, e};
 }
 __device__ __forceinline__ float gelu_f(float x) {
+#ifdef FZ_NO_EPI_MATH  // (measurement build of fused.hip only: identity instead of GELU)
+  return x;
+#endif
   const GeluParts g = gelu_parts(x);
   // x Phi(x) = max(x, 0) - |x| Phi(-|x|): one max and one fma (|x| and the sign are source modifiers) instead of
   // mul + sub + compare + select

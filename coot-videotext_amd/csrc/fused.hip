@@ -92,6 +92,10 @@ __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RF][3]) {
 //   weights: 5 k-blocks (15 KB per wave) in flight.  Full tiles: a pass is at the MFMA time of 2 waves/SIMD, PD = 2 (3 / 4: no faster).
 //   NB must divide every pass's KB (12, 6): a pass then starts at ring slot 0 whatever preceded it.
 constexpr int kPdFull = 2;       // k-blocks in flight on full tiles (3 / 4 measured no faster)
+#ifndef FZ_PD_SMALL
+#define FZ_PD_SMALL 5
+#endif
+constexpr int kPdSmall = FZ_PD_SMALL;  // k-blocks in flight on 16 / 32-row tiles (the global networks' latency chains)
 //   CARRY: 128-row tiles do not carry (the PD x 12 ring registers live across an epilogue that already holds 96 accumulators + its
 //   chunk registers: 104-148 B of scratch per lane; measured 0.25 % faster WITH the spills, profiles/r04_ab_carry_ring.txt — not
 //   adopted); their passes start with their own first k-blocks.  A ring type's CARRY decides for every pass run on it.  (Round 4 kept
@@ -99,16 +103,20 @@ constexpr int kPdFull = 2;       // k-blocks in flight on full tiles (3 / 4 meas
 constexpr int kCarryMaxRF = 4;
 template <int PD_, bool CARRY_>
 struct WRing { static constexpr int PD = PD_, NB = PD_ + 1; static constexpr bool CARRY = CARRY_; bf16x8_t w[PD_ + 1][3]; };
-template <int RF> using TileRing = WRing<(RF <= 2 ? 5 : kPdFull), (RF <= kCarryMaxRF)>;
+template <int RF> using TileRing = WRing<(RF <= 2 ? kPdSmall : kPdFull), (RF <= kCarryMaxRF)>;
 
 // the first PD k-blocks of weight group wg -> ring slots 0 .. PD - 1 (the first pass of a kernel; later passes inherit theirs)
 template <typename Ring>
 __device__ __forceinline__ void gemm_load_first(Ring& R, const bf16_t* wg, int lane) {
   const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(wg) + lane;
+#ifndef FZ_NO_WLOAD  // (measurement build FZ_NO_WLOAD: the passes run on whatever the ring registers hold — no weight stream from L2)
 #pragma unroll
   for (int s = 0; s < Ring::PD; ++s)
 #pragma unroll
     for (int b = 0; b < 3; ++b) R.w[s][b] = wp[(s * 3 + b) * 64];
+#else
+  (void)wp;
+#endif
   // pin the loads where they are written: hipcc otherwise sinks them next to their first use
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -135,6 +143,7 @@ __device__ __forceinline__ void gemm_run(Ring& R, const bf16_t* As, const bf16_t
   for (int a = 0; a < RF; ++a) xf[a] = *reinterpret_cast<const bf16x8_t*>(arow + a * 16 * APITCH);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
+#ifndef FZ_NO_WLOAD
     if (kb + PD < KB) {
 #pragma unroll
       for (int b = 0; b < 3; ++b) R.w[(kb + PD) % NB][b] = wp[((kb + PD) * 3 + b) * 64];
@@ -142,13 +151,22 @@ __device__ __forceinline__ void gemm_run(Ring& R, const bf16_t* As, const bf16_t
 #pragma unroll
       for (int b = 0; b < 3; ++b) R.w[(kb + PD) % NB][b] = np[((kb + PD - KB) * 3 + b) * 64];
     }
+#else
+    (void)wp; (void)np;
+#endif
     // pin the prefetches where they are written: without this hipcc sinks the weight loads next to their first use
     // (vmcnt(0) in front of every k-block: one full L2 round trip per 24 MFMAs)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int a = 0; a < RF; ++a) {
 #pragma unroll
-      for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R.w[kb % NB][b], xf[a], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 3; ++b) {
+#ifndef FZ_NO_MFMA  // (measurement build FZ_NO_MFMA: the operands are consumed by one VALU op per fragment instead of the matrix pipe)
+        acc[a][b] = COOT_MFMA_16x16x32(R.w[kb % NB][b], xf[a], acc[a][b]);
+#else
+        acc[a][b][0] += __builtin_bit_cast(float, (int)(__builtin_bit_cast(u32x4_t, R.w[kb % NB][b])[0] ^ __builtin_bit_cast(u32x4_t, xf[a])[b]));
+#endif
+      }
       if (kb + 1 < KB) xf[a] = *reinterpret_cast<const bf16x8_t*>(arow + a * 16 * APITCH + (kb + 1) * 32);
     }
   }
@@ -347,6 +365,9 @@ __device__ __forceinline__ float attn_drop_f(unsigned key, unsigned row, int k, 
 
 template <bool DROP>
 __device__ __forceinline__ void apply_drop(const DropK& d, unsigned long long idx0, float (&v)[8]) {
+#ifdef FZ_NO_EPI_MATH  // (measurement build: no dropout hash, identity instead of GELU — the epilogues keep their staging, loads and stores)
+  return;
+#endif
   if constexpr (DROP) {
     float sc[8];
     drop_scales_key<8>(d.key, idx0, d.thr, d.inv_keep, sc);
@@ -1720,7 +1741,7 @@ __global__ __launch_bounds__(512) void infc_qkv_fwd_kernel(InfcQkvFwd p) {
       for (int a = 0; a < RF; ++a) {
         const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(ab + a * 16 * XPITCH + kk * 32);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2 * S3 + kk][b], xf, acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 3; ++b) acc[a][b] = COOT_MFMA_16x16x32(w[2 * S3 + kk][b], xf, acc[a][b]);
       }
     // slab s + 1 (register set 1 - PAR) -> the other LDS buffer (its readers finished before the last barrier), then that
     // set takes the loads of slab s + 3

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+          acc[a][b] = COOT_MFMA_16x16x32(wf[b], xf[a], acc[a][b]);
     }
     if (kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmNT g) {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f][s], xf[s], acc[f], 0, 0, 0);
+      for (int f = 0; f < NF; ++f) acc[f] = COOT_MFMA_16x16x32(wf[f][s], xf[s], acc[f]);
   }
   // acc[f][j] = C[token row0 + l15][feature col0 + 16 f + 4 l4 + j]
   const GemmEpi& e = g.epi;
@@ -601,7 +601,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& g, int bx, int by, in
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+          acc[a][b] = COOT_MFMA_16x16x32(bfr[b], af[a], acc[a][b]);
     }
     if (st + 1 < nsteps) { if (do_cs) cs_acc(); sstore(buf ^ 1); }
     __syncthreads();
@@ -783,7 +783,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const GemmTN& g, int bx, int b
         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
         // lane reg j = C[row = m0 + wm*96 + a*16 + (lane&15)][col = n0 + wn*64 + b*16 + (lane>>4)*4 + j]
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af, acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b) acc[a][b] = COOT_MFMA_16x16x32(bfr[b], af, acc[a][b]);
       }
     }
     TNW_PT(1);
@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void gemm_tn_dma_body(const GemmTN& g, int bx, int by
     for (int a = 0; a < 6; ++a) {
       const bf16x8_t af = a < 2 ? ac[a] : read_a(st, a);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[b], af, acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b) acc[a][b] = COOT_MFMA_16x16x32(bc[b], af, acc[a][b]);
       if (a == 3) preload(stn, bn, an);  // (past the last stage: a buffer nobody needs — harmless)
     }
   };

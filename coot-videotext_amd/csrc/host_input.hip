@@ -28,6 +28,13 @@ namespace {
 #define COOT_HOST_CLONES __attribute__((target_clones("arch=x86-64-v4", "arch=x86-64-v3", "default")))
 #endif
 COOT_HOST_CLONES void convert_bf16_rne(const float* __restrict__ s, uint16_t* __restrict__ o, int64_t n) {
+#ifdef COOT_OPERAND_F16  // the f16 build stages IEEE half (the name keeps "bf16": the 16-bit operand of the build, common.h)
+  for (int64_t k = 0; k < n; ++k) {
+    const _Float16 h = (_Float16)s[k];
+    std::memcpy(o + k, &h, 2);
+  }
+  return;
+#endif
   for (int64_t k = 0; k < n; ++k) {
     uint32_t u;
     std::memcpy(&u, s + k, 4);

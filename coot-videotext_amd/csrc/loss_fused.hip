@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
       }
 #pragma unroll
       for (int j = 0; j < 12; ++j)
-        if (k0 + j < kbs) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xfrag + (k0 + j) * 32), yf[j], acc, 0, 0, 0);
+        if (k0 + j < kbs) acc = COOT_MFMA_16x16x32(*reinterpret_cast<const bf16x8_t*>(xfrag + (k0 + j) * 32), yf[j], acc);
     }
     // acc[r] = S[i0 + l4*4 + r][cb*16 + l15]
     const int j = cb * 16 + l15;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * CL_NW) void cl_half_kernel(ClHalfArgs A) {
       for (int j = 0; j < 4; ++j)
         if (k0 + j < nkb) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[j], yf[j][q], acc[q], 0, 0, 0);
+          for (int q = 0; q < 3; ++q) acc[q] = COOT_MFMA_16x16x32(gf[j], yf[j][q], acc[q]);
         }
     }
 #pragma unroll
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(64 * CLS_NW) void cl_small_kernel(ClSmallArgs A) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 6  // (d % 32 == 0; LDS reads of the next k-blocks under the dependent MFMA chain)
     for (int kb = 0; kb < kbs; ++kb)
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xfrag + kb * 32),
-                                                    *reinterpret_cast<const bf16x8_t*>(yfrag + kb * 32), acc, 0, 0, 0);
+      acc = COOT_MFMA_16x16x32(*reinterpret_cast<const bf16x8_t*>(xfrag + kb * 32),
+                                                    *reinterpret_cast<const bf16x8_t*>(yfrag + kb * 32), acc);
     const int j = cb * 16 + l15;
     const float dj = j < N ? diag[j] : 0.f;
 #pragma unroll
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64 * CLS_NW) void cl_small_kernel(ClSmallArgs A) {
       if (kb < nkb) {
         const u32x4_t w = {(unsigned)e[kb][0] | ((unsigned)e[kb][1] << 16), (unsigned)e[kb][2] | ((unsigned)e[kb][3] << 16),
                            (unsigned)e[kb][4] | ((unsigned)e[kb][5] << 16), (unsigned)e[kb][6] | ((unsigned)e[kb][7] << 16)};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[kb], *reinterpret_cast<const bf16x8_t*>(&w), acc, 0, 0, 0);
+        acc = COOT_MFMA_16x16x32(gf[kb], *reinterpret_cast<const bf16x8_t*>(&w), acc);
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

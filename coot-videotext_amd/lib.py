@@ -12,8 +12,14 @@ import os
 from typing import List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# COOT_HIP_LIB: another build of the same library (tools/build_variant.sh: A/B of compile-time kernel variants on one GPU box)
-LIB_PATH = os.environ.get("COOT_HIP_LIB") or os.path.join(_HERE, "lib", "libcoot_hip.so")
+# Two builds of the same sources ship (csrc/build.sh, csrc/common.h): libcoot_hip.so computes on bfloat16 MFMA operands (the default,
+# what bench.py times), libcoot_hip_f16.so on IEEE half operands — the reference's GPU arithmetic (fp16 autocast,
+# coot/trainer_retrieval.py:264; BASELINE.json configs[3]) — forward-only.  COOT_OPERAND=f16 selects the second one for the process
+# (one library per process); COOT_HIP_LIB: any other build (tools/build_variant.sh: A/B of compile-time kernel variants on one GPU box).
+OPERAND_ENV = os.environ.get("COOT_OPERAND", "bf16")
+if OPERAND_ENV not in ("bf16", "f16"):
+    raise RuntimeError(f"COOT_OPERAND={OPERAND_ENV}: bf16 or f16")
+LIB_PATH = os.environ.get("COOT_HIP_LIB") or os.path.join(_HERE, "lib", "libcoot_hip_f16.so" if OPERAND_ENV == "f16" else "libcoot_hip.so")
 
 EXPORTS = [
     "coot_last_error", "coot_version", "coot_set_option", "coot_get_option", "coot_debug_timestamps", "coot_debug_step_stamps", "coot_debug_dropout_scales", "coot_debug_attn_dropout_scales", "coot_net_param_numel", "coot_net_param_count",
@@ -43,7 +49,7 @@ class ContrastiveConfig(C.Structure):
 
 
 SOURCE_PADDED, SOURCE_PACKED_F32, SOURCE_PACKED_BF16 = 0, 1, 2  # COOT_SOURCE_* (include/coot_hip.h)
-DTYPE_BF16, DTYPE_F32 = 0, 1  # COOT_DTYPE_* (coot_net_config.dtype)
+DTYPE_BF16, DTYPE_F32, DTYPE_F16 = 0, 1, 2  # COOT_DTYPE_* (coot_net_config.dtype)
 STEP_OPTIMIZER, STEP_REPACK, STEP_PACKS_FRESH, STEP_DEFER_TEXT_JOIN, STEP_INPUT_STAGES, STEP_STAGE_ANNOUNCED = 1, 2, 4, 8, 16, 32  # coot_train_step do_optimizer bits (include/coot_hip.h)
 FWD_PACKS_FRESH, FWD_INPUT_STAGES, FWD_STAGE_ANNOUNCED = 1, 2, 4  # coot_step_forward packs_fresh bits
 UPDATE_REPACK, UPDATE_DEFER_TEXT_JOIN, UPDATE_SKIP_GLOBAL, UPDATE_GLOBAL_ONLY = 1, 2, 4, 8  # coot_step_update repack bits
@@ -85,6 +91,13 @@ class StepBatch(C.Structure):
 
 _lib = None
 ABI_VERSION = 6  # include/coot_hip.h: COOT_ABI_VERSION
+
+
+def operand() -> str:
+    """The 16-bit MFMA operand format of the LOADED library: "bf16" or "f16" (coot_get_option("operand_f16"))."""
+    v = C.c_int(0)
+    check(load().coot_get_option(b"operand_f16", C.byref(v)), "coot_get_option")
+    return "f16" if v.value else "bf16"
 
 
 def build_hint() -> str:

@@ -126,7 +126,7 @@ class TransformerHip(nn.Module):
         """"bf16" (default): the fast path.  "f32": the fp32 reference mode of the library (coot_net_config.dtype = COOT_DTYPE_F32: the
         reference's op sequence and its derivative in fp32, eval mode) — outputs agree with the reference to ~1e-6 of their scale,
         parameter gradients to ~1e-5, so comparing the two modes measures the bf16 rounding of the fast path."""
-        assert dtype in ("bf16", "f32"), dtype
+        assert dtype in ("bf16", "f16", "f32"), dtype  # ("f16" / "bf16": whichever build is loaded — the other one is refused by the library)
         self.cfg.dtype = dtype
         self.c_cfg = self.cfg.to_c()
 

@@ -79,6 +79,12 @@ typedef struct coot_net_config {
 } coot_net_config;
 #define COOT_DTYPE_BF16 0
 #define COOT_DTYPE_F32 1
+#define COOT_DTYPE_F16 2 /* IEEE half operands: the SECOND BUILD of these sources, libcoot_hip_f16.so (csrc/build.sh, -DCOOT_OPERAND_F16) — the
+                            arithmetic of the reference's GPU path (fp16 autocast, coot/trainer_retrieval.py:264; BASELINE.json configs[3]).  The
+                            16-bit operand format is a property of the build: libcoot_hip.so accepts COOT_DTYPE_BF16 (and _F32),
+                            libcoot_hip_f16.so COOT_DTYPE_F16 (and _F32); coot_get_option("operand_f16") tells which one is loaded.  The f16
+                            build is FORWARD-ONLY (coot_net_fwd, coot_step_forward, the loss forward): the reference trains its fp16 path under a
+                            GradScaler (coot/trainer_retrieval.py:277-285), which is not built; its backward entry points refuse.            */
 
 const char* coot_last_error(void);
 /* ABI version of this header: struct layouts (coot_net_config gained `dtype`, coot_step_buffers `decay_block_all` in round 4) and the
