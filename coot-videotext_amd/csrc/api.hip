@@ -424,9 +424,20 @@ static int layer_fwd(const coot_net_config& c, const float* P, const LayerP& lp,
   AttnArgs a; a.q = b.q; a.ldq = b.ldq; a.k = b.k; a.ldk = b.ldk; a.v = b.v; a.ldv = b.ldv; a.o = b.ctx; a.ldo = D; a.lse = b.lse;
   a.H = H; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
   a.drop = mkdrop(train, pdrop, seed, site_base + SITE_ATTN);
-  RUN(attention_all(a, sg, !self, false, st));
-  if (lw.f_wo && g_use_fused && (rows_q >= g_fused_min_rows || pool || g_fused_fwd_small)) {  // out-proj ... LN2 (and the GenPool score MLP) as ONE launch over token tiles
+  const bool post_fused = lw.f_wo && g_use_fused && (rows_q >= g_fused_min_rows || pool || g_fused_fwd_small);
+  // the self-attention inside the token-tile chain (fused.h: FusedAttn) when every 16-row fragment of a tile lies in one
+  // sequence — padded layout, sequence lengths multiples of 16 (ActivityNet: 80 frames, 64 / 16 words), one q | k | v matrix
+  const bool attn_in_chain = post_fused && self && !sg.cu && H == 8 && dh == 48 && b.ldq == 3 * D && b.ldk == 3 * D && b.ldv == 3 * D &&
+                             b.k == b.q + D && b.v == b.q + 2 * D && rows_q == sg.Tpad() &&
+                             post_attn_can_fuse_attention(rows_q, pool != nullptr, sg.N[0], sg.L[0], sg.n > 1 ? sg.N[1] : 0, sg.n > 1 ? sg.L[1] : 0);
+  if (!attn_in_chain) RUN(attention_all(a, sg, !self, false, st));
+  if (post_fused) {  // out-proj ... LN2 (and the GenPool score MLP) as ONE launch over token tiles
     PostAttnFwd f; f.T = rows_q; f.ctx = b.ctx; f.xres = xq; f.wo = lw.f_wo; f.w1 = lw.f_w1; f.w2 = lw.f_w2;
+    if (attn_in_chain) {
+      f.attn.on = 1; f.attn.qkv = b.q; f.attn.lse = b.lse; f.ctx_w = b.ctx; f.attn.drop = a.drop; f.attn.scale = a.scale;
+      f.attn.N0 = sg.N[0]; f.attn.L0 = sg.L[0]; f.attn.lens0 = sg.lens[0];
+      if (sg.n > 1) { f.attn.N1 = sg.N[1]; f.attn.L1 = sg.L[1]; f.attn.lens1 = sg.lens[1]; f.attn.seed2_delta = 0x9E3779B97F4A7C15ull; }
+    }
     f.bo = P + lp.bo; f.ln1g = P + lp.ln1g; f.ln1b = P + lp.ln1b; f.b1 = P + lp.b1; f.b2 = P + lp.b2; f.ln2g = P + lp.ln2g; f.ln2b = P + lp.ln2b;
     f.r1 = b.r1; f.z1 = b.z1; f.h1 = b.h1; f.a1 = b.a1; f.r2 = b.r2; f.z2 = b.z2; f.z2_f32 = z2_f32; f.ldz2_f32 = ldz2_f32;
     f.d_postln = mkdrop(train, pdrop, seed, site_base + SITE_POSTLN); f.d_ff1 = mkdrop(train, pdrop, seed, site_base + SITE_FF1);
@@ -640,6 +651,7 @@ int coot_get_option(const char* name, int* value) {
   if (!strcmp(name, "xcd_order")) { *value = get_xcd_order(); return 0; }
   if (!strcmp(name, "tn_mode")) { *value = get_tn_mode(); return 0; }
   if (!strcmp(name, "stage_hits")) { *value = coot_internal_stage_hits(); return 0; }  // steps of this thread that used a prepared input stage
+  if (!strcmp(name, "fused_attn_launches")) { *value = fused_attn_launches(); return 0; }
   if (!strcmp(name, "operand_f16")) { *value = COOT_OPERAND_IS_F16; return 0; }  // which build this is (common.h)
   if (!strcmp(name, "det_bypasses")) { *value = det_bypass_count(); return 0; }  // deterministic mode: addends that took the float atomic (synchronises; -1: mode off)
   set_error("get_option: unknown or write-only option %s", name);
@@ -653,6 +665,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "glob_fused_bwd")) { g_use_glob_fused_bwd = value; return 0; }
   if (!strcmp(name, "packed")) { g_use_packed = value; return 0; }
   if (!strcmp(name, "fused_infc")) { g_use_fused_infc = value; return 0; }
+  if (!strcmp(name, "fused_attn")) { set_fused_attn(value); return 0; }  // 0: the self-attention of the local networks stays a launch of its own
   if (!strcmp(name, "tn_dma")) { set_tn_dma(value); return 0; }
   if (!strcmp(name, "pack_lazy")) { g_pack_lazy = value; return 0; }
   if (!strcmp(name, "pack_poison")) { g_pack_poison = value; return 0; }

@@ -24,8 +24,26 @@ __host__ __device__ inline long p48_offset(int n, int k, int K) {
 // out-proj + residual + LN1 + FF1 + GELU + FF2 + residual + LN2 (+ GenPool FC1 + GELU + FC2) of one encoder layer,
 // forward (nntrainer/models/transformer_legacy.py:420-467, :582-605; poolers.py:156-190).  Writes exactly the tensors
 // the unfused path saves for the backward pass.
+// The layer's self-attention INSIDE post_attn_fwd_kernel (nntrainer/models/transformer_legacy.py:536-563): with fixed-length
+// sequences whose length is a multiple of 16 every 16-row fragment of a token tile lies in ONE sequence, so the tile computes
+// softmax(Q K^T / sqrt(dh)) V for its own rows from the q | k | v rows infc_qkv_fwd / qkv_fwd wrote (head by head: K_h, V_h of the
+// <= 3 sequences the tile touches staged in LDS, one 16-query fragment per wave, S^T = K Q^T so that a lane owns one query) and the
+// result lands in the LDS tile that is the out-projection's operand — no attention launch, no ctx read.  ctx and lse are still
+// written (the backward reads them).  Same masks, mask fill, dropout map and summation order per (query, head) as attn_short_fwd.
+struct FusedAttn {
+  int on = 0;
+  const bf16_t* qkv = nullptr;      // [T, 1152]: q | k | v, head h at columns 48 h of each third
+  float* lse = nullptr;             // [T, 8]
+  int N0 = 0, L0 = 0, N1 = 0, L1 = 0;                // up to two segments of N sequences x L rows (padded layout)
+  const long long *lens0 = nullptr, *lens1 = nullptr;  // valid keys per sequence
+  DropCfg drop; unsigned long long seed2_delta = 0;  // dropout on the probabilities; the second segment's seed offset
+  float scale = 0.f;
+};
+constexpr int FZ_ATTN_MAX_ROWS = 256;  // key rows of one head a tile can stage (K and V, 112-byte rows, in the staging + vector area)
 struct PostAttnFwd {
   int T = 0;
+  FusedAttn attn;                // attn.on: ctx is an OUTPUT (ctx_w) computed by the kernel
+  bf16_t* ctx_w = nullptr;
   const bf16_t* ctx = nullptr;   // [T, 384] attention output (heads concatenated)
   const bf16_t* xres = nullptr;  // [T, 384] sublayer input (residual)
   const bf16_t *wo = nullptr, *w1 = nullptr, *w2 = nullptr, *pw1 = nullptr, *pw2 = nullptr;  // P48 packs
@@ -39,6 +57,12 @@ struct PostAttnFwd {
   unsigned long long* tstamps = nullptr;  // profiling aid: s_memtime stamps of block 0 at the phase boundaries
 };
 int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st);
+// whether launch_post_attn_fwd(T, do_pool) can take the self-attention of these segments along (tile height of the launch, sequence
+// lengths multiples of 16 and <= 128, segment boundary on a tile boundary, staged key rows <= FZ_ATTN_MAX_ROWS); coot_set_option
+// ("fused_attn", 0) switches it off
+bool post_attn_can_fuse_attention(int T, bool do_pool, int N0, int L0, int N1, int L1);
+void set_fused_attn(int on);
+int fused_attn_launches();
 
 // Backward of the same chain, from the GenPool score gradients (or the gradient wrt the layer output) down to the
 // gradient wrt the attention output: pooling MLP dX, LN2 backward, FF2 / FF1 dX (GELU'), LN1 backward, out-proj dX.

@@ -376,6 +376,21 @@ __device__ __forceinline__ void apply_drop(const DropK& d, unsigned long long id
   }
 }
 
+// Backward of a dropout site whose POST-dropout value the forward saved and the backward loads anyway (h1, hp: the pre-GELU values):
+// an element was dropped iff the saved value is zero, so the mask needs no hash — dy * (saved != 0 ? 1 / keep : 0).  (A kept element
+// that is exactly 0.0 after rounding — |x| < 1e-40 in bf16 — reads as dropped: its gradient goes to zero instead of dy GELU'(0) / keep;
+// the forward's masks themselves are unchanged.)  The backward chain hashed 1 920 elements per token for its masks, 1 152 of them here.
+template <bool DROP>
+__device__ __forceinline__ void mask_from_saved(const DropK& d, const float (&saved)[8], float (&v)[8]) {
+  if constexpr (DROP) {
+#ifdef FZ_NO_EPI_MATH
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = saved[j] != 0.0f ? v[j] * d.inv_keep : 0.0f;
+  }
+}
+
 // COOT LayerNorm (nntrainer/models/normalizations.py:98-101) of every tile row, in place.  Wave w owns rows
 // [2 RF w, 2 RF w + 2 RF); 16 lanes share a row (4 rows per wave in flight): lane j holds the three 8-element chunks at
 // columns 8 j, 128 + 8 j, 256 + 8 j (16-byte LDS / global accesses), reductions are 4 DPP steps.
@@ -436,6 +451,143 @@ __device__ __forceinline__ void ln_tile(bf16_t* As, const float* gain, const flo
 struct PreNone {};
 struct PreRes { u32x4_t res; };
 
+// ---- the layer's self-attention on the tile's own rows (fused.h: FusedAttn) ---------------------------------------------------------
+// One head per round: K_h | V_h of the key rows [k_lo, k_lo + nrows) the tile's sequences cover go to LDS (KV: the staging + vector
+// area, 112-byte rows: conflict-free 8-byte fragment reads), wave w < RF computes the 16 queries of tile fragment w against the
+// L / 16 key fragments of ITS sequence, exactly as attn_short_fwd_kernel does for one (sequence, head): S^T = K Q^T on the 16 x 16 x 16
+// MFMA (a lane owns one query and 4 keys per tile), single-pass softmax, O^T = V^T P^T with V^T from the LDS transpose read.  The
+// next head's rows and query fragments are loaded into registers while the current head is computed.  Output: bf16 into the LDS
+// tile (columns 48 h ..), lse to global.
+template <int RF>
+__device__ __forceinline__ void fused_self_attn(const PostAttnFwd& p, bf16_t* As, bf16_t* KV, int row0, unsigned long long sbase) {
+  constexpr int DH = 48, RP = DH + 8, NK = DH / 16, H = 8, CPR = DH / 8, NST = (FZ_ATTN_MAX_ROWS * 2 * CPR) / NTHR, LDQ = 3 * FZ_D;
+  static_assert((FZ_ATTN_MAX_ROWS * 2 * CPR) % NTHR == 0, "staging chunks per thread");
+  const FusedAttn& A = p.attn;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4;
+  // the tile's segment (a tile never straddles the two: launch_post_attn_fwd checks it)
+  const int T0 = A.N0 * A.L0;
+  const bool second = row0 >= T0;
+  const int L = second ? A.L1 : A.L0, segbase = second ? T0 : 0, segend = second ? p.T : T0;
+  const long long* lens = second ? A.lens1 : A.lens0;
+  const int last = (row0 + 16 * RF < segend ? row0 + 16 * RF : segend) - 1;
+  const int s_first = (row0 - segbase) / L, s_last = (last - segbase) / L;
+  const int k_lo = segbase + s_first * L, nrows = (s_last - s_first + 1) * L;  // staged key rows (<= FZ_ATTN_MAX_ROWS)
+  // this wave's query fragment: rows g0 .. g0 + 15 of sequence sq, keys = the L rows of that sequence
+  const int g0 = row0 + 16 * wave;
+  const bool active = wave < RF && g0 < segend;
+  const int sq = active ? (g0 - segbase) / L : s_first;
+  const int kb = segbase + sq * L - k_lo;  // first key row of the sequence inside the staged block
+  const int nkt = L >> 4;
+  const int nvalid = active ? (int)lens[sq] : 0;
+  const int qpos = g0 - segbase - sq * L + lq;
+  const unsigned dkey = A.drop.thr ? drop_key(A.drop.seed + (second ? A.seed2_delta : 0ull) + sbase, A.drop.site) : 0u;
+  bf16_t* Ks = KV;
+  bf16_t* Vs = KV + FZ_ATTN_MAX_ROWS * RP;
+  const int half = nrows * CPR;  // chunks of K (then as many of V)
+  u32x4_t st[NST];
+  s16x4_t qn[NK];
+  auto load_head = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int c = tid + NTHR * i, kv = c >= half ? 1 : 0, cc = c - kv * half, r = cc / CPR, ch = cc - r * CPR;
+      st[i] = u32x4_t{0u, 0u, 0u, 0u};
+      if (c < 2 * half) st[i] = gld16(A.qkv, (unsigned)((k_lo + r) * LDQ + FZ_D * (1 + kv) + h * DH + ch * 8) * 2u);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      qn[ks] = s16x4_t{0, 0, 0, 0};
+      if (active) qn[ks] = *reinterpret_cast<const s16x4_t*>(A.qkv + (long)(g0 + lq) * LDQ + h * DH + ks * 16 + lg * 4);
+    }
+  };
+  load_head(0);
+#pragma unroll 1
+  for (int h = 0; h < H; ++h) {
+    lds_barrier();  // the previous head's fragments have been read
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int c = tid + NTHR * i, kv = c >= half ? 1 : 0, cc = c - kv * half, r = cc / CPR, ch = cc - r * CPR;
+      if (c < 2 * half) *reinterpret_cast<u32x4_t*>(&(kv ? Vs : Ks)[r * RP + ch * 8]) = st[i];
+    }
+    s16x4_t qf[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) qf[ks] = qn[ks];
+    if (h + 1 < H) load_head(h + 1);  // flies during this head's MFMAs
+    lds_barrier();
+    if (active) {
+      f32x4_t sc[8];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        if (kt < nkt) {
+          sc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) {
+            const s16x4_t kf = *reinterpret_cast<const s16x4_t*>(&Ks[(kb + kt * 16 + lq) * RP + ks * 16 + lg * 4]);
+            sc[kt] = COOT_MFMA_16x16x16(kf, qf[ks], sc[kt]);  // sc[i] = S^T[key kt * 16 + lg * 4 + i][query lq]
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = sc[kt][i] * A.scale;
+            if (kt * 16 + lg * 4 + i >= nvalid) v = kMaskFill;  // masked_fill(mask, -INF) (transformer_legacy.py:544)
+            sc[kt][i] = v;
+            mx = fmaxf(mx, v);
+          }
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+      s16x4_t pf[8];
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        if (kt < nkt) {
+          float pr[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            pr[i] = __expf(sc[kt][i] - mx);
+            sum += pr[i];
+            if (A.drop.thr)
+              pr[i] *= attn_drop_f(dkey, (unsigned)((sq * H + h) * L + qpos), kt * 16 + lg * 4 + i, (unsigned)(L + 1) >> 1, A.drop.thr, A.drop.inv_keep);
+          }
+          const unsigned lo = pack2bf(pr[0], pr[1]), hi = pack2bf(pr[2], pr[3]);
+          pf[kt] = s16x4_t{(short)(lo & 0xFFFF), (short)(lo >> 16), (short)(hi & 0xFFFF), (short)(hi >> 16)};
+        }
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt) {
+        f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+          if (kt < nkt) {
+            // A = V^T [dim][key]: LDS transpose read of the 16 x 16 block (keys kb + 16 kt .., dims 16 dt ..)
+            const bf16_t* blk = &Vs[(kb + kt * 16) * RP + dt * 16];
+            const bf16_t* addr = blk + (4 * lg + (lq >> 2)) * RP + (lq & 3) * 4;
+            const s16x4_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(addr));
+            o = COOT_MFMA_16x16x16(vt, pf[kt], o);
+          }
+        }
+        // o[i] = O^T[dim 16 dt + 4 lg + i][query lq]: 8 bytes of tile row 16 wave + lq
+        *reinterpret_cast<u32x2_t*>(&As[(16 * wave + lq) * APITCH + h * DH + dt * 16 + lg * 4]) = u32x2_t{pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv)};
+      }
+      if (lg == 0) A.lse[(long)(g0 + lq) * H + h] = mx + __logf(sum);
+    } else if (wave < RF) {  // a fragment past the last row: defined (zero) operand rows for the GEMM passes
+#pragma unroll
+      for (int dt = 0; dt < NK; ++dt) *reinterpret_cast<u32x2_t*>(&As[(16 * wave + lq) * APITCH + h * DH + dt * 16 + lg * 4]) = u32x2_t{0u, 0u};
+    }
+  }
+  lds_barrier();
+  // ctx for the backward pass (attention backward, out-projection weight gradient): 16-byte row-contiguous stores from the tile
+  for (int c = tid; c < 16 * RF * 48; c += NTHR) {
+    const int r = c / 48, ch = c - r * 48;
+    if (row0 + r < p.T) gst16(p.ctx_w, (unsigned)((row0 + r) * FZ_D + ch * 8) * 2u, *reinterpret_cast<const u32x4_t*>(&As[r * APITCH + ch * 8]));
+  }
+}
+
 template <int RF, bool DROP>
 __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   constexpr int BT = 16 * RF, RR = RF >= 2 ? 32 : 16;
@@ -453,12 +605,15 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   const unsigned long long fz_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
   f32x4_t acc[RF][3];
-  {
+  auto load_vectors = [&]() {
     const float* vecs[7] = {p.bo, p.b1, p.b2, p.ln1g, p.ln1b, p.ln2g, p.ln2b};
 #pragma unroll
     for (int k = 0; k < 7; ++k)
       if (threadIdx.x < FZ_D / 4) reinterpret_cast<f32x4_t*>(Bsm + k * FZ_D)[threadIdx.x] = reinterpret_cast<const f32x4_t*>(vecs[k])[threadIdx.x];
-  }
+  };
+  bool fuse_attn = false;
+  if constexpr (RF >= 4) fuse_attn = p.attn.on != 0;
+  if (!fuse_attn) load_vectors();  // (with the attention inside, the vector area is part of its K / V staging first)
   int tsn = 0;
   // (the pointer is re-read from its SGPR pair at every stamp: as a VGPR address hoisted to the kernel's entry it was the last spill)
   auto stamp = [&]() {
@@ -475,8 +630,19 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
 
   // ---- attention output projection + residual -> r1 ------------------------------------------------------------
   TileRing<RF> R;  // weight ring, carried from pass to pass (gemm_run)
-  gemm_issue(R, p.wo + wave * GSZ, lane);  // (flies during the tile load)
-  load_tile<RF>(As, p.ctx, FZ_D, 0, row0);
+  if constexpr (RF >= 4) {
+    if (fuse_attn) {
+      fused_self_attn<RF>(p, As, reinterpret_cast<bf16_t*>(Stg), row0, sbase);
+      gemm_issue(R, p.wo + wave * GSZ, lane);
+      load_vectors();
+    } else {
+      gemm_issue(R, p.wo + wave * GSZ, lane);  // (flies during the tile load)
+      load_tile<RF>(As, p.ctx, FZ_D, 0, row0);
+    }
+  } else {
+    gemm_issue(R, p.wo + wave * GSZ, lane);
+    load_tile<RF>(As, p.ctx, FZ_D, 0, row0);
+  }
   __syncthreads();
   stamp();
   zero_acc<RF>(acc);
@@ -807,7 +973,11 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
             unpack8(pr.res, a);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+#ifdef FZ_HASH_BWD_MASKS  // (A/B build: the masks of these two sites re-drawn from the hash, as through round 5)
             apply_drop<DROP>(d_pool1, (unsigned long long)row * (2 * FZ_D) + h * FZ_D + col, v);
+#else
+            mask_from_saved<DROP>(d_pool1, a, v);  // hp = dropout(z W1 + b1): the mask is in the saved value
+#endif
             if (row < T) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) cs[i][j] += v[j];
@@ -852,7 +1022,11 @@ __global__ __launch_bounds__(512) void pre_attn_bwd_kernel(PreAttnBwd p) {
         unpack8(pr.res, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+#ifdef FZ_HASH_BWD_MASKS
         apply_drop<DROP>(d_ff1, (unsigned long long)row * FZ_D + col, v);
+#else
+        mask_from_saved<DROP>(d_ff1, a, v);  // h1 = dropout(z1 W1 + b1)
+#endif
         if (row < T) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) cs[i][j] += v[j];
@@ -1921,8 +2095,43 @@ static int g_half_max[4] = {256 * 64, 256 * 64, 256 * 64, 256 * 64};
 bool half_tiles(int T, int kernel) { return T <= g_half_max[kernel & 3]; }
 void set_half_tiles_max(int kernel, int max_tokens) { g_half_max[kernel & 3] = max_tokens; }
 
+static int g_fused_attn = 0;  // coot_set_option("fused_attn", 1): the local networks' forward self-attention inside post_attn_fwd_kernel.  Built and
+// parity-green in round 6; NOT faster (1.235 against 1.229 ms per step, profiles/r06_ab_fused_attn.txt): the chain workgroup — one per
+// CU, two waves per SIMD, in lockstep — computes the attention in +37 us per 128-row launch, the 2 560-workgroup kernel it replaces
+// takes 20-45 us of stream time at full occupancy.  Off by default; tests/test_gpu_fused_attn.py keeps it pinned.
+void set_fused_attn(int on) { g_fused_attn = on; }
+static int g_fused_attn_launches = 0;  // launches that took the attention along (coot_get_option("fused_attn_launches"): tests)
+int fused_attn_launches() { return g_fused_attn_launches; }
+// tile height launch_post_attn_fwd picks for T tokens (0: the 32-row kernel of small launches, which never takes the attention along)
+static int post_attn_tile_rows(int T, bool do_pool) {
+  if (!do_pool && T < 1024) return 0;
+  return half_tiles(T, 1) ? 64 : 128;
+}
+bool post_attn_can_fuse_attention(int T, bool do_pool, int N0, int L0, int N1, int L1) {
+  if (!g_fused_attn) return false;
+  const int BT = post_attn_tile_rows(T, do_pool);
+  if (BT == 0 || N0 <= 0 || L0 <= 0 || L0 % 16 != 0 || L0 > 128 || (long)N0 * L0 + (long)N1 * L1 != (long)T) return false;
+  if (N1 > 0 && (L1 <= 0 || L1 % 16 != 0 || L1 > 128 || ((long)N0 * L0) % BT != 0)) return false;
+  // key rows a tile stages: from the start of the sequence its first row lies in to the end of the one its last row lies in
+  for (int s = 0; s < (N1 > 0 ? 2 : 1); ++s) {
+    const long base = s ? (long)N0 * L0 : 0, end = s ? T : (long)N0 * L0, L = s ? L1 : L0;
+    for (long r0 = base / BT * BT; r0 < end; r0 += BT) {
+      const long a = r0 < base ? base : r0, b = (r0 + BT < end ? r0 + BT : end) - 1;
+      if (((b - base) / L - (a - base) / L + 1) * L > FZ_ATTN_MAX_ROWS) return false;
+    }
+  }
+  return true;
+}
+
 int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
-  COOT_REQUIRE(p.ctx && p.xres && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.ln1g && p.ln1b && p.ln2g && p.ln2b && p.r1 && p.z1 &&
+  if (p.attn.on) {
+    COOT_REQUIRE(p.attn.qkv && p.attn.lse && p.ctx_w && p.attn.lens0 && (p.attn.N1 == 0 || p.attn.lens1), "post_attn_fwd: fused attention pointers");
+    COOT_REQUIRE(post_attn_can_fuse_attention(p.T, p.do_pool != 0, p.attn.N0, p.attn.L0, p.attn.N1, p.attn.L1),
+                 "post_attn_fwd: these segments cannot take the attention along (post_attn_can_fuse_attention)");
+    COOT_REQUIRE((long)p.T * 3 * FZ_D * 2 < (1l << 32), "post_attn_fwd: qkv beyond the 32-bit byte offsets of the fused attention");
+    ++g_fused_attn_launches;
+  }
+  COOT_REQUIRE((p.ctx || p.attn.on) && p.xres && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.ln1g && p.ln1b && p.ln2g && p.ln2b && p.r1 && p.z1 &&
                p.h1 && p.a1 && p.r2 && p.z2, "post_attn_fwd: null pointer");
   COOT_REQUIRE(!p.do_pool || (p.pw1 && p.pw2 && p.pb1 && p.pb2 && p.hp && p.ap && p.s), "post_attn_fwd: pooling pointers");
   if (p.T <= 0) return 0;
