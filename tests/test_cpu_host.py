@@ -34,6 +34,12 @@ def test_library_exports_every_declared_symbol(cva):
     out = subprocess.run(["nm", "-D", "--defined-only", cva.lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     assert exported == declared, (sorted(exported - declared)[:5], sorted(declared - exported)[:5])
+    # the IEEE-half build of the same sources (csrc/build.sh: libcoot_hip_f16.so) has the same dynamic symbol table and ABI version
+    f16 = os.path.join(os.path.dirname(cva.lib.LIB_PATH), "libcoot_hip_f16.so" if cva.lib.OPERAND_ENV == "bf16" else "libcoot_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", f16], capture_output=True, text=True, check=True).stdout
+    assert {ln.split()[-1] for ln in out.splitlines() if ln.strip()} == declared
+    import ctypes
+    assert ctypes.CDLL(f16).coot_version() == cva.lib.ABI_VERSION
 
 
 def _header_prototypes():
@@ -501,7 +507,7 @@ def test_option_switches_named_in_the_integration_notes_exist(cva):
     para = para[:para.index("`coot_get_option` reads")]
     names = [n for n in re.findall(r"`([a-z0-9_]+)`", para) if not n.startswith("coot_") and n != "gemm_nt"]  # (`gemm_nt`: a kernel named in the text)
     assert {"fused", "cl_small", "cl_col_split", "grad_write", "pack_lazy", "xcd_order", "step_stamps"} <= set(names)
-    value = {"cl_col_split": 0, "pack_poison": 0, "grad_poison": 0, "fz_debug": 0, "step_stamps": 0}  # defaults that are not 1
+    value = {"cl_col_split": 0, "pack_poison": 0, "grad_poison": 0, "fz_debug": 0, "step_stamps": 0, "fused_attn": 0}  # defaults that are not 1
     sizes = {"fused_min_rows", "tn_target_wgs"}  # a size, not a switch: left alone (no read-back)
     for n in names:
         if n in sizes:
@@ -512,5 +518,5 @@ def test_option_switches_named_in_the_integration_notes_exist(cva):
     assert lib.coot_set_option(b"half_tiles", 1) != 0  # removed in round 4
     assert b"unknown option" in lib.coot_last_error()
     v = ctypes.c_int32(-1)
-    for n in ("tn_dma", "xcd_order", "tn_mode", "stage_hits"):
+    for n in ("tn_dma", "xcd_order", "tn_mode", "stage_hits", "operand_f16", "fused_attn_launches"):
         assert lib.coot_get_option(n.encode(), ctypes.byref(v)) == 0 and v.value >= 0, n
