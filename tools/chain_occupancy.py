@@ -12,11 +12,16 @@ from tests import helpers as H
 
 lib = cva.lib.load()
 cfg = O.NetConfig(input_dim=2048, hidden_dim=384, num_heads=8, ff_dim=384, pool_hidden=768, pool_heads=2)
-net = H.make_hip_net(cfg, O.make_params(cfg, 3), dropout=0.025)
+ZERO = os.environ.get("COOT_PROBE_ZERO") == "1"  # all-zero inputs and weights: same instruction stream, minimal datapath toggling
+P = O.make_params(cfg, 3)
+if ZERO:
+    import numpy as np
+    P = {k: np.zeros_like(v) for k, v in P.items()}
+net = H.make_hip_net(cfg, P, dropout=0.025)
 net.train(True)
 out = []
 for N in (320, 200, 100, 13):
-    x = torch.randn(N, 80, 2048, device="cuda")
+    x = torch.zeros(N, 80, 2048, device="cuda") if ZERO else torch.randn(N, 80, 2048, device="cuda")
     lens = torch.full((N,), 80, dtype=torch.long, device="cuda")
     mask = torch.zeros(N, 80, dtype=torch.bool, device="cuda")
     with torch.no_grad():
@@ -31,4 +36,4 @@ for N in (320, 200, 100, 13):
         cva.lib.check(lib.coot_timing_collect(5, C.byref(ms), C.byref(fl), C.byref(n)), "timing_collect")
         lib.coot_timing_enable(0)
     out.append(f"{(N * 80 + 127) // 128} tiles {1e3 * ms.value / 10:.1f} us")
-print(os.path.basename(os.environ.get("COOT_HIP_LIB", "default")), "|", " | ".join(out))
+print(os.path.basename(os.environ.get("COOT_HIP_LIB", "default")) + (" zero-data" if ZERO else ""), "|", " | ".join(out))
