@@ -537,7 +537,7 @@ def main():
         # The same family in the committed rocprofv3 kernel trace of this command (profiles/*_kernel_stats_bench_train_anet.csv: sum of the
         # four chain kernels' total time / steps in the trace): a launch's duration there runs from its first workgroup's start to its last
         # one's end under the profiler's own interleaving of the two streams, and differs from the HIP-event figure of the free-running
-        # step by how long the text side's 64-row launches wait for CUs.  Both are reported; `frac` is the live one.
+        # step by how long the text side's 64-row launches wait for CUs (docs/NOTEBOOK_r1-r5.md section 12).  Both are reported; `frac` is the live one.
         trace = None
         if fam_key == "fused" and args.workload == "anet" and not args.eval:
             csvs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_kernel_stats_bench_train_anet.csv")))

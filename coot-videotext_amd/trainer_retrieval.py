@@ -250,7 +250,7 @@ class RetrievalTrainer:
         This is the AUTOGRAD route (torch autograd + torch.optim around the library's per-network calls): always eager.  A captured
         (hipGraph) step exists on the native route only — train_step_native(use_graph=True), one C call inside the capture; the
         autograd route's whole-step capture (rounds 1-5) was removed in round 6: its replay crashed inside hipGraphLaunch under one
-        test ordering and was never root-caused, and nothing defaulted to it."""
+        test ordering and was never root-caused (docs/NOTEBOOK_r1-r5.md 12), and nothing defaulted to it."""
         return self._step_impl(batch, vid_counts, clip_counts)
 
     def _step_prepare_seed(self, batch, nets) -> None:
