@@ -519,7 +519,7 @@ def main():
         from sources_hash import sources_sha16
         live_sha = sources_sha16(here)
         cands = sorted(glob.glob(os.path.join(here, "profiles", "r*_traffic.json")))
-        if cands:
+        if cands and args.workload == "anet" and not args.eval:  # (the committed PMC passes are of THIS command: the default workload's train step)
             try:
                 tj = json.load(open(cands[-1]))
                 traffic_src = os.path.relpath(cands[-1], here)
