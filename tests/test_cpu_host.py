@@ -520,3 +520,23 @@ def test_option_switches_named_in_the_integration_notes_exist(cva):
     v = ctypes.c_int32(-1)
     for n in ("tn_dma", "xcd_order", "tn_mode", "stage_hits", "operand_f16", "fused_attn_launches"):
         assert lib.coot_get_option(n.encode(), ctypes.byref(v)) == 0 and v.value >= 0, n
+
+
+def test_committed_traffic_profile_was_taken_on_these_kernel_sources():
+    """bench.py quotes roofline.traffic from the newest profiles/r*_traffic.json only if that profile carries the hash of the kernel
+    sources (csrc/*.hip, csrc/*.h, include/*.h) of the run (tools/sources_hash.py; VERDICT round 5: the line must be able to notice a
+    traffic regression).  This test keeps the two from drifting apart silently: after a change to the kernel sources the PMC passes
+    (tools/profile_round.sh) are re-run and the new summary committed — or this fails, as the bench line's `traffic: null` +
+    `traffic_stale` would tell the driver."""
+    import glob
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sources_hash import sources_sha16
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    assert cands
+    newest = json.load(open(cands[-1]))
+    assert newest.get("kernel_sources_sha16") == sources_sha16(ROOT), (
+        f"{os.path.basename(cands[-1])} was collected on kernel sources {newest.get('kernel_sources_sha16')}, the tree is {sources_sha16(ROOT)}: "
+        "re-run tools/profile_round.sh on a GPU box and commit profiles/<tag>_traffic.json")
+    assert newest["families"]["fused"]["hbm_bytes_per_launch"] > 0
