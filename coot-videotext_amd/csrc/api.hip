@@ -384,13 +384,12 @@ struct PoolFuseBwd { const bf16_t *ds, *dzp, *hp, *pw2, *pw1; bf16_t* dhp; float
 static int g_use_fused_infc = 1;  // coot_set_option("fused_infc", 0/1): input FC + QKV in one launch (+1.4 % on the step once its K loop was pipelined two slabs deep)
 static int g_use_fused = 1;
 static int g_grad_poison = 0;  // coot_set_option("grad_poison", 1) (tests): coot_nets_zero_grads fills the matrices it skips with NaN
-static int g_ln_wgs = 0;       // coot_set_option("ln_stream_wgs", n): workgroup cap of the prefetched input LayerNorm; 0 = by size (ln_stream_cap below).
-                               // Measured on the ActivityNet shape (profiles/README.md, round 3): no cap 1.227, 1024: 1.235, 512: 1.217,
-                               // 256: 1.213-1.228, 128: 1.259 ms per step (1.238 without the prefetch)
+// Workgroup cap of the prefetched input LayerNorm.  Measured on the ActivityNet shape (profiles/README.md, round 3): no cap 1.227, 1024: 1.235,
+// 512: 1.217, 256: 1.213-1.228, 128: 1.259 ms per step (1.238 without the prefetch).  (The A/B switch "ln_stream_wgs" went in round 6.)
 // The cap keeps the streaming launch from evicting the weights the single-launch global passes live on.  A feature stream of several
 // hundred MB (BASELINE.json configs[4]: 64 clips per video, where the global networks run their per-op kernels for a millisecond) has the
 // time and needs the bandwidth: 512 workgroups deliver 3.4 TB/s, 2 048 4.5, 4 096 5.1 at the same step time: the cap is lifted from 256 MB of input on (round 5, profiles/README.md).
-static int ln_stream_cap(size_t input_bytes) { return g_ln_wgs > 0 ? g_ln_wgs : (input_bytes >= ((size_t)256 << 20) ? 4096 : 512); }
+static int ln_stream_cap(size_t input_bytes) { return input_bytes >= ((size_t)256 << 20) ? 4096 : 512; }
 constexpr int g_ln_nt = 1;     // ... with streaming (non-temporal) loads / stores: next to the global networks it must not evict their weights from L2
 static int g_pack_lazy = 1, g_pack_poison = 0;  // coot_set_option("pack_lazy" / "pack_poison"): lazily packed per-op layouts (below)
 static int g_fz_debug = 0;
@@ -676,8 +675,6 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "cl_col_split")) { set_cl_col_split(value); return 0; }
   if (!strcmp(name, "cl_small")) { set_cl_small(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
-  if (!strcmp(name, "ln_stream_wgs")) { g_ln_wgs = value; return 0; }
-  if (!strncmp(name, "half_tiles_", 11) && name[11] >= '0' && name[11] <= '3' && !name[12]) { set_half_tiles_max(name[11] - '0', value); return 0; }
   if (!strcmp(name, "fused_min_rows")) { g_fused_min_rows = value; return 0; }
   set_error("unknown option %s", name);
   return -2;

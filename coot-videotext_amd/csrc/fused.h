@@ -191,7 +191,6 @@ void glob_xcd_set(int first, int count);
 
 constexpr int FZ_BWD_NCS = 9 * FZ_D;  // floats per tile in PreAttnBwd::part
 bool half_tiles(int T, int kernel);  // the chain kernel `kernel` (0 infc_qkv_fwd, 1 post_attn_fwd, 2 pre_attn_bwd, 3 qkv_bwd) runs on 64-row tiles for this many tokens
-void set_half_tiles_max(int kernel, int max_tokens);
 int launch_pre_attn_bwd(const PreAttnBwd& p, hipStream_t st);
 
 }  // namespace coot

@@ -2100,12 +2100,10 @@ __global__ __launch_bounds__(256) void colsum_scatter_kernel(ScatterArgs a) {
 // the per-tile latency, however few tiles there are.  Up to 16 384 tokens (the text side of every shipped config, ragged batches
 // with packed rows, small batches) 64-row tiles still fit in one wave and each takes about half as long; above, 128-row tiles
 // (half the weight traffic per token) stay one wave up to 32 768 tokens.
-// (per kernel — 0 input FC + QKV, 1 forward chain, 2 backward chain, 3 QKV dX — so that a threshold can be A/B-ed on its own:
-// coot_set_option("half_tiles_<k>", max tokens); round 5 measured the forward kernels of the 25 600-token video side on 64-row tiles
-// too, profiles/README.md)
-static int g_half_max[4] = {256 * 64, 256 * 64, 256 * 64, 256 * 64};
-bool half_tiles(int T, int kernel) { return T <= g_half_max[kernel & 3]; }
-void set_half_tiles_max(int kernel, int max_tokens) { g_half_max[kernel & 3] = max_tokens; }
+// (round 5 measured the forward kernels of the 25 600-token video side on 64-row tiles too — 5 % slower, profiles/README.md; the
+// per-kernel A/B switches "half_tiles_<k>" went in round 6: `kernel` only names the caller)
+constexpr int kHalfTilesMax = 256 * 64;
+bool half_tiles(int T, int /*kernel*/) { return T <= kHalfTilesMax; }
 
 static int g_fused_attn = 0;  // coot_set_option("fused_attn", 1): the local networks' forward self-attention inside post_attn_fwd_kernel.  Built and
 // parity-green in round 6; NOT faster (1.235 against 1.229 ms per step, profiles/r06_ab_fused_attn.txt): the chain workgroup — one per
