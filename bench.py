@@ -571,7 +571,9 @@ def main():
                                   "unit": "GB/s", "frac": round(by[dom]["algorithmic_bytes_per_launch"] / by[dom]["avg_launch_us"] / 1e3 / 8000.0, 4)}
                                  if by[dom].get("algorithmic_bytes_per_launch") and by[dom]["avg_launch_us"] else None),
                     "note": "algorithmic 2*M*N*K per launch / HIP-event duration on the launch stream, measured while both "
-                            "sides (two streams) run concurrently; 'by_kernel' lists every MFMA kernel family the same way",
+                            "sides (two streams) run concurrently; 'by_kernel' lists every MFMA kernel family the same way.  Since round 6 the "
+                            "family's post_attn_fwd launches also compute the layer's forward self-attention (formerly two attn_short_fwd launches "
+                            "per step, ~135 us of kernel time, HBM bound, 3.6 GFLOP): their durations and FLOPs are in this figure",
                     "all_mfma_kernels": allk, "input_fc_instances": infc, "by_kernel": by,
                     "input_layernorm_hbm": {"achieved_GBps": round(inln["achieved"] * 1e3, 1), "frac_of_8TBps": round(inln["achieved"] / 8.0, 4),
                                             "launches_per_step": inln["launches_per_step"], "avg_launch_us": inln["avg_launch_us"],

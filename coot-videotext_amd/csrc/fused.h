@@ -26,9 +26,9 @@ __host__ __device__ inline long p48_offset(int n, int k, int K) {
 // the unfused path saves for the backward pass.
 // The layer's self-attention INSIDE post_attn_fwd_kernel (nntrainer/models/transformer_legacy.py:536-563): with fixed-length
 // sequences whose length is a multiple of 16 every 16-row fragment of a token tile lies in ONE sequence, so the tile computes
-// softmax(Q K^T / sqrt(dh)) V for its own rows from the q | k | v rows infc_qkv_fwd / qkv_fwd wrote (head by head: K_h, V_h of the
-// <= 3 sequences the tile touches staged in LDS, one 16-query fragment per wave, S^T = K Q^T so that a lane owns one query) and the
-// result lands in the LDS tile that is the out-projection's operand — no attention launch, no ctx read.  ctx and lse are still
+// softmax(Q K^T / sqrt(dh)) V for its own rows from the q | k | v rows infc_qkv_fwd / qkv_fwd wrote (wave h = head h: K_h, V_h of one
+// sequence at a time in the wave's own LDS slice, no workgroup barrier; S^T = K Q^T so that a lane owns one query) and the result
+// lands in the LDS tile that is the out-projection's operand — no attention launch, no ctx read.  ctx and lse are still
 // written (the backward reads them).  Same masks, mask fill, dropout map and summation order per (query, head) as attn_short_fwd.
 struct FusedAttn {
   int on = 0;
@@ -39,7 +39,11 @@ struct FusedAttn {
   DropCfg drop; unsigned long long seed2_delta = 0;  // dropout on the probabilities; the second segment's seed offset
   float scale = 0.f;
 };
-constexpr int FZ_ATTN_MAX_ROWS = 256;  // key rows of one head a tile can stage (K and V, 112-byte rows, in the staging + vector area)
+// in-chain attention: LDS row pitch (bf16 elements) of a wave's K | V slice and the longest sequence it holds, by tile height — the
+// workgroup's LDS (162 816 B at 128 rows, 111 616 B at 64) is cut into 8 slices: 2 L RP 2 bytes each
+constexpr int FZ_ATTN_RP(int) { return 56; }                       // 112-byte rows: 16-byte aligned, conflict-free 8-byte fragment reads
+constexpr int FZ_ATTN_LMAX(int RF) { return RF == 8 ? 80 : 64; }   // 8 x 2 x 80 x 112 = 143 360 B; 8 x 2 x 64 x 112 = 114 688 B (the 64-row kernel declares that much)
+constexpr int FZ_ATTN_SMEM(int RF) { return RF >= 4 ? 8 * 2 * FZ_ATTN_LMAX(RF) * FZ_ATTN_RP(RF) * 2 : 0; }
 struct PostAttnFwd {
   int T = 0;
   FusedAttn attn;                // attn.on: ctx is an OUTPUT (ctx_w) computed by the kernel
@@ -58,7 +62,7 @@ struct PostAttnFwd {
 };
 int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st);
 // whether launch_post_attn_fwd(T, do_pool) can take the self-attention of these segments along (tile height of the launch, sequence
-// lengths multiples of 16 and <= 128, segment boundary on a tile boundary, staged key rows <= FZ_ATTN_MAX_ROWS); coot_set_option
+// lengths multiples of 16 and <= FZ_ATTN_LMAX, segment boundary on a tile boundary); coot_set_option
 // ("fused_attn", 0) switches it off
 bool post_attn_can_fuse_attention(int T, bool do_pool, int N0, int L0, int N1, int L1);
 void set_fused_attn(int on);

@@ -464,20 +464,21 @@ struct PreNone {};
 struct PreRes { u32x4_t res; };
 
 // ---- the layer's self-attention on the tile's own rows (fused.h: FusedAttn) ---------------------------------------------------------
-// One head per round: K_h | V_h of the key rows [k_lo, k_lo + nrows) the tile's sequences cover go to LDS (KV: the staging + vector
-// area, 112-byte rows: conflict-free 8-byte fragment reads), wave w < RF computes the 16 queries of tile fragment w against the
-// L / 16 key fragments of ITS sequence, exactly as attn_short_fwd_kernel does for one (sequence, head): S^T = K Q^T on the 16 x 16 x 16
-// MFMA (a lane owns one query and 4 keys per tile), single-pass softmax, O^T = V^T P^T with V^T from the LDS transpose read.  The
-// next head's rows and query fragments are loaded into registers while the current head is computed.  Output: bf16 into the LDS
-// tile (columns 48 h ..), lse to global.
+// Wave h computes HEAD h for every 16-query fragment of the tile.  Sequence by sequence (a tile touches <= 3): the wave stages K_h | V_h
+// of the sequence's L rows into ITS OWN slice of the workgroup's LDS (the whole 160 KB is free here: the tile receives the result only
+// at the end) — wave-private, so the phase needs no workgroup barrier and every wave runs its own stream of loads, MFMAs and softmax —
+// then runs the fragments of that sequence exactly as attn_short_fwd_kernel does for one (sequence, head): S^T = K Q^T on the
+// 16 x 16 x 16 MFMA (a lane owns one query and 4 keys per tile), single-pass softmax, O^T = V^T P^T with V^T from the LDS transpose read.
+// The bf16 results wait in registers (6 per fragment); after one barrier they go into the LDS tile (columns 48 h ..), lse to global.
+// (Round 6's first version — wave = fragment, one head per round, K / V of all the tile's sequences shared through LDS, two barriers per
+// head — cost +37 us per 128-row launch: profiles/r06_ab_fused_attn.txt.)
 template <int RF>
-__device__ __forceinline__ void fused_self_attn(const PostAttnFwd& p, bf16_t* As, bf16_t* KV, int row0, unsigned long long sbase) {
-  constexpr int DH = 48, RP = DH + 8, NK = DH / 16, H = 8, CPR = DH / 8, NST = (FZ_ATTN_MAX_ROWS * 2 * CPR) / NTHR, LDQ = 3 * FZ_D;
-  static_assert((FZ_ATTN_MAX_ROWS * 2 * CPR) % NTHR == 0, "staging chunks per thread");
+__device__ __forceinline__ void fused_self_attn(const PostAttnFwd& p, bf16_t* As, unsigned char* smem_base, int row0, unsigned long long sbase) {
+  constexpr int DH = 48, RP = FZ_ATTN_RP(RF), NK = DH / 16, H = 8, CPR = DH / 8, LDQ = 3 * FZ_D, LMAX = FZ_ATTN_LMAX(RF);
   const FusedAttn& A = p.attn;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
-  const int lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4;
+  const int lane = tid & 63, h = tid >> 6, lq = lane & 15, lg = lane >> 4;
   // the tile's segment (a tile never straddles the two: launch_post_attn_fwd checks it)
   const int T0 = A.N0 * A.L0;
   const bool second = row0 >= T0;
@@ -485,113 +486,150 @@ __device__ __forceinline__ void fused_self_attn(const PostAttnFwd& p, bf16_t* As
   const long long* lens = second ? A.lens1 : A.lens0;
   const int last = (row0 + 16 * RF < segend ? row0 + 16 * RF : segend) - 1;
   const int s_first = (row0 - segbase) / L, s_last = (last - segbase) / L;
-  const int k_lo = segbase + s_first * L, nrows = (s_last - s_first + 1) * L;  // staged key rows (<= FZ_ATTN_MAX_ROWS)
-  // this wave's query fragment: rows g0 .. g0 + 15 of sequence sq, keys = the L rows of that sequence
-  const int g0 = row0 + 16 * wave;
-  const bool active = wave < RF && g0 < segend;
-  const int sq = active ? (g0 - segbase) / L : s_first;
-  const int kb = segbase + sq * L - k_lo;  // first key row of the sequence inside the staged block
   const int nkt = L >> 4;
-  const int nvalid = active ? (int)lens[sq] : 0;
-  const int qpos = g0 - segbase - sq * L + lq;
   const unsigned dkey = A.drop.thr ? drop_key(A.drop.seed + (second ? A.seed2_delta : 0ull) + sbase, A.drop.site) : 0u;
-  bf16_t* Ks = KV;
-  bf16_t* Vs = KV + FZ_ATTN_MAX_ROWS * RP;
-  const int half = nrows * CPR;  // chunks of K (then as many of V)
-  u32x4_t st[NST];
-  s16x4_t qn[NK];
-  auto load_head = [&](int h) {
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_base) + h * (2 * LMAX * RP);  // this wave's slice
+  bf16_t* Vs = Ks + LMAX * RP;
+  u32x2_t out[RF][NK];
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int c = tid + NTHR * i, kv = c >= half ? 1 : 0, cc = c - kv * half, r = cc / CPR, ch = cc - r * CPR;
+  for (int f = 0; f < RF; ++f)
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) out[f][dt] = u32x2_t{0u, 0u};
+  const int half = L * CPR;  // chunks of K (then as many of V)
+  // this head's query fragments of the whole tile, requested up front: they land during the first sequence's staging round trip
+  // (64-row tiles only: on 128-row tiles the 48 extra registers spill — there a fragment's q is loaded when its turn comes)
+  constexpr bool QALL = RF <= 4;
+  s16x4_t qall[QALL ? RF : 1][NK];
+  if constexpr (QALL) {
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        qall[f][ks] = s16x4_t{0, 0, 0, 0};
+        if (row0 + 16 * f < segend) qall[f][ks] = *reinterpret_cast<const s16x4_t*>(A.qkv + (long)(row0 + 16 * f + lq) * LDQ + h * DH + ks * 16 + lg * 4);
+      }
+  }
+  constexpr int NH = (LMAX * CPR + 63) / 64;  // 16-byte staging chunks per lane and matrix
+  u32x4_t sk[NH], sv[NH];
+  auto ld = [&](int kb0, int kv, u32x4_t (&st)[NH]) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int c = lane + 64 * i, r = c / CPR, ch = c - r * CPR;
       st[i] = u32x4_t{0u, 0u, 0u, 0u};
-      if (c < 2 * half) st[i] = gld16(A.qkv, (unsigned)((k_lo + r) * LDQ + FZ_D * (1 + kv) + h * DH + ch * 8) * 2u);
-    }
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      qn[ks] = s16x4_t{0, 0, 0, 0};
-      if (active) qn[ks] = *reinterpret_cast<const s16x4_t*>(A.qkv + (long)(g0 + lq) * LDQ + h * DH + ks * 16 + lg * 4);
+      if (c < half) st[i] = gld16(A.qkv, (unsigned)((kb0 + r) * LDQ + FZ_D * (1 + kv) + h * DH + ch * 8) * 2u);
     }
   };
-  load_head(0);
-#pragma unroll 1
-  for (int h = 0; h < H; ++h) {
-    lds_barrier();  // the previous head's fragments have been read
+  auto sto = [&](bf16_t* dst, const u32x4_t (&st)[NH]) {
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int c = tid + NTHR * i, kv = c >= half ? 1 : 0, cc = c - kv * half, r = cc / CPR, ch = cc - r * CPR;
-      if (c < 2 * half) *reinterpret_cast<u32x4_t*>(&(kv ? Vs : Ks)[r * RP + ch * 8]) = st[i];
+    for (int i = 0; i < NH; ++i) {
+      const int c = lane + 64 * i, r = c / CPR, ch = c - r * CPR;
+      if (c < half) *reinterpret_cast<u32x4_t*>(&dst[r * RP + ch * 8]) = st[i];
     }
-    s16x4_t qf[NK];
+  };
+  // 64-row tiles request a sequence's rows one sequence ahead (they fly while the previous one's fragments are computed); on 128-row
+  // tiles the 64 registers that would stay live across the compute spill (measured: the gain is gone) — there the rows are loaded
+  // when the sequence's turn comes
+  constexpr bool KVPRE = RF <= 4;
+  if constexpr (KVPRE) { ld(segbase + s_first * L, 0, sk); ld(segbase + s_first * L, 1, sv); }
+#pragma unroll 1
+  for (int sq = s_first; sq <= s_last; ++sq) {
+    const int kbase = segbase + sq * L;  // first row of the sequence
+    if constexpr (!KVPRE) { ld(kbase, 0, sk); ld(kbase, 1, sv); }
+    // K_h and V_h of the sequence -> the wave's LDS slice
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's fragment reads of the previous sequence are done)
+    sto(Ks, sk);
+    sto(Vs, sv);
+    if constexpr (KVPRE) { if (sq < s_last) { ld(kbase + L, 0, sk); ld(kbase + L, 1, sv); } }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private data: DS operations of a wave execute in order, no barrier
+    const int nvalid = (int)lens[sq];
+    // the tile's fragments that lie in this sequence
+    const int f_lo = kbase > row0 ? (kbase - row0) >> 4 : 0;
+    const int f_hi_row = (kbase + L < row0 + 16 * RF ? kbase + L : row0 + 16 * RF);
+    const int f_hi = ((f_hi_row < segend ? f_hi_row : segend) - row0) >> 4;  // exclusive
+    // 128-row tiles: the query fragment one ahead is in flight while a fragment is computed (rows past the segment are allocated:
+    // the token matrices come in whole 128-row tiles, api.hip: layout_saved)
+    s16x4_t qnext[NK];
+    auto qload = [&](int f, s16x4_t (&q)[NK]) {
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) qf[ks] = qn[ks];
-    if (h + 1 < H) load_head(h + 1);  // flies during this head's MFMAs
-    lds_barrier();
-    if (active) {
-      f32x4_t sc[8];
-      float mx = -INFINITY;
+      for (int ks = 0; ks < NK; ++ks) q[ks] = *reinterpret_cast<const s16x4_t*>(A.qkv + (long)(row0 + 16 * f + lq) * LDQ + h * DH + ks * 16 + lg * 4);
+    };
+    if constexpr (!QALL) { if (f_lo < f_hi) qload(f_lo, qnext); }
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
-        if (kt < nkt) {
-          sc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < RF; ++f) {
+      if (f >= f_lo && f < f_hi) {
+        const int g0 = row0 + 16 * f, qpos = g0 - kbase + lq;
+        s16x4_t qf[NK];
 #pragma unroll
-          for (int ks = 0; ks < NK; ++ks) {
-            const s16x4_t kf = *reinterpret_cast<const s16x4_t*>(&Ks[(kb + kt * 16 + lq) * RP + ks * 16 + lg * 4]);
-            sc[kt] = COOT_MFMA_16x16x16(kf, qf[ks], sc[kt]);  // sc[i] = S^T[key kt * 16 + lg * 4 + i][query lq]
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float v = sc[kt][i] * A.scale;
-            if (kt * 16 + lg * 4 + i >= nvalid) v = kMaskFill;  // masked_fill(mask, -INF) (transformer_legacy.py:544)
-            sc[kt][i] = v;
-            mx = fmaxf(mx, v);
-          }
+        for (int ks = 0; ks < NK; ++ks) {
+          if constexpr (QALL) qf[ks] = qall[f][ks];
+          else qf[ks] = qnext[ks];
         }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-      s16x4_t pf[8];
+        if constexpr (!QALL) { if (f + 1 < f_hi) qload(f + 1, qnext); }
+        f32x4_t sc[LMAX / 16];
+        float mx = -INFINITY;
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
-        if (kt < nkt) {
-          float pr[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            pr[i] = __expf(sc[kt][i] - mx);
-            sum += pr[i];
-            if (A.drop.thr)
-              pr[i] *= attn_drop_f(dkey, (unsigned)((sq * H + h) * L + qpos), kt * 16 + lg * 4 + i, (unsigned)(L + 1) >> 1, A.drop.thr, A.drop.inv_keep);
-          }
-          const unsigned lo = pack2bf(pr[0], pr[1]), hi = pack2bf(pr[2], pr[3]);
-          pf[kt] = s16x4_t{(short)(lo & 0xFFFF), (short)(lo >> 16), (short)(hi & 0xFFFF), (short)(hi >> 16)};
-        }
-      }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.0f / sum;
-#pragma unroll
-      for (int dt = 0; dt < NK; ++dt) {
-        f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
+        for (int kt = 0; kt < LMAX / 16; ++kt) {
           if (kt < nkt) {
-            // A = V^T [dim][key]: LDS transpose read of the 16 x 16 block (keys kb + 16 kt .., dims 16 dt ..)
-            const bf16_t* blk = &Vs[(kb + kt * 16) * RP + dt * 16];
-            const bf16_t* addr = blk + (4 * lg + (lq >> 2)) * RP + (lq & 3) * 4;
-            const s16x4_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(addr));
-            o = COOT_MFMA_16x16x16(vt, pf[kt], o);
+            sc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+              const s16x4_t kf = *reinterpret_cast<const s16x4_t*>(&Ks[(kt * 16 + lq) * RP + ks * 16 + lg * 4]);
+              sc[kt] = COOT_MFMA_16x16x16(kf, qf[ks], sc[kt]);  // sc[i] = S^T[key kt * 16 + lg * 4 + i][query lq]
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float v = sc[kt][i] * A.scale;
+              if (kt * 16 + lg * 4 + i >= nvalid) v = kMaskFill;  // masked_fill(mask, -INF) (transformer_legacy.py:544)
+              sc[kt][i] = v;
+              mx = fmaxf(mx, v);
+            }
           }
         }
-        // o[i] = O^T[dim 16 dt + 4 lg + i][query lq]: 8 bytes of tile row 16 wave + lq
-        *reinterpret_cast<u32x2_t*>(&As[(16 * wave + lq) * APITCH + h * DH + dt * 16 + lg * 4]) = u32x2_t{pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv)};
-      }
-      if (lg == 0) A.lse[(long)(g0 + lq) * H + h] = mx + __logf(sum);
-    } else if (wave < RF) {  // a fragment past the last row: defined (zero) operand rows for the GEMM passes
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        s16x4_t pf[LMAX / 16];
 #pragma unroll
-      for (int dt = 0; dt < NK; ++dt) *reinterpret_cast<u32x2_t*>(&As[(16 * wave + lq) * APITCH + h * DH + dt * 16 + lg * 4]) = u32x2_t{0u, 0u};
+        for (int kt = 0; kt < LMAX / 16; ++kt) {
+          if (kt < nkt) {
+            float pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              pr[i] = __expf(sc[kt][i] - mx);
+              sum += pr[i];
+              if (A.drop.thr)
+                pr[i] *= attn_drop_f(dkey, (unsigned)((sq * H + h) * L + qpos), kt * 16 + lg * 4 + i, (unsigned)(L + 1) >> 1, A.drop.thr, A.drop.inv_keep);
+            }
+            const unsigned lo = pack2bf(pr[0], pr[1]), hi = pack2bf(pr[2], pr[3]);
+            pf[kt] = s16x4_t{(short)(lo & 0xFFFF), (short)(lo >> 16), (short)(hi & 0xFFFF), (short)(hi >> 16)};
+          }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int dt = 0; dt < NK; ++dt) {
+          f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < LMAX / 16; ++kt) {
+            if (kt < nkt) {
+              // A = V^T [dim][key]: LDS transpose read of the 16 x 16 block (keys 16 kt .., dims 16 dt ..)
+              const bf16_t* addr = &Vs[(kt * 16) * RP + dt * 16] + (4 * lg + (lq >> 2)) * RP + (lq & 3) * 4;
+              const s16x4_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(addr));
+              o = COOT_MFMA_16x16x16(vt, pf[kt], o);
+            }
+          }
+          out[f][dt] = u32x2_t{pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv)};  // O^T[dim 16 dt + 4 lg + i][query lq]
+        }
+        if (lg == 0) A.lse[(long)(g0 + lq) * H + h] = mx + __logf(sum);
+      }
     }
   }
+  __syncthreads();  // every wave is done with its staging slice (the slices overlap the tile)
+#pragma unroll
+  for (int f = 0; f < RF; ++f)
+#pragma unroll
+    for (int dt = 0; dt < NK; ++dt) *reinterpret_cast<u32x2_t*>(&As[(16 * f + lq) * APITCH + h * DH + dt * 16 + lg * 4]) = out[f][dt];
   lds_barrier();
   // ctx for the backward pass (attention backward, out-projection weight gradient): 16-byte row-contiguous stores from the tile
   for (int c = tid; c < 16 * RF * 48; c += NTHR) {
@@ -605,7 +643,9 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   constexpr int BT = 16 * RF, RR = RF >= 2 ? 32 : 16;
   // LDS: token tile | fp32 staging | 7 parameter vectors of 384 floats (bo, b1, b2, ln1 gain/bias, ln2 gain/bias; the
   // first three slots are re-used for the pooling biases once the encoder layer is done) = 162,816 B of the 160 KiB
-  __shared__ __attribute__((aligned(16))) unsigned char smem[BT * APITCH * 2 + RR * SPITCH * 4 + 7 * FZ_D * 4];
+  constexpr int SMEM_CHAIN = BT * APITCH * 2 + RR * SPITCH * 4 + 7 * FZ_D * 4;
+  constexpr int SMEM = SMEM_CHAIN > FZ_ATTN_SMEM(RF) ? SMEM_CHAIN : FZ_ATTN_SMEM(RF);  // (64-row tiles: the in-chain attention's slices need 3 KB more)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);
   float* Stg = reinterpret_cast<float*>(smem + BT * APITCH * 2);
   float* Bsm = reinterpret_cast<float*>(smem + BT * APITCH * 2 + RR * SPITCH * 4);
@@ -644,7 +684,7 @@ __global__ __launch_bounds__(512) void post_attn_fwd_kernel(PostAttnFwd p) {
   TileRing<RF> R;  // weight ring, carried from pass to pass (gemm_run)
   if constexpr (RF >= 4) {
     if (fuse_attn) {
-      fused_self_attn<RF>(p, As, reinterpret_cast<bf16_t*>(Stg), row0, sbase);
+      fused_self_attn<RF>(p, As, smem, row0, sbase);
       gemm_issue(R, p.wo + wave * GSZ, lane);
       load_vectors();
     } else {
@@ -2105,10 +2145,11 @@ __global__ __launch_bounds__(256) void colsum_scatter_kernel(ScatterArgs a) {
 constexpr int kHalfTilesMax = 256 * 64;
 bool half_tiles(int T, int /*kernel*/) { return T <= kHalfTilesMax; }
 
-static int g_fused_attn = 0;  // coot_set_option("fused_attn", 1): the local networks' forward self-attention inside post_attn_fwd_kernel.  Built and
-// parity-green in round 6; NOT faster (1.235 against 1.229 ms per step, profiles/r06_ab_fused_attn.txt): the chain workgroup — one per
-// CU, two waves per SIMD, in lockstep — computes the attention in +37 us per 128-row launch, the 2 560-workgroup kernel it replaces
-// takes 20-45 us of stream time at full occupancy.  Off by default; tests/test_gpu_fused_attn.py keeps it pinned.
+static int g_fused_attn = 1;  // coot_set_option("fused_attn", 0): the local networks' forward self-attention as launches of their own (attn_short_fwd).
+// Round 6: inside post_attn_fwd_kernel for fixed-length sequences of 16 k <= 80 (64 on 64-row tiles) rows — ActivityNet's 80 frames and
+// 64 / 16 words; other shapes, packed rows and every backward keep the attention kernels.  First version (wave = fragment, head by head
+// through shared LDS, two barriers per head): 1.235 against 1.229 ms per step, not adopted.  Second (wave = head, wave-private K / V
+// slices, no workgroup barrier): 1.197 against 1.210 ms, six of six alternating pairs (profiles/r06_ab_fused_attn.txt): on.
 void set_fused_attn(int on) { g_fused_attn = on; }
 static int g_fused_attn_launches = 0;  // launches that took the attention along (coot_get_option("fused_attn_launches"): tests)
 int fused_attn_launches() { return g_fused_attn_launches; }
@@ -2120,16 +2161,10 @@ static int post_attn_tile_rows(int T, bool do_pool) {
 bool post_attn_can_fuse_attention(int T, bool do_pool, int N0, int L0, int N1, int L1) {
   if (!g_fused_attn) return false;
   const int BT = post_attn_tile_rows(T, do_pool);
-  if (BT == 0 || N0 <= 0 || L0 <= 0 || L0 % 16 != 0 || L0 > 128 || (long)N0 * L0 + (long)N1 * L1 != (long)T) return false;
-  if (N1 > 0 && (L1 <= 0 || L1 % 16 != 0 || L1 > 128 || ((long)N0 * L0) % BT != 0)) return false;
-  // key rows a tile stages: from the start of the sequence its first row lies in to the end of the one its last row lies in
-  for (int s = 0; s < (N1 > 0 ? 2 : 1); ++s) {
-    const long base = s ? (long)N0 * L0 : 0, end = s ? T : (long)N0 * L0, L = s ? L1 : L0;
-    for (long r0 = base / BT * BT; r0 < end; r0 += BT) {
-      const long a = r0 < base ? base : r0, b = (r0 + BT < end ? r0 + BT : end) - 1;
-      if (((b - base) / L - (a - base) / L + 1) * L > FZ_ATTN_MAX_ROWS) return false;
-    }
-  }
+  if (BT == 0) return false;
+  const int lmax = BT == 128 ? FZ_ATTN_LMAX(8) : FZ_ATTN_LMAX(4);  // a wave's LDS slice holds K | V of one head of one sequence
+  if (N0 <= 0 || L0 <= 0 || L0 % 16 != 0 || L0 > lmax || (long)N0 * L0 + (long)N1 * L1 != (long)T) return false;
+  if (N1 > 0 && (L1 <= 0 || L1 % 16 != 0 || L1 > lmax || ((long)N0 * L0) % BT != 0)) return false;
   return true;
 }
 
@@ -2146,7 +2181,9 @@ int launch_post_attn_fwd(const PostAttnFwd& p, hipStream_t st) {
   COOT_REQUIRE(!p.do_pool || (p.pw1 && p.pw2 && p.pb1 && p.pb2 && p.hp && p.ap && p.s), "post_attn_fwd: pooling pointers");
   if (p.T <= 0) return 0;
   // GEMM passes of the chain: out-proj, FF1, FF2 (+ pool FC1 768 wide, FC2 384 wide): 2 * T * 384 * 384 each
-  void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 384.0 * (p.do_pool ? 6.0 : 3.0), 0, st);
+  // (+ the in-chain attention's own products: Q K^T and P V, 4 L^2 d_model per sequence)
+  const double attn_flops = p.attn.on ? 4.0 * 384.0 * ((double)p.attn.N0 * p.attn.L0 * p.attn.L0 + (double)p.attn.N1 * p.attn.L1 * p.attn.L1) : 0.0;
+  void* ts = timing_begin(TIMING_FUSED, 2.0 * p.T * 384.0 * 384.0 * (p.do_pool ? 6.0 : 3.0) + attn_flops, 0, st);
   const bool drop = p.d_postln.thr || p.d_ff1.thr || p.d_ff2.thr || p.d_pool1.thr || p.d_pool2.thr;
   if (drop)
     COOT_REQUIRE(p.d_postln.thr && p.d_ff1.thr && p.d_ff2.thr && (!p.do_pool || (p.d_pool1.thr && p.d_pool2.thr)), "post_attn_fwd: dropout on some sites only");

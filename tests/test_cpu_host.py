@@ -507,7 +507,7 @@ def test_option_switches_named_in_the_integration_notes_exist(cva):
     para = para[:para.index("`coot_get_option` reads")]
     names = [n for n in re.findall(r"`([a-z0-9_]+)`", para) if not n.startswith("coot_") and n != "gemm_nt"]  # (`gemm_nt`: a kernel named in the text)
     assert {"fused", "cl_small", "cl_col_split", "grad_write", "pack_lazy", "xcd_order", "step_stamps"} <= set(names)
-    value = {"cl_col_split": 0, "pack_poison": 0, "grad_poison": 0, "fz_debug": 0, "step_stamps": 0, "fused_attn": 0}  # defaults that are not 1
+    value = {"cl_col_split": 0, "pack_poison": 0, "grad_poison": 0, "fz_debug": 0, "step_stamps": 0}  # defaults that are not 1
     sizes = {"fused_min_rows", "tn_target_wgs"}  # a size, not a switch: left alone (no read-back)
     for n in names:
         if n in sizes:
