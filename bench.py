@@ -65,6 +65,9 @@ def parse():
                     "and after the timed steps, to stderr")
     ap.add_argument("--idle-ms", type=float, default=0.0, help="regime probe: leave the device idle for this long between the warm-up and the timed steps")
     ap.add_argument("--lr0", action="store_true", help="regime probe: learning rate and weight decay 0 — every step computes on the same weights")
+    ap.add_argument("--extra-streams", type=int, default=0, help="regime probe: create and use N unrelated HIP streams before the trainer exists — shifts "
+                    "HIP's stream -> hardware-queue mapping (creation order, 4 queues); the step's streams are verified to run concurrently "
+                    "(coot_stream_create_concurrent), so the result must not depend on N (profiles/r06_stream_queues.txt)")
     ap.add_argument("--eval", action="store_true", help="forward-only (eval mode) throughput instead of training")
     ap.add_argument("--padded", action="store_true", help="ragged workloads: run the reference's padded layout instead of packed (varlen) rows")
     ap.add_argument("--mode", default="native", choices=["native", "native-graph", "autograd"],
@@ -211,13 +214,14 @@ def main():
         try:
             dist.init_process_group(args.dp_backend, rank=rank, world_size=world)
             dist.barrier()  # creates the communicator now, inside the redirection
+            dp = cdist.DataParallelContext()
+            dp.prepare_device_collectives()  # ... and the step's own (direct RCCL calls on its streams: dist.DirectRccl)
             torch.cuda.synchronize()
         finally:
             C.CDLL(None).fflush(None)  # RCCL writes through C stdio: its buffer must be drained while fd 1 still is stderr
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-        dp = cdist.DataParallelContext()
         assert dist.get_world_size() == world
     w = cva.synthetic.WORKLOADS[args.workload]
     cfg = cva.load_named_config(*cva.synthetic.WORKLOAD_CONFIG[args.workload])
@@ -225,6 +229,10 @@ def main():
     if args.lr0:
         cfg.optimizer.lr, cfg.optimizer.weight_decay = 0.0, 0.0
     mgr = cva.RetrievalModelManager(cfg).cuda()
+    _extra = [torch.cuda.Stream() for _ in range(args.extra_streams)]
+    for _s in _extra:
+        with torch.cuda.stream(_s):
+            torch.zeros(1, device="cuda")
     trainer = cva.RetrievalTrainer(cfg, mgr, is_test=args.eval)
     if dp is not None:
         trainer.dp = dp
@@ -612,6 +620,8 @@ def main():
                                    f"Lc=Lv={w['Lc']}, Ls={w['Ls']}, Lp={w['Lp']}, Dv={w['Dv']}, Dt={w['Dt']}, d_model=384",
                        "global_batch_videos": w["B"] * world, "clip_pairs_per_step": clip_pairs,
                        "parallelism": f"dp{world}", "mode": "eval" if args.eval else "train",
+                       **({"collectives": {"direct": "RCCL calls on the step's own streams (dist.DirectRccl)", "torch": "torch.distributed"}[dp.collectives_route()]}
+                          if (dp is not None and not args.eval) else {}),
                        "launch": "eval" if args.eval else mode,
                        **({"batches": "two different synthetic batches in turn"} if (not args.eval and two_batches) else {}),
                        **({"input_lookahead": "each step runs the NEXT batch's input LayerNorm (one per side per step, as without it) next to its global networks"}
@@ -634,6 +644,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
     if dp is not None:
+        dp.close()  # (the direct RCCL communicator of the step's collectives)
         torch.distributed.destroy_process_group()
 
 

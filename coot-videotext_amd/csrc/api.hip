@@ -643,6 +643,7 @@ int coot_debug_timestamps(void* dev_u64) { g_fz_tstamps = (unsigned long long*)d
 extern "C" void coot_step_stamps_enable(int on);  // api_step.hip
 extern "C" void coot_step_grad_write(int on);
 extern "C" int coot_internal_stage_hits(void);
+extern "C" int coot_internal_stream_counter(int which);  // api_step.hip: StreamPicker
 extern "C++" { namespace coot { int det_bypass_count(); } }  // det.hip
 int coot_get_option(const char* name, int* value) {
   if (!value) { set_error("get_option: null result"); return -1; }
@@ -651,6 +652,11 @@ int coot_get_option(const char* name, int* value) {
   if (!strcmp(name, "tn_mode")) { *value = get_tn_mode(); return 0; }
   if (!strcmp(name, "stage_hits")) { *value = coot_internal_stage_hits(); return 0; }  // steps of this thread that used a prepared input stage
   if (!strcmp(name, "fused_attn_launches")) { *value = fused_attn_launches(); return 0; }
+  // concurrent-stream selection of this thread (coot_stream_create_concurrent, the library's own stream): spin-kernel tests run,
+  // candidates that shared a hardware queue with a stream they have to run beside, selections that found no concurrent stream at all
+  if (!strcmp(name, "stream_overlap_tests")) { *value = coot_internal_stream_counter(0); return 0; }
+  if (!strcmp(name, "stream_candidates_rejected")) { *value = coot_internal_stream_counter(1); return 0; }
+  if (!strcmp(name, "stream_unresolved")) { *value = coot_internal_stream_counter(2); return 0; }
   if (!strcmp(name, "operand_f16")) { *value = COOT_OPERAND_IS_F16; return 0; }  // which build this is (common.h)
   if (!strcmp(name, "det_bypasses")) { *value = det_bypass_count(); return 0; }  // deterministic mode: addends that took the float atomic (synchronises; -1: mode off)
   set_error("get_option: unknown or write-only option %s", name);

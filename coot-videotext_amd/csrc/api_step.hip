@@ -188,16 +188,118 @@ StageLayout stage_layout(const coot_step_config& c, const coot_step_dims& d, voi
   L.xv = b ? b + oxv : nullptr; L.xt = b ? b + oxt : nullptr; L.pv = b ? b + opv : nullptr; L.pt = b ? b + opt : nullptr; L.bytes = off;
   return L;
 }
+// ---- streams that really run concurrently (include/coot_hip.h: coot_stream_create_concurrent) ----------------------------------------
+// HIP multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in the order they are created; two
+// streams on one queue run their kernels one after the other whatever the events between them say.  The step's two sides on one queue:
+// 1.72 instead of 1.22 ms (profiles/r06_stream_queues.txt: one more stream created anywhere in the process before the trainer's shifts
+// the mapping).  So no stream of the step is taken on trust: a candidate is accepted when a 100-us spin kernel on it and one on every
+// stream it has to run beside finish in the time of one.
+__global__ void spin_kernel(int ticks /* of the 100 MHz real-time counter */) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
+}
+struct StreamPicker {
+  static constexpr int kSpinTicks = 10000, kMaxLive = 64, kNice = 3, kTries = 12;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  hipStream_t live[kMaxLive]; int n_live = 0;  // streams handed out by coot_stream_create_concurrent and not destroyed yet
+  int tests = 0, rejected = 0, unresolved = 0;  // coot_get_option("stream_overlap_tests" / "stream_candidates_rejected" / "stream_unresolved")
+  int init() {
+    if (e0) return 0;
+    RUN(check_hip(hipEventCreate(&e0), "hipEventCreate"));
+    RUN(check_hip(hipEventCreate(&e2), "hipEventCreate"));
+    RUN(check_hip(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "hipEventCreate"));
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, nullptr, 1);  // (code object loaded before anything is timed)
+    return check_hip(hipDeviceSynchronize(), "deviceSynchronize");
+  }
+  // 1: kernels on a and b overlap; 0: they run one after the other; < 0: error.  Synchronises the device.
+  int overlap(hipStream_t a, hipStream_t b) {
+    if (a == b) return 0;
+    if (init()) return -1;
+    ++tests;
+    if (check_hip(hipDeviceSynchronize(), "deviceSynchronize")) return -1;
+    bool ok = hipEventRecord(e0, a) == hipSuccess;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, kSpinTicks);
+    ok = ok && hipStreamWaitEvent(b, e0, 0) == hipSuccess;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, kSpinTicks);
+    ok = ok && hipEventRecord(e1, b) == hipSuccess && hipStreamWaitEvent(a, e1, 0) == hipSuccess && hipEventRecord(e2, a) == hipSuccess;
+    ok = ok && hipEventSynchronize(e2) == hipSuccess;
+    float ms = 0.f;
+    ok = ok && hipEventElapsedTime(&ms, e0, e2) == hipSuccess;
+    if (!ok) { set_error("stream overlap test: %s", hipGetErrorString(hipGetLastError())); return -1; }
+    return ms < 1.6f * (kSpinTicks * 1e-5f) ? 1 : 0;  // one spin: 0.1 ms; two in a row: 0.2 ms
+  }
+  // a new stream whose kernels overlap those of every stream in must[] — and, if there is such a candidate, of every stream in nice[].
+  // Candidates stay alive until the choice is made (a destroyed stream's queue slot may be handed to the next one created).
+  int create(const hipStream_t* must, int n_must, const hipStream_t* nice, int n_nice, int priority, hipStream_t* out, int* concurrent) {
+    RUN(init());
+    int lo = 0, hi = 0;
+    RUN(check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "streamPriorityRange"));  // lo: numerically largest = lowest priority
+    const int prio = priority > 0 ? lo : (priority < 0 ? hi : 0);
+    hipStream_t cand[kTries]; int n = 0, pick = -1, pick_must = -1;
+    for (; n < kTries && pick < 0; ++n) {
+      RUN(check_hip(hipStreamCreateWithPriority(&cand[n], hipStreamNonBlocking, prio), "hipStreamCreate"));
+      bool ok = true;
+      for (int i = 0; i < n_must && ok; ++i) { const int r = overlap(cand[n], must[i]); if (r < 0) return 1; ok = r == 1; }
+      if (!ok) { ++rejected; continue; }
+      if (pick_must < 0) pick_must = n;
+      for (int i = 0; i < n_nice && ok; ++i) { const int r = overlap(cand[n], nice[i]); if (r < 0) return 1; ok = r == 1; }
+      if (ok) pick = n; else ++rejected;
+      if (n + 1 >= 8 && pick < 0 && pick_must >= 0) { ++n; break; }  // two rounds over the queues without a full match: settle for must[]
+    }
+    const bool full = pick >= 0;
+    if (pick < 0) pick = pick_must >= 0 ? pick_must : n - 1;
+    if (concurrent) *concurrent = (full || pick_must >= 0) ? 1 : 0;
+    if (!full && pick_must < 0) {
+      ++unresolved;
+      fprintf(stderr, "coot: no stream found that runs concurrently with the step's streams (%d candidates; GPU_MAX_HW_QUEUES too small, "
+                      "or a tool that serialises the queues): the step's sides will run one after the other\n", n);
+    }
+    for (int i = 0; i < n; ++i) if (i != pick) (void)hipStreamDestroy(cand[i]);
+    *out = cand[pick];
+    return 0;
+  }
+};
+thread_local StreamPicker g_streams;
+
 struct InputPipe {
   void* stage[2] = {nullptr, nullptr}; size_t bytes = 0;
   bool next_valid = false; coot_step_batch next_x; coot_step_dims next_d;  // the batch of the NEXT step (one-shot: consumed by a step)
   bool ready = false; int idx = 0; coot_step_batch have_x; coot_step_dims have_d;  // stage[idx] holds x^ of (have_x, have_d)
   hipEvent_t done = nullptr; hipStream_t stream = nullptr;
   int hits = 0;  // steps of this thread that found their x^ prepared (coot_get_option("stage_hits"): tests assert the timed mode ran)
+  hipStream_t beside[2] = {nullptr, nullptr}; bool checked = false;  // the side streams `stream` was verified against
   int init() {
     if (stream) return 0;
     RUN(check_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate"));
     return check_hip(hipEventCreateWithFlags(&done, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate");
+  }
+  // At the head of a step, before anything is enqueued: the library's own stream (next batch's input LayerNorm, early update of the
+  // global networks) must run BESIDE the step's two sides, not in one hardware queue with one of them.  Verified once per pair of side
+  // streams (a new trainer brings new ones); replaced if it collides.  Synchronises the device when it has to test; never while `sm`
+  // is being captured (a captured step uses neither the input stages nor the early update).
+  int ensure_beside(hipStream_t sm, hipStream_t sv, hipStream_t st) {
+    if (checked && beside[0] == sv && beside[1] == st) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(sm, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (cs != hipStreamCaptureStatusNone) return 0;
+    bool keep = stream != nullptr;
+    if (keep) {
+      const int a = g_streams.overlap(stream, sv), b = g_streams.overlap(stream, st);
+      if (a < 0 || b < 0) return 1;
+      keep = a == 1 && b == 1;
+    }
+    if (!keep) {
+      const hipStream_t must[2] = {sv, st};
+      hipStream_t fresh = nullptr; int conc = 0;
+      // ... and beside the most recent streams handed to the caller (a data-parallel step's communication stream), if the queues allow
+      const int nn = g_streams.n_live < StreamPicker::kNice ? g_streams.n_live : StreamPicker::kNice;
+      RUN(g_streams.create(must, 2, g_streams.live + (g_streams.n_live - nn), nn, 0, &fresh, &conc));
+      if (stream) { RUN(check_hip(hipStreamSynchronize(stream), "streamSynchronize")); (void)hipStreamDestroy(stream); }
+      stream = fresh;
+      if (!done) RUN(check_hip(hipEventCreateWithFlags(&done, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate"));
+    }
+    beside[0] = sv; beside[1] = st; checked = true;
+    return 0;
   }
 };
 thread_local InputPipe g_pipe;
@@ -521,6 +623,7 @@ int coot_step_forward(const coot_step_config* cfg, const coot_step_buffers* b, c
   const SidePacked pk = side_packed(*x, *d);
   COOT_REQUIRE(!A.overflow, "step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
+  RUN(g_pipe.ensure_beside(sm, sv, st));
   RUN(g_hops.hop(0, sm, sv));
   RUN(g_hops.hop(1, sm, st));
   const bool fresh = (packs_fresh & COOT_FWD_PACKS_FRESH) != 0;
@@ -630,6 +733,7 @@ int coot_train_step(const coot_step_config* cfg, const coot_step_buffers* b, con
   COOT_REQUIRE(!A.overflow, "train_step: workspace too small (%zu < %zu)", workspace_bytes, A.off);
   hipStream_t sm = (hipStream_t)main_s, sv = (hipStream_t)side_v, st = (hipStream_t)side_t;
   COOT_REQUIRE(sv != st, "train_step: the two side streams must differ");
+  RUN(g_pipe.ensure_beside(sm, sv, st));
   const int D = cfg->net[0].hidden_dim;
   const bool optimize = (do_optimizer & COOT_STEP_OPTIMIZER) != 0, repack = optimize && (do_optimizer & COOT_STEP_REPACK) != 0;
   const bool pack_first = (do_optimizer & COOT_STEP_PACKS_FRESH) == 0;
@@ -826,6 +930,32 @@ int coot_stream_hop(coot_stream_t from, coot_stream_t to) {
   RUN(check_hip(hipEventRecord(e, (hipStream_t)from), "eventRecord"));
   return check_hip(hipStreamWaitEvent((hipStream_t)to, e, 0), "streamWait");
 }
+int coot_streams_overlap(coot_stream_t a, coot_stream_t b) { return g_streams.overlap((hipStream_t)a, (hipStream_t)b); }
+int coot_stream_create_concurrent(const coot_stream_t* others, int n_others, int priority, coot_stream_t* out, int* concurrent) {
+  COOT_REQUIRE(out && n_others >= 0 && n_others <= 8 && (others || n_others == 0), "stream_create_concurrent: arguments");
+  COOT_REQUIRE(g_streams.n_live < StreamPicker::kMaxLive, "stream_create_concurrent: %d streams are live (coot_stream_destroy)", g_streams.n_live);
+  hipStream_t must[8];
+  for (int i = 0; i < n_others; ++i) must[i] = (hipStream_t)others[i];
+  hipStream_t s = nullptr;
+  // beside the caller's streams — and, if the queues allow it, beside the library's own stream too
+  const hipStream_t nice[1] = {g_pipe.stream};
+  RUN(g_streams.create(must, n_others, nice, g_pipe.stream ? 1 : 0, priority, &s, concurrent));
+  g_streams.live[g_streams.n_live++] = s;
+  *out = (coot_stream_t)s;
+  return 0;
+}
+int coot_stream_destroy(coot_stream_t s) {
+  for (int i = 0; i < g_streams.n_live; ++i)
+    if (g_streams.live[i] == (hipStream_t)s) {
+      g_streams.live[i] = g_streams.live[--g_streams.n_live];
+      RUN(check_hip(hipStreamSynchronize((hipStream_t)s), "streamSynchronize"));
+      if (g_pipe.checked && (g_pipe.beside[0] == (hipStream_t)s || g_pipe.beside[1] == (hipStream_t)s)) g_pipe.checked = false;  // (the handle may be reused)
+      return check_hip(hipStreamDestroy((hipStream_t)s), "streamDestroy");
+    }
+  set_error("stream_destroy: not a stream of coot_stream_create_concurrent (of this thread)");
+  return 1;
+}
+int coot_internal_stream_counter(int which) { return which == 0 ? g_streams.tests : (which == 1 ? g_streams.rejected : g_streams.unresolved); }
 void coot_step_grad_write(int on) { g_grad_write = on ? 1 : 0; }
 
 // text table of the last step's stamps (ms since "step starts"); synchronises the device.  Returns the number of stamps.

@@ -16,10 +16,99 @@ outputs gathered to GPU 0, loss on the full batch).  Same semantics here, restat
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+class DirectRccl:
+    """The step's collectives as direct RCCL calls on the CALLER'S HIP stream (ncclAllGather / ncclAllReduce of the librccl.so the
+    process already has loaded through torch), on a communicator of the same ranks as the torch group.  torch.distributed's wrapper
+    around the same two calls costs ~7 us of device time per collective even with one rank (work-tracking events around it, each a
+    barrier packet on the stream: 1.229 -> 1.208 ms per step with the step's four collectives stubbed out, round 6), and a step has
+    four.  The torch group stays what it is for everything off the step's device path (setup, shape exchange, the agreement below).
+    Creation is collective and its outcome is AGREED over the torch group: either every rank gets a communicator or none does
+    (DataParallelContext then keeps the torch.distributed calls and says so once)."""
+
+    FLOAT32, SUM = 7, 0  # ncclFloat32, ncclSum (rccl.h)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_ubyte * 128)]  # NCCL_UNIQUE_ID_BYTES (c_ubyte: a c_char array reads back cut at the first NUL)
+
+    def __init__(self, group=None, lib_path: Optional[str] = None):
+        self.comm = None
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # (the agreement tensors live where the torch group's backend wants them: a gloo group in the CPU tests exercises this
+        # constructor's control flow up to the communicator that cannot exist without a GPU)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        err = None
+        try:
+            lib = C.CDLL(lib_path or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+            lib.ncclGetUniqueId.argtypes = [C.POINTER(self.UniqueId)]
+            lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, self.UniqueId, C.c_int]
+            lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+            lib.ncclGetErrorString.argtypes, lib.ncclGetErrorString.restype = [C.c_int], C.c_char_p
+            self.lib = lib
+        except (OSError, AttributeError) as e:
+            err, self.lib = e, None
+        if not self._agree(self.lib is not None, dev):  # a rank without the library must not leave the others inside the init
+            self._report(f"librccl.so not loadable on every rank ({err})")
+            return
+        # rank 0's id to everyone through the torch group (bytes in a one-element object list)
+        uid = self.UniqueId()
+        if self.rank == 0:
+            self._check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        box = [bytes(uid.internal) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        assert isinstance(box[0], bytes) and len(box[0]) == 128
+        C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        rc = lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)  # collective
+        if not self._agree(rc == 0, dev):
+            if rc == 0:
+                lib.ncclCommDestroy(comm)
+            self._report(f"ncclCommInitRank failed on a rank (here: {self._err(rc)})")
+            return
+        self.comm = comm
+
+    def _agree(self, ok: bool, dev) -> bool:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item()) == 1
+
+    def _report(self, why: str) -> None:
+        if self.rank == 0:
+            print(f"coot dist: no direct RCCL communicator ({why}); the step's collectives go through torch.distributed", flush=True)
+
+    def _err(self, rc: int) -> str:
+        return "ok" if rc == 0 else (self.lib.ncclGetErrorString(rc) or b"?").decode()
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self._err(rc)}")
+
+    def all_gather(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        assert send.dtype == torch.float32 and recv.dtype == torch.float32 and recv.numel() == self.world * send.numel()
+        assert send.is_contiguous() and recv.is_contiguous() and send.is_cuda and recv.is_cuda
+        self._check(self.lib.ncclAllGather(send.data_ptr(), recv.data_ptr(), send.numel(), self.FLOAT32, self.comm,
+                                           torch.cuda.current_stream().cuda_stream), "ncclAllGather")
+
+    def all_reduce_sum(self, t: torch.Tensor) -> None:
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), self.FLOAT32, self.SUM, self.comm,
+                                           torch.cuda.current_stream().cuda_stream), "ncclAllReduce")
+
+    def close(self) -> None:
+        if self.comm is not None:
+            torch.cuda.synchronize()
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
 
 
 class _GatherRows(torch.autograd.Function):
@@ -166,11 +255,49 @@ class DataParallelContext:
     def gather_block(self, send: torch.Tensor, recv: torch.Tensor) -> None:
         """ONE all-gather of equally sized blocks: recv [world * n] <- every rank's send [n] in rank order (the native step lays
         its six embedding sets out in one block and the loss reads the gathered blocks in place)."""
-        _all_gather_into(recv, send, self.group)
+        r = self._direct(send)
+        if r is not None:
+            r.all_gather(recv, send)
+        else:
+            _all_gather_into(recv, send, self.group)
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
         """In-place sum over ranks on the current stream."""
-        _all_reduce(t, dist.ReduceOp.SUM, self.group)
+        r = self._direct(t)
+        if r is not None:
+            r.all_reduce_sum(t)
+        else:
+            _all_reduce(t, dist.ReduceOp.SUM, self.group)
+
+    def _direct(self, t: torch.Tensor) -> Optional[DirectRccl]:
+        """The direct RCCL communicator for the step's device collectives (backend "nccl", fp32 device tensors), created collectively
+        at the first one — every rank's first is the step's embedding gather.  COOT_DP_COLLECTIVES=torch keeps torch.distributed's."""
+        d = getattr(self, "_rccl", None)
+        if d is None:
+            use = (t.is_cuda and t.dtype == torch.float32 and dist.get_backend(self.group) == "nccl"
+                   and os.environ.get("COOT_DP_COLLECTIVES", "direct") != "torch")
+            d = self._rccl = DirectRccl(self.group) if use else False
+            if d is not False and d.comm is None:
+                d = self._rccl = False
+        return d if d is not False else None
+
+    def prepare_device_collectives(self) -> str:
+        """Create the direct communicator NOW (collective) instead of at the first step's gather — e.g. while the caller has stdout
+        redirected: RCCL prints its version banner there when a process creates its first communicator.  Returns the route."""
+        if dist.get_backend(self.group) == "nccl":
+            self._direct(torch.empty(1, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device())))
+        return self.collectives_route()
+
+    def collectives_route(self) -> str:
+        """"direct" once the step's collectives run as direct RCCL calls, "torch" if they go through torch.distributed."""
+        d = getattr(self, "_rccl", None)
+        return "direct" if (d is not None and d is not False) else "torch"
+
+    def close(self) -> None:
+        d = getattr(self, "_rccl", None)
+        if d is not None and d is not False:
+            d.close()
+        self._rccl = None
 
     def gather_embeddings(self, vis, txt, clip_counts: Optional[List[int]] = None, vid_counts: Optional[List[int]] = None):
         """Returns the six full-batch embedding sets (vid_emb, par_emb, clip_emb, sent_emb, vid_ctx, par_ctx).

@@ -30,6 +30,7 @@ EXPORTS = [
     "coot_timing_collect", "coot_step_workspace_bytes", "coot_train_step", "coot_step_forward", "coot_step_backward",
     "coot_adam_step", "coot_radam_step", "coot_step_update", "coot_step_set_global_done_events", "coot_step_device_state_bytes", "coot_step_set_device_state", "coot_collate_level", "coot_collate_packed", "coot_sample_cycle_indices", "coot_step_set_cycle_indices", "coot_step_input_stage_bytes", "coot_step_set_input_stages", "coot_step_set_next_batch", "coot_contrastive_fwd_bwd_dp", "coot_contrastive_fwd_bwd_dp_blocks", "coot_retrieval_workspace_bytes", "coot_retrieval_ranks",
     "coot_det_shadow_bytes", "coot_det_configure", "coot_det_flush", "coot_event_record", "coot_event_wait", "coot_event_handle", "coot_stream_hop",
+    "coot_stream_create_concurrent", "coot_stream_destroy", "coot_streams_overlap",
 ]
 
 
@@ -90,7 +91,29 @@ class StepBatch(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 6  # include/coot_hip.h: COOT_ABI_VERSION
+ABI_VERSION = 7  # include/coot_hip.h: COOT_ABI_VERSION
+
+
+class ConcurrentStream:
+    """A HIP stream whose kernels really overlap those of `others` (coot_stream_create_concurrent: HIP maps a process's streams onto
+    a few hardware queues in creation order, and two streams on one queue run one after the other — include/coot_hip.h), wrapped
+    for torch (`with torch.cuda.stream(s.torch)`, s.cuda_stream).  priority > 0: the device's lowest.  close() destroys it."""
+
+    def __init__(self, others, priority: int = 0):
+        import torch
+        lib = load()
+        ptrs = [int(getattr(o, "cuda_stream", o) or 0) for o in others]
+        arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
+        out, conc = C.c_void_p(), C.c_int(0)
+        check(lib.coot_stream_create_concurrent(arr, len(ptrs), int(priority), C.byref(out), C.byref(conc)), "coot_stream_create_concurrent")
+        self.cuda_stream = out.value
+        self.concurrent = bool(conc.value)
+        self.torch = torch.cuda.ExternalStream(self.cuda_stream)
+
+    def close(self) -> None:
+        if self.cuda_stream is not None and _lib is not None:
+            _lib.coot_stream_destroy(self.cuda_stream)
+        self.cuda_stream = None
 
 
 def operand() -> str:
@@ -165,6 +188,9 @@ def load():
     lib.coot_event_handle.restype = vp
     lib.coot_event_handle.argtypes = [i32]
     lib.coot_stream_hop.argtypes = [vp, vp]
+    lib.coot_stream_create_concurrent.argtypes = [C.POINTER(vp), i32, i32, C.POINTER(vp), C.POINTER(i32)]
+    lib.coot_stream_destroy.argtypes = [vp]
+    lib.coot_streams_overlap.argtypes = [vp, vp]
     lib.coot_gemm_nt.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp, i64, i32, vp]
     lib.coot_gemm_tn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i64, vp, sz, vp]
     lib.coot_gemm_tn_batch.argtypes = [C.POINTER(TnProblem), i32, vp, sz, vp, vp]

@@ -158,7 +158,7 @@ class RetrievalTrainer:
         carry this trainer's buffers.  Called by __del__; a caller that frees the trainer's tensors earlier calls it first.
         Idempotent; a trainer that never ran a native step has nothing registered."""
         st = self.__dict__.get("_native")
-        if st is None and not self.__dict__.get("deterministic", False):
+        if st is None and not self.__dict__.get("deterministic", False) and not self.__dict__.get("_side_cs"):
             return
         try:
             lib = _lib.load()
@@ -175,6 +175,15 @@ class RetrievalTrainer:
                         lib.coot_step_set_input_stages(None, None, 0)
                         RetrievalTrainer._stage_owner = None
                     st.stages = None
+                for name in ("text_cs", "comm_cs"):
+                    cs = st.__dict__.get(name)
+                    if cs is not None:
+                        cs.close()
+                        setattr(st, name, None)
+                st.comm = None
+            for cs in self.__dict__.get("_side_cs", ()):
+                cs.close()
+            self._side_cs, self._side_streams = (), None
             self._next_desc = None
             if self.__dict__.get("deterministic", False):
                 self.set_deterministic(False)
@@ -221,8 +230,10 @@ class RetrievalTrainer:
         stream its forward ran on, so the backward passes overlap the same way."""
         if not (self.overlap_sides and batch.vid_feat.is_cuda):
             return self.model_mgr.encode_visual(batch), self.model_mgr.encode_text(batch)
-        if getattr(self, "_side_streams", None) is None:
-            self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        if getattr(self, "_side_streams", None) is None:  # two streams verified to overlap each other (_lib.ConcurrentStream)
+            a = _lib.ConcurrentStream([])
+            self._side_cs = (a, _lib.ConcurrentStream([a]))
+            self._side_streams = tuple(c.torch for c in self._side_cs)
         main = torch.cuda.current_stream()
         sv, st = self._side_streams
         sv.wait_stream(main)
@@ -381,13 +392,11 @@ class RetrievalTrainer:
                 st.decay_all.append((pad.view(nb, 1024).min(dim=1).values == 1.0).to(torch.uint8).contiguous())
             st.bufs = _lib.StepBuffers()
             st.losses = torch.zeros(3, dtype=torch.float32, device=dev)
-            # text side: a LOW priority stream — it has slack, the video side is the critical path of the step
-            prio = int(os.environ.get("COOT_TEXT_STREAM_PRIORITY", "1"))
-            try:
-                text_stream = torch.cuda.Stream(priority=prio)
-            except Exception:  # priority not supported by this runtime
-                text_stream = torch.cuda.Stream()
-            st.streams = (torch.cuda.Stream(), text_stream)
+            # text side: a stream that is VERIFIED to run
+            # beside the caller's stream (which carries the video side): _lib.ConcurrentStream.  A stream taken on trust may share a
+            # hardware queue with it (HIP maps streams to 4 queues in creation order) and the two sides then run one after the other.
+            st.text_cs = st.comm_cs = None
+            self._bind_text_stream(st, torch.cuda.current_stream())
             st.step = 0
             st.dims_key = None
             self._native = st
@@ -753,6 +762,25 @@ class RetrievalTrainer:
             n.mark_packed()
         return st.losses[0], st.losses[1], st.losses[2]
 
+    @staticmethod
+    def _bind_text_stream(st, main) -> None:
+        """st.streams[1] = a stream whose kernels overlap those of `main` (re-made when the caller comes with another current stream)."""
+        if st.text_cs is not None and st.text_main == main.cuda_stream:
+            return
+        if st.text_cs is not None:
+            torch.cuda.synchronize()
+            st.text_cs.close()
+            if st.comm_cs is not None:
+                st.comm_cs.close()
+                st.comm_cs = st.comm = None
+        # Default priority, as every stream of the step always had in effect (rounds 2-5 asked torch for priority 1, which torch clamps to
+        # its lowest = HIP's default).  A REAL low-priority queue (COOT_TEXT_STREAM_PRIORITY=1) is time-sliced against the default ones:
+        # 8-us kernels take 50 us on both sides and the step 1.9-2.3 ms, depending on where the queues land
+        # (profiles/r06_stream_queues.txt).
+        st.text_cs = _lib.ConcurrentStream([main], priority=int(os.environ.get("COOT_TEXT_STREAM_PRIORITY", "0")))
+        st.text_main = main.cuda_stream
+        st.streams = (None, st.text_cs.torch)
+
     def join_streams(self) -> None:
         """Orders the current stream after the native step's text stream (train_step_native(defer_join=True) leaves the text side's
         update running there).  Call before reading the text networks' parameters or weight packs on the current stream (validation,
@@ -793,6 +821,7 @@ class RetrievalTrainer:
             seed = (torch.initial_seed() * 1000003 + 7919 * (self.total_step + 1)) & 0xFFFFFFFFFFFFFFFF
         train = 1 if self.model_mgr.is_train else 0
         main = torch.cuda.current_stream()
+        self._bind_text_stream(st, main)
         # the video side runs on the caller's stream itself (no cross-stream hop on the critical path), the text side on a side stream
         flags = 0
         if do_optimizer:
@@ -908,13 +937,17 @@ class RetrievalTrainer:
             st.cl_word = st.gall[off + 1:off + 2]  # this rank's share of the contrastive loss (its rows against the gathered batch)
             st.cc_word = st.gall[off + 2:off + 3]
             st.g_loc_v = st.gall[cuts[0]:off + 3]  # video local network + the loss words
-            st.comm = torch.cuda.Stream()
+            st.comm = None
             # stream ordering through the library's fence-free events (include/coot_hip.h: coot_event_* / coot_stream_hop): a default event
             # — torch.cuda.Event, wait_stream — performs a system-scope L2 writeback / invalidation at every record
-            st.EV_GLOB_V, st.EV_GLOB_T, st.EV_TEXT = 0, 1, 2
+            st.EV_GLOB_V, st.EV_GLOB_T, st.EV_TEXT, st.EV_GLOB_RED = 0, 1, 2, 3
         local_v, local_t, glob_v, glob_t, resh_v, resh_t = st.emb
         d_local_v, d_local_t, d_glob_v, d_glob_t, d_resh_v, d_resh_t = st.demb
         main = torch.cuda.current_stream()
+        self._bind_text_stream(st, main)
+        if getattr(st, "comm", None) is None:  # the communication stream: beside both sides (their backward runs under the buckets)
+            st.comm_cs = _lib.ConcurrentStream([main, st.streams[1]])
+            st.comm = st.comm_cs.torch
         sv, stt = main, st.streams[1]  # video side on the caller's stream (no hop), text on a side stream
         sp = main.cuda_stream
         # the backward WRITES the weight-matrix gradients (coot_net_grads_overwrite): only the vectors that are still accumulated (biases,
@@ -1022,10 +1055,19 @@ class RetrievalTrainer:
                 cs = st.comm.cuda_stream
                 _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), _lib.UPDATE_REPACK | _lib.UPDATE_GLOBAL_ONLY,
                                                 None, cs, cs, cs), "coot_step_update (global networks)")
+            _lib.check(lib.coot_event_record(st.EV_GLOB_RED, st.comm.cuda_stream), "coot_event_record")
             _lib.check(lib.coot_event_wait(st.EV_TEXT, st.comm.cuda_stream), "coot_event_wait")
             dp.all_reduce_sum(st.g_loc_t)
         dp.all_reduce_sum(st.g_loc_v)
-        _lib.check(lib.coot_stream_hop(st.comm.cuda_stream, main.cuda_stream), "coot_stream_hop")
+        if do_optimizer and defer_join:
+            # Each side's update waits for ITS buckets only: the video side (this stream) for the global networks' bucket and its own
+            # local one, the text side for the communication stream's end.  The text side's backward ends up to 90 us after the video
+            # side's (it gets the CUs the video side leaves); with one join of the communication stream into this stream the video
+            # side's update — and the next step's video forward behind it — waited for the text bucket it never reads.
+            _lib.check(lib.coot_event_wait(st.EV_GLOB_RED, main.cuda_stream), "coot_event_wait")
+            _lib.check(lib.coot_stream_hop(st.comm.cuda_stream, stt.cuda_stream), "coot_stream_hop")
+        else:  # the caller reads every gradient behind this call on its stream
+            _lib.check(lib.coot_stream_hop(st.comm.cuda_stream, main.cuda_stream), "coot_stream_hop")
         if do_optimizer:  # (the video side's update launch also writes total = contrastive + cycle-consistency)
             flags = _lib.UPDATE_REPACK | (_lib.UPDATE_DEFER_TEXT_JOIN if defer_join else 0) | (_lib.UPDATE_SKIP_GLOBAL if early else 0)
             _lib.check(lib.coot_step_update(C.byref(st.cfg), C.byref(st.bufs), max(st.step, 1), flags, st.losses.data_ptr(), main.cuda_stream,

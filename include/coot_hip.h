@@ -90,7 +90,7 @@ const char* coot_last_error(void);
 /* ABI version of this header: struct layouts (coot_net_config gained `dtype`, coot_step_buffers `decay_block_all` in round 4) and the
  * meaning of flag words (coot_step_update's `repack` is a bit mask since round 4).  coot_version() returns the value the library was
  * built with; a binding compares the two when it loads the library (coot-videotext_amd/lib.py does) and refuses a mismatch. */
-#define COOT_ABI_VERSION 6
+#define COOT_ABI_VERSION 7
 int coot_version(void);
 /* Option switches for A/B measurements and tests ("fused", "packed", "tn_dma", "grad_poison", ...: the names coot_set_option
  * accepts are listed in csrc/api.hip).  They are PROCESS-GLOBAL ints read at launch time without synchronisation: set them
@@ -416,6 +416,23 @@ int coot_step_set_global_done_events(void* ev_video, void* ev_text);
  * coot_event_wait (slot 0 .. COOT_SYNC_EVENTS - 1; coot_event_handle returns the hipEvent_t, e.g. for
  * coot_step_set_global_done_events), coot_stream_hop = everything enqueued on `to` afterwards runs behind everything enqueued on `from`
  * before (internal event ring).  Thread-local, like the streams' owner. */
+/* Streams that really run CONCURRENTLY.  HIP multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+ * default) in the order they are created; two streams that land on one queue run their kernels one after the other whatever the
+ * events between them say — with the step's video and text side on one queue the ActivityNet step costs 1.72 instead of 1.22 ms, and
+ * one more stream created anywhere in the process before the trainer's is enough to get there (profiles/r06_stream_queues.txt).
+ * coot_stream_create_concurrent creates (non-blocking) candidate streams until one's kernels overlap those of every stream in
+ * others[0 .. n_others) (n_others <= 8; NULL entries = the null stream): a 100-us spin kernel on both must finish in the time of one.
+ * It also keeps clear of the library's own stream (next batch's input LayerNorm, early update) when the queues allow it.
+ * priority: 0 normal, > 0 the device's lowest, < 0 its highest.  *concurrent (may be NULL) = 1 if such a stream was found within 12
+ * candidates, else 0 with the last candidate returned and a line on stderr (GPU_MAX_HW_QUEUES=1, a tool that serialises the
+ * queues).  Release with coot_stream_destroy (synchronises the stream).  coot_streams_overlap(a, b): the test itself — 1 kernels overlap,
+ * 0 they run one after the other, < 0 error.  All three SYNCHRONISE THE DEVICE: setup calls, not step calls.  Thread-local bookkeeping
+ * (at most 64 live streams per thread).  The library verifies its own stream the same way against (side_v, side_t) at the head of the
+ * first coot_train_step / coot_step_forward that brings a new pair (one device synchronisation; never under capture).
+ * coot_get_option: stream_overlap_tests / stream_candidates_rejected / stream_unresolved. */
+int coot_stream_create_concurrent(const coot_stream_t* others, int n_others, int priority, coot_stream_t* out, int* concurrent);
+int coot_stream_destroy(coot_stream_t stream);
+int coot_streams_overlap(coot_stream_t a, coot_stream_t b);
 #define COOT_SYNC_EVENTS 8
 int coot_event_record(int slot, coot_stream_t stream);
 int coot_event_wait(int slot, coot_stream_t stream);

@@ -128,3 +128,40 @@ def test_gather_rows_backward_is_own_slice():
         assert torch.equal(x.grad, torch.arange(15.0).view(5, 3))
     finally:
         dist.destroy_process_group()
+
+
+def _rccl_worker(rank, world, port, break_rank, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import coot_videotext_amd  # noqa: F401
+    from coot_videotext_amd import dist as cdist
+    # break_rank cannot even load the library: the others must not enter the (collective) communicator init alone
+    r = cdist.DirectRccl(lib_path="/nonexistent/librccl.so" if rank == break_rank else None)
+    out.put((rank, r.comm is None, r.lib is not None))
+    # the torch group is still usable afterwards (the fallback route): one collective to prove it
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)
+    assert float(t) == 3.0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_rank", [-1, 1])
+def test_direct_rccl_creation_is_agreed_between_ranks(break_rank):
+    """dist.DirectRccl (the step's collectives as direct RCCL calls) is created COLLECTIVELY: library load and communicator init are
+    agreed over the torch group, so a rank that fails never leaves the others inside ncclCommInitRank and every rank ends on the same
+    route.  Two gloo ranks without a GPU: the unique id is really created and broadcast, the init fails on both (no device) — or one
+    rank cannot load the library at all — and both come back with no communicator instead of hanging."""
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, break_rank, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    res = sorted(out.get() for _ in range(2))
+    assert all(no_comm for _, no_comm, _ in res)
+    assert [lib for _, _, lib in res] == [True, break_rank != 1]

@@ -89,3 +89,23 @@ def test_bench_gpus_2_self_spawned():
     contr = d["config"]["final_losses"][1]
     want = _union_contrastive(world)
     assert abs(contr - want) <= 2e-4 * abs(want), (contr, want)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("route", ["direct", "torch"])
+def test_bench_one_rank_over_rccl_prints_one_json_line(route):
+    """`bench.py --force-dp` with the real backend (nccl = RCCL, one rank: all this box can hold): the step's collectives as direct
+    RCCL calls on its own streams (dist.DirectRccl; default) or through torch.distributed (COOT_DP_COLLECTIVES=torch).  STDOUT must
+    be exactly the one JSON line — RCCL prints a version banner to stdout when a process creates its first communicator, so both
+    communicators have to be created inside bench.py's redirection — and the line names the route that ran."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dp", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["COOT_DP_COLLECTIVES"] = route
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1" and d["value"] > 0
+    assert d["config"]["collectives"].startswith("RCCL calls" if route == "direct" else "torch.distributed"), d["config"]["collectives"]

@@ -610,10 +610,13 @@ def test_train_model_native_epochs(env):
     assert float((d > 0.5 * base).float().mean()) > 0.05
 
 
-def test_native_dp_step_matches_single_gpu_native(env):
+@pytest.mark.parametrize("route", ["direct", "torch"])
+def test_native_dp_step_matches_single_gpu_native(env, route, monkeypatch):
     """The data-parallel native step (phase calls + RCCL collectives, here a 1-rank nccl group) must produce the same
-    gradients, losses and updated parameters as the single-call native step (dropout 0, no cycle loss => no RNG)."""
+    gradients, losses and updated parameters as the single-call native step (dropout 0, no cycle loss => no RNG) — with the
+    step's collectives as direct RCCL calls on its own streams (dist.DirectRccl, the default) and through torch.distributed."""
     torch, cva = env
+    monkeypatch.setenv("COOT_DP_COLLECTIVES", route)
     import torch.distributed as dist
     from coot_videotext_amd import dist as cdist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -637,6 +640,7 @@ def test_native_dp_step_matches_single_gpu_native(env):
             la = ta.train_step_native(batch)
             lb = tb.train_step_native(batch, vid_counts=[6], clip_counts=[sum(counts)])
             torch.cuda.synchronize()
+            assert tb.dp.collectives_route() == route  # (a communicator that could not be created would fall back and say so)
             if it == 0:  # identical state: tight; later steps only loosely (noise-gradient elements move +-lr, see above)
                 assert abs(float(la[0]) - float(lb[0])) < 1e-5 * max(1.0, abs(float(la[0]))), (float(la[0]), float(lb[0]))
                 for na, nb in zip(mgr_a.model_dict.values(), mgr_b.model_dict.values()):
@@ -655,6 +659,7 @@ def test_native_dp_step_matches_single_gpu_native(env):
         torch.cuda.synchronize()
         assert all(np.isfinite(float(v)) for v in l) and float(l[2]) > 0
         assert abs(float(l[0]) - float(l[1]) - float(l[2])) < 1e-6
+        tb.dp.close(); tc.dp.close()
     finally:
         if own_pg:
             dist.destroy_process_group()

@@ -1,0 +1,105 @@
+"""Concurrent streams (include/coot_hip.h: coot_stream_create_concurrent / coot_streams_overlap).  HIP maps a process's streams onto
+4 hardware queues in creation order; two streams on one queue serialise.  The step's side streams are therefore VERIFIED to overlap:
+with one more stream created anywhere in the process before the trainer's, streams taken on trust put both sides of the step in one
+queue (1.72 instead of 1.22 ms, profiles/r06_stream_queues.txt)."""
+import ctypes as C
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import coot_videotext_amd as cva
+    return torch, cva
+
+
+def _opt(cva, name):
+    v = C.c_int(0)
+    cva.lib.check(cva.lib.load().coot_get_option(name.encode(), C.byref(v)), name)
+    return v.value
+
+
+def test_overlap_test_sees_shared_queues(env):
+    """The hazard is real and the test sees it: among nine streams taken from torch's pool at least two share one of the 4 hardware
+    queues (their spin kernels run one after the other), and a stream never overlaps itself."""
+    torch, cva = env
+    lib = cva.lib.load()
+    streams = [torch.cuda.Stream() for _ in range(9)]
+    for s in streams:
+        with torch.cuda.stream(s):
+            torch.zeros(1, device="cuda")
+    assert lib.coot_streams_overlap(streams[0].cuda_stream, streams[0].cuda_stream) == 0
+    res = {(i, j): lib.coot_streams_overlap(streams[i].cuda_stream, streams[j].cuda_stream) for i in range(9) for j in range(i + 1, 9)}
+    assert all(r in (0, 1) for r in res.values()), res
+    assert any(r == 0 for r in res.values()), "nine streams, every pair concurrent: more hardware queues than expected?"
+    assert any(r == 1 for r in res.values()), "no two streams run concurrently"
+
+
+@pytest.mark.parametrize("before", [0, 1, 2, 3])
+def test_created_streams_overlap_whatever_was_created_before(env, before):
+    torch, cva = env
+    lib = cva.lib.load()
+    junk = [torch.cuda.Stream() for _ in range(before)]
+    for s in junk:
+        with torch.cuda.stream(s):
+            torch.zeros(1, device="cuda")
+    main = torch.cuda.current_stream()
+    a = cva.lib.ConcurrentStream([main], priority=1)
+    b = cva.lib.ConcurrentStream([main, a])
+    c = cva.lib.ConcurrentStream([main, a, b])
+    try:
+        assert a.concurrent and b.concurrent and c.concurrent
+        hs = [main.cuda_stream, a.cuda_stream, b.cuda_stream, c.cuda_stream]
+        for i in range(4):
+            for j in range(i + 1, 4):
+                assert lib.coot_streams_overlap(hs[i], hs[j]) == 1, (i, j)
+        with torch.cuda.stream(a.torch):  # usable from torch
+            x = torch.ones(8, device="cuda") * 2
+        torch.cuda.synchronize()
+        assert float(x.sum()) == 16.0
+    finally:
+        for s in (a, b, c):
+            s.close()
+    assert _opt(cva, "stream_unresolved") == 0
+    assert lib.coot_stream_destroy(C.c_void_p(12345)) != 0  # not one of ours
+
+
+@pytest.mark.parametrize("before", [0, 1, 2, 3])
+def test_step_streams_are_concurrent_in_every_creation_order(env, before):
+    """The trainer's text stream overlaps the caller's stream and the library's own stream finds a queue beside both, whatever number
+    of unrelated streams the process created first; the step's result does not depend on it."""
+    torch, cva = env
+    from oracle import coot_oracle as O
+    from tests import helpers as H
+    lib = cva.lib.load()
+    junk = [torch.cuda.Stream() for _ in range(before)]
+    for s in junk:
+        with torch.cuda.stream(s):
+            torch.zeros(1, device="cuda")
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batch = cva.synthetic.make_batch(7, 6, [1, 2, 3, 4, 2, 1], 12, 10, 9, 6, dims[0], dims[1], ragged=True)
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+    mgr.set_all_models_train()
+    tr = cva.RetrievalTrainer(cfg, mgr)
+    losses = tr.train_step_native(batch, do_optimizer=False)
+    torch.cuda.synchronize()
+    st = tr._native
+    assert st.text_cs.concurrent
+    assert lib.coot_streams_overlap(torch.cuda.current_stream().cuda_stream, st.streams[1].cuda_stream) == 1
+    assert _opt(cva, "stream_unresolved") == 0
+    val = float(losses[0])
+    assert val == val and val > 0
+    # a caller that comes with another current stream gets a text stream verified against THAT one
+    other = torch.cuda.Stream()
+    other.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(other):
+        l2 = tr.train_step_native(batch, do_optimizer=False)
+        torch.cuda.synchronize()
+        assert lib.coot_streams_overlap(other.cuda_stream, tr._native.streams[1].cuda_stream) == 1
+    assert abs(float(l2[0]) - val) <= 1e-6 * max(1.0, abs(val))
+    tr.close()
