@@ -13,6 +13,7 @@
 #include "pool.h"
 #include "rowops.h"
 
+#include <vector>
 using namespace coot;
 
 #define RUN(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
@@ -199,9 +200,9 @@ __global__ void spin_kernel(int ticks /* of the 100 MHz real-time counter */) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
 }
 struct StreamPicker {
-  static constexpr int kSpinTicks = 10000, kMaxLive = 64, kNice = 3, kTries = 12;
+  static constexpr int kSpinTicks = 10000, kNice = 3, kTries = 32, kSettle = 16;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-  hipStream_t live[kMaxLive]; int n_live = 0;  // streams handed out by coot_stream_create_concurrent and not destroyed yet
+  std::vector<hipStream_t> live;  // streams handed out by coot_stream_create_concurrent and not destroyed yet
   int tests = 0, rejected = 0, unresolved = 0;  // coot_get_option("stream_overlap_tests" / "stream_candidates_rejected" / "stream_unresolved")
   int init() {
     if (e0) return 0;
@@ -244,7 +245,9 @@ struct StreamPicker {
       if (pick_must < 0) pick_must = n;
       for (int i = 0; i < n_nice && ok; ++i) { const int r = overlap(cand[n], nice[i]); if (r < 0) return 1; ok = r == 1; }
       if (ok) pick = n; else ++rejected;
-      if (n + 1 >= 8 && pick < 0 && pick_must >= 0) { ++n; break; }  // two rounds over the queues without a full match: settle for must[]
+      // HIP hands a new stream the least-loaded queue: with many streams alive the candidates can sit on ONE queue until its load catches
+      // up with the others', so the search is long; without a full match after kSettle candidates: settle for must[]
+      if (n + 1 >= kSettle && pick < 0 && pick_must >= 0) { ++n; break; }
     }
     const bool full = pick >= 0;
     if (pick < 0) pick = pick_must >= 0 ? pick_must : n - 1;
@@ -292,8 +295,8 @@ struct InputPipe {
       const hipStream_t must[2] = {sv, st};
       hipStream_t fresh = nullptr; int conc = 0;
       // ... and beside the most recent streams handed to the caller (a data-parallel step's communication stream), if the queues allow
-      const int nn = g_streams.n_live < StreamPicker::kNice ? g_streams.n_live : StreamPicker::kNice;
-      RUN(g_streams.create(must, 2, g_streams.live + (g_streams.n_live - nn), nn, 0, &fresh, &conc));
+      const int nl = (int)g_streams.live.size(), nn = nl < StreamPicker::kNice ? nl : StreamPicker::kNice;
+      RUN(g_streams.create(must, 2, g_streams.live.data() + (nl - nn), nn, 0, &fresh, &conc));
       if (stream) { RUN(check_hip(hipStreamSynchronize(stream), "streamSynchronize")); (void)hipStreamDestroy(stream); }
       stream = fresh;
       if (!done) RUN(check_hip(hipEventCreateWithFlags(&done, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate"));
@@ -933,21 +936,20 @@ int coot_stream_hop(coot_stream_t from, coot_stream_t to) {
 int coot_streams_overlap(coot_stream_t a, coot_stream_t b) { return g_streams.overlap((hipStream_t)a, (hipStream_t)b); }
 int coot_stream_create_concurrent(const coot_stream_t* others, int n_others, int priority, coot_stream_t* out, int* concurrent) {
   COOT_REQUIRE(out && n_others >= 0 && n_others <= 8 && (others || n_others == 0), "stream_create_concurrent: arguments");
-  COOT_REQUIRE(g_streams.n_live < StreamPicker::kMaxLive, "stream_create_concurrent: %d streams are live (coot_stream_destroy)", g_streams.n_live);
   hipStream_t must[8];
   for (int i = 0; i < n_others; ++i) must[i] = (hipStream_t)others[i];
   hipStream_t s = nullptr;
   // beside the caller's streams — and, if the queues allow it, beside the library's own stream too
   const hipStream_t nice[1] = {g_pipe.stream};
   RUN(g_streams.create(must, n_others, nice, g_pipe.stream ? 1 : 0, priority, &s, concurrent));
-  g_streams.live[g_streams.n_live++] = s;
+  g_streams.live.push_back(s);
   *out = (coot_stream_t)s;
   return 0;
 }
 int coot_stream_destroy(coot_stream_t s) {
-  for (int i = 0; i < g_streams.n_live; ++i)
+  for (size_t i = 0; i < g_streams.live.size(); ++i)
     if (g_streams.live[i] == (hipStream_t)s) {
-      g_streams.live[i] = g_streams.live[--g_streams.n_live];
+      g_streams.live.erase(g_streams.live.begin() + i);
       RUN(check_hip(hipStreamSynchronize((hipStream_t)s), "streamSynchronize"));
       if (g_pipe.checked && (g_pipe.beside[0] == (hipStream_t)s || g_pipe.beside[1] == (hipStream_t)s)) g_pipe.checked = false;  // (the handle may be reused)
       return check_hip(hipStreamDestroy((hipStream_t)s), "streamDestroy");

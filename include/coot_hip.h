@@ -423,11 +423,10 @@ int coot_step_set_global_done_events(void* ev_video, void* ev_text);
  * coot_stream_create_concurrent creates (non-blocking) candidate streams until one's kernels overlap those of every stream in
  * others[0 .. n_others) (n_others <= 8; NULL entries = the null stream): a 100-us spin kernel on both must finish in the time of one.
  * It also keeps clear of the library's own stream (next batch's input LayerNorm, early update) when the queues allow it.
- * priority: 0 normal, > 0 the device's lowest, < 0 its highest.  *concurrent (may be NULL) = 1 if such a stream was found within 12
+ * priority: 0 normal, > 0 the device's lowest, < 0 its highest.  *concurrent (may be NULL) = 1 if such a stream was found within 32
  * candidates, else 0 with the last candidate returned and a line on stderr (GPU_MAX_HW_QUEUES=1, a tool that serialises the
  * queues).  Release with coot_stream_destroy (synchronises the stream).  coot_streams_overlap(a, b): the test itself — 1 kernels overlap,
- * 0 they run one after the other, < 0 error.  All three SYNCHRONISE THE DEVICE: setup calls, not step calls.  Thread-local bookkeeping
- * (at most 64 live streams per thread).  The library verifies its own stream the same way against (side_v, side_t) at the head of the
+ * 0 they run one after the other, < 0 error.  All three SYNCHRONISE THE DEVICE: setup calls, not step calls.   Thread-local bookkeeping.  The library verifies its own stream the same way against (side_v, side_t) at the head of the
  * first coot_train_step / coot_step_forward that brings a new pair (one device synchronisation; never under capture).
  * coot_get_option: stream_overlap_tests / stream_candidates_rejected / stream_unresolved. */
 int coot_stream_create_concurrent(const coot_stream_t* others, int n_others, int priority, coot_stream_t* out, int* concurrent);
