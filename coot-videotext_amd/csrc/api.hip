@@ -23,6 +23,13 @@
 namespace coot {
 
 static thread_local char g_err[512] = "";
+// stream that takes the global network's batched weight-gradient launch (null: the pass's own stream), set around the global
+// coot_net_bwd of a step with an early update (api_step.hip: side_backward); ordering event of the hand-over
+static thread_local hipStream_t g_glob_flush_stream = nullptr;
+static thread_local hipEvent_t g_glob_flush_ev = nullptr;
+static int g_glob_flush_aux = 1;  // coot_set_option("glob_flush_aux", 0/1)
+static inline int coot_option_glob_flush_aux() { return g_glob_flush_aux; }
+extern "C" void coot_internal_set_glob_flush_stream(void* s) { g_glob_flush_stream = (hipStream_t)s; }
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -678,6 +685,7 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_target_wgs")) { set_tn_target_wgs(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "grad_write")) { coot_step_grad_write(value); return 0; }
+  if (!strcmp(name, "glob_flush_aux")) { g_glob_flush_aux = value; return 0; }  // 0: the global network's weight-gradient launch stays on its side's stream
   if (!strcmp(name, "cl_col_split")) { set_cl_col_split(value); return 0; }
   if (!strcmp(name, "cl_small")) { set_cl_small(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
@@ -1240,8 +1248,19 @@ int coot_net_bwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       RUN(tn(ds.dr1, D, bs.ctx, D, T, D, D, G + lp.wo, G + lp.bo));
       RUN(tn(ds.dq, 3 * D, S.z0, D, T, 3 * D, D, G + lp.wqkv, G + lp.bq));
     }
-    RUN(tn_batch_flush(st));
-    RUN(colsum_defer_flush(st));
+    // The weight gradients (and the deferred bias / LayerNorm column sums) of the global network are read by its UPDATE only, not by the
+    // local backward that follows on this stream: a step that updates the global network early on another stream (api_step.hip:
+    // early_update_fire) takes the batched launch over there (coot_internal_set_glob_flush_stream) — it left 18-33 us of kernel plus a
+    // launch gap between the global backward and the first kernel of the local backward on each side's critical stream.
+    hipStream_t fs = st;
+    if (g_glob_flush_stream && g_glob_flush_stream != st && coot_option_glob_flush_aux()) {
+      fs = g_glob_flush_stream;
+      if (!g_glob_flush_ev) RUN(check_hip(hipEventCreateWithFlags(&g_glob_flush_ev, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate"));
+      RUN(check_hip(hipEventRecord(g_glob_flush_ev, st), "eventRecord"));
+      RUN(check_hip(hipStreamWaitEvent(fs, g_glob_flush_ev, 0), "streamWait"));
+    }
+    RUN(tn_batch_flush(fs));
+    RUN(colsum_defer_flush(fs));
     return 0;
   }
   // pooling MLP dX + the last encoder layer's LN / FF / out-proj dX in one fused launch (fused.hip: pre_attn_bwd_kernel)

@@ -178,6 +178,7 @@ StepStamps g_stamps;
 // on 8-16 CUs with the memory system idle.  With two caller-owned stages, step t normalises batch t + 1 into the stage it does not
 // use, on its own stream behind both sides' local forward passes; step t + 1 finds its x^ ready and starts with the input FC.
 extern "C" void coot_internal_set_input_stage(void* xhat, void* pos, int mode);  // api.hip
+extern "C" void coot_internal_set_glob_flush_stream(void* stream);            // api.hip
 struct StageLayout { char *xv, *xt, *pv, *pt; size_t bytes; };
 StageLayout stage_layout(const coot_step_config& c, const coot_step_dims& d, void* base) {
   auto pad = [](size_t t) { return (t + 127) & ~(size_t)127; };  // whole 128-row tiles, as the saved arena (api.hip: layout_saved)
@@ -399,10 +400,13 @@ int side_backward(const coot_step_config& c, const coot_step_buffers& b, int li,
   const size_t sz_glob = coot_net_scratch_bytes(&c.net[gi], d.B, Cmax, 0, 0);
   COOT_REQUIRE(sz_loc + sz_glob <= sz_scratch, "step backward: scratch too small (%zu < %zu)", sz_scratch, sz_loc + sz_glob);
   glob_xcd_set(side == 0 ? 0 : 4, 4);
+  // with an early update the global network's weight gradients are consumed on the library's own stream: their launch goes there too
+  if (g_early.on[side] && g_pipe.init() == 0) coot_internal_set_glob_flush_stream(g_pipe.stream);
   const int rc_g = coot_net_bwd(&c.net[gi], b.params[gi], b.wpack[gi], b.pe[gi], resh, item_num, d.B, Cmax, nullptr, nullptr, 0, 0, local_out, d_glob,
                                 b.grads[gi], dhid, dfeat, saved_g, sz_g, (char*)scratch + sz_loc, sz_glob, train, seed + 11 * gi, g_step_seed_dev, st,
                                 nullptr);
   glob_xcd_set(0, 8);
+  coot_internal_set_glob_flush_stream(nullptr);
   RUN(rc_g);
   g_stamps.mark(li == 0 ? "video: global backward done" : "text: global backward done", st);
   // data parallel: the global network's gradients are final here — the caller's communication stream may start reducing them under
