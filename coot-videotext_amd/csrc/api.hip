@@ -30,6 +30,19 @@ static thread_local hipEvent_t g_glob_flush_ev = nullptr;
 static int g_glob_flush_aux = 1;  // coot_set_option("glob_flush_aux", 0/1)
 static inline int coot_option_glob_flush_aux() { return g_glob_flush_aux; }
 extern "C" void coot_internal_set_glob_flush_stream(void* s) { g_glob_flush_stream = (hipStream_t)s; }
+// Hand-over request of a step around its LOCAL network's forward (api_step.hip: side_forward): the pooling kernel writes the item
+// embeddings into the global network's padded [B, Cmax, D] layout itself (pool.h: pk_*).  One-shot: a call that can serve the request
+// takes it (`taken`); the caller launches the stand-alone pack kernel otherwise.
+struct PoolHandover { const long long* counts = nullptr; int B = 0, Cmax = 0; float* out = nullptr; unsigned char* mask = nullptr; long long* lens = nullptr;
+                      bool fwd = false, taken = false; };
+static thread_local PoolHandover g_pool_handover;
+static int g_pool_handover_on = 1;  // coot_set_option("pool_handover", 0/1)
+extern "C" void coot_internal_set_pool_pack(const long long* counts, int B, int Cmax, float* out, unsigned char* mask, long long* lens) {
+  g_pool_handover = PoolHandover{};
+  if (counts && g_pool_handover_on) { g_pool_handover.counts = counts; g_pool_handover.B = B; g_pool_handover.Cmax = Cmax; g_pool_handover.out = out;
+                                      g_pool_handover.mask = mask; g_pool_handover.lens = lens; g_pool_handover.fwd = true; }
+}
+extern "C" int coot_internal_pool_handover_taken(void) { const int t = g_pool_handover.taken ? 1 : 0; g_pool_handover = PoolHandover{}; return t; }
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -685,7 +698,8 @@ int coot_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_target_wgs")) { set_tn_target_wgs(value); return 0; }
   if (!strcmp(name, "xcd_order")) { set_xcd_order(value); return 0; }
   if (!strcmp(name, "grad_write")) { coot_step_grad_write(value); return 0; }
-  if (!strcmp(name, "glob_flush_aux")) { g_glob_flush_aux = value; return 0; }  // 0: the global network's weight-gradient launch stays on its side's stream
+  if (!strcmp(name, "glob_flush_aux")) { g_glob_flush_aux = value; return 0; }
+  if (!strcmp(name, "pool_handover")) { g_pool_handover_on = value; return 0; }  // 0: the pack between the local and the global forward stays a launch of its own  // 0: the global network's weight-gradient launch stays on its side's stream
   if (!strcmp(name, "cl_col_split")) { set_cl_col_split(value); return 0; }
   if (!strcmp(name, "cl_small")) { set_cl_small(value); return 0; }
   if (!strcmp(name, "fz_debug")) { g_fz_debug = value; return 0; }
@@ -1137,6 +1151,11 @@ int coot_net_fwd(const coot_net_config* cfg, const float* P, const void* wpack, 
       p.pooled_copy = S.pooled + (size_t)n0 * D; p.smax = S.smax + (size_t)n0 * D; p.ssum = S.ssum + (size_t)n0 * D;
       p.drop_w = mkdrop(train, c.pool_dropout, seed + 977u * sidx, 16u * 15 + SITE_POOL3);
       row += (long)sg.N[sidx] * sg.L[sidx]; n0 += sg.N[sidx];
+    }
+    if (g_pool_handover.fwd && sg.n == 2 && !c.use_context) {  // the item segment's rows also go into the global network's padded layout
+      PoolArgs& p = ps[1]; const PoolHandover& h = g_pool_handover;
+      p.pk_counts = h.counts; p.pk_B = h.B; p.pk_Cmax = h.Cmax; p.pk_out = h.out; p.pk_mask = h.mask; p.pk_lens = h.lens;
+      g_pool_handover.taken = true;
     }
     RUN(launch_pool_fwd2(ps, sg.n, st));  // both segments (e.g. videos and clips) in one launch
   } else {

@@ -179,6 +179,9 @@ StepStamps g_stamps;
 // use, on its own stream behind both sides' local forward passes; step t + 1 finds its x^ ready and starts with the input FC.
 extern "C" void coot_internal_set_input_stage(void* xhat, void* pos, int mode);  // api.hip
 extern "C" void coot_internal_set_glob_flush_stream(void* stream);            // api.hip
+extern "C" void coot_internal_set_pool_pack(const long long* counts, int B, int Cmax, float* out, unsigned char* mask, long long* lens);
+extern "C" int coot_internal_pool_handover_taken(void);
+
 struct StageLayout { char *xv, *xt, *pv, *pt; size_t bytes; };
 StageLayout stage_layout(const coot_step_config& c, const coot_step_dims& d, void* base) {
   auto pad = [](size_t t) { return (t + 127) & ~(size_t)127; };  // whole 128-row tiles, as the saved arena (api.hip: layout_saved)
@@ -368,11 +371,15 @@ int side_forward(const coot_step_config& c, const coot_step_buffers& b, int li, 
     { const int two[2] = {li, gi}; RUN(pack_nets(c, b, two, 2, st)); }
   }
   g_stamps.mark(li == 0 ? "video: weights packed" : "text: weights packed", st);
-  RUN(coot_net_fwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
-                   nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, g_step_seed_dev, st, pk));
+  // the local network's pooling kernel writes the item embeddings into the global network's padded layout itself if it can (pool.h: pk_*)
+  if (d.Nc > 0) coot_internal_set_pool_pack((const long long*)item_num, d.B, Cmax, resh, mask, lens);
+  const int rc_lf = coot_net_fwd(&c.net[li], b.params[li], b.wpack[li], b.pe[li], ctx_feat, ctx_len, d.B, Lctx, item_feat, item_len, d.Nc, Litem,
+                                 nullptr, local_out, nullptr, saved_l, sz_l, nullptr, 0, train, seed + 11 * li, g_step_seed_dev, st, pk);
+  const bool packed_by_pool = coot_internal_pool_handover_taken() != 0;
+  RUN(rc_lf);
   g_stamps.mark(li == 0 ? "video: local forward done" : "text: local forward done", st);
   if (local_done_slot >= 0) RUN(g_hops.record(local_done_slot, st));  // the local embeddings exist: the other side may start on their loss terms
-  RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
+  if (!packed_by_pool) RUN(launch_pack_fwd(local_out + (size_t)d.B * D, (const long long*)item_num, d.B, Cmax, D, resh, mask, lens, st));
   // the two sides' global passes run at the same time: each on its own half of the XCDs (its 3.5 MB of weights then own those L2s;
   // measured harmless rather than useful: the passes are latency chains, profiles/README.md round 3)
   glob_xcd_set(li == 0 ? 0 : 4, 4);

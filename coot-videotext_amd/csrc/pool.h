@@ -24,6 +24,14 @@ struct PoolArgs {
   float* part_ws = nullptr;                  // internal: [N][D] partials
   DropCfg drop_s; long drop_s_ld = 0;        // dropout2 mask (same indexing as the GEMM epilogue)
   long drop_s_row0 = 0;                      // global row index of this segment's first token
+  // Hand-over from the ITEM segment (clips / sentences: item n = video b's c-th item, n = sum_{i < b} counts[i] + c) to the global network's
+  // padded [B, Cmax, D] layout by the pooling kernel itself (= launch_pack_fwd, which was a 7-us launch plus a launch gap on the latency
+  // chain between the local and the global forward: 1.191 -> 1.184 ms per step): pooled rows also go to pk_out [B, Cmax, D] (padding rows
+  // zero), pk_mask [B, Cmax] (1 = padding), pk_lens [B].  (The backward's counterpart — the global network's gradients joining dpooled inside
+  // pool_bwd_kernel — was built and measured 1 % slower: the prefix search and the dependent loads at the head of every workgroup cost what
+  // the launch saved; profiles/r06_ab_handover.txt.)
+  const long long* pk_counts = nullptr; int pk_B = 0, pk_Cmax = 0;
+  float* pk_out = nullptr; unsigned char* pk_mask = nullptr; long long* pk_lens = nullptr;
 };
 int launch_pool_fwd(const PoolArgs& p, hipStream_t stream);
 int launch_pool_bwd(const PoolArgs& p, hipStream_t stream);

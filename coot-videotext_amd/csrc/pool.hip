@@ -26,6 +26,44 @@ __host__ __device__ inline int pool_cpb(int D) { return (D % 128 == 0) ? 16 : D 
 
 struct PoolArgs2 { PoolArgs seg[2]; int n0; };  // sequences [0, n0) = segment 0, the rest segment 1
 
+// (video b, position c, count of b) of item n: prefix search over counts[0 .. B) by the whole 256-thread workgroup, result through LDS
+// (sh: 8 ints).  Its one global load is issued before the kernel's main loop, so the search costs a scan, not a memory round trip.
+__device__ __forceinline__ void pool_find_video(const long long* counts, int B, int n, int* sh, int& b, int& c, int& cnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long carry = 0;
+  if (tid == 0) sh[4] = -1;
+  for (int base = 0; base < B; base += 256) {
+    const int v = (base + tid < B) ? (int)counts[base + tid] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += sh[w];
+    const int tot = sh[0] + sh[1] + sh[2] + sh[3];
+    const long excl = carry + woff + inc - v;
+    if (v > 0 && n >= excl && n < excl + v) { sh[4] = base + tid; sh[5] = (int)(n - excl); sh[6] = v; }
+    __syncthreads();
+    if (sh[4] >= 0) break;
+    carry += tot;
+  }
+  b = sh[4]; c = sh[5]; cnt = sh[6];
+}
+// forward hand-over, rows of video vb the items do not cover (cntb .. Cmax - 1) of this workgroup's channels -> 0; channel block 0 also
+// writes the video's mask row and length
+__device__ __forceinline__ void pool_pack_rest(const PoolArgs& p, int vb, int cntb, int cpb) {
+  const int Cm = p.pk_Cmax, nch = cpb * 8;
+  for (int i = threadIdx.x; i < (Cm - cntb) * nch; i += 256) {
+    const int r = cntb + i / nch, ch = blockIdx.y * nch + i % nch;
+    p.pk_out[((long)vb * Cm + r) * p.D + ch] = 0.f;
+  }
+  if (blockIdx.y == 0) {
+    if (p.pk_mask) for (int r = threadIdx.x; r < Cm; r += 256) p.pk_mask[(long)vb * Cm + r] = r < cntb ? 0 : 1;
+    if (p.pk_lens && threadIdx.x == 0) p.pk_lens[vb] = cntb;
+  }
+}
+
 __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs2 pp) {
   __shared__ float red[3][256 * 8 + 8];
   const bool second = (int)blockIdx.x >= pp.n0;
@@ -36,6 +74,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs2 pp) {
   const int len = (int)p.lens[n];
   const long r0 = p.cu ? (long)p.cu[n] : (long)n * p.L;
   const int Lp = p.cu ? len : p.L;  // rows the sequence occupies (padded length, or its own when packed)
+  __shared__ int pk_sh[8];
+  int vb = -1, vc = 0, vcnt = 0;
+  if (p.pk_out) pool_find_video(p.pk_counts, p.pk_B, n, pk_sh, vb, vc, vcnt);
   float m[8], z[8], a[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; z[j] = 0.f; a[j] = 0.f; }
@@ -94,6 +135,14 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs2 pp) {
     p.pooled[(long)n * p.ldp + ch] = pooled;
     if (p.pooled_copy) p.pooled_copy[(long)n * p.D + ch] = pooled;
     if (p.smax) { p.smax[(long)n * p.D + ch] = mm; p.ssum[(long)n * p.D + ch] = zz; }
+    if (vb >= 0) p.pk_out[((long)vb * p.pk_Cmax + vc) * p.D + ch] = pooled;
+  }
+  if (vb >= 0) {
+    // the rest of the padded layout: a video's padding rows, mask and length by its LAST item; videos without items by the first item
+    // of the next video that has some (those in front of it) and by the very last item (those behind it)
+    if (vc == vcnt - 1) pool_pack_rest(p, vb, vcnt, cpb);
+    if (vc == 0) for (int e = vb - 1; e >= 0 && p.pk_counts[e] == 0; --e) pool_pack_rest(p, e, 0, cpb);
+    if (n == p.N - 1) for (int e = vb + 1; e < p.pk_B; ++e) pool_pack_rest(p, e, 0, cpb);
   }
 }
 

@@ -105,3 +105,51 @@ def test_step_streams_are_concurrent_in_every_creation_order(env, before):
         assert lib.coot_streams_overlap(other.cuda_stream, tr._native.streams[1].cuda_stream) == 1
     assert abs(float(l2[0]) - val) <= 1e-6 * max(1.0, abs(val))
     tr.close()
+
+
+@pytest.mark.parametrize("counts", [[1, 2, 3, 4, 2, 1], [4, 4, 4, 4, 4, 4], [1, 1, 5, 1, 2, 3]])
+def test_pool_kernel_packs_items_like_the_pack_launch(env, counts):
+    """The local network's pooling kernel writes the item embeddings into the global network's padded [B, Cmax, D] layout itself
+    (csrc/pool.h: pk_*; coot_set_option("pool_handover", 0) = the stand-alone pack launch of coot/model_retrieval.py:121-136's loop).
+    Both must give the same bits on a ragged batch — packed rows, ZERO padding rows (the buffers are NaN-poisoned first) and, through
+    the mask and the lengths, the global network's outputs."""
+    torch, cva = env
+    from oracle import coot_oracle as O
+    from tests import helpers as H
+    lib = cva.lib.load()
+    dims = (64, 48, 64, 4, 64, 128)
+    cfgs = H.full_cfgs(*dims)
+    Ps = [O.make_params(cfgs[i], 1 + i, scale=0.02) for i in range(4)]
+    batch = cva.synthetic.make_batch(7, len(counts), counts, 12, 10, 9, 6, dims[0], dims[1], ragged=True)
+    cfg, mgr = H.make_manager(cfgs, Ps, dropout=0.0, cc_weight=0.0)
+    mgr.set_all_models_eval()
+    tr = cva.RetrievalTrainer(cfg, mgr)
+    tr.train_step_native(batch, do_optimizer=False)  # (sets the native state up)
+    st = tr._native
+    _, x = tr._native_setup(batch)
+    B, Nc, D = st.dims.B, st.dims.Nc, cfgs[0]["hidden_dim"] if isinstance(cfgs[0], dict) else st.cfg.net[0].hidden_dim
+    dev = batch.vid_feat.device
+    outs = {}
+    try:
+        for mode in (0, 1):
+            cva.lib.check(lib.coot_set_option(b"pool_handover", mode), "pool_handover")
+            t = [torch.full((B + Nc, D), float("nan"), device=dev), torch.full((B + Nc, D), float("nan"), device=dev),
+                 torch.full((B, 2 * D), float("nan"), device=dev), torch.full((B, 2 * D), float("nan"), device=dev),
+                 torch.full((B, st.dims.Cmax_clip, D), float("nan"), device=dev), torch.full((B, st.dims.Cmax_sent, D), float("nan"), device=dev)]
+            main = torch.cuda.current_stream()
+            cva.lib.check(lib.coot_step_forward(C.byref(st.cfg), C.byref(st.bufs), C.byref(x), C.byref(st.dims), *[v.data_ptr() for v in t],
+                                                st.ws.data_ptr(), st.ws.numel(), 0, 0, 0, main.cuda_stream, main.cuda_stream,
+                                                st.streams[1].cuda_stream), "coot_step_forward")
+            torch.cuda.synchronize()
+            outs[mode] = [v.cpu().numpy() for v in t]
+    finally:
+        cva.lib.check(lib.coot_set_option(b"pool_handover", 1), "pool_handover")
+    import numpy as np
+    for a, b_ in zip(outs[0], outs[1]):
+        assert np.isfinite(a).all() and np.array_equal(a, b_)
+    resh = outs[1][4]
+    for v, cnt in enumerate(counts):  # padding rows are zero, item rows are the flat rows in order
+        assert not resh[v, cnt:].any()
+    flat = outs[1][0][B:]
+    assert np.array_equal(np.concatenate([resh[v, :cnt] for v, cnt in enumerate(counts)]), flat)
+    tr.close()
